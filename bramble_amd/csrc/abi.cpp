@@ -1,0 +1,811 @@
+// C ABI of libbramble_amd.so (include/bramble_amd.h): index build, contexts and
+// the HIP projection pipeline.  Host side of the drop-in boundary; the reference
+// counterparts are cited per function in the header.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <random>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/bramble_amd.h"
+#include "device_types.h"
+#include "kernels.h"
+
+using namespace br;
+
+#define HIPCHK(expr)                                                                          \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess) {                                                                   \
+      fprintf(stderr, "[bramble_amd] HIP error %s at %s:%d: %s\n", hipGetErrorName(_e), __FILE__, \
+              __LINE__, #expr);                                                               \
+      return BR_ERR_HIP;                                                                      \
+    }                                                                                         \
+  } while (0)
+
+// ---------------------------------------------------------------------------
+// index
+// ---------------------------------------------------------------------------
+struct br_index {
+  int device = -1;
+  std::vector<std::string> names;
+  std::vector<uint32_t> lengths;
+  uint32_t n_refs = 0;
+  bool has_seq = false;
+  // host copies of the flattened tables
+  std::vector<uint32_t> slab_off, s_start, s_end, s_pmax, tx_first;
+  std::vector<uint4> s_pay, tx_ex;
+  std::vector<uint8_t> seq_pool;
+  // device copies
+  void *d_slab_off = nullptr, *d_s_start = nullptr, *d_s_end = nullptr, *d_s_pmax = nullptr,
+       *d_s_pay = nullptr, *d_tx_ex = nullptr, *d_tx_first = nullptr, *d_seq_pool = nullptr;
+  size_t device_bytes = 0;
+  DevIndex dev{};
+};
+
+static int check_device(int device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0 || device >= n) return BR_ERR_NO_DEVICE;
+  return BR_OK;
+}
+
+template <typename T>
+static int upload(void **dst, const std::vector<T> &src, size_t &acc) {
+  size_t bytes = std::max<size_t>(src.size() * sizeof(T), 16);
+  HIPCHK(hipMalloc(dst, bytes));
+  if (!src.empty()) HIPCHK(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+  acc += bytes;
+  return BR_OK;
+}
+
+// Common builder over flat arrays: transcript t has reference tx_ref[t], strand
+// tx_strand[t] and exons [tx_exon_off[t], tx_exon_off[t+1]) in (ex_start, ex_end).
+static int build_index_flat(size_t n_tx, const int32_t *tx_ref, const int8_t *tx_strand, const uint64_t *tx_exon_off,
+                            const uint32_t *ex_start, const uint32_t *ex_end, std::vector<std::string> &&names,
+                            size_t n_refs, const std::vector<const br_fasta_seq *> &fasta_by_ref, bool has_seq,
+                            int device, br_index **out) {
+  if (n_tx >= 0xffffffffull) return BR_ERR_CAPACITY;
+  br_index *ix = new br_index();
+  ix->n_refs = (uint32_t)n_refs;
+  ix->has_seq = has_seq;
+  ix->names = std::move(names);
+  struct Row { uint32_t start, end, tid, gidx, pos_start; };
+  std::vector<std::vector<Row>> slabs(2 * n_refs);
+  ix->tx_first.reserve(n_tx + 1);
+  std::vector<br_exon> ex;
+  std::vector<uint32_t> pos_start;
+  for (size_t t = 0; t < n_tx; t++) {
+    int32_t refid = tx_ref[t];
+    if (refid < 0 || (size_t)refid >= n_refs) { delete ix; return BR_ERR_ANNOTATION; }
+    ex.clear();
+    for (uint64_t k = tx_exon_off[t]; k < tx_exon_off[t + 1]; k++) ex.push_back({ex_start[k], ex_end[k]});
+    std::stable_sort(ex.begin(), ex.end(), [](const br_exon &a, const br_exon &b) { return a.start < b.start; });
+    for (size_t i = 0; i < ex.size(); i++) {
+      if (ex[i].end < ex[i].start || (i + 1 < ex.size() && ex[i].end > ex[i + 1].start)) {
+        fprintf(stderr, "[bramble_amd] transcript '%s': exons overlap or are inverted\n", ix->names[t].c_str());
+        delete ix; return BR_ERR_ANNOTATION;
+      }
+    }
+    uint32_t tlen = 0;
+    for (auto &e : ex) tlen += e.end - e.start;
+    ix->lengths.push_back(tlen);
+    ix->tx_first.push_back((uint32_t)ix->tx_ex.size());
+    char strand = (char)tx_strand[t];
+    bool minus = strand == '-';
+    bool stranded = strand == '+' || strand == '-';
+    const br_fasta_seq *fa = has_seq ? fasta_by_ref[(size_t)refid] : nullptr;
+    // pos_start: cumulative spliced offset in TRANSCRIPT order (src/bramble.cpp:161-175)
+    uint32_t acc = 0;
+    pos_start.assign(ex.size(), 0);
+    if (!minus) { for (size_t i = 0; i < ex.size(); i++) { pos_start[i] = acc; acc += ex[i].end - ex[i].start; } }
+    else { for (size_t i = ex.size(); i-- > 0;) { pos_start[i] = acc; acc += ex[i].end - ex[i].start; } }
+    for (size_t i = 0; i < ex.size(); i++) {
+      uint32_t seq_off = 0;
+      if (has_seq) {  // src/g2t.cpp:50-55: upper-cased exon sequence
+        seq_off = (uint32_t)ix->seq_pool.size();
+        for (uint32_t p = ex[i].start; p < ex[i].end; p++) {
+          char ch = (fa && p >= 1 && (uint64_t)(p - 1) < fa->len) ? fa->seq[p - 1] : 'N';
+          if (ch >= 'a' && ch <= 'z') ch = (char)(ch - 'a' + 'A');
+          ix->seq_pool.push_back((uint8_t)ch);
+        }
+      }
+      ix->tx_ex.push_back(make_uint4(ex[i].start, ex[i].end, pos_start[i], seq_off));
+      if (stranded) slabs[2 * (size_t)refid + (minus ? 1 : 0)].push_back({ex[i].start, ex[i].end, (uint32_t)t, (uint32_t)i, pos_start[i]});
+    }
+    ix->tx_ex.push_back(make_uint4(0xffffffffu, 0xffffffffu, 0, 0));  // sentinel
+    if (ix->tx_ex.size() >= 0xfffffff0ull || ix->seq_pool.size() >= 0xfffffff0ull) { delete ix; return BR_ERR_CAPACITY; }
+  }
+  ix->tx_first.push_back((uint32_t)ix->tx_ex.size());
+  ix->slab_off.push_back(0);
+  for (auto &rows : slabs) {
+    std::stable_sort(rows.begin(), rows.end(), [](const Row &a, const Row &b) { return a.start < b.start; });
+    uint32_t m = 0;
+    for (auto &r : rows) {
+      m = std::max(m, r.end);
+      ix->s_start.push_back(r.start); ix->s_end.push_back(r.end); ix->s_pmax.push_back(m);
+      ix->s_pay.push_back(make_uint4(r.tid, r.gidx, r.pos_start, ix->tx_first[r.tid]));
+    }
+    ix->slab_off.push_back((uint32_t)ix->s_start.size());
+  }
+  ix->device = device;
+  if (device >= 0) {
+    int rc = check_device(device);
+    if (rc != BR_OK) { delete ix; return rc; }
+    HIPCHK(hipSetDevice(device));
+    size_t acc = 0;
+    if ((rc = upload(&ix->d_slab_off, ix->slab_off, acc)) || (rc = upload(&ix->d_s_start, ix->s_start, acc)) ||
+        (rc = upload(&ix->d_s_end, ix->s_end, acc)) || (rc = upload(&ix->d_s_pmax, ix->s_pmax, acc)) ||
+        (rc = upload(&ix->d_s_pay, ix->s_pay, acc)) || (rc = upload(&ix->d_tx_ex, ix->tx_ex, acc)) ||
+        (rc = upload(&ix->d_tx_first, ix->tx_first, acc)) || (rc = upload(&ix->d_seq_pool, ix->seq_pool, acc))) {
+      br_index_free(ix); return rc;
+    }
+    ix->device_bytes = acc;
+    DevIndex &d = ix->dev;
+    d.n_refs = ix->n_refs; d.n_tx = (uint32_t)n_tx; d.n_rows = (uint32_t)ix->s_start.size();
+    d.slab_off = (const uint32_t *)ix->d_slab_off; d.s_start = (const uint32_t *)ix->d_s_start;
+    d.s_end = (const uint32_t *)ix->d_s_end; d.s_pmax = (const uint32_t *)ix->d_s_pmax;
+    d.s_pay = (const uint4 *)ix->d_s_pay; d.tx_ex = (const uint4 *)ix->d_tx_ex;
+    d.tx_first = (const uint32_t *)ix->d_tx_first; d.seq_pool = (const uint8_t *)ix->d_seq_pool;
+  }
+  *out = ix;
+  return BR_OK;
+}
+
+extern "C" int br_index_build(const br_transcript *transcripts, size_t n_transcripts,
+                              const char *const *refnames, size_t n_refnames, const br_fasta_seq *fasta,
+                              size_t n_fasta, int device, br_index **out) {
+  if (!out || (!transcripts && n_transcripts) || (!refnames && n_refnames)) return BR_ERR_INVALID_ARG;
+  *out = nullptr;
+  std::unordered_map<std::string, uint32_t> ref_of;
+  for (size_t i = 0; i < n_refnames; i++) ref_of.emplace(refnames[i], (uint32_t)i);
+  std::vector<const br_fasta_seq *> fa_by_ref(n_refnames, nullptr);
+  for (size_t i = 0; i < n_fasta; i++) { auto it = ref_of.find(fasta[i].name ? fasta[i].name : ""); if (it != ref_of.end()) fa_by_ref[it->second] = &fasta[i]; }
+  std::vector<int32_t> tx_ref(n_transcripts); std::vector<int8_t> tx_strand(n_transcripts);
+  std::vector<uint64_t> off(n_transcripts + 1, 0); std::vector<uint32_t> es, ee; std::vector<std::string> names;
+  for (size_t t = 0; t < n_transcripts; t++) {
+    const br_transcript &tx = transcripts[t];
+    names.emplace_back(tx.id ? tx.id : "");
+    auto it = ref_of.find(tx.seqname ? tx.seqname : "");
+    if (it == ref_of.end()) {  // bramble-rs/src/g2t.rs:442-444
+      fprintf(stderr, "[bramble_amd] reference '%s' of transcript '%s' not in refnames\n",
+              tx.seqname ? tx.seqname : "", tx.id ? tx.id : "");
+      return BR_ERR_ANNOTATION;
+    }
+    tx_ref[t] = (int32_t)it->second; tx_strand[t] = (int8_t)tx.strand;
+    for (uint32_t k = 0; k < tx.n_exons; k++) { es.push_back(tx.exons[k].start); ee.push_back(tx.exons[k].end); }
+    off[t + 1] = es.size();
+  }
+  return build_index_flat(n_transcripts, tx_ref.data(), tx_strand.data(), off.data(), es.data(), ee.data(),
+                          std::move(names), n_refnames, fa_by_ref, n_fasta > 0, device, out);
+}
+
+extern "C" int br_index_build_flat(size_t n_tx, const int32_t *tx_ref_id, const int8_t *tx_strand,
+                                   const uint64_t *tx_exon_off, const uint32_t *ex_start, const uint32_t *ex_end,
+                                   const char *const *tx_names, size_t n_refs, const br_fasta_seq *fasta_by_ref,
+                                   int device, br_index **out) {
+  if (!out || (n_tx && (!tx_ref_id || !tx_strand || !tx_exon_off))) return BR_ERR_INVALID_ARG;
+  *out = nullptr;
+  std::vector<std::string> names(n_tx);
+  for (size_t t = 0; t < n_tx; t++) names[t] = tx_names ? tx_names[t] : ("tx" + std::to_string(t));
+  std::vector<const br_fasta_seq *> fa(n_refs, nullptr);
+  if (fasta_by_ref) for (size_t r = 0; r < n_refs; r++) fa[r] = fasta_by_ref[r].seq ? &fasta_by_ref[r] : nullptr;
+  return build_index_flat(n_tx, tx_ref_id, tx_strand, tx_exon_off, ex_start, ex_end, std::move(names), n_refs, fa,
+                          fasta_by_ref != nullptr, device, out);
+}
+
+extern "C" void br_index_free(br_index *ix) {
+  if (!ix) return;
+  if (ix->device >= 0) {
+    (void)hipSetDevice(ix->device);
+    void *ptrs[] = {ix->d_slab_off, ix->d_s_start, ix->d_s_end, ix->d_s_pmax, ix->d_s_pay, ix->d_tx_ex,
+                    ix->d_tx_first, ix->d_seq_pool};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+  }
+  delete ix;
+}
+extern "C" size_t br_index_num_transcripts(const br_index *ix) { return ix ? ix->names.size() : 0; }
+extern "C" const char *br_index_transcript_name(const br_index *ix, uint32_t tid) {
+  return (ix && tid < ix->names.size()) ? ix->names[tid].c_str() : nullptr;
+}
+extern "C" int64_t br_index_transcript_len(const br_index *ix, uint32_t tid) {
+  return (ix && tid < ix->lengths.size()) ? (int64_t)ix->lengths[tid] : -1;
+}
+extern "C" size_t br_index_num_intervals(const br_index *ix) { return ix ? ix->s_start.size() : 0; }
+extern "C" size_t br_index_device_bytes(const br_index *ix) { return ix ? ix->device_bytes : 0; }
+
+// ---------------------------------------------------------------------------
+// configuration
+// ---------------------------------------------------------------------------
+extern "C" void br_config_short_read(br_config *c) { memset(c, 0, sizeof(*c)); c->junc_miss_discount = 1.0; }
+extern "C" void br_config_long_read(br_config *c) { memset(c, 0, sizeof(*c)); c->lr = 1; c->junc_miss_discount = 1.0; }
+
+// src/evaluate.cpp:1136-1221: presets (+ overrides).  The LR branch comes before
+// LR_HQ, and --strict only reaches short-read runs.
+extern "C" int br_config_resolve(const br_config *c, br_thresholds *t) {
+  if (!c || !t) return BR_ERR_INVALID_ARG;
+  if (c->junc_miss_discount != 1.0 && c->junc_miss_discount != 0.0) return BR_ERR_UNSUPPORTED;
+  bool longr = c->lr || c->lr_hq;
+  uint32_t mc, mji, mjg, mee; float thr;
+  if (!longr) { mc = c->strict ? 0 : 5; mji = 0; mjg = 0; thr = 1.0f; mee = 0; }
+  else if (c->lr) { mc = 40; mji = 40; mjg = 40; thr = (float)0.60; mee = 35; }
+  else { mc = 5; mji = 10; mjg = 10; thr = (float)0.90; mee = 35; }
+  if (c->has_max_clip) mc = c->max_clip;
+  if (c->has_max_junc_ins) mji = c->max_junc_ins;
+  if (c->has_max_junc_gap) mjg = c->max_junc_gap;
+  if (c->has_sim_thr) thr = c->sim_thr;
+  if (c->has_max_error_exon) mee = c->max_error_exon;
+  t->max_clip = mc; t->max_junc_ins = mji; t->max_junc_gap = mjg; t->max_error_exon = mee;
+  t->ignore_small_exons = mee > 0; t->similarity_threshold = thr;
+  t->filter_by_similarity = thr < 1.0;
+  return BR_OK;
+}
+
+static int make_devcfg(const br_config *c, DevCfg &d) {
+  br_thresholds t;
+  int rc = br_config_resolve(c, &t);
+  if (rc) return rc;
+  d.max_clip = t.max_clip; d.max_junc_ins = t.max_junc_ins; d.max_junc_gap = t.max_junc_gap;
+  d.max_error_exon = t.max_error_exon; d.ignore_small_exons = t.ignore_small_exons;
+  d.filter_by_similarity = t.filter_by_similarity; d.long_reads = (c->lr || c->lr_hq) ? 1 : 0;
+  d.use_fasta = c->use_fasta ? 1 : 0; d.fr = c->fr ? 1 : 0; d.rf = c->rf ? 1 : 0;
+  d.thr = (double)t.similarity_threshold;  // float widened to double (include/evaluate.h:281)
+  return BR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// host-side input contract: name groups + mate index
+// ---------------------------------------------------------------------------
+extern "C" int br_batch_prepare(const br_batch *b, int32_t *mate_idx, uint32_t *group_off, int64_t *n_groups) {
+  if (!b || !mate_idx || !group_off || !n_groups) return BR_ERR_INVALID_ARG;
+  int64_t n = b->n_aln;
+  if (n >= 0x7fffffffll) return BR_ERR_CAPACITY;
+  int64_t ng = 0;
+  for (int64_t i = 0; i < n; i++) mate_idx[i] = -1;
+  std::vector<std::pair<int32_t, int32_t>> open_small;  // (ref_start, index) of still-unpaired records
+  std::unordered_map<int32_t, int32_t> open_big;
+  int64_t i = 0;
+  while (i < n) {
+    int64_t j = i + 1;
+    uint64_t len = b->name_off[i + 1] - b->name_off[i];
+    const char *nm = b->names + b->name_off[i];
+    while (j < n && b->name_off[j + 1] - b->name_off[j] == len && memcmp(b->names + b->name_off[j], nm, len) == 0) j++;
+    group_off[ng++] = (uint32_t)i;
+    // src/bramble.cpp:272-311 (process_pairs): key = name + '-' + start; within a
+    // name group the name part is constant, so the key is the start.
+    bool big = (j - i) > 32;
+    open_small.clear();
+    if (big) open_big.clear();
+    for (int64_t k = i; k < j; k++) {
+      if (!(b->flags[k] & 0x1)) continue;
+      if (b->ref_id[k] != b->mate_ref_id[k]) continue;
+      int32_t ms = b->mate_start[k], rs = b->ref_start[k];
+      int32_t found = -1;
+      if (big) {
+        auto it = open_big.find(ms);
+        if (it != open_big.end()) { found = it->second; open_big.erase(it); }
+      } else {
+        for (size_t q = 0; q < open_small.size(); q++)
+          if (open_small[q].first == ms) { found = open_small[q].second; open_small.erase(open_small.begin() + q); break; }
+      }
+      if (found >= 0) {
+        mate_idx[k] = found; mate_idx[found] = (int32_t)k;
+      } else if (big) {
+        open_big[rs] = (int32_t)k;
+      } else {
+        bool repl = false;
+        for (auto &p : open_small) if (p.first == rs) { p.second = (int32_t)k; repl = true; break; }
+        if (!repl) open_small.emplace_back(rs, (int32_t)k);
+      }
+    }
+    i = j;
+  }
+  group_off[ng] = (uint32_t)n;
+  *n_groups = ng;
+  return BR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------
+struct DevBuf {
+  void *p = nullptr; size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return BR_OK;
+    if (p) { HIPCHK(hipFree(p)); p = nullptr; cap = 0; }
+    size_t want = bytes + bytes / 4 + 256;
+    HIPCHK(hipMalloc(&p, want));
+    cap = want;
+    return BR_OK;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <typename T> T *as() { return (T *)p; }
+};
+
+struct KEvent { int which; hipEvent_t a, b; };
+
+struct br_ctx {
+  const br_index *ix = nullptr;
+  int group_lanes = 64;
+  int blocks_per_cu = 8;
+  int n_cu = 256;
+  bool profiling = false;
+  std::vector<KEvent> events; size_t events_used = 0;
+  double k_ms[BR_K_NUM] = {0}; int32_t k_launches[BR_K_NUM] = {0};
+  uint64_t counters[8] = {0};
+  // device scratch
+  DevBuf seg, meta, n_matches, ranges, mask, match_off, cig_base, tile_sums, totals, counters_d;
+  DevBuf m_tid, m_pos, m_ncig, m_aux, m_strand, m_cigoff, m_sim, m_junc, m_refc, m_clip, cig_arena;
+  DevBuf n_rows, row_off, r_input, r_match, r_nh, r_hi, r_mapq, r_group, r_flags, r_mate_tid, r_mate_pos,
+      r_isize, r_tid, r_pos, r_ncig, r_strand, r_sim, r_clip, r_junc, r_refc, r_cigoff, cigar_out;
+  DevBuf r_paired, r_same, r_first;  // unpacked flag bytes for the public row view
+  // device staging of host batches (br_project_batch)
+  DevBuf b_ref_id, b_ref_start, b_flags, b_xs, b_ts, b_cigar_off, b_cigar, b_mate_idx, b_group_off, b_lqseq;
+  uint64_t *h_totals = nullptr;  // pinned, 8 words
+  // host result storage (br_project_batch / br_project_group)
+  std::vector<int32_t> h_input, h_clip, h_junc, h_refc, h_mate_tid, h_mate_pos, h_isize;
+  std::vector<uint32_t> h_tid, h_pos, h_nh, h_hi, h_mapq, h_group, h_cigar;
+  std::vector<int8_t> h_strand;
+  std::vector<uint64_t> h_cigoff;
+  std::vector<double> h_sim;
+  std::vector<uint8_t> h_primary, h_paired, h_same, h_first;
+  std::vector<br_projected> h_proj;
+  DevBuf *all() { return &seg; }
+};
+
+extern "C" int br_ctx_new(const br_index *ix, br_ctx **out) {
+  if (!ix || !out) return BR_ERR_INVALID_ARG;
+  *out = nullptr;
+  if (ix->device < 0) return BR_ERR_NO_DEVICE;
+  int rc = check_device(ix->device);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(ix->device));
+  br_ctx *c = new br_ctx();
+  c->ix = ix;
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, ix->device));
+  c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  HIPCHK(hipHostMalloc((void **)&c->h_totals, 8 * sizeof(uint64_t), hipHostMallocDefault));
+  const char *g = getenv("BRAMBLE_AMD_GROUP_LANES");
+  if (g) { int v = atoi(g); if (v == 8 || v == 16 || v == 32 || v == 64) c->group_lanes = v; }
+  *out = c;
+  return BR_OK;
+}
+
+extern "C" void br_ctx_free(br_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->ix->device);
+  DevBuf *bufs[] = {&c->seg, &c->meta, &c->n_matches, &c->ranges, &c->mask, &c->match_off, &c->cig_base,
+                    &c->tile_sums, &c->totals, &c->counters_d, &c->m_tid, &c->m_pos, &c->m_ncig, &c->m_aux,
+                    &c->m_strand, &c->m_cigoff, &c->m_sim, &c->m_junc, &c->m_refc, &c->m_clip, &c->cig_arena,
+                    &c->n_rows, &c->row_off, &c->r_input, &c->r_match, &c->r_nh, &c->r_hi, &c->r_mapq,
+                    &c->r_group, &c->r_flags, &c->r_mate_tid, &c->r_mate_pos, &c->r_isize, &c->r_tid, &c->r_pos,
+                    &c->r_ncig, &c->r_strand, &c->r_sim, &c->r_clip, &c->r_junc, &c->r_refc, &c->r_cigoff,
+                    &c->cigar_out, &c->r_paired, &c->r_same, &c->r_first, &c->b_ref_id, &c->b_ref_start,
+                    &c->b_flags, &c->b_xs, &c->b_ts, &c->b_cigar_off, &c->b_cigar, &c->b_mate_idx,
+                    &c->b_group_off, &c->b_lqseq};
+  for (DevBuf *b : bufs) b->release();
+  for (auto &e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  if (c->h_totals) (void)hipHostFree(c->h_totals);
+  delete c;
+}
+
+extern "C" int br_ctx_set_profiling(br_ctx *c, int enabled) { if (!c) return BR_ERR_INVALID_ARG; c->profiling = enabled != 0; return BR_OK; }
+extern "C" int br_ctx_set_param(br_ctx *c, const char *key, int64_t v) {
+  if (!c || !key) return BR_ERR_INVALID_ARG;
+  if (!strcmp(key, "group_lanes")) { if (v != 8 && v != 16 && v != 32 && v != 64) return BR_ERR_INVALID_ARG; c->group_lanes = (int)v; return BR_OK; }
+  if (!strcmp(key, "blocks_per_cu")) { if (v < 1 || v > 64) return BR_ERR_INVALID_ARG; c->blocks_per_cu = (int)v; return BR_OK; }
+  return BR_ERR_INVALID_ARG;
+}
+extern "C" int br_ctx_kernel_ms(br_ctx *c, int which, double *ms, int32_t *launches) {
+  if (!c || which < 0 || which >= BR_K_NUM) return BR_ERR_INVALID_ARG;
+  if (ms) *ms = c->k_ms[which];
+  if (launches) *launches = c->k_launches[which];
+  return BR_OK;
+}
+extern "C" int br_ctx_last_counters(br_ctx *c, uint64_t out[8]) {
+  if (!c || !out) return BR_ERR_INVALID_ARG;
+  memcpy(out, c->counters, sizeof(c->counters));
+  return BR_OK;
+}
+
+namespace {
+
+struct Prof {
+  br_ctx *c; hipStream_t st;
+  int begin(int which) {
+    if (!c->profiling) return BR_OK;
+    if (c->events_used == c->events.size()) {
+      KEvent e; e.which = which;
+      HIPCHK(hipEventCreate(&e.a)); HIPCHK(hipEventCreate(&e.b));
+      c->events.push_back(e);
+    }
+    c->events[c->events_used].which = which;
+    HIPCHK(hipEventRecord(c->events[c->events_used].a, st));
+    return BR_OK;
+  }
+  int end() {
+    if (!c->profiling) return BR_OK;
+    HIPCHK(hipEventRecord(c->events[c->events_used].b, st));
+    c->events_used++;
+    return BR_OK;
+  }
+  int collect() {
+    for (int k = 0; k < BR_K_NUM; k++) { c->k_ms[k] = 0; c->k_launches[k] = 0; }
+    if (!c->profiling) return BR_OK;
+    for (size_t i = 0; i < c->events_used; i++) {
+      float ms = 0;
+      HIPCHK(hipEventSynchronize(c->events[i].b));
+      HIPCHK(hipEventElapsedTime(&ms, c->events[i].a, c->events[i].b));
+      c->k_ms[c->events[i].which] += ms; c->k_launches[c->events[i].which]++;
+    }
+    c->events_used = 0;
+    return BR_OK;
+  }
+};
+
+#define RC(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+
+// The HIP pipeline over a device-resident batch.
+int run_device(br_ctx *c, const br_config *cfg, const br_device_batch *b, hipStream_t st, br_device_rows *out) {
+  const br_index *ix = c->ix;
+  memset(out, 0, sizeof(*out));
+  DevCfg dc;
+  RC(make_devcfg(cfg, dc));
+  if (dc.use_fasta) return BR_ERR_UNSUPPORTED;  // -S clip rescue (k_ksw2) is not built yet
+  int64_t n = b->n_aln, ng = b->n_groups;
+  if (n < 0 || ng < 0 || n >= 0x7fffffffll || b->n_cigar_words >= 0xffffffffll - n) return BR_ERR_CAPACITY;
+  HIPCHK(hipSetDevice(ix->device));
+  Prof pf{c, st};
+  c->events_used = 0;
+  out->total_processed = (uint64_t)n;
+  if (n == 0) { pf.collect(); return BR_OK; }
+
+  int64_t tiles = std::max<int64_t>(scan_tiles_for(std::max<int64_t>(n, ng) + 1), 1);
+  RC(c->seg.ensure((size_t)(b->n_cigar_words + n) * sizeof(uint2)));
+  RC(c->meta.ensure((size_t)n * sizeof(AlnMeta)));
+  RC(c->n_matches.ensure((size_t)n * 4)); RC(c->ranges.ensure((size_t)n * sizeof(uint4)));
+  RC(c->mask.ensure((size_t)n * 8)); RC(c->match_off.ensure((size_t)(n + 1) * 4));
+  RC(c->cig_base.ensure((size_t)(n + 1) * 8)); RC(c->tile_sums.ensure((size_t)tiles * 8));
+  RC(c->totals.ensure(8 * 8)); RC(c->counters_d.ensure(4 * 8));
+  uint64_t *d_tot = c->totals.as<uint64_t>();
+
+  // a1/a2/a6: CIGAR -> read exons
+  RC(pf.begin(BR_K_SEGMENT));
+  launch_segment(st, n, b->ref_id, b->ref_start, b->flags, b->xs, b->ts, b->cigar_off, b->cigar, dc, ix->n_refs,
+                 c->seg.as<uint2>(), c->meta.as<AlnMeta>());
+  RC(pf.end());
+
+  ProjectArgs A{};
+  A.ix = ix->dev; A.cfg = dc; A.n_aln = n; A.ref_id = b->ref_id; A.cigar_off = b->cigar_off; A.cigar = b->cigar;
+  A.seg = c->seg.as<uint2>(); A.meta = c->meta.as<AlnMeta>(); A.n_matches = c->n_matches.as<uint32_t>();
+  A.ranges = c->ranges.as<uint4>(); A.mask = c->mask.as<uint64_t>();
+  A.match_off = c->match_off.as<uint32_t>(); A.cig_base = c->cig_base.as<uint64_t>();
+  int n_blocks = c->n_cu * c->blocks_per_cu;
+  RC(pf.begin(BR_K_COUNT));
+  launch_project(st, A, false, c->group_lanes, n_blocks);
+  RC(pf.end());
+
+  ScanArgs S{};
+  S.n = n; S.src32 = c->n_matches.as<uint32_t>(); S.cigar_off = b->cigar_off; S.meta = c->meta.as<AlnMeta>();
+  S.tile_sums = c->tile_sums.as<uint64_t>();
+  RC(pf.begin(BR_K_SCAN));
+  launch_scan(st, S, 0, c->match_off.p, false, d_tot + 0);
+  launch_scan(st, S, 1, c->cig_base.p, true, d_tot + 1);
+  RC(pf.end());
+  HIPCHK(hipMemcpyAsync(c->h_totals, d_tot, 2 * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  uint64_t n_matches = c->h_totals[0], n_cig_arena = c->h_totals[1];
+  if (n_matches >= 0xffffffffull) return BR_ERR_CAPACITY;
+  out->n_matches = (int64_t)n_matches;
+
+  size_t nm = (size_t)std::max<uint64_t>(n_matches, 1);
+  RC(c->m_tid.ensure(nm * 4)); RC(c->m_pos.ensure(nm * 4)); RC(c->m_ncig.ensure(nm * 4)); RC(c->m_aux.ensure(nm * 4));
+  RC(c->m_strand.ensure(nm)); RC(c->m_cigoff.ensure(nm * 8)); RC(c->m_sim.ensure(nm * 8));
+  RC(c->m_junc.ensure(nm * 4)); RC(c->m_refc.ensure(nm * 4)); RC(c->m_clip.ensure(nm * 4));
+  RC(c->cig_arena.ensure((size_t)std::max<uint64_t>(n_cig_arena, 1) * 4));
+  A.m_tid = c->m_tid.as<uint32_t>(); A.m_pos = c->m_pos.as<uint32_t>(); A.m_ncig = c->m_ncig.as<uint32_t>();
+  A.m_aux = c->m_aux.as<uint32_t>(); A.m_strand = c->m_strand.as<int8_t>(); A.m_cigoff = c->m_cigoff.as<uint64_t>();
+  A.m_sim = c->m_sim.as<double>(); A.m_junc = c->m_junc.as<int32_t>(); A.m_refc = c->m_refc.as<int32_t>();
+  A.m_clip = c->m_clip.as<int32_t>(); A.cig_arena = c->cig_arena.as<uint32_t>();
+  if (n_matches) {
+    RC(pf.begin(BR_K_EMIT));
+    launch_project(st, A, true, c->group_lanes, n_blocks);
+    RC(pf.end());
+  }
+
+  // a16/a17: pairing + NH
+  RC(c->n_rows.ensure((size_t)std::max<int64_t>(ng, 1) * 4)); RC(c->row_off.ensure((size_t)(ng + 1) * 8));
+  HIPCHK(hipMemsetAsync(c->counters_d.p, 0, 4 * 8, st));
+  PairArgs P{};
+  P.n_groups = ng; P.long_reads = dc.long_reads; P.group_off = b->group_off; P.mate_idx = b->mate_idx;
+  P.match_off = c->match_off.as<uint32_t>(); P.m_tid = A.m_tid; P.m_pos = A.m_pos; P.l_qseq = b->l_qseq;
+  P.n_rows = c->n_rows.as<uint32_t>(); P.row_off = c->row_off.as<uint64_t>(); P.counters = c->counters_d.as<uint64_t>();
+  RC(pf.begin(BR_K_PAIR_COUNT));
+  launch_pair(st, P, false);
+  RC(pf.end());
+  ScanArgs S2{};
+  S2.n = ng; S2.src32 = c->n_rows.as<uint32_t>(); S2.tile_sums = c->tile_sums.as<uint64_t>();
+  RC(pf.begin(BR_K_SCAN));
+  launch_scan(st, S2, 2, c->row_off.p, true, d_tot + 2);
+  RC(pf.end());
+  HIPCHK(hipMemcpyAsync(c->h_totals + 2, d_tot + 2, 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(c->h_totals + 4, c->counters_d.p, 4 * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  uint64_t n_rows = c->h_totals[2];
+  out->n_rows = (int64_t)n_rows;
+  out->total_complete = n_rows; out->total_unique = c->h_totals[5]; out->dropped_reads = c->h_totals[6];
+
+  size_t nr = (size_t)std::max<uint64_t>(n_rows, 1);
+  RC(c->r_input.ensure(nr * 4)); RC(c->r_match.ensure(nr * 4)); RC(c->r_nh.ensure(nr * 4)); RC(c->r_hi.ensure(nr * 4));
+  RC(c->r_mapq.ensure(nr * 4)); RC(c->r_group.ensure(nr * 4)); RC(c->r_flags.ensure(nr));
+  RC(c->r_mate_tid.ensure(nr * 4)); RC(c->r_mate_pos.ensure(nr * 4)); RC(c->r_isize.ensure(nr * 4));
+  RC(c->r_tid.ensure(nr * 4)); RC(c->r_pos.ensure(nr * 4)); RC(c->r_ncig.ensure(nr * 4)); RC(c->r_strand.ensure(nr));
+  RC(c->r_sim.ensure(nr * 8)); RC(c->r_clip.ensure(nr * 4)); RC(c->r_junc.ensure(nr * 4)); RC(c->r_refc.ensure(nr * 4));
+  RC(c->r_cigoff.ensure((nr + 1) * 8));
+  RC(c->r_paired.ensure(nr)); RC(c->r_same.ensure(nr)); RC(c->r_first.ensure(nr));
+  P.r_input = c->r_input.as<int32_t>(); P.r_match = c->r_match.as<uint32_t>(); P.r_nh = c->r_nh.as<uint32_t>();
+  P.r_hi = c->r_hi.as<uint32_t>(); P.r_mapq = c->r_mapq.as<uint32_t>(); P.r_group = c->r_group.as<uint32_t>();
+  P.r_flags = c->r_flags.as<uint8_t>(); P.r_mate_tid = c->r_mate_tid.as<int32_t>();
+  P.r_mate_pos = c->r_mate_pos.as<int32_t>(); P.r_isize = c->r_isize.as<int32_t>();
+  uint64_t n_out_words = 0;
+  if (n_rows) {
+    RC(pf.begin(BR_K_PAIR_EMIT));
+    launch_pair(st, P, true);
+    RC(pf.end());
+    RowArgs R{};
+    R.n_rows = (int64_t)n_rows; R.r_match = P.r_match; R.m_tid = A.m_tid; R.m_pos = A.m_pos; R.m_ncig = A.m_ncig;
+    R.m_strand = A.m_strand; R.m_cigoff = A.m_cigoff; R.m_sim = A.m_sim; R.m_junc = A.m_junc; R.m_refc = A.m_refc;
+    R.m_clip = A.m_clip; R.cig_arena = A.cig_arena; R.r_tid = c->r_tid.as<uint32_t>(); R.r_pos = c->r_pos.as<uint32_t>();
+    R.r_ncig = c->r_ncig.as<uint32_t>(); R.r_strand = c->r_strand.as<int8_t>(); R.r_sim = c->r_sim.as<double>();
+    R.r_clip = c->r_clip.as<int32_t>(); R.r_junc = c->r_junc.as<int32_t>(); R.r_refc = c->r_refc.as<int32_t>();
+    R.r_cigoff = c->r_cigoff.as<uint64_t>();
+    R.r_flags = c->r_flags.as<uint8_t>(); R.r_paired = c->r_paired.as<uint8_t>(); R.r_same = c->r_same.as<uint8_t>();
+    R.r_first = c->r_first.as<uint8_t>();
+    RC(pf.begin(BR_K_GATHER));
+    launch_row_fill(st, R);
+    RC(pf.end());
+    ScanArgs S3{};
+    S3.n = (int64_t)n_rows; S3.src32 = c->r_ncig.as<uint32_t>(); S3.tile_sums = c->tile_sums.as<uint64_t>();
+    RC(c->tile_sums.ensure((size_t)std::max<int64_t>(scan_tiles_for((int64_t)n_rows + 1), 1) * 8));
+    S3.tile_sums = c->tile_sums.as<uint64_t>();
+    RC(pf.begin(BR_K_SCAN));
+    launch_scan(st, S3, 2, c->r_cigoff.p, true, d_tot + 3);
+    RC(pf.end());
+    HIPCHK(hipMemcpyAsync(c->h_totals + 3, d_tot + 3, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    n_out_words = c->h_totals[3];
+    RC(c->cigar_out.ensure((size_t)std::max<uint64_t>(n_out_words, 1) * 4));
+    R.cigar_out = c->cigar_out.as<uint32_t>();
+    RC(pf.begin(BR_K_GATHER));
+    launch_gather(st, R);
+    RC(pf.end());
+  } else {
+    HIPCHK(hipMemsetAsync(c->r_cigoff.p, 0, 8, st));
+  }
+  HIPCHK(hipStreamSynchronize(st));
+  RC(pf.collect());
+
+  out->n_cigar_words = (int64_t)n_out_words;
+  out->input_index = c->r_input.as<int32_t>(); out->transcript_id = c->r_tid.as<uint32_t>();
+  out->pos = c->r_pos.as<uint32_t>(); out->strand = c->r_strand.as<int8_t>();
+  out->cigar_off = c->r_cigoff.as<uint64_t>(); out->cigar = c->cigar_out.as<uint32_t>();
+  out->similarity_score = c->r_sim.as<double>(); out->clip_score = c->r_clip.as<int32_t>();
+  out->junc_hits = c->r_junc.as<int32_t>(); out->aligned_len = c->r_refc.as<int32_t>();
+  out->nh = c->r_nh.as<uint32_t>(); out->hi = c->r_hi.as<uint32_t>(); out->mapq = c->r_mapq.as<uint32_t>();
+  out->is_paired = c->r_paired.as<uint8_t>(); out->same_transcript_as_mate = c->r_same.as<uint8_t>();
+  out->is_first = c->r_first.as<uint8_t>();
+  out->mate_transcript_id = c->r_mate_tid.as<int32_t>(); out->mate_pos = c->r_mate_pos.as<int32_t>();
+  out->insert_size = c->r_isize.as<int32_t>(); out->group = c->r_group.as<uint32_t>();
+  c->counters[6] = n_matches; c->counters[7] = n_out_words;
+  return BR_OK;
+}
+
+}  // namespace
+
+extern "C" int br_project_batch_device(br_ctx *c, const br_config *cfg, const br_device_batch *b, void *stream,
+                                       br_device_rows *out) {
+  if (!c || !cfg || !b || !out) return BR_ERR_INVALID_ARG;
+  return run_device(c, cfg, b, (hipStream_t)stream, out);
+}
+
+// ---------------------------------------------------------------------------
+// host-batch entry: upload, run, download, finalise primary flags
+// ---------------------------------------------------------------------------
+template <typename T>
+static int h2d(DevBuf &buf, const T *src, size_t n, hipStream_t st) {
+  RC(buf.ensure(std::max<size_t>(n, 1) * sizeof(T)));
+  if (n) HIPCHK(hipMemcpyAsync(buf.p, src, n * sizeof(T), hipMemcpyHostToDevice, st));
+  return BR_OK;
+}
+template <typename T>
+static int d2h(std::vector<T> &dst, const void *src, size_t n, hipStream_t st) {
+  dst.resize(n);
+  if (n) HIPCHK(hipMemcpyAsync(dst.data(), src, n * sizeof(T), hipMemcpyDeviceToHost, st));
+  return BR_OK;
+}
+
+// src/core.cpp:214-218
+static int32_t get_rand(uint32_t x, uint64_t seed_key) {
+  std::mt19937_64 gen(seed_key);
+  std::uniform_int_distribution<uint32_t> dis(0, x - 1);
+  return (int32_t)dis(gen);
+}
+
+extern "C" int br_project_batch(br_ctx *c, const br_config *cfg, const br_batch *b, br_rows *out) {
+  if (!c || !cfg || !b || !out) return BR_ERR_INVALID_ARG;
+  memset(out, 0, sizeof(*out));
+  int64_t n = b->n_aln;
+  if (n < 0 || n >= 0x7fffffffll) return BR_ERR_CAPACITY;
+  uint64_t n_words = n ? b->cigar_off[n] : 0;
+  if (n_words >= 0xfffffff0ull - (uint64_t)n) return BR_ERR_CAPACITY;
+  HIPCHK(hipSetDevice(c->ix->device));
+  hipStream_t st = nullptr;
+
+  std::vector<int32_t> mate((size_t)std::max<int64_t>(n, 1));
+  std::vector<uint32_t> goff((size_t)n + 1);
+  int64_t ng = 0;
+  RC(br_batch_prepare(b, mate.data(), goff.data(), &ng));
+  std::vector<uint32_t> coff((size_t)n + 1);
+  uint32_t max_nc = 0;
+  for (int64_t i = 0; i <= n; i++) coff[i] = (uint32_t)(n ? b->cigar_off[i] : 0);
+  for (int64_t i = 0; i < n; i++) max_nc = std::max(max_nc, coff[i + 1] - coff[i]);
+
+  RC(h2d(c->b_ref_id, b->ref_id, (size_t)n, st)); RC(h2d(c->b_ref_start, b->ref_start, (size_t)n, st));
+  RC(h2d(c->b_flags, b->flags, (size_t)n, st)); RC(h2d(c->b_xs, b->xs, (size_t)n, st));
+  RC(h2d(c->b_ts, b->ts, (size_t)n, st)); RC(h2d(c->b_cigar_off, coff.data(), (size_t)n + 1, st));
+  RC(h2d(c->b_cigar, b->cigar, (size_t)n_words, st)); RC(h2d(c->b_mate_idx, mate.data(), (size_t)n, st));
+  RC(h2d(c->b_group_off, goff.data(), (size_t)ng + 1, st));
+  std::vector<int32_t> lq((size_t)std::max<int64_t>(n, 1), 0);
+  if (b->l_qseq) memcpy(lq.data(), b->l_qseq, (size_t)n * 4);
+  RC(h2d(c->b_lqseq, lq.data(), (size_t)n, st));
+  HIPCHK(hipStreamSynchronize(st));
+
+  br_device_batch db{};
+  db.n_aln = n; db.n_groups = ng; db.ref_id = c->b_ref_id.as<int32_t>(); db.ref_start = c->b_ref_start.as<int32_t>();
+  db.flags = c->b_flags.as<uint16_t>(); db.xs = c->b_xs.as<int8_t>(); db.ts = c->b_ts.as<int8_t>();
+  db.cigar_off = c->b_cigar_off.as<uint32_t>(); db.cigar = c->b_cigar.as<uint32_t>();
+  db.mate_idx = c->b_mate_idx.as<int32_t>(); db.group_off = c->b_group_off.as<uint32_t>();
+  db.l_qseq = c->b_lqseq.as<int32_t>(); db.n_cigar_words = (int64_t)n_words; db.max_n_cigar = (int32_t)max_nc;
+  br_device_rows dr;
+  RC(run_device(c, cfg, &db, st, &dr));
+
+  size_t nr = (size_t)dr.n_rows;
+  RC(d2h(c->h_input, dr.input_index, nr, st)); RC(d2h(c->h_tid, dr.transcript_id, nr, st));
+  RC(d2h(c->h_pos, dr.pos, nr, st)); RC(d2h(c->h_strand, dr.strand, nr, st));
+  RC(d2h(c->h_cigoff, dr.cigar_off, nr + 1, st)); RC(d2h(c->h_cigar, dr.cigar, (size_t)dr.n_cigar_words, st));
+  RC(d2h(c->h_sim, dr.similarity_score, nr, st)); RC(d2h(c->h_clip, dr.clip_score, nr, st));
+  RC(d2h(c->h_junc, dr.junc_hits, nr, st)); RC(d2h(c->h_refc, dr.aligned_len, nr, st));
+  RC(d2h(c->h_nh, dr.nh, nr, st)); RC(d2h(c->h_hi, dr.hi, nr, st)); RC(d2h(c->h_mapq, dr.mapq, nr, st));
+  RC(d2h(c->h_paired, dr.is_paired, nr, st)); RC(d2h(c->h_same, dr.same_transcript_as_mate, nr, st));
+  RC(d2h(c->h_first, dr.is_first, nr, st)); RC(d2h(c->h_mate_tid, dr.mate_transcript_id, nr, st));
+  RC(d2h(c->h_mate_pos, dr.mate_pos, nr, st)); RC(d2h(c->h_isize, dr.insert_size, nr, st));
+  RC(d2h(c->h_group, dr.group, nr, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (nr == 0) c->h_cigoff.assign(1, 0);
+
+  // primary / secondary per read name (src/core.cpp:243-307); an emitted pair is
+  // two consecutive rows (read1 side first).
+  c->h_primary.assign(nr, 0);
+  for (size_t r0 = 0; r0 < nr;) {
+    size_t r1 = r0;
+    while (r1 < nr && c->h_group[r1] == c->h_group[r0]) r1++;
+    std::vector<size_t> units;
+    for (size_t r = r0; r < r1; r += c->h_paired[r] ? 2 : 1) units.push_back(r);
+    double best = -std::numeric_limits<double>::infinity(); size_t best_u = 0; int at_best = 0;
+    auto score_of = [&](size_t r) {
+      double s = c->h_sim[r];
+      if (c->h_paired[r]) s = std::max(s, c->h_sim[r + 1]);
+      return s;
+    };
+    for (size_t u = 0; u < units.size(); u++) {
+      double s = score_of(units[u]);
+      if (s > best) { best = s; best_u = u; at_best = 1; } else if (s == best) at_best++;
+    }
+    if (!units.empty()) {
+      size_t pick = units[best_u];
+      if (at_best > 1) {
+        std::vector<size_t> tied;
+        for (size_t u = 0; u < units.size(); u++) if (score_of(units[u]) == best) tied.push_back(units[u]);
+        uint32_t g = c->h_group[r0];
+        uint32_t a0 = goff[g];
+        std::string name(b->names + b->name_off[a0], b->names + b->name_off[a0 + 1]);
+        uint64_t seed_key = std::hash<std::string>{}(name);
+        pick = tied[(size_t)get_rand((uint32_t)tied.size(), seed_key)];
+      }
+      c->h_primary[pick] = 1;
+      if (c->h_paired[pick]) c->h_primary[pick + 1] = 1;
+    }
+    r0 = r1;
+  }
+
+  out->n_rows = (int64_t)nr;
+  out->input_index = c->h_input.data(); out->transcript_id = c->h_tid.data(); out->pos = c->h_pos.data();
+  out->strand = c->h_strand.data(); out->cigar_off = c->h_cigoff.data(); out->cigar = c->h_cigar.data();
+  out->similarity_score = c->h_sim.data(); out->clip_score = c->h_clip.data(); out->junc_hits = c->h_junc.data();
+  out->aligned_len = c->h_refc.data(); out->nh = c->h_nh.data(); out->hi = c->h_hi.data(); out->mapq = c->h_mapq.data();
+  out->is_primary = c->h_primary.data(); out->is_paired = c->h_paired.data();
+  out->same_transcript_as_mate = c->h_same.data(); out->is_first = c->h_first.data();
+  out->mate_transcript_id = c->h_mate_tid.data(); out->mate_pos = c->h_mate_pos.data();
+  out->insert_size = c->h_isize.data(); out->group = c->h_group.data();
+  out->total_complete = dr.total_complete; out->total_unique = dr.total_unique;
+  out->dropped_reads = dr.dropped_reads; out->total_processed = dr.total_processed;
+  return BR_OK;
+}
+
+// project_group_with (bramble-rs/src/api.rs:285-290): one query name, AoS in/out
+extern "C" int br_project_group(br_ctx *c, const br_config *cfg, const br_alignment *alns, size_t n,
+                                const br_projected **out, size_t *n_out) {
+  if (!c || !cfg || (!alns && n) || !out || !n_out) return BR_ERR_INVALID_ARG;
+  *out = nullptr; *n_out = 0;
+  std::vector<int32_t> ref_id(n), ref_start(n), mate_ref(n), mate_start(n), lq(n);
+  std::vector<uint16_t> flags(n); std::vector<int8_t> xs(n), ts(n);
+  std::vector<uint64_t> coff(n + 1, 0), noff(n + 1, 0);
+  std::vector<uint32_t> cig; std::string names;
+  std::string name0 = n ? (alns[0].query_name ? alns[0].query_name : "") : "";
+  for (size_t i = 0; i < n; i++) {
+    const br_alignment &a = alns[i];
+    ref_id[i] = a.ref_id; ref_start[i] = (int32_t)a.ref_start;
+    uint16_t f = 0;
+    if (a.is_paired) { f |= 0x1; if (a.mate_is_unmapped) f |= 0x8; f |= a.is_first_in_pair ? 0x40 : 0x80; }
+    if (a.is_reverse) f |= 0x10;
+    flags[i] = f; xs[i] = (int8_t)a.xs_strand; ts[i] = (int8_t)a.ts_strand;
+    mate_ref[i] = a.mate_ref_id; mate_start[i] = (int32_t)a.mate_ref_start;
+    cig.insert(cig.end(), a.cigar, a.cigar + a.n_cigar); coff[i + 1] = cig.size();
+    names += name0; noff[i + 1] = names.size();  // one group: every alignment carries the group's name
+    lq[i] = (int32_t)(a.read_len ? a.read_len : a.sequence_len);
+  }
+  br_batch b{};
+  b.n_aln = (int64_t)n; b.ref_id = ref_id.data(); b.ref_start = ref_start.data(); b.flags = flags.data();
+  b.xs = xs.data(); b.ts = ts.data(); b.cigar_off = coff.data(); b.cigar = cig.data();
+  b.mate_ref_id = mate_ref.data(); b.mate_start = mate_start.data(); b.name_off = noff.data();
+  b.names = names.data(); b.l_qseq = lq.data();
+  br_rows rows;
+  RC(br_project_batch(c, cfg, &b, &rows));
+  c->h_proj.resize((size_t)rows.n_rows);
+  for (int64_t r = 0; r < rows.n_rows; r++) {
+    br_projected &p = c->h_proj[(size_t)r];
+    p.transcript_id = rows.transcript_id[r];
+    p.transcript_start = rows.pos[r];
+    p.aligned_len = (uint32_t)std::max(rows.aligned_len[r], 0);
+    uint64_t e = (uint64_t)p.transcript_start + p.aligned_len;  // saturating add, then saturating sub 1
+    if (e > 0xffffffffull) e = 0xffffffffull;
+    p.transcript_end = e ? (uint32_t)(e - 1) : 0;
+    const uint32_t *cg = rows.cigar + rows.cigar_off[r];
+    uint32_t nc = (uint32_t)(rows.cigar_off[r + 1] - rows.cigar_off[r]);
+    uint32_t qa = 0;
+    for (uint32_t k = 0; k < nc; k++) {
+      uint32_t op = cg[k] & 0xf;
+      if (op == OP_M || op == OP_EQ || op == OP_X || op == OP_I || op == OP_MATCH_OVR || op == OP_INS_OVR) qa += cg[k] >> 4;
+    }
+    p.query_aligned_len = qa;
+    p.is_reverse = rows.strand[r] == '-';
+    p.similarity_score = rows.similarity_score[r];
+    p.nh = rows.nh[r]; p.hi = rows.hi[r]; p.is_primary = rows.is_primary[r];
+    p.same_transcript_as_mate = rows.same_transcript_as_mate[r]; p.is_paired_out = rows.is_paired[r];
+    p.insert_size = rows.insert_size[r]; p.input_index = (uint64_t)rows.input_index[r];
+    p.mapq = rows.mapq[r]; p.cigar = cg; p.n_cigar = nc;
+  }
+  *out = c->h_proj.data(); *n_out = c->h_proj.size();
+  return BR_OK;
+}
+
+extern "C" const char *br_version(void) { return "bramble_amd 0.1.0 (gfx950)"; }
+extern "C" const char *br_strerror(int code) {
+  switch (code) {
+    case BR_OK: return "ok";
+    case BR_ERR_INVALID_ARG: return "invalid argument";
+    case BR_ERR_NO_DEVICE: return "no usable HIP device (the projection path has no CPU fallback)";
+    case BR_ERR_HIP: return "HIP runtime error";
+    case BR_ERR_ANNOTATION: return "invalid annotation";
+    case BR_ERR_CAPACITY: return "batch exceeds 32-bit device offsets; split it";
+    case BR_ERR_UNSUPPORTED: return "unsupported configuration";
+    default: return "unknown error";
+  }
+}

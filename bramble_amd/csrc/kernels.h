@@ -1,0 +1,89 @@
+// Launch interface between the host pipeline (abi.cpp) and project_kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_types.h"
+
+namespace br {
+
+struct ProjectArgs {
+  DevIndex ix;
+  DevCfg cfg;
+  int64_t n_aln;
+  const int32_t *ref_id;
+  const uint32_t *cigar_off;
+  const uint32_t *cigar;
+  const uint2 *seg;
+  const AlnMeta *meta;
+  // count pass outputs / emit pass inputs
+  uint32_t *n_matches;   // [n_aln]
+  uint4 *ranges;         // [n_aln] candidate row ranges (lo+,hi+,lo-,hi-)
+  uint64_t *mask;        // [n_aln] survivor bit per candidate row (<= 64 rows)
+  const uint32_t *match_off;  // [n_aln + 1]
+  const uint64_t *cig_base;   // [n_aln + 1]
+  // match table (emit)
+  uint32_t *m_tid, *m_pos, *m_ncig, *m_aux;
+  int8_t *m_strand;
+  uint64_t *m_cigoff;
+  double *m_sim;
+  int32_t *m_junc, *m_refc, *m_clip;
+  uint32_t *cig_arena;
+};
+
+struct ScanArgs {
+  int64_t n;
+  const uint32_t *src32;
+  const uint32_t *cigar_off;  // mode 1 only
+  const AlnMeta *meta;        // mode 1 only
+  uint64_t *tile_sums;
+};
+
+struct PairArgs {
+  int64_t n_groups;
+  int32_t long_reads;
+  const uint32_t *group_off;
+  const int32_t *mate_idx;
+  const uint32_t *match_off;
+  const uint32_t *m_tid, *m_pos;
+  const int32_t *l_qseq;
+  uint32_t *n_rows;         // count pass
+  const uint64_t *row_off;  // emit pass
+  int32_t *r_input;
+  uint32_t *r_match, *r_nh, *r_hi, *r_mapq, *r_group;
+  uint8_t *r_flags;
+  int32_t *r_mate_tid, *r_mate_pos, *r_isize;
+  uint64_t *counters;       // [4] total_complete, total_unique, dropped_reads, total_processed
+};
+
+struct RowArgs {
+  int64_t n_rows;
+  const uint32_t *r_match;
+  const uint32_t *m_tid, *m_pos, *m_ncig;
+  const int8_t *m_strand;
+  const uint64_t *m_cigoff;
+  const double *m_sim;
+  const int32_t *m_junc, *m_refc, *m_clip;
+  const uint32_t *cig_arena;
+  uint32_t *r_tid, *r_pos, *r_ncig;
+  int8_t *r_strand;
+  double *r_sim;
+  int32_t *r_clip, *r_junc, *r_refc;
+  const uint64_t *r_cigoff;  // [n_rows + 1]
+  uint32_t *cigar_out;
+  const uint8_t *r_flags;    // packed RF_* bits from k_pair
+  uint8_t *r_paired, *r_same, *r_first;
+};
+
+void launch_segment(hipStream_t st, int64_t n_aln, const int32_t *ref_id, const int32_t *ref_start,
+                    const uint16_t *flags, const int8_t *xs, const int8_t *ts, const uint32_t *cigar_off,
+                    const uint32_t *cigar, const DevCfg &cfg, uint32_t n_refs, uint2 *seg, AlnMeta *meta);
+void launch_project(hipStream_t st, const ProjectArgs &A, bool emit, int group_lanes, int n_blocks);
+int64_t scan_tiles_for(int64_t n);
+// mode 0: src32 as is; 1: n_matches * CIGAR slot capacity; 2: src32 as is (alias of 0)
+void launch_scan(hipStream_t st, const ScanArgs &S, int mode, void *out, bool out64, uint64_t *total_out);
+void launch_pair(hipStream_t st, const PairArgs &P, bool emit);
+void launch_row_fill(hipStream_t st, const RowArgs &R);
+void launch_gather(hipStream_t st, const RowArgs &R);
+
+}  // namespace br

@@ -1,0 +1,1014 @@
+// Hand-written HIP kernels of the projection hot path for gfx950 (CDNA4, wave64).
+//
+// Integer interval work: no MFMA.  The design is candidate-centric instead of
+// query-centric: the reference re-queries its interval tree for every read exon
+// and intersects per-tid hash maps (src/evaluate.cpp:184-282); here one lane owns
+// one candidate (transcript, first exon) found by a coalesced search of the
+// start-sorted exon slab, and walks THAT transcript's own exon table against the
+// read's exon list.  Equivalence with the reference's "query + intersect"
+// formulation is argued in DESIGN.md and enforced by tests against oracle/.
+//
+// Kernels:
+//   k_segment     a1,a2,a6 of SURVEY.md 8a: packed CIGAR -> read exons, clips, strands
+//   k_project<G,EMIT>  a4,a5,a7,a8,a11-a15: candidates, exon-chain walk, ideal
+//                 CIGAR, similarity, CIGAR merge.  EMIT=false counts matches,
+//                 EMIT=true writes them at scanned offsets (tid-sorted per read).
+//   k_pair<EMIT>  a16,a17: mate-pair transcript-set intersection, NH/HI/MAPQ
+//   k_gather      packs the rewritten CIGARs of the emitted rows densely
+//   k_scan_*      exclusive scans (u32 / u64)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_types.h"
+#include "kernels.h"
+
+namespace br {
+
+#define CIG_OP(c) ((c) & 0xfu)
+#define CIG_LEN(c) ((c) >> 4)
+#define CIG_GEN(l, o) (((l) << 4) | (o))
+
+// ---------------------------------------------------------------------------
+// k_segment: one lane per alignment.
+//   gclib/GSam.cpp:197-291 (setupCoordinates) + src/bramble.cpp:246-255 (end++)
+//   src/bramble.cpp:213-244 (get_strand) + gclib/GSam.cpp:338-349 (spliceStrand)
+//   src/evaluate.cpp:58-67 (strands to check), :69-109 (get_clips)
+// Exons of alignment a go to seg[cigar_off[a] + a ...] (at most n_cigar, or 1
+// when the CIGAR is empty).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_segment(int64_t n_aln, const int32_t *__restrict__ ref_id,
+                                                 const int32_t *__restrict__ ref_start,
+                                                 const uint16_t *__restrict__ flags,
+                                                 const int8_t *__restrict__ xs, const int8_t *__restrict__ ts,
+                                                 const uint32_t *__restrict__ cigar_off,
+                                                 const uint32_t *__restrict__ cigar, DevCfg cfg,
+                                                 uint32_t n_refs, uint2 *__restrict__ seg,
+                                                 AlnMeta *__restrict__ meta) {
+  int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= n_aln) return;
+  uint32_t c0 = cigar_off[a], c1 = cigar_off[a + 1];
+  uint32_t n_cigar = c1 - c0;
+  const uint32_t *cg = cigar + c0;
+  uint2 *out = seg + (size_t)c0 + (size_t)a;
+  int32_t pos0 = ref_start[a] - 1;
+  int l = 0, exstart = pos0;
+  bool exon_started = false, intron = false, ins = false;
+  uint32_t n = 0;
+  uint32_t ex_start = 0, ex_end = 0;  // GSeg exon (zero-initialised)
+  for (uint32_t i = 0; i < n_cigar; ++i) {
+    uint32_t w = cg[i], op = CIG_OP(w), len = CIG_LEN(w);
+    switch (op) {
+      case OP_EQ: case OP_X: case OP_M:
+        exon_started = true; l += (int)len; intron = false; ins = false; break;
+      case OP_D: l += (int)len; ins = false; break;
+      case OP_I: ins = true; break;
+      case OP_N:
+        if (!exon_started) break;
+        if (!ins || !intron) {
+          ex_end = (uint32_t)(pos0 + l); ex_start = (uint32_t)(exstart + 1);
+          out[n++] = make_uint2(ex_start, ex_end + 1);
+        }
+        l += (int)len; exstart = pos0 + l; intron = true;
+        break;
+      case OP_S: case OP_H: ins = false; break;
+      default: break;
+    }
+  }
+  if (!intron) {
+    ex_start = (uint32_t)(exstart + 1); ex_end = (uint32_t)(pos0 + l);
+    out[n++] = make_uint2(ex_start, ex_end + 1);
+  }
+  if (ex_end == 0) n = 0;  // the reference aborts here (GSam.cpp:290); we project nothing
+  int32_t rid = ref_id[a];
+  if (rid < 0 || (uint32_t)rid >= n_refs) n = 0;  // no tree for this refid (src/g2t.cpp:278-287)
+
+  // strand of the read, then the strands to try
+  uint32_t smode = 3;
+  uint16_t f = flags[a];
+  if (!cfg.long_reads) {
+    char c = (char)xs[a];
+    if (c == 0) {
+      char m = (char)ts[a];
+      if (m == '+' || m == '-') c = (f & 0x10) ? ((m == '+') ? '-' : '+') : m;
+    }
+    char strand = (c == '+' || c == '-') ? c : '.';
+    if (strand == '.' && (cfg.fr || cfg.rf)) {
+      bool is_rev = f & 0x10;
+      bool cond = (cfg.rf && is_rev) || (cfg.fr && !is_rev);
+      if (f & 0x1) {
+        int order = (f & 0x40) ? 1 : ((f & 0x80) ? 2 : 0);
+        strand = (order == 1) ? (cond ? '-' : '+') : (cond ? '+' : '-');
+      } else {
+        strand = cond ? '-' : '+';
+      }
+    }
+    smode = (strand == '+') ? 1u : (strand == '-') ? 2u : 3u;
+  }
+  uint32_t lclip = 0, rclip = 0;
+  if (cfg.long_reads) {
+    if (n_cigar == 0) { n = 0; }  // "alignment is missing CIGAR" -> failure (evaluate.cpp:76-81)
+    else {
+      uint32_t w0 = cg[0];
+      if (CIG_OP(w0) == OP_H) { if (n_cigar > 1 && CIG_OP(cg[1]) == OP_S) lclip = CIG_LEN(cg[1]); }
+      else if (CIG_OP(w0) == OP_S) lclip = CIG_LEN(w0);
+      uint32_t wl = cg[n_cigar - 1];
+      if (CIG_OP(wl) == OP_H) { if (n_cigar >= 2 && CIG_OP(cg[n_cigar - 2]) == OP_S) rclip = CIG_LEN(cg[n_cigar - 2]); }
+      else if (CIG_OP(wl) == OP_S) rclip = CIG_LEN(wl);
+    }
+  }
+  AlnMeta m; m.n_seg = n; m.smode = smode; m.n_left_clip = lclip; m.n_right_clip = rclip;
+  meta[a] = m;
+}
+
+// ---------------------------------------------------------------------------
+// per-lane building blocks
+// ---------------------------------------------------------------------------
+struct Hit { uint32_t pos, left_ins, right_ins, left_gap, right_gap; };
+
+// Tolerance table of IntervalTree::findOverlapping (src/g2t.cpp:144-227),
+// including the '-' strand right-overhang quirk at :204.
+__device__ __forceinline__ bool classify(bool minus, int status, uint32_t qs, uint32_t qe, uint32_t s,
+                                         uint32_t e, uint32_t pos_start, const DevCfg &c, Hit &h) {
+  h.pos = 0; h.left_ins = 0; h.right_ins = 0; h.left_gap = 0; h.right_gap = 0;
+  bool junc_left = (status == ST_MIDDLE || status == ST_LAST);
+  bool junc_right = (status == ST_FIRST || status == ST_MIDDLE);
+  if (!minus) {
+    if (s <= qs) {
+      h.left_gap = qs - s; h.pos = h.left_gap + pos_start;
+      if (junc_left && h.left_gap > c.max_junc_gap) return false;
+    } else {
+      h.pos = pos_start; h.left_ins = s - qs;
+      if (h.left_ins > (junc_left ? c.max_junc_ins : c.max_clip)) return false;
+    }
+    if (e < qe) {
+      h.right_ins = qe - e;
+      if (h.right_ins > (junc_right ? c.max_junc_ins : c.max_clip)) return false;
+    } else if (qe < e) {
+      h.right_gap = e - qe;
+      if (junc_right && h.right_gap > c.max_junc_gap) return false;
+    }
+  } else {
+    if (qe <= e) {
+      h.right_gap = e - qe; h.pos = h.right_gap + pos_start;
+      if (junc_right && h.right_gap > c.max_junc_gap) return false;
+    } else {
+      h.pos = pos_start; h.right_ins = qe - e;
+      if (h.right_ins > c.max_junc_ins) return false;  // always max_junc_ins (g2t.cpp:204)
+    }
+    if (qs < s) {
+      h.left_ins = s - qs;
+      if (h.left_ins > (junc_left ? c.max_junc_ins : c.max_clip)) return false;
+    } else if (s < qs) {
+      h.left_gap = qs - s;
+      if (junc_left && h.left_gap > c.max_junc_gap) return false;
+    }
+  }
+  return true;
+}
+
+// Ideal-CIGAR accumulator: Cigar::add_operation (include/evaluate.h:108-126).
+// One pending op lives in registers; completed ops go to `buf` (may be null
+// when only the accumulators are wanted).
+struct IdealSink {
+  uint32_t *buf; uint32_t n; uint32_t cur; bool has;
+  __device__ __forceinline__ void init(uint32_t *b) { buf = b; n = 0; cur = 0; has = false; }
+  __device__ __forceinline__ void add(uint32_t len, uint32_t op) {
+    if (!has) { cur = CIG_GEN(len, op); has = true; return; }
+    if (CIG_OP(cur) == op) { cur = CIG_GEN(CIG_LEN(cur) + len, op); return; }
+    if (buf) buf[n] = cur;
+    n++; cur = CIG_GEN(len, op);
+  }
+  __device__ __forceinline__ uint32_t finish() { if (has) { if (buf) buf[n] = cur; n++; has = false; } return n; }
+};
+
+// ExonChainMatch accumulators (include/evaluate.h:168-181, create_match :658-673)
+struct Acc {
+  double cov, ops;
+  int32_t ref_consumed, junc_hits, clip_score;
+  uint32_t prev_op;
+  __device__ __forceinline__ void init() { cov = 0; ops = 0; ref_consumed = 0; junc_hits = 0; clip_score = 0; prev_op = OP_M; }
+};
+
+// build_cigar_match (src/evaluate.cpp:675-786)
+__device__ __forceinline__ void build_match(Acc &m, IdealSink &sk, const Hit &h, int status, uint32_t qs,
+                                            uint32_t qe, uint32_t gs, uint32_t ge, bool first_match,
+                                            bool last_match, bool has_lc, bool has_rc) {
+  if (h.left_ins > 0) {
+    if (status == ST_FIRST || status == ST_ONLY) {
+      if (!has_lc) { sk.add(h.left_ins, OP_S); m.ops += h.left_ins; m.prev_op = OP_S; }
+    } else {  // MIDDLE / LAST (|| has_left_clip is then irrelevant)
+      sk.add(h.left_ins, OP_I); m.ops += h.left_ins;
+      if (m.prev_op == OP_D) m.cov += h.left_ins;
+      else if (m.prev_op == OP_I) m.ops += (m.ops * 0.2);
+      m.prev_op = OP_I;
+    }
+  } else if (h.left_gap > 0) {
+    if (!first_match && (status == ST_MIDDLE || status == ST_LAST || has_lc)) {
+      sk.add(h.left_gap, OP_D); m.ops += h.left_gap; m.ref_consumed += (int32_t)h.left_gap;
+      if (m.prev_op == OP_I) m.cov += h.left_gap;
+      else if (m.prev_op == OP_D) m.ops += (m.ops * 0.2);
+      m.prev_op = OP_D;
+    }
+  } else {
+    m.junc_hits++;
+  }
+  uint32_t os = qs > gs ? qs : gs, oe = qe < ge ? qe : ge;
+  if (oe >= os) {
+    uint32_t ml = oe - os;
+    sk.add(ml, OP_M); m.ops += ml; m.cov += ml; m.ref_consumed += (int32_t)ml; m.prev_op = OP_M;
+  }
+  if (h.right_ins > 0) {
+    if (status == ST_LAST || status == ST_ONLY) {
+      if (!has_rc) { sk.add(h.right_ins, OP_S); m.ops += h.right_ins; m.prev_op = OP_S; }
+    } else {
+      sk.add(h.right_ins, OP_I); m.ops += h.right_ins;
+      if (m.prev_op == OP_D) m.cov += h.right_ins;
+      m.prev_op = OP_I;
+    }
+  } else if (h.right_gap > 0) {
+    if (!last_match && (status == ST_FIRST || status == ST_MIDDLE || has_rc)) {
+      sk.add(h.right_gap, OP_D); m.ops += h.right_gap; m.ref_consumed += (int32_t)h.right_gap;
+      if (m.prev_op == OP_I) m.cov += h.right_gap;
+      m.prev_op = OP_D;
+    }
+  } else {
+    m.junc_hits++;
+  }
+}
+
+// merge_ops (src/bam.cpp:22-111); 95 ('_') = drop.
+__device__ __forceinline__ uint32_t merge_ops(uint32_t r, uint32_t i) {
+  bool r_ms = (r == OP_M || r == OP_S);
+  if (r_ms && i == OP_CLIP_OVR) return OP_S;
+  if (r_ms && i == OP_MATCH_OVR) return OP_M;
+  if (r_ms && i == OP_INS_OVR) return OP_I;
+  if (r_ms && i == OP_DEL_OVR) return OP_D;
+  if (r == OP_D && (i == OP_S || i == OP_CLIP_OVR)) return 95u;
+  if (r == OP_D && i == OP_MATCH_OVR) return OP_D;
+  if (r == OP_I && i == OP_CLIP_OVR) return OP_S;
+  if (r == OP_I && i == OP_MATCH_OVR) return OP_I;
+  if (i == OP_CLIP_OVR) return OP_S;
+  if (i == OP_MATCH_OVR) return OP_M;
+  if (i == OP_INS_OVR) return OP_I;
+  if (i == OP_DEL_OVR) return OP_D;
+  if (r == OP_P) return i;
+  if (r == OP_H) return OP_H;
+  if (r == OP_I && i == OP_S) return OP_S;
+  if (i == OP_S || i == OP_D || i == OP_I) return i;
+  if (r == OP_S || r == OP_D || r == OP_I) return r;
+  if (i == OP_M || i == OP_EQ) return OP_M;
+  if (i == OP_X) return OP_X;
+  if (r == OP_M || r == OP_EQ) return OP_M;
+  if (r == OP_X) return OP_X;
+  return i;
+}
+
+// get_new_cigar + merge_cigars (src/bam.cpp:443-472, :113-315).  `real` is the
+// alignment's packed CIGAR, `ideal` the lane's ideal CIGAR; the rewritten CIGAR
+// goes to `out` (room for n_real + n_ideal words).  Returns its length.
+__device__ uint32_t merge_cigars(const uint32_t *__restrict__ real, uint32_t n_real,
+                                 const uint32_t *ideal, uint32_t n_ideal, uint32_t *out) {
+  uint32_t front_h = 0, front_s = 0, ci = 0;
+  if (n_real > 0 && CIG_OP(real[0]) == OP_H) { front_h = CIG_LEN(real[0]); ci++; }
+  if (ci < n_real && CIG_OP(real[ci]) == OP_S) front_s = CIG_LEN(real[ci]);
+
+  uint32_t ridx = 0, ri = 0, ii = 0, real_pos = 0, ideal_pos = 0;
+  uint32_t last = 0;  // copy of out[ridx-1]
+#define ADD_OP(OPV, LENV)                                                          \
+  do {                                                                             \
+    uint32_t _op = (OPV), _len = (LENV);                                           \
+    if (_len != 0 && _op != 95u) {                                                 \
+      if (ridx > 0 && CIG_OP(last) == (_op & 0xffu)) { last += (_len << 4); out[ridx - 1] = last; } \
+      else { last = CIG_GEN(_len, _op); out[ridx++] = last; }                      \
+    }                                                                              \
+  } while (0)
+
+  uint32_t clips = front_h;
+  while (clips > 0 && ri < n_real) {
+    uint32_t rw = real[ri];
+    uint32_t avail = CIG_LEN(rw) - real_pos;
+    uint32_t chunk = clips < avail ? clips : avail;
+    ADD_OP(CIG_OP(rw), chunk);
+    clips -= chunk; real_pos += chunk;
+    if (real_pos >= CIG_LEN(rw)) { ri++; real_pos = 0; }
+  }
+  clips = front_s;
+  while (clips > 0 && ri < n_real) {
+    uint32_t rw = real[ri];
+    uint32_t real_op = CIG_OP(rw);
+    bool have_i = ii < n_ideal;
+    uint32_t iw = have_i ? ideal[ii] : 0;
+    uint32_t ideal_op = have_i ? CIG_OP(iw) : 0xffu;
+    uint32_t real_rem = CIG_LEN(rw) - real_pos;
+    uint32_t ideal_rem = have_i ? CIG_LEN(iw) - ideal_pos : 0xffffffffu;
+    bool is_ovr = have_i && (ideal_op >= OP_MATCH_OVR && ideal_op <= OP_CLIP_OVR);
+    if (is_ovr) {
+      if (ideal_op == OP_DEL_OVR) {
+        uint32_t chunk = ideal_rem;
+        ADD_OP(merge_ops(real_op, ideal_op), chunk);
+        ideal_pos += chunk;
+        if (ideal_pos >= CIG_LEN(iw)) { ii++; ideal_pos = 0; }
+      } else {
+        uint32_t chunk = clips;
+        if (chunk > real_rem) chunk = real_rem;
+        if (chunk > ideal_rem) chunk = ideal_rem;
+        ADD_OP(merge_ops(real_op, ideal_op), chunk);
+        clips -= chunk; real_pos += chunk; ideal_pos += chunk;
+        if (real_pos >= CIG_LEN(rw)) { ri++; real_pos = 0; }
+        if (ideal_pos >= CIG_LEN(iw)) { ii++; ideal_pos = 0; }
+      }
+    } else {
+      uint32_t chunk = clips;
+      if (chunk > real_rem) chunk = real_rem;
+      ADD_OP(merge_ops(real_op, ideal_op), chunk);
+      clips -= chunk; real_pos += chunk;
+      if (real_pos >= CIG_LEN(rw)) { ri++; real_pos = 0; }
+    }
+  }
+  while (ri < n_real || ii < n_ideal) {
+    if (ri >= n_real) {
+      uint32_t iw = ideal[ii];
+      ADD_OP(CIG_OP(iw), CIG_LEN(iw) - ideal_pos);
+      ii++; ideal_pos = 0;
+      continue;
+    }
+    uint32_t rw = real[ri];
+    if (ii >= n_ideal) {
+      ADD_OP(CIG_OP(rw), CIG_LEN(rw) - real_pos);
+      ri++; real_pos = 0;
+      continue;
+    }
+    uint32_t iw = ideal[ii];
+    uint32_t real_op = CIG_OP(rw), ideal_op = CIG_OP(iw);
+    uint32_t real_rem = CIG_LEN(rw) - real_pos, ideal_rem = CIG_LEN(iw) - ideal_pos;
+    if (real_op == OP_N) {
+      ri++; real_pos = 0;
+    } else if (real_op == OP_D && (ideal_op == OP_S || ideal_op == OP_CLIP_OVR || ideal_op == OP_I ||
+                                   ideal_op == OP_INS_OVR)) {
+      uint32_t chunk = real_rem < ideal_rem ? real_rem : ideal_rem;
+      real_pos += chunk; ideal_pos += chunk;
+      if (real_pos >= CIG_LEN(rw)) { ri++; real_pos = 0; }
+      if (ideal_pos >= CIG_LEN(iw)) { ii++; ideal_pos = 0; }
+    } else if (real_op == OP_I) {
+      ADD_OP(OP_I, real_rem);
+      ri++; real_pos = 0;
+    } else if (ideal_op == OP_D || ideal_op == OP_DEL_OVR) {
+      ADD_OP(OP_D, ideal_rem);
+      ii++; ideal_pos = 0;
+    } else {
+      uint32_t chunk = real_rem < ideal_rem ? real_rem : ideal_rem;
+      ADD_OP(merge_ops(real_op, ideal_op), chunk);
+      real_pos += chunk; ideal_pos += chunk;
+      if (real_pos >= CIG_LEN(rw)) { ri++; real_pos = 0; }
+      if (ideal_pos >= CIG_LEN(iw)) { ii++; ideal_pos = 0; }
+    }
+  }
+#undef ADD_OP
+  // "I between clips -> clip" fix-up (bam.cpp:292-300), then re-coalesce (:302-311)
+  for (uint32_t i = 1; i + 1 < ridx; i++) {
+    uint32_t w = out[i];
+    if (CIG_OP(w) != OP_I) continue;
+    uint32_t prev = CIG_OP(out[i - 1]), next = CIG_OP(out[i + 1]);
+    if ((prev == OP_S || prev == OP_H) && (next == OP_S || next == OP_H)) out[i] = CIG_GEN(CIG_LEN(w), prev);
+  }
+  uint32_t nidx = 0, lastw = 0;
+  for (uint32_t i = 0; i < ridx; i++) {
+    uint32_t w = out[i];
+    if (nidx > 0 && CIG_OP(lastw) == CIG_OP(w)) { lastw += (CIG_LEN(w) << 4); out[nidx - 1] = lastw; }
+    else { lastw = w; out[nidx++] = w; }
+  }
+  return nidx;
+}
+
+// Lane-local "does ANY row of the slab pass the tolerance test for this read
+// exon" = the return value of g2tTree::getGuideExons (src/g2t.cpp:334-344).
+// Needed only for the INS_EXON rule (src/evaluate.cpp:250-273).
+__device__ bool any_pass_global(const DevIndex &ix, uint32_t sb, uint32_t se, bool minus, int status,
+                                uint32_t qs, uint32_t qe, const DevCfg &cfg) {
+  uint32_t a = sb, b = se;  // hi: first row with start >= qe
+  while (a < b) { uint32_t m = (a + b) >> 1; if (ix.s_start[m] < qe) a = m + 1; else b = m; }
+  uint32_t hi = a;
+  a = sb; b = hi;           // lo: first row whose running max end exceeds qs
+  while (a < b) { uint32_t m = (a + b) >> 1; if (ix.s_pmax[m] <= qs) a = m + 1; else b = m; }
+  for (uint32_t r = a; r < hi; r++) {
+    uint32_t e = ix.s_end[r];
+    if (e <= qs) continue;
+    Hit h;
+    if (classify(minus, status, qs, qe, ix.s_start[r], e, 0, cfg, h)) return true;
+  }
+  return false;
+}
+
+// Result of advancing one candidate over read exon j >= 1.
+enum { STEP_DEAD = 0, STEP_HIT = 1, STEP_INS = 2 };
+
+struct Walker {
+  const uint4 *E;       // transcript's exon table (genomic order, sentinel-terminated)
+  uint32_t g0;          // genomic exon index of E[0] within the transcript (always 0)
+  bool minus;
+};
+
+// One read exon against the candidate's transcript: the passing hits of this
+// tid (src/evaluate.cpp:205-237), correct_for_gaps (:111-182) and the
+// injectivity rules (:1023-1047) folded together.  i_last = table index of the
+// last guide segment; on STEP_HIT i_hit/h/gap2 are set (gap2: a GAP_EXON segment
+// for exon i_hit-1 precedes the match segment).
+__device__ __forceinline__ int step_exon(const DevIndex &ix, const DevCfg &cfg, const uint4 *E, bool minus,
+                                         uint32_t sb, uint32_t se, uint32_t i_last, int status, uint32_t qs,
+                                         uint32_t qe, uint32_t &i_hit, Hit &h, uint4 &ge, bool &gap2) {
+  uint32_t cnt = 0;
+  Hit hh; uint4 ee;
+  for (uint32_t i = i_last;; i++) {
+    uint4 e = E[i];
+    if (e.x >= qe) break;             // start >= qend (sentinel start = ~0u)
+    if (e.y <= qs) continue;          // end <= qstart: no overlap
+    if (classify(minus, status, qs, qe, e.x, e.y, e.z, cfg, hh)) {
+      if (cnt == 0) { i_hit = i; h = hh; ee = e; }
+      cnt++;
+    }
+  }
+  gap2 = false;
+  if (cnt == 0) {
+    if (status == ST_MIDDLE && cfg.ignore_small_exons && (qe - qs <= cfg.max_error_exon)) {
+      if (!any_pass_global(ix, sb, se, minus, status, qs, qe, cfg)) return STEP_INS;
+    }
+    return STEP_DEAD;
+  }
+  if (cnt >= 2) return STEP_DEAD;      // two guide exons for one query exon
+  ge = ee;
+  uint32_t gap = (i_hit - i_last) & 0xffu;  // uint8_t exon_id arithmetic
+  if (!cfg.long_reads) { if (gap != 1) return STEP_DEAD; }
+  else {
+    if (gap > 2) return STEP_DEAD;
+    if (gap == 2) {
+      uint4 pe = E[i_hit - 1];         // genomic predecessor (i_hit >= 2 here)
+      if (pe.y - pe.x > cfg.max_error_exon) return STEP_DEAD;
+      gap2 = true;
+    }
+  }
+  if (i_hit == i_last) return STEP_DEAD;  // same guide exon for two query exons
+  return STEP_HIT;
+}
+
+// G-wide cooperative lower bound: first index in [a,b) where pred fails.
+// LE=false: pred = arr[i] <  key;  LE=true: pred = arr[i] <= key.
+template <int G, bool LE>
+__device__ __forceinline__ uint32_t group_lower_bound(const uint32_t *__restrict__ arr, uint32_t a, uint32_t b,
+                                                      uint32_t key, int gl, int gbase) {
+  const uint64_t gmask = (G == 64) ? ~0ull : ((1ull << G) - 1);
+  while (b - a > (uint32_t)G) {
+    uint32_t n = b - a;
+    uint32_t p = a + (uint32_t)(((uint64_t)(gl + 1) * n) / (uint32_t)(G + 1));
+    uint32_t v = arr[p];
+    bool t = LE ? (v <= key) : (v < key);
+    uint64_t m = (__ballot(t) >> gbase) & gmask;
+    int c = __popcll(m);
+    uint32_t pa = __shfl(p, c > 0 ? c - 1 : 0, G);
+    uint32_t pb = __shfl(p, c < G ? c : G - 1, G);
+    if (c > 0) a = pa + 1;
+    if (c < G) b = pb;
+  }
+  uint32_t p = a + (uint32_t)gl;
+  bool t = false;
+  if (p < b) { uint32_t v = arr[p]; t = LE ? (v <= key) : (v < key); }
+  uint64_t m = (__ballot(t) >> gbase) & gmask;
+  return a + (uint32_t)__popcll(m);
+}
+
+// Everything one lane needs about its alignment.
+struct ReadCtx {
+  const uint2 *seg;      // read exons (global)
+  uint32_t n_seg;
+  const uint32_t *real;  // packed real CIGAR
+  uint32_t n_real;
+};
+
+struct CandOut {
+  bool alive;
+  uint32_t fwpos, rcpos, n_seg, n_gex;
+};
+
+// Pass 1 (src/evaluate.cpp:1004-1065): survival, segment counts, fwpos/rcpos.
+__device__ __forceinline__ CandOut walk_pass1(const DevIndex &ix, const DevCfg &cfg, const ReadCtx &rd,
+                                              const uint4 *E, bool minus, uint32_t sb, uint32_t se,
+                                              uint32_t i0, const Hit &h0) {
+  CandOut o; o.alive = true; o.fwpos = h0.pos; o.rcpos = h0.pos; o.n_seg = 1; o.n_gex = 1;
+  uint32_t i_last = i0;
+  uint2 pq = rd.seg[0];
+  for (uint32_t j = 1; j < rd.n_seg; j++) {
+    uint2 q = rd.seg[j];
+    int status = (j < rd.n_seg - 1) ? ST_MIDDLE : ST_LAST;
+    uint32_t i_hit = 0; Hit h; uint4 ge; bool gap2;
+    int r = step_exon(ix, cfg, E, minus, sb, se, i_last, status, q.x, q.y, i_hit, h, ge, gap2);
+    if (r == STEP_DEAD || (q.x == pq.x && q.y == pq.y)) { o.alive = false; break; }
+    pq = q;
+    if (r == STEP_INS) { o.n_seg++; continue; }
+    if (gap2) { o.n_seg++; o.n_gex++; }
+    o.n_seg++; o.n_gex++;
+    i_last = i_hit;
+    if (minus) o.rcpos = h.pos;
+  }
+  return o;
+}
+
+// Pass 2 (src/evaluate.cpp:1070-1106): ideal CIGAR + accumulators.
+__device__ __forceinline__ void walk_pass2(const DevIndex &ix, const DevCfg &cfg, const ReadCtx &rd,
+                                           const uint4 *E, bool minus, uint32_t sb, uint32_t se, uint32_t i0,
+                                           const Hit &h0, const CandOut &p1, Acc &acc, IdealSink &sk) {
+  acc.init();
+  uint32_t k = 0;
+  uint2 q0 = rd.seg[0];
+  uint4 e0 = E[i0];
+  int st0 = (rd.n_seg == 1) ? ST_ONLY : ST_FIRST;
+  build_match(acc, sk, h0, st0, q0.x, q0.y, e0.x, e0.y, k == 0, k == p1.n_gex - 1, false, false);
+  k++;
+  uint32_t i_last = i0;
+  for (uint32_t j = 1; j < rd.n_seg; j++) {
+    uint2 q = rd.seg[j];
+    int status = (j < rd.n_seg - 1) ? ST_MIDDLE : ST_LAST;
+    uint32_t i_hit = 0; Hit h; uint4 ge; bool gap2;
+    int r = step_exon(ix, cfg, E, minus, sb, se, i_last, status, q.x, q.y, i_hit, h, ge, gap2);
+    if (r == STEP_INS) {  // build_cigar_ins (:788-806) + junc_hits (:1089-1091)
+      uint32_t len = q.y - q.x;
+      bool edge = (k == 0 || k == p1.n_seg - 1);
+      if (edge) { sk.add(len, OP_S); acc.prev_op = OP_S; } else { sk.add(len, OP_I); acc.prev_op = OP_I; }
+      acc.ops += len; acc.cov += len;
+      acc.junc_hits -= edge ? 1 : 2;
+      k++;
+      continue;
+    }
+    if (gap2) {          // build_cigar_gap (:808-822) + junc_hits (:1093-1095)
+      uint4 pe = E[i_hit - 1];
+      uint32_t len = pe.y - pe.x;
+      sk.add(len, OP_D); acc.prev_op = OP_D; acc.ops += len; acc.cov += len; acc.ref_consumed += (int32_t)len;
+      acc.junc_hits -= 2;
+      k++;
+    }
+    build_match(acc, sk, h, status, q.x, q.y, ge.x, ge.y, k == 0, k == p1.n_gex - 1, false, false);
+    k++;
+    i_last = i_hit;
+  }
+  if (acc.junc_hits < 0) acc.junc_hits = 0;
+}
+
+// similarity filter (src/evaluate.cpp:843-865); returns keep, sets score
+__device__ __forceinline__ bool similarity(const DevCfg &cfg, const Acc &acc, double &score) {
+  score = 0.0;
+  if (!cfg.filter_by_similarity) return true;
+  double sim = (acc.ops > 0) ? (acc.cov / acc.ops) : 0.0;
+  if (sim > cfg.thr) {
+    double x = ((sim - cfg.thr) / (1.0 - cfg.thr));
+    score = (x * x * (double)(acc.junc_hits + 1));
+    return true;
+  }
+  return false;
+}
+
+// ---------------------------------------------------------------------------
+// k_project<G, EMIT>: one G-lane group per alignment, grid-stride.
+// ---------------------------------------------------------------------------
+template <int G, bool EMIT>
+__global__ void __launch_bounds__(256) k_project(ProjectArgs A) {
+  const int gl = threadIdx.x & (G - 1);
+  const int gbase = (threadIdx.x & 63) & ~(G - 1);
+  const uint64_t gmask = (G == 64) ? ~0ull : ((1ull << G) - 1);
+  const int64_t groups_total = (int64_t)gridDim.x * (blockDim.x / G);
+  const int64_t gid = (int64_t)blockIdx.x * (blockDim.x / G) + threadIdx.x / G;
+  const DevIndex &ix = A.ix;
+  const DevCfg &cfg = A.cfg;
+
+  for (int64_t a = gid; a < A.n_aln; a += groups_total) {
+    AlnMeta mt = A.meta[a];
+    if (mt.n_seg == 0) { if (!EMIT && gl == 0) { A.n_matches[a] = 0; A.ranges[a] = make_uint4(0, 0, 0, 0); A.mask[a] = 0; } continue; }
+    uint32_t c0 = A.cigar_off[a];
+    ReadCtx rd;
+    rd.seg = A.seg + (size_t)c0 + (size_t)a;
+    rd.n_seg = mt.n_seg;
+    rd.real = A.cigar + c0;
+    rd.n_real = A.cigar_off[a + 1] - c0;
+    uint2 q0 = rd.seg[0];
+    int st0 = (rd.n_seg == 1) ? ST_ONLY : ST_FIRST;
+    uint32_t rid = (uint32_t)A.ref_id[a];
+
+    // candidate row ranges of read exon 0 on the strands to try
+    uint32_t lo[2] = {0, 0}, hi[2] = {0, 0}, sb[2], se[2];
+    sb[0] = ix.slab_off[2 * rid]; se[0] = ix.slab_off[2 * rid + 1];
+    sb[1] = se[0]; se[1] = ix.slab_off[2 * rid + 2];
+    if (EMIT) {
+      uint4 rg = A.ranges[a];
+      lo[0] = rg.x; hi[0] = rg.y; lo[1] = rg.z; hi[1] = rg.w;
+    } else {
+#pragma unroll
+      for (int s = 0; s < 2; s++) {
+        if (!((mt.smode >> s) & 1u) || sb[s] == se[s]) continue;
+        hi[s] = group_lower_bound<G, false>(ix.s_start, sb[s], se[s], q0.y, gl, gbase);
+        lo[s] = group_lower_bound<G, true>(ix.s_pmax, sb[s], hi[s], q0.x, gl, gbase);
+      }
+      if (gl == 0) A.ranges[a] = make_uint4(lo[0], hi[0], lo[1], hi[1]);
+    }
+    uint32_t n0 = hi[0] - lo[0], n1 = hi[1] - lo[1];
+    uint32_t n_items = n0 + n1;
+
+    uint32_t total = 0;        // matches counted so far (COUNT)
+    uint64_t mask_all = 0;     // survivor bit per item (valid while n_items <= 64)
+    uint64_t mask_in = 0;
+    bool have_mask = false;
+    uint32_t moff = 0; uint64_t cbase = 0; uint32_t cap = 0, ideal_cap = 0;
+    if (EMIT) {
+      if (A.n_matches[a] == 0) continue;
+      moff = A.match_off[a]; cbase = A.cig_base[a];
+      ideal_cap = 4u * rd.n_seg + 2u;
+      cap = rd.n_real + 2u * ideal_cap;
+      have_mask = n_items <= 64;
+      mask_in = A.mask[a];
+    }
+
+    // EMIT without a stored mask (n_items > 64): first sweep records every
+    // survivor's tid in aux[], second sweep ranks against that list.
+    const int n_sweeps = (EMIT && !have_mask) ? 2 : 1;
+    uint32_t aux_n = 0;
+    for (int sweep = 0; sweep < n_sweeps; sweep++) {
+      for (uint32_t base = 0; base < n_items; base += G) {
+        uint32_t item = base + (uint32_t)gl;
+        bool valid = item < n_items;
+        bool alive = false;
+        int s = 0; uint32_t row = 0;
+        uint4 pay = make_uint4(0, 0, 0, 0);
+        Hit h0; CandOut p1; const uint4 *E = nullptr; uint32_t i0 = 0;
+        p1.alive = false; p1.fwpos = 0; p1.rcpos = 0; p1.n_seg = 0; p1.n_gex = 0;
+        h0.pos = 0; h0.left_ins = h0.right_ins = h0.left_gap = h0.right_gap = 0;
+        if (valid) {
+          s = item < n0 ? 0 : 1;
+          row = s == 0 ? lo[0] + item : lo[1] + (item - n0);
+          bool want = true;
+          if (EMIT && have_mask) want = (mask_in >> item) & 1ull;
+          if (want) {
+            uint32_t gs = ix.s_start[row], gend = ix.s_end[row];
+            if (gend > q0.x) {
+              pay = ix.s_pay[row];
+              if (classify(s == 1, st0, q0.x, q0.y, gs, gend, pay.z, cfg, h0)) {
+                E = ix.tx_ex + pay.w; i0 = pay.y;
+                // first-exon duplicate tid: the LAST passing row of the tid wins
+                // (src/evaluate.cpp:218-224); later rows of the same tid are the
+                // following exons of its table.
+                bool superseded = false;
+                for (uint32_t i = i0 + 1;; i++) {
+                  uint4 e = E[i];
+                  if (e.x >= q0.y) break;
+                  Hit hx;
+                  if (e.y > q0.x && classify(s == 1, st0, q0.x, q0.y, e.x, e.y, e.z, cfg, hx)) { superseded = true; break; }
+                }
+                if (!superseded) {
+                  p1 = walk_pass1(ix, cfg, rd, E, s == 1, sb[s], se[s], i0, h0);
+                  alive = p1.alive;
+                }
+              }
+            }
+          }
+        }
+        // similarity filter needs the pass-2 accumulators (long reads only)
+        Acc acc; IdealSink sk; double score = 0.0;
+        if (!EMIT) {
+          if (alive && cfg.filter_by_similarity) {
+            sk.init(nullptr);
+            walk_pass2(ix, cfg, rd, E, s == 1, sb[s], se[s], i0, h0, p1, acc, sk);
+            alive = similarity(cfg, acc, score);
+          }
+          uint64_t m = (__ballot(alive) >> gbase) & gmask;
+          total += (uint32_t)__popcll(m);
+          if (base < 64) mask_all |= (G == 64) ? m : (m << base);
+        } else if (have_mask) {
+          // rank among the read's survivors by tid: tids of the masked items
+          if (alive) {
+            uint32_t rank = 0;
+            uint64_t mm = mask_in;
+            while (mm) {
+              int b = __ffsll((long long)mm) - 1; mm &= mm - 1;
+              uint32_t r2 = (uint32_t)b < n0 ? lo[0] + (uint32_t)b : lo[1] + ((uint32_t)b - n0);
+              uint32_t t2 = ix.s_pay[r2].x;
+              rank += (t2 < pay.x) ? 1u : 0u;
+            }
+            uint32_t *slot = A.cig_arena + cbase + (uint64_t)rank * cap;
+            uint32_t *ideal = slot + rd.n_real + ideal_cap;
+            sk.init(ideal);
+            walk_pass2(ix, cfg, rd, E, s == 1, sb[s], se[s], i0, h0, p1, acc, sk);
+            uint32_t n_ideal = sk.finish();
+            similarity(cfg, acc, score);
+            uint32_t n_out = merge_cigars(rd.real, rd.n_real, ideal, n_ideal, slot);
+            uint32_t mi = moff + rank;
+            A.m_tid[mi] = pay.x;
+            A.m_pos[mi] = (s == 0) ? p1.fwpos : p1.rcpos;
+            A.m_strand[mi] = (s == 0) ? (int8_t)'+' : (int8_t)'-';
+            A.m_ncig[mi] = n_out;
+            A.m_cigoff[mi] = cbase + (uint64_t)rank * cap;
+            A.m_sim[mi] = score;
+            A.m_junc[mi] = acc.junc_hits;
+            A.m_refc[mi] = acc.ref_consumed;
+            A.m_clip[mi] = acc.clip_score;
+          }
+        } else {
+          // big alignment (> 64 candidate rows): survivors are not known yet
+          if (alive && cfg.filter_by_similarity) {
+            sk.init(nullptr);
+            walk_pass2(ix, cfg, rd, E, s == 1, sb[s], se[s], i0, h0, p1, acc, sk);
+            alive = similarity(cfg, acc, score);
+          }
+          uint64_t m = (__ballot(alive) >> gbase) & gmask;
+          if (sweep == 0) {
+            if (alive) {
+              uint32_t k = aux_n + (uint32_t)__popcll(m & ((1ull << gl) - 1ull));
+              A.m_aux[moff + k] = pay.x;
+            }
+            aux_n += (uint32_t)__popcll(m);
+          } else if (alive) {
+            uint32_t rank = 0;
+            for (uint32_t k = 0; k < aux_n; k++) rank += (A.m_aux[moff + k] < pay.x) ? 1u : 0u;
+            uint32_t *slot = A.cig_arena + cbase + (uint64_t)rank * cap;
+            uint32_t *ideal = slot + rd.n_real + ideal_cap;
+            sk.init(ideal);
+            walk_pass2(ix, cfg, rd, E, s == 1, sb[s], se[s], i0, h0, p1, acc, sk);
+            uint32_t n_ideal = sk.finish();
+            similarity(cfg, acc, score);
+            uint32_t n_out = merge_cigars(rd.real, rd.n_real, ideal, n_ideal, slot);
+            uint32_t mi = moff + rank;
+            A.m_tid[mi] = pay.x;
+            A.m_pos[mi] = (s == 0) ? p1.fwpos : p1.rcpos;
+            A.m_strand[mi] = (s == 0) ? (int8_t)'+' : (int8_t)'-';
+            A.m_ncig[mi] = n_out;
+            A.m_cigoff[mi] = cbase + (uint64_t)rank * cap;
+            A.m_sim[mi] = score;
+            A.m_junc[mi] = acc.junc_hits;
+            A.m_refc[mi] = acc.ref_consumed;
+            A.m_clip[mi] = acc.clip_score;
+          }
+        }
+      }
+      if (EMIT && !have_mask && sweep == 0) __threadfence_block();  // aux[] written above is read below
+    }
+    if (!EMIT && gl == 0) { A.n_matches[a] = total; A.mask[a] = mask_all; }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// exclusive scans.  Tile = 256 threads x 8 items.
+// ---------------------------------------------------------------------------
+#define SCAN_ITEMS 8
+#define SCAN_TILE (256 * SCAN_ITEMS)
+
+__device__ __forceinline__ uint64_t block_excl_scan_256(uint64_t v, uint64_t *sh, uint64_t &block_total) {
+  // wave-level inclusive scan by shuffles, then across the 4 waves through LDS
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint64_t x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint64_t y = __shfl_up(x, d, 64);
+    if (lane >= d) x += y;
+  }
+  if (lane == 63) sh[w] = x;
+  __syncthreads();
+  uint64_t wbase = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) { if (i < w) wbase += sh[i]; tot += sh[i]; }
+  __syncthreads();
+  block_total = tot;
+  return wbase + x - v;
+}
+
+// value of element i: MODE 0: n_matches[i]; MODE 1: n_matches[i] * cap(i); MODE 2: src32[i]
+template <int MODE>
+__device__ __forceinline__ uint64_t scan_value(const ScanArgs &S, int64_t i) {
+  if (MODE == 0 || MODE == 2) return S.src32[i];
+  uint32_t nm = S.src32[i];
+  if (nm == 0) return 0;
+  uint32_t n_real = S.cigar_off[i + 1] - S.cigar_off[i];
+  uint32_t ideal_cap = 4u * S.meta[i].n_seg + 2u;
+  return (uint64_t)nm * (uint64_t)(n_real + 2u * ideal_cap);
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256) k_scan_tiles(ScanArgs S) {
+  __shared__ uint64_t sh[4];
+  int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+  uint64_t sum = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; k++) { int64_t i = base + k; if (i < S.n) sum += scan_value<MODE>(S, i); }
+  uint64_t tot;
+  block_excl_scan_256(sum, sh, tot);
+  if (threadIdx.x == 0) S.tile_sums[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(256) k_scan_top(uint64_t *tile_sums, int64_t n_tiles, uint64_t *total_out) {
+  __shared__ uint64_t sh[4];
+  uint64_t carry = 0;
+  for (int64_t base = 0; base < n_tiles; base += 256) {
+    int64_t i = base + threadIdx.x;
+    uint64_t v = i < n_tiles ? tile_sums[i] : 0;
+    uint64_t tot;
+    uint64_t ex = block_excl_scan_256(v, sh, tot);
+    if (i < n_tiles) tile_sums[i] = carry + ex;
+    carry += tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total_out = carry;
+}
+
+template <int MODE, typename OutT>
+__global__ void __launch_bounds__(256) k_scan_apply(ScanArgs S, OutT *out) {
+  __shared__ uint64_t sh[4];
+  int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+  uint64_t v[SCAN_ITEMS];
+  uint64_t sum = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; k++) { int64_t i = base + k; v[k] = i < S.n ? scan_value<MODE>(S, i) : 0; sum += v[k]; }
+  uint64_t tot;
+  uint64_t ex = block_excl_scan_256(sum, sh, tot) + S.tile_sums[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; k++) { int64_t i = base + k; if (i < S.n) out[i] = (OutT)ex; ex += v[k]; }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) out[S.n] = (OutT)ex;
+}
+
+// ---------------------------------------------------------------------------
+// k_pair<EMIT>: one lane per read-name group.
+//   src/core.cpp:343-426 (which alignments pair up), src/mates.cpp:150-261
+//   (transcript-set cases), src/core.cpp:237-258,309-325 (NH, HI, MAPQ),
+//   src/bam.cpp:531-588 (mate fields).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mapq_of(uint32_t nh, bool long_reads) {  // src/core.cpp:46-58
+  if (!long_reads) { return nh == 1 ? 255u : nh == 2 ? 3u : (nh == 3 || nh == 4) ? 1u : 0u; }
+  return nh > 1 ? 0u : 3u;
+}
+
+template <bool EMIT>
+__global__ void __launch_bounds__(256) k_pair(PairArgs P) {
+  int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= P.n_groups) return;
+  uint32_t a0 = P.group_off[g], a1 = P.group_off[g + 1];
+  uint32_t rows = 0;
+  uint64_t r0 = 0; uint32_t nh = 0, mq = 0;
+  bool any_match = false;
+  if (EMIT) { r0 = P.row_off[g]; nh = (uint32_t)(P.row_off[g + 1] - r0); mq = mapq_of(nh, P.long_reads); if (nh == 0) return; }
+  for (uint32_t i = a0; i < a1; i++) {
+    int32_t m = P.mate_idx[i];
+    uint32_t mi0 = P.match_off[i], ni = P.match_off[i + 1] - mi0;
+    if (ni) any_match = true;
+    if (m >= 0 && (uint32_t)m < i && (uint32_t)m >= a0) continue;  // handled as the mate of an earlier leader
+    if (ni == 0) continue;                    // leader without matches: pair dropped (mates.cpp:153)
+    uint32_t nm = 0, mm0 = 0;
+    if (m >= 0 && (uint32_t)m > i && (uint32_t)m < a1) { mm0 = P.match_off[m]; nm = P.match_off[m + 1] - mm0; }
+    if (nm == 0) {
+      // unpaired emission: one record per transcript, ascending tid (mates.cpp:157-176)
+      if (EMIT) {
+        for (uint32_t k = 0; k < ni; k++) {
+          uint64_t r = r0 + rows + k; uint32_t x = mi0 + k;
+          P.r_input[r] = (int32_t)i; P.r_match[r] = x; P.r_nh[r] = nh; P.r_hi[r] = rows + k + 1; P.r_mapq[r] = mq;
+          P.r_flags[r] = RF_FIRST; P.r_mate_tid[r] = -1; P.r_mate_pos[r] = -1; P.r_isize[r] = 0;
+          P.r_group[r] = (uint32_t)g;
+        }
+      }
+      rows += ni;
+      continue;
+    }
+    // both mates matched: sorted-set intersection
+    uint32_t x = 0, y = 0, common = 0;
+    while (x < ni && y < nm) {
+      uint32_t tx = P.m_tid[mi0 + x], ty = P.m_tid[mm0 + y];
+      if (tx < ty) x++;
+      else if (ty < tx) y++;
+      else {
+        if (EMIT) {
+          uint64_t r = r0 + rows + 2ull * common;
+          uint32_t xr = mi0 + x, xm = mm0 + y;
+          int32_t rpos = (int32_t)P.m_pos[xr], mpos = (int32_t)P.m_pos[xm];
+          int32_t lq_r = P.l_qseq[i], lq_m = P.l_qseq[m];
+          P.r_input[r] = (int32_t)i; P.r_match[r] = xr; P.r_nh[r] = nh; P.r_hi[r] = rows + 2 * common + 1; P.r_mapq[r] = mq;
+          P.r_flags[r] = RF_FIRST | RF_PAIRED | RF_SAME_TX; P.r_mate_tid[r] = (int32_t)tx; P.r_mate_pos[r] = mpos;
+          P.r_isize[r] = (rpos <= mpos) ? (mpos + lq_r) - rpos : -((rpos + lq_r) - mpos);
+          P.r_group[r] = (uint32_t)g;
+          r++;
+          P.r_input[r] = m; P.r_match[r] = xm; P.r_nh[r] = nh; P.r_hi[r] = rows + 2 * common + 2; P.r_mapq[r] = mq;
+          P.r_flags[r] = RF_PAIRED | RF_SAME_TX; P.r_mate_tid[r] = (int32_t)tx; P.r_mate_pos[r] = rpos;
+          P.r_isize[r] = (mpos <= rpos) ? (rpos + lq_m) - mpos : -((mpos + lq_m) - rpos);
+          P.r_group[r] = (uint32_t)g;
+        }
+        common++; x++; y++;
+      }
+    }
+    if (common) { rows += 2 * common; continue; }
+    if (ni == 1 && nm == 1) {  // one transcript each, different ones (mates.cpp:227-231)
+      if (EMIT) {
+        uint64_t r = r0 + rows;
+        uint32_t xr = mi0, xm = mm0;
+        P.r_input[r] = (int32_t)i; P.r_match[r] = xr; P.r_nh[r] = nh; P.r_hi[r] = rows + 1; P.r_mapq[r] = mq;
+        P.r_flags[r] = RF_FIRST | RF_PAIRED; P.r_mate_tid[r] = (int32_t)P.m_tid[xm]; P.r_mate_pos[r] = (int32_t)P.m_pos[xm];
+        P.r_isize[r] = 0; P.r_group[r] = (uint32_t)g;
+        r++;
+        P.r_input[r] = m; P.r_match[r] = xm; P.r_nh[r] = nh; P.r_hi[r] = rows + 2; P.r_mapq[r] = mq;
+        P.r_flags[r] = RF_PAIRED; P.r_mate_tid[r] = (int32_t)P.m_tid[xr]; P.r_mate_pos[r] = (int32_t)P.m_pos[xr];
+        P.r_isize[r] = 0; P.r_group[r] = (uint32_t)g;
+      }
+      rows += 2;
+    }
+  }
+  if (!EMIT) {
+    P.n_rows[g] = rows;
+    // counters of src/bramble.cpp:729-736
+    if (rows == 1) atomicAdd((unsigned long long *)&P.counters[1], 1ull);
+    if (!any_match) atomicAdd((unsigned long long *)&P.counters[2], 1ull);
+  }
+}
+
+// rows -> dense outputs: per-row fields copied from the match table, n_cigar per row
+__global__ void __launch_bounds__(256) k_row_fill(RowArgs R) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R.n_rows) return;
+  uint32_t x = R.r_match[r];
+  R.r_tid[r] = R.m_tid[x]; R.r_pos[r] = R.m_pos[x]; R.r_strand[r] = R.m_strand[x];
+  R.r_sim[r] = R.m_sim[x]; R.r_clip[r] = R.m_clip[x]; R.r_junc[r] = R.m_junc[x]; R.r_refc[r] = R.m_refc[x];
+  R.r_ncig[r] = R.m_ncig[x];
+  uint8_t f = R.r_flags[r];
+  R.r_paired[r] = (f & RF_PAIRED) ? 1 : 0; R.r_same[r] = (f & RF_SAME_TX) ? 1 : 0; R.r_first[r] = (f & RF_FIRST) ? 1 : 0;
+}
+
+// k_gather: one lane per row copies its rewritten CIGAR to the dense pool
+__global__ void __launch_bounds__(256) k_gather(RowArgs R) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R.n_rows) return;
+  uint32_t x = R.r_match[r];
+  const uint32_t *src = R.cig_arena + R.m_cigoff[x];
+  uint64_t d0 = R.r_cigoff[r];
+  uint32_t n = R.m_ncig[x];
+  for (uint32_t k = 0; k < n; k++) R.cigar_out[d0 + k] = src[k];
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+static inline int grid_for(int64_t n, int per_block) { return (int)((n + per_block - 1) / per_block); }
+
+void launch_segment(hipStream_t st, int64_t n_aln, const int32_t *ref_id, const int32_t *ref_start,
+                    const uint16_t *flags, const int8_t *xs, const int8_t *ts, const uint32_t *cigar_off,
+                    const uint32_t *cigar, const DevCfg &cfg, uint32_t n_refs, uint2 *seg, AlnMeta *meta) {
+  if (n_aln <= 0) return;
+  hipLaunchKernelGGL(k_segment, dim3(grid_for(n_aln, 256)), dim3(256), 0, st, n_aln, ref_id, ref_start, flags,
+                     xs, ts, cigar_off, cigar, cfg, n_refs, seg, meta);
+}
+
+template <int G>
+static void launch_project_g(hipStream_t st, const ProjectArgs &A, bool emit, int n_blocks) {
+  if (emit) hipLaunchKernelGGL((k_project<G, true>), dim3(n_blocks), dim3(256), 0, st, A);
+  else hipLaunchKernelGGL((k_project<G, false>), dim3(n_blocks), dim3(256), 0, st, A);
+}
+
+void launch_project(hipStream_t st, const ProjectArgs &A, bool emit, int group_lanes, int n_blocks) {
+  if (A.n_aln <= 0) return;
+  int64_t groups = A.n_aln;
+  int per_block = 256 / group_lanes;
+  int64_t need = (groups + per_block - 1) / per_block;
+  if (need < n_blocks) n_blocks = (int)need;
+  if (n_blocks < 1) n_blocks = 1;
+  switch (group_lanes) {
+    case 8: launch_project_g<8>(st, A, emit, n_blocks); break;
+    case 16: launch_project_g<16>(st, A, emit, n_blocks); break;
+    case 32: launch_project_g<32>(st, A, emit, n_blocks); break;
+    default: launch_project_g<64>(st, A, emit, n_blocks); break;
+  }
+}
+
+int64_t scan_tiles_for(int64_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE; }
+
+void launch_scan(hipStream_t st, const ScanArgs &S, int mode, void *out, bool out64, uint64_t *total_out) {
+  int64_t tiles = scan_tiles_for(S.n);
+  if (tiles < 1) tiles = 1;
+  dim3 g((unsigned)tiles), b(256);
+  if (mode == 0) hipLaunchKernelGGL((k_scan_tiles<0>), g, b, 0, st, S);
+  else if (mode == 1) hipLaunchKernelGGL((k_scan_tiles<1>), g, b, 0, st, S);
+  else hipLaunchKernelGGL((k_scan_tiles<2>), g, b, 0, st, S);
+  hipLaunchKernelGGL(k_scan_top, dim3(1), b, 0, st, S.tile_sums, tiles, total_out);
+  if (mode == 0) {
+    if (out64) hipLaunchKernelGGL((k_scan_apply<0, uint64_t>), g, b, 0, st, S, (uint64_t *)out);
+    else hipLaunchKernelGGL((k_scan_apply<0, uint32_t>), g, b, 0, st, S, (uint32_t *)out);
+  } else if (mode == 1) {
+    hipLaunchKernelGGL((k_scan_apply<1, uint64_t>), g, b, 0, st, S, (uint64_t *)out);
+  } else {
+    if (out64) hipLaunchKernelGGL((k_scan_apply<2, uint64_t>), g, b, 0, st, S, (uint64_t *)out);
+    else hipLaunchKernelGGL((k_scan_apply<2, uint32_t>), g, b, 0, st, S, (uint32_t *)out);
+  }
+}
+
+void launch_pair(hipStream_t st, const PairArgs &P, bool emit) {
+  if (P.n_groups <= 0) return;
+  if (emit) hipLaunchKernelGGL((k_pair<true>), dim3(grid_for(P.n_groups, 256)), dim3(256), 0, st, P);
+  else hipLaunchKernelGGL((k_pair<false>), dim3(grid_for(P.n_groups, 256)), dim3(256), 0, st, P);
+}
+
+void launch_row_fill(hipStream_t st, const RowArgs &R) {
+  if (R.n_rows <= 0) return;
+  hipLaunchKernelGGL(k_row_fill, dim3(grid_for(R.n_rows, 256)), dim3(256), 0, st, R);
+}
+
+void launch_gather(hipStream_t st, const RowArgs &R) {
+  if (R.n_rows <= 0) return;
+  hipLaunchKernelGGL(k_gather, dim3(grid_for(R.n_rows, 256)), dim3(256), 0, st, R);
+}
+
+}  // namespace br

@@ -1,0 +1,367 @@
+"""ctypes binding of libbramble_amd.so (C ABI: include/bramble_amd.h).
+
+The projection path is HIP only: if the shared library is missing, or no HIP
+device is usable, every call raises -- there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbramble_amd.so")
+_P = C.POINTER
+
+K_SEGMENT, K_COUNT, K_EMIT, K_PAIR_COUNT, K_PAIR_EMIT, K_GATHER, K_SCAN, K_NUM = range(8)
+KERNEL_NAMES = ["k_segment", "k_project<count>", "k_project<emit>", "k_pair<count>", "k_pair<emit>",
+                "k_row_fill+k_gather", "k_scan_*"]
+
+
+class BrambleError(RuntimeError):
+    pass
+
+
+class BrExon(C.Structure):
+    _fields_ = [("start", C.c_uint32), ("end", C.c_uint32)]
+
+
+class BrTranscript(C.Structure):
+    _fields_ = [("id", C.c_char_p), ("seqname", C.c_char_p), ("strand", C.c_char),
+                ("exons", _P(BrExon)), ("n_exons", C.c_uint32)]
+
+
+class BrFastaSeq(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("seq", C.c_char_p), ("len", C.c_uint64)]
+
+
+class BrConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("lr", "lr_hq", "strict", "use_fasta", "fr", "rf", "has_max_clip", "has_max_junc_ins",
+                 "has_max_junc_gap", "has_sim_thr", "has_max_error_exon")] + \
+               [(n, C.c_uint32) for n in ("max_clip", "max_junc_ins", "max_junc_gap", "max_error_exon")] + \
+               [("sim_thr", C.c_float), ("junc_miss_discount", C.c_double)]
+
+
+class BrThresholds(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("max_clip", "max_junc_ins", "max_junc_gap", "max_error_exon")] + \
+               [("ignore_small_exons", C.c_int32), ("filter_by_similarity", C.c_int32),
+                ("similarity_threshold", C.c_float)]
+
+
+class BrBatch(C.Structure):
+    _fields_ = [("n_aln", C.c_int64), ("ref_id", C.c_void_p), ("ref_start", C.c_void_p), ("flags", C.c_void_p),
+                ("xs", C.c_void_p), ("ts", C.c_void_p), ("cigar_off", C.c_void_p), ("cigar", C.c_void_p),
+                ("mate_ref_id", C.c_void_p), ("mate_start", C.c_void_p), ("name_off", C.c_void_p),
+                ("names", C.c_void_p), ("seq_off", C.c_void_p), ("seqs", C.c_void_p), ("l_qseq", C.c_void_p)]
+
+
+_ROW_FIELDS = [("input_index", np.int32), ("transcript_id", np.uint32), ("pos", np.uint32), ("strand", np.int8),
+               ("cigar_off", np.uint64), ("cigar", np.uint32), ("similarity_score", np.float64),
+               ("clip_score", np.int32), ("junc_hits", np.int32), ("aligned_len", np.int32),
+               ("nh", np.uint32), ("hi", np.uint32), ("mapq", np.uint32)]
+_ROW_TAIL = [("is_paired", np.uint8), ("same_transcript_as_mate", np.uint8), ("is_first", np.uint8),
+             ("mate_transcript_id", np.int32), ("mate_pos", np.int32), ("insert_size", np.int32),
+             ("group", np.uint32)]
+_COUNTERS = [("total_complete", C.c_uint64), ("total_unique", C.c_uint64), ("dropped_reads", C.c_uint64),
+             ("total_processed", C.c_uint64)]
+
+
+class BrRows(C.Structure):
+    _fields_ = [("n_rows", C.c_int64)] + [(n, C.c_void_p) for n, _ in _ROW_FIELDS] + \
+               [("is_primary", C.c_void_p)] + [(n, C.c_void_p) for n, _ in _ROW_TAIL] + _COUNTERS
+
+
+class BrDeviceBatch(C.Structure):
+    _fields_ = [("n_aln", C.c_int64), ("n_groups", C.c_int64), ("ref_id", C.c_void_p), ("ref_start", C.c_void_p),
+                ("flags", C.c_void_p), ("xs", C.c_void_p), ("ts", C.c_void_p), ("cigar_off", C.c_void_p),
+                ("cigar", C.c_void_p), ("mate_idx", C.c_void_p), ("group_off", C.c_void_p), ("l_qseq", C.c_void_p),
+                ("seq_off", C.c_void_p), ("seqs", C.c_void_p), ("n_cigar_words", C.c_int64),
+                ("max_n_cigar", C.c_int32)]
+
+
+class BrDeviceRows(C.Structure):
+    _fields_ = [("n_rows", C.c_int64), ("n_matches", C.c_int64), ("n_cigar_words", C.c_int64)] + \
+               [(n, C.c_void_p) for n, _ in _ROW_FIELDS] + [(n, C.c_void_p) for n, _ in _ROW_TAIL] + _COUNTERS
+
+
+# every symbol include/bramble_amd.h declares
+EXPORTS = ["br_index_build", "br_index_build_flat", "br_index_free", "br_index_num_transcripts", "br_index_transcript_name",
+           "br_index_transcript_len", "br_index_num_intervals", "br_index_device_bytes", "br_config_short_read",
+           "br_config_long_read", "br_config_resolve", "br_batch_prepare", "br_ctx_new", "br_ctx_free",
+           "br_project_batch", "br_project_batch_device", "br_project_group", "br_ctx_set_profiling",
+           "br_ctx_set_param", "br_ctx_kernel_ms", "br_ctx_last_counters", "br_version", "br_strerror"]
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise BrambleError("libbramble_amd.so is not built (run __graft_entry__.build() or "
+                               "`make -C bramble_amd/csrc`); there is no CPU fallback for the projection path")
+        L = C.CDLL(LIB_PATH)
+        L.br_index_build.argtypes = [_P(BrTranscript), C.c_size_t, _P(C.c_char_p), C.c_size_t, _P(BrFastaSeq),
+                                     C.c_size_t, C.c_int, _P(C.c_void_p)]
+        L.br_index_build_flat.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_size_t, _P(BrFastaSeq), C.c_int, _P(C.c_void_p)]
+        L.br_index_free.argtypes = [C.c_void_p]
+        L.br_index_num_transcripts.restype = C.c_size_t
+        L.br_index_num_transcripts.argtypes = [C.c_void_p]
+        L.br_index_transcript_name.restype = C.c_char_p
+        L.br_index_transcript_name.argtypes = [C.c_void_p, C.c_uint32]
+        L.br_index_transcript_len.restype = C.c_int64
+        L.br_index_transcript_len.argtypes = [C.c_void_p, C.c_uint32]
+        L.br_index_num_intervals.restype = C.c_size_t
+        L.br_index_num_intervals.argtypes = [C.c_void_p]
+        L.br_index_device_bytes.restype = C.c_size_t
+        L.br_index_device_bytes.argtypes = [C.c_void_p]
+        L.br_config_short_read.argtypes = [_P(BrConfig)]
+        L.br_config_long_read.argtypes = [_P(BrConfig)]
+        L.br_config_resolve.argtypes = [_P(BrConfig), _P(BrThresholds)]
+        L.br_batch_prepare.argtypes = [_P(BrBatch), C.c_void_p, C.c_void_p, _P(C.c_int64)]
+        L.br_ctx_new.argtypes = [C.c_void_p, _P(C.c_void_p)]
+        L.br_ctx_free.argtypes = [C.c_void_p]
+        L.br_project_batch.argtypes = [C.c_void_p, _P(BrConfig), _P(BrBatch), _P(BrRows)]
+        L.br_project_batch_device.argtypes = [C.c_void_p, _P(BrConfig), _P(BrDeviceBatch), C.c_void_p,
+                                              _P(BrDeviceRows)]
+        L.br_ctx_set_profiling.argtypes = [C.c_void_p, C.c_int]
+        L.br_ctx_set_param.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        L.br_ctx_kernel_ms.argtypes = [C.c_void_p, C.c_int, _P(C.c_double), _P(C.c_int32)]
+        L.br_ctx_last_counters.argtypes = [C.c_void_p, C.c_void_p]
+        L.br_version.restype = C.c_char_p
+        L.br_strerror.restype = C.c_char_p
+        L.br_strerror.argtypes = [C.c_int]
+        _LIB = L
+    return _LIB
+
+
+def check(rc, what):
+    if rc != 0:
+        raise BrambleError("%s failed: %s (%d)" % (what, lib().br_strerror(rc).decode(), rc))
+
+
+def make_config(**kw):
+    """lr, lr_hq, strict, use_fasta, fr, rf + optional max_clip, max_junc_ins, max_junc_gap,
+    max_error_exon, sim_thr overrides (bramble CLI flags, src/bramble.cpp:457-485)."""
+    c = BrConfig()
+    lib().br_config_short_read(C.byref(c))
+    for k, v in kw.items():
+        if k in ("max_clip", "max_junc_ins", "max_junc_gap", "max_error_exon", "sim_thr"):
+            setattr(c, "has_" + k, 1)
+        setattr(c, k, v)
+    return c
+
+
+def resolve_config(cfg):
+    t = BrThresholds()
+    check(lib().br_config_resolve(C.byref(cfg), C.byref(t)), "br_config_resolve")
+    return {"max_clip": t.max_clip, "max_junc_ins": t.max_junc_ins, "max_junc_gap": t.max_junc_gap,
+            "max_error_exon": t.max_error_exon, "ignore_small_exons": bool(t.ignore_small_exons),
+            "filter_by_similarity": bool(t.filter_by_similarity),
+            "similarity_threshold": float(t.similarity_threshold)}
+
+
+class Index:
+    """g2tTree replacement: flattened exon tables, uploaded to `device` (-1: host only)."""
+
+    def __init__(self, annotation, device=0):
+        L = lib()
+        txs = annotation["transcripts"]
+        refnames = [r.encode() for r in annotation["refnames"]]
+        arr = (BrTranscript * max(len(txs), 1))()
+        keep = []
+        for i, t in enumerate(txs):
+            ex = (BrExon * max(len(t["exons"]), 1))()
+            for k, (s, e) in enumerate(t["exons"]):
+                ex[k].start, ex[k].end = int(s), int(e)
+            keep.append(ex)
+            arr[i].id = t["id"].encode()
+            arr[i].seqname = (t["seqname"] if "seqname" in t else annotation["refnames"][t["ref_id"]]).encode()
+            arr[i].strand = t["strand"].encode()
+            arr[i].exons = ex
+            arr[i].n_exons = len(t["exons"])
+        rn = (C.c_char_p * max(len(refnames), 1))(*refnames)
+        fa, nfa = None, 0
+        seqs = annotation.get("ref_seqs")
+        if seqs:
+            items = sorted(seqs.items())
+            fa = (BrFastaSeq * len(items))()
+            for i, (rid, s) in enumerate(items):
+                sb = s.encode() if isinstance(s, str) else bytes(s)
+                keep.append(sb)
+                fa[i].name = annotation["refnames"][rid].encode()
+                fa[i].seq = sb
+                fa[i].len = len(sb)
+            nfa = len(items)
+        h = C.c_void_p()
+        check(L.br_index_build(arr, len(txs), rn, len(refnames), fa, nfa, device, C.byref(h)), "br_index_build")
+        self.h = h
+        self.device = device
+
+    @classmethod
+    def from_flat(cls, flat, device=0):
+        """flat: dict with n_refs, tx_ref int32[], tx_strand int8[], tx_exon_off uint64[], ex_start/ex_end
+        uint32[] (half-open) and optional ref_seqs (list of bytes or None per reference)."""
+        self = cls.__new__(cls)
+        ref = np.ascontiguousarray(flat["tx_ref"], dtype=np.int32)
+        strand = np.ascontiguousarray(flat["tx_strand"], dtype=np.int8)
+        off = np.ascontiguousarray(flat["tx_exon_off"], dtype=np.uint64)
+        es = np.ascontiguousarray(flat["ex_start"], dtype=np.uint32)
+        ee = np.ascontiguousarray(flat["ex_end"], dtype=np.uint32)
+        fa = None
+        keep = []
+        if flat.get("ref_seqs") is not None:
+            fa = (BrFastaSeq * flat["n_refs"])()
+            for r, sq in enumerate(flat["ref_seqs"]):
+                if sq is None:
+                    continue
+                sb = sq if isinstance(sq, (bytes, bytearray)) else bytes(sq)
+                keep.append(sb)
+                fa[r].name = b"ref%d" % r
+                fa[r].seq = sb
+                fa[r].len = len(sb)
+        h = C.c_void_p()
+        check(lib().br_index_build_flat(len(ref), ref.ctypes.data, strand.ctypes.data, off.ctypes.data,
+                                        es.ctypes.data, ee.ctypes.data, None, int(flat["n_refs"]), fa, device,
+                                        C.byref(h)), "br_index_build_flat")
+        self.h = h
+        self.device = device
+        return self
+
+    def num_transcripts(self):
+        return lib().br_index_num_transcripts(self.h)
+
+    def transcript_name(self, tid):
+        s = lib().br_index_transcript_name(self.h, tid)
+        return s.decode() if s is not None else None
+
+    def transcript_len(self, tid):
+        v = lib().br_index_transcript_len(self.h, tid)
+        return None if v < 0 else int(v)
+
+    def num_intervals(self):
+        return lib().br_index_num_intervals(self.h)
+
+    def device_bytes(self):
+        return lib().br_index_device_bytes(self.h)
+
+    def close(self):
+        if self.h:
+            lib().br_index_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _batch_struct(batch, keep):
+    b = BrBatch()
+    b.n_aln = int(batch["n_aln"])
+
+    def put(name, dtype):
+        a = np.ascontiguousarray(batch[name], dtype=dtype)
+        keep.append(a)
+        setattr(b, name, a.ctypes.data)
+
+    for name, dt in (("ref_id", np.int32), ("ref_start", np.int32), ("flags", np.uint16), ("xs", np.int8),
+                     ("ts", np.int8), ("cigar_off", np.uint64), ("cigar", np.uint32), ("mate_ref_id", np.int32),
+                     ("mate_start", np.int32), ("name_off", np.uint64), ("names", np.uint8), ("l_qseq", np.int32)):
+        put(name, dt)
+    if batch.get("seq_off") is not None:
+        put("seq_off", np.uint64)
+        put("seqs", np.uint8)
+    return b
+
+
+def prepare_batch(batch):
+    """Host-side input contract (br_batch_prepare): returns (mate_idx int32[n], group_off uint32[g+1])."""
+    keep = []
+    b = _batch_struct(batch, keep)
+    n = int(batch["n_aln"])
+    mate = np.full(max(n, 1), -1, dtype=np.int32)
+    goff = np.zeros(n + 1, dtype=np.uint32)
+    ng = C.c_int64()
+    check(lib().br_batch_prepare(C.byref(b), mate.ctypes.data, goff.ctypes.data, C.byref(ng)), "br_batch_prepare")
+    return mate[:n], goff[:ng.value + 1].copy()
+
+
+def _view(ptr, n, dtype):
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype=dtype)
+    buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=n).copy()
+
+
+class Context:
+    """ProjectionContext: device scratch + stream-ordered pipeline for one index."""
+
+    def __init__(self, index):
+        h = C.c_void_p()
+        check(lib().br_ctx_new(index.h, C.byref(h)), "br_ctx_new")
+        self.h = h
+        self.index = index
+
+    def set_param(self, key, value):
+        check(lib().br_ctx_set_param(self.h, key.encode(), int(value)), "br_ctx_set_param")
+
+    def set_profiling(self, enabled):
+        check(lib().br_ctx_set_profiling(self.h, 1 if enabled else 0), "br_ctx_set_profiling")
+
+    def kernel_ms(self):
+        out = {}
+        for k in range(K_NUM):
+            ms, ln = C.c_double(), C.c_int32()
+            check(lib().br_ctx_kernel_ms(self.h, k, C.byref(ms), C.byref(ln)), "br_ctx_kernel_ms")
+            out[KERNEL_NAMES[k]] = (ms.value, ln.value)
+        return out
+
+    def project_batch(self, cfg, batch):
+        """Host batch in, rows (dict of numpy arrays) out: convert_reads minus BAM writing."""
+        keep = []
+        b = _batch_struct(batch, keep)
+        r = BrRows()
+        check(lib().br_project_batch(self.h, C.byref(cfg), C.byref(b), C.byref(r)), "br_project_batch")
+        n = r.n_rows
+        rows = {"n_rows": n}
+        for name, dt in _ROW_FIELDS + [("is_primary", np.uint8)] + _ROW_TAIL:
+            if name == "cigar_off":
+                rows[name] = _view(r.cigar_off, n + 1, dt)
+            elif name == "cigar":
+                continue
+            else:
+                rows[name] = _view(getattr(r, name), n, dt)
+        rows["cigar"] = _view(r.cigar, int(rows["cigar_off"][-1]) if n else 0, np.uint32)
+        for name, _ in _COUNTERS:
+            rows[name] = int(getattr(r, name))
+        return rows
+
+    def project_batch_device(self, cfg, dev_batch, stream=0):
+        """dev_batch: dict of torch CUDA tensors (see bramble_amd.device.upload_batch).  Returns the
+        BrDeviceRows struct (device pointers owned by the context)."""
+        db = BrDeviceBatch()
+        db.n_aln = dev_batch["n_aln"]
+        db.n_groups = dev_batch["n_groups"]
+        for name in ("ref_id", "ref_start", "flags", "xs", "ts", "cigar_off", "cigar", "mate_idx", "group_off",
+                     "l_qseq"):
+            setattr(db, name, dev_batch[name].data_ptr())
+        db.n_cigar_words = dev_batch["n_cigar_words"]
+        db.max_n_cigar = dev_batch["max_n_cigar"]
+        out = BrDeviceRows()
+        check(lib().br_project_batch_device(self.h, C.byref(cfg), C.byref(db), C.c_void_p(stream), C.byref(out)),
+              "br_project_batch_device")
+        return out
+
+    def close(self):
+        if self.h:
+            lib().br_ctx_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,287 @@
+/* bramble_amd -- MI355X-native genome -> transcriptome projection engine.
+ *
+ * C ABI of libbramble_amd.so: the drop-in boundary for bramble's projection hot
+ * path.  Every entry point names the reference interface it replaces
+ * (paths relative to the bramble tree).  No torch / HIP types appear here:
+ * plain pointers, sizes and opaque handles only.  Device pointers are passed as
+ * `void *` / typed pointers that the caller obtained from its own allocator
+ * (hipMalloc, a torch tensor's data_ptr, ...).
+ *
+ * Conventions (same as the reference):
+ *   - exon intervals are 1-based half-open [start, end) (GTF end + 1;
+ *     src/bramble.cpp:164-165, bramble-rs/src/annotation.rs:52-64);
+ *   - ref_start / mate_start are 1-based SAM POS; projected `pos` is the 0-based
+ *     BAM core.pos the reference writes (src/core.cpp:153-158);
+ *   - CIGAR words are BAM-packed (len << 4 | op), ops 0..9 as in the SAM spec;
+ *   - input batches are name-collated: all alignments of one query name are
+ *     contiguous (README.md:39-52).
+ *
+ * All functions return BR_OK (0) or a negative BR_ERR_* code; none aborts.
+ * The library never falls back to a CPU path: without a usable HIP device the
+ * device entry points return BR_ERR_NO_DEVICE.
+ */
+#ifndef BRAMBLE_AMD_H
+#define BRAMBLE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BR_OK 0
+#define BR_ERR_INVALID_ARG (-1)
+#define BR_ERR_NO_DEVICE (-2)
+#define BR_ERR_HIP (-3)
+#define BR_ERR_ANNOTATION (-4) /* unknown seqname, overlapping exons inside a transcript, ... */
+#define BR_ERR_CAPACITY (-5)   /* batch exceeds 32-bit device offsets; split it */
+#define BR_ERR_UNSUPPORTED (-6)
+
+/* ---- annotation ------------------------------------------------------------ */
+
+/* bramble-rs/src/annotation.rs:13-17 (Exon) */
+typedef struct br_exon { uint32_t start, end; } br_exon;
+
+/* bramble-rs/src/annotation.rs:19-25 (Transcript); strand '+' or '-' */
+typedef struct br_transcript {
+  const char *id;
+  const char *seqname;
+  char strand;
+  const br_exon *exons;
+  uint32_t n_exons;
+} br_transcript;
+
+/* bramble-rs/src/fasta.rs:21-108 (FastaDb::from_seqs): one named sequence */
+typedef struct br_fasta_seq { const char *name; const char *seq; uint64_t len; } br_fasta_seq;
+
+typedef struct br_index br_index; /* immutable after build; shareable across threads (g2tTree) */
+typedef struct br_ctx br_ctx;     /* per host thread / per stream scratch (ProjectionContext) */
+
+/* Replaces build_g2t_tree (src/bramble.cpp:132-211) / build_g2t_from_refnames
+ * (bramble-rs/src/g2t.rs:515-532).  tid = position in `transcripts`.  `device`
+ * is the HIP device ordinal the flattened exon tables are uploaded to; pass -1
+ * for a host-only index (accessors work, projection does not).  `fasta` may be
+ * NULL (no -S). */
+int br_index_build(const br_transcript *transcripts, size_t n_transcripts, const char *const *refnames,
+                   size_t n_refnames, const br_fasta_seq *fasta, size_t n_fasta, int device,
+                   br_index **out);
+/* Same index from flat arrays (the form a GTF loader or a generator holds):
+ * transcript t lies on reference tx_ref_id[t] (0-based, < n_refs) with strand
+ * tx_strand[t] and exons [tx_exon_off[t], tx_exon_off[t+1]) of (ex_start, ex_end).
+ * tx_names may be NULL ("tx<t>"); fasta_by_ref is NULL or n_refs entries
+ * (seq == NULL: no sequence for that reference). */
+int br_index_build_flat(size_t n_tx, const int32_t *tx_ref_id, const int8_t *tx_strand,
+                        const uint64_t *tx_exon_off, const uint32_t *ex_start, const uint32_t *ex_end,
+                        const char *const *tx_names, size_t n_refs, const br_fasta_seq *fasta_by_ref,
+                        int device, br_index **out);
+void br_index_free(br_index *);
+/* bramble-rs/src/g2t.rs:320-342 accessors */
+size_t br_index_num_transcripts(const br_index *);
+const char *br_index_transcript_name(const br_index *, uint32_t tid); /* NULL if out of range */
+int64_t br_index_transcript_len(const br_index *, uint32_t tid);      /* -1 if out of range */
+size_t br_index_num_intervals(const br_index *);                      /* transcript-exon rows */
+size_t br_index_device_bytes(const br_index *);
+
+/* ---- configuration --------------------------------------------------------- */
+
+/* ProjectionConfig (bramble-rs/src/api.rs:184-206) widened with the C++ CLI
+ * switches that select the evaluator presets (src/bramble.cpp:457-485,
+ * src/evaluate.cpp:1136-1221).  has_* = the matching --max-... / --similarity-
+ * threshold override was given. */
+typedef struct br_config {
+  int32_t lr, lr_hq, strict; /* --lr, --lr-hq, --strict */
+  int32_t use_fasta;         /* -S given (index must have been built with sequences) */
+  int32_t fr, rf;            /* --fr, --rf */
+  int32_t has_max_clip, has_max_junc_ins, has_max_junc_gap, has_sim_thr, has_max_error_exon;
+  uint32_t max_clip, max_junc_ins, max_junc_gap, max_error_exon;
+  float sim_thr;
+  double junc_miss_discount; /* Rust-only knob (api.rs:197-205); must be 1.0 (C++ has none) */
+} br_config;
+
+void br_config_short_read(br_config *); /* ProjectionConfig::short_read, api.rs:210-216 */
+void br_config_long_read(br_config *);  /* ProjectionConfig::long_read (= --lr), api.rs:219-225 */
+
+/* Resolved evaluator thresholds (ReadEvaluationConfig, include/evaluate.h:275-285) */
+typedef struct br_thresholds {
+  uint32_t max_clip, max_junc_ins, max_junc_gap, max_error_exon;
+  int32_t ignore_small_exons, filter_by_similarity;
+  float similarity_threshold;
+} br_thresholds;
+int br_config_resolve(const br_config *, br_thresholds *out);
+
+/* ---- struct-of-arrays batches (host memory) --------------------------------- */
+
+/* Flat form of GenomicAlignment[] (bramble-rs/src/api.rs:73-126). */
+typedef struct br_batch {
+  int64_t n_aln;
+  const int32_t *ref_id;     /* 0-based; < 0: alignment skipped (api.rs:316-318) */
+  const int32_t *ref_start;  /* 1-based */
+  const uint16_t *flags;     /* SAM flag bits: 0x1 paired, 0x10 reverse, 0x40 read1, 0x80 read2 */
+  const int8_t *xs;          /* first char of XS tag or 0 */
+  const int8_t *ts;          /* first char of ts tag or 0 */
+  const uint64_t *cigar_off; /* n_aln + 1 */
+  const uint32_t *cigar;
+  const int32_t *mate_ref_id; /* -1 if none */
+  const int32_t *mate_start;  /* 1-based, 0 if none */
+  const uint64_t *name_off;   /* n_aln + 1 */
+  const char *names;
+  const uint64_t *seq_off;    /* n_aln + 1 or NULL */
+  const char *seqs;           /* ASCII bases */
+  const int32_t *l_qseq;
+} br_batch;
+
+/* Input contract of convert_reads computed on the host: read-name groups
+ * (src/core.cpp:347-380) and the mate index of process_pairs
+ * (src/bramble.cpp:272-311; at most one mate per alignment).  group_off must
+ * hold n_aln + 1 entries; *n_groups receives the group count. */
+int br_batch_prepare(const br_batch *, int32_t *mate_idx, uint32_t *group_off, int64_t *n_groups);
+
+/* One emitted BAM record (ProjectedAlignment, bramble-rs/src/api.rs:135-176, plus
+ * the fields the C++ writer sets: rewritten CIGAR, MAPQ, mate fields;
+ * src/core.cpp:96-212, src/bam.cpp:531-588).  Struct-of-arrays; arrays are owned
+ * by the context and stay valid until the next projection call on it. */
+typedef struct br_rows {
+  int64_t n_rows;
+  const int32_t *input_index;
+  const uint32_t *transcript_id;
+  const uint32_t *pos;            /* 0-based transcript position (fwpos / rcpos by strand) */
+  const int8_t *strand;           /* transcript strand '+' / '-' */
+  const uint64_t *cigar_off;      /* n_rows + 1, into cigar */
+  const uint32_t *cigar;          /* rewritten CIGAR (update_cigar, src/bam.cpp:502-528) */
+  const double *similarity_score;
+  const int32_t *clip_score;
+  const int32_t *junc_hits;
+  const int32_t *aligned_len;     /* ref_consumed: transcript bases spanned */
+  const uint32_t *nh, *hi, *mapq;
+  const uint8_t *is_primary;      /* host API only (needs read names; src/core.cpp:243-307) */
+  const uint8_t *is_paired;       /* emitted together with its mate */
+  const uint8_t *same_transcript_as_mate;
+  const uint8_t *is_first;        /* read1 side of the emitted pair */
+  const int32_t *mate_transcript_id, *mate_pos, *insert_size;
+  const uint32_t *group;          /* read-name group index */
+  /* counters of src/bramble.cpp:729-736 */
+  uint64_t total_complete, total_unique, dropped_reads, total_processed;
+} br_rows;
+
+/* ---- contexts and projection ------------------------------------------------ */
+
+int br_ctx_new(const br_index *, br_ctx **out);
+void br_ctx_free(br_ctx *);
+
+/* Replaces convert_reads minus BAM writing (include/evaluate.h:377-381; sole
+ * caller process_bundle, src/threads.cpp:100-104): host batch in, rows out.
+ * Uploads, runs the HIP pipeline on the context's stream, downloads, and
+ * finalises primary flags on the host. */
+int br_project_batch(br_ctx *, const br_config *, const br_batch *, br_rows *out);
+
+/* Device-resident form: every pointer is a device pointer on the index's
+ * device; offsets are 32-bit.  mate_idx / group_off come from
+ * br_batch_prepare.  `stream` is a hipStream_t (NULL = default stream). */
+typedef struct br_device_batch {
+  int64_t n_aln, n_groups;
+  const int32_t *ref_id;
+  const int32_t *ref_start;
+  const uint16_t *flags;
+  const int8_t *xs, *ts;
+  const uint32_t *cigar_off; /* n_aln + 1 */
+  const uint32_t *cigar;
+  const int32_t *mate_idx;   /* n_aln */
+  const uint32_t *group_off; /* n_groups + 1 */
+  const int32_t *l_qseq;
+  const uint32_t *seq_off;   /* n_aln + 1 or NULL */
+  const uint8_t *seqs;
+  int64_t n_cigar_words;     /* total words in cigar */
+  int32_t max_n_cigar;       /* longest single CIGAR in the batch */
+} br_device_batch;
+
+/* Rows as device pointers (same field meaning as br_rows; is_primary stays 0).
+ * Valid until the next projection call on the context. */
+typedef struct br_device_rows {
+  int64_t n_rows, n_matches, n_cigar_words;
+  const int32_t *input_index;
+  const uint32_t *transcript_id, *pos;
+  const int8_t *strand;
+  const uint64_t *cigar_off;
+  const uint32_t *cigar;
+  const double *similarity_score;
+  const int32_t *clip_score, *junc_hits, *aligned_len;
+  const uint32_t *nh, *hi, *mapq;
+  const uint8_t *is_paired, *same_transcript_as_mate, *is_first;
+  const int32_t *mate_transcript_id, *mate_pos, *insert_size;
+  const uint32_t *group;
+  uint64_t total_complete, total_unique, dropped_reads, total_processed;
+} br_device_rows;
+
+int br_project_batch_device(br_ctx *, const br_config *, const br_device_batch *, void *stream,
+                            br_device_rows *out);
+
+/* AoS convenience mirroring project_group_with (bramble-rs/src/api.rs:285-290):
+ * all alignments of ONE query name in, one br_projected per emitted record out
+ * (array owned by the context). */
+typedef struct br_alignment { /* GenomicAlignment, api.rs:73-126 */
+  const char *query_name;
+  int32_t ref_id;
+  int64_t ref_start;
+  uint8_t is_reverse, is_paired, is_first_in_pair, mate_is_unmapped;
+  char xs_strand, ts_strand; /* 0 = absent */
+  int32_t hit_index;
+  int32_t mate_ref_id;       /* -1 = none */
+  int64_t mate_ref_start;    /* 0 = none */
+  const uint32_t *cigar;     /* BAM-packed */
+  uint32_t n_cigar;
+  const char *sequence;      /* ASCII or NULL */
+  uint32_t sequence_len;
+  uint32_t read_len;
+} br_alignment;
+
+typedef struct br_projected { /* ProjectedAlignment, api.rs:135-176 */
+  uint32_t transcript_id;
+  uint32_t transcript_start; /* align_pos (groups.rs:362-368): fwpos / rcpos */
+  uint32_t transcript_end;   /* transcript_start + aligned_len - 1, saturating */
+  uint32_t aligned_len, query_aligned_len;
+  uint8_t is_reverse;        /* transcript strand '-' */
+  double similarity_score;
+  uint32_t nh, hi;
+  uint8_t is_primary, same_transcript_as_mate, is_paired_out;
+  int32_t insert_size;
+  uint64_t input_index;
+  uint32_t mapq;
+  const uint32_t *cigar;     /* rewritten CIGAR, owned by the context */
+  uint32_t n_cigar;
+} br_projected;
+
+int br_project_group(br_ctx *, const br_config *, const br_alignment *alns, size_t n,
+                     const br_projected **out, size_t *n_out);
+
+/* ---- measurement hooks ------------------------------------------------------ */
+
+/* Kernel names reported by br_ctx_kernel_ms / rocprof. */
+#define BR_K_SEGMENT 0
+#define BR_K_COUNT 1
+#define BR_K_EMIT 2
+#define BR_K_PAIR_COUNT 3
+#define BR_K_PAIR_EMIT 4
+#define BR_K_GATHER 5
+#define BR_K_SCAN 6
+#define BR_K_NUM 7
+/* When enabled, every launch is bracketed by hipEvents on the launch stream. */
+int br_ctx_set_profiling(br_ctx *, int enabled);
+/* Launch tuning: "group_lanes" (8|16|32|64 lanes cooperating on one alignment),
+ * "blocks_per_cu" (grid size of the grid-stride projection kernels). */
+int br_ctx_set_param(br_ctx *, const char *key, int64_t value);
+/* Device time (ms) of kernel `which` during the last projection call, summed
+ * over its launches; *launches receives the launch count. */
+int br_ctx_kernel_ms(br_ctx *, int which, double *ms, int32_t *launches);
+/* Exact algorithmic byte counters of the last call (SURVEY.md 8d formula):
+ * out[0]=B_in, out[1]=B_idx, out[2]=B_out, out[3]=sum n_cigar, out[4]=read exons,
+ * out[5]=overlap hits, out[6]=matches, out[7]=output cigar words. */
+int br_ctx_last_counters(br_ctx *, uint64_t out[8]);
+
+const char *br_version(void);
+const char *br_strerror(int code);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BRAMBLE_AMD_H */

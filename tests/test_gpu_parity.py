@@ -1,0 +1,123 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the CPU oracle on
+the same seeded inputs, and against the reference's known answers."""
+import numpy as np
+import pytest
+
+from bramble_amd import lib, synth
+from bramble_amd.batch import annotation_from_gtf_like, make_batch
+from oracle import oracle_binding as ob
+from tests.parity import assert_rows_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def run_both(ann_dict, batch, group_lanes=64, **flags):
+    idx = lib.Index(ann_dict, device=0)
+    ctx = lib.Context(idx)
+    ctx.set_param("group_lanes", group_lanes)
+    prod = ctx.project_batch(lib.make_config(**flags), batch)
+    oi = ob.OracleIndex(ann_dict)
+    orc, _, _ = ob.run(oi, ob.make_flags(**flags), batch, want_matches=False)
+    ctx.close()
+    idx.close()
+    return prod, orc
+
+
+def test_reference_known_answers(golden):
+    fx = golden["projection"]
+    ann = annotation_from_gtf_like(fx["refnames"], fx["transcripts"])
+    names = [t["id"] for t in ann["transcripts"]]
+    idx = lib.Index(ann, device=0)
+    ctx = lib.Context(idx)
+    for rd in fx["reads"]:
+        batch = make_batch([{"name": rd["name"], "ref_id": rd["ref_id"], "ref_start": rd["ref_start"],
+                             "cigar": rd["cigar"], "read_len": rd["read_len"]}])
+        rows = ctx.project_batch(lib.make_config(), batch)
+        assert rows["n_rows"] == len(rd["expect"])
+        for k, exp in enumerate(rd["expect"]):
+            assert names[rows["transcript_id"][k]] == exp["transcript"]
+            assert rows["pos"][k] == exp["pos"] and chr(rows["strand"][k]) == exp["strand"]
+            assert rows["nh"][k] == exp["nh"] and rows["hi"][k] == exp["hi"] and rows["mapq"][k] == exp["mapq"]
+            assert rows["junc_hits"][k] == exp["junc_hits"]
+            c0, c1 = int(rows["cigar_off"][k]), int(rows["cigar_off"][k + 1])
+            assert ob.format_cigar(rows["cigar"][c0:c1]) == exp["out"]
+
+
+@pytest.mark.parametrize("group_lanes", [64, 16])
+@pytest.mark.parametrize("mode,flags", [("se", {}), ("pe", {}), ("pe", {"strict": 1}), ("pe", {"fr": 1}),
+                                        ("pe", {"rf": 1}), ("pe", {"max_clip": 2, "max_junc_ins": 3, "max_junc_gap": 3})])
+def test_small_annotation_short_reads(mode, flags, group_lanes):
+    ann = synth.Annotation("S")
+    b = ann.reads(10000, mode)
+    prod, orc = run_both(ann.as_dict(), b, group_lanes=group_lanes, **flags)
+    assert orc["n_rows"] > 1000
+    assert_rows_equal(prod, orc)
+
+
+def test_config1_10k_single_end(golden):
+    """BASELINE.json configs[0]: 10k single-end short reads, 1 chr / ~100 transcripts."""
+    ann = synth.Annotation("S")
+    b = ann.reads(10000, "se")
+    prod, orc = run_both(ann.as_dict(), b)
+    assert_rows_equal(prod, orc)
+
+
+def test_stranded_xs_tags():
+    ann = synth.Annotation("S")
+    b = ann.reads(5000, "pe", xs_tag=True)
+    prod, orc = run_both(ann.as_dict(), b)
+    assert_rows_equal(prod, orc)
+
+
+def test_all_matches_visible_when_unpaired():
+    """Clearing the paired flag emits every match of every alignment: compares the full
+    evaluate-level table (tid, pos, rewritten CIGAR) rather than the pair-filtered rows."""
+    ann = synth.Annotation("G", n_genes=3000, n_refs=3)
+    b = ann.reads(20000, "pe")
+    b["flags"] = (b["flags"] & ~np.uint16(0x1)).astype(np.uint16)
+    prod, orc = run_both(ann.as_dict(), b)
+    assert_rows_equal(prod, orc)
+
+
+@pytest.mark.parametrize("group_lanes", [64, 32, 16, 8])
+def test_gencode_shaped_paired(group_lanes):
+    ann = synth.Annotation("G", n_genes=4000, n_refs=4)
+    b = ann.reads(40000, "pe")
+    prod, orc = run_both(ann.as_dict(), b, group_lanes=group_lanes)
+    assert orc["n_rows"] > 100000
+    assert_rows_equal(prod, orc)
+
+
+@pytest.mark.parametrize("mode,flags", [("hifi", {"lr_hq": 1}), ("hifi", {"lr": 1}), ("ont", {"lr": 1}),
+                                        ("hifi", {"lr_hq": 1, "strict": 1, "sim_thr": 0.95}),
+                                        ("ont", {"lr": 1, "max_error_exon": 0}), ("pe", {"max_error_exon": 30})])
+def test_long_read_presets_without_fasta(mode, flags):
+    ann = synth.Annotation("G", n_genes=3000, n_refs=3)
+    b = ann.reads(6000, mode)
+    prod, orc = run_both(ann.as_dict(), b, **flags)
+    assert orc["n_rows"] > 1000
+    assert_rows_equal(prod, orc)
+
+
+def test_empty_and_degenerate_inputs():
+    ann = synth.Annotation("S").as_dict()
+    idx = lib.Index(ann, device=0)
+    ctx = lib.Context(idx)
+    empty = make_batch([])
+    rows = ctx.project_batch(lib.make_config(), empty)
+    assert rows["n_rows"] == 0 and rows["total_processed"] == 0
+    recs = [
+        {"name": "a", "ref_id": -1, "ref_start": 100, "cigar": "50M"},          # no reference
+        {"name": "b", "ref_id": 7, "ref_start": 100, "cigar": "50M"},           # reference without a tree
+        {"name": "c", "ref_id": 0, "ref_start": 1, "cigar": "20S"},             # no aligned base
+        {"name": "d", "ref_id": 0, "ref_start": 2000000000, "cigar": "50M"},    # far beyond every exon
+        {"name": "e", "ref_id": 0, "ref_start": 5000, "cigar": "10N50M"},       # leading intron (uLTRA quirk)
+        {"name": "f", "ref_id": 0, "ref_start": 5000, "cigar": "20M100N5I100N20M"},  # insertion inside an intron
+        {"name": "g", "ref_id": 0, "ref_start": 5000, "cigar": "3H5S40M2D10M5S3H"},
+    ]
+    b = make_batch(recs)
+    prod = ctx.project_batch(lib.make_config(), b)
+    orc, _, _ = ob.run(ob.OracleIndex(ann), ob.make_flags(), b, want_matches=False)
+    assert_rows_equal(prod, orc)
+    ctx.close()
+    idx.close()
