@@ -679,7 +679,7 @@ extern "C" int br_project_batch(br_ctx *c, const br_config *cfg, const br_batch 
   size_t nr = (size_t)dr.n_rows;
   RC(d2h(c->h_input, dr.input_index, nr, st)); RC(d2h(c->h_tid, dr.transcript_id, nr, st));
   RC(d2h(c->h_pos, dr.pos, nr, st)); RC(d2h(c->h_strand, dr.strand, nr, st));
-  RC(d2h(c->h_cigoff, dr.cigar_off, nr + 1, st)); RC(d2h(c->h_cigar, dr.cigar, (size_t)dr.n_cigar_words, st));
+  RC(d2h(c->h_cigoff, dr.cigar_off, nr ? nr + 1 : 0, st)); RC(d2h(c->h_cigar, dr.cigar, (size_t)dr.n_cigar_words, st));
   RC(d2h(c->h_sim, dr.similarity_score, nr, st)); RC(d2h(c->h_clip, dr.clip_score, nr, st));
   RC(d2h(c->h_junc, dr.junc_hits, nr, st)); RC(d2h(c->h_refc, dr.aligned_len, nr, st));
   RC(d2h(c->h_nh, dr.nh, nr, st)); RC(d2h(c->h_hi, dr.hi, nr, st)); RC(d2h(c->h_mapq, dr.mapq, nr, st));

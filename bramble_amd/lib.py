@@ -100,6 +100,14 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise BrambleError("libbramble_amd.so is not built (run __graft_entry__.build() or "
                                "`make -C bramble_amd/csrc`); there is no CPU fallback for the projection path")
+        # One HIP runtime per process: torch bundles its own libamdhip64 (same SONAME as
+        # /opt/rocm's).  Importing torch first makes libbramble_amd.so bind to that copy,
+        # so torch tensors' device pointers and streams are valid for our launches; two
+        # runtimes side by side leave the second one without a usable device.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.br_index_build.argtypes = [_P(BrTranscript), C.c_size_t, _P(C.c_char_p), C.c_size_t, _P(BrFastaSeq),
                                      C.c_size_t, C.c_int, _P(C.c_void_p)]
