@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""Headline benchmark: projected alignments/sec against a GENCODE-scale annotation.
+
+One "step" = one pass of the projection hot path (k_segment -> k_project count ->
+scans -> k_project emit -> k_pair -> k_gather) over one synthetic name-collated
+batch that is already resident in HBM.  At N=1 the workload is BASELINE.json
+configs[1] (paired-end short reads vs a GENCODE-shaped annotation, 1 x MI355X);
+N>1 shards read-name groups across ranks (one process per GPU, a private index
+replica each, no collective on the data path) -- weak scaling.
+
+  python bench.py --gpus N --steps K --warmup W [--pairs P]
+
+Rank 0 prints ONE JSON line (contract in the task statement) that also carries
+`roofline` (dominant kernel, algorithmic bytes / live hipEvent duration) and
+`cpu_baseline` (the CPU oracle = restatement of the reference algorithm, timed on
+a bounded sample of the same workload on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs", type=int, default=int(os.environ.get("BENCH_PAIRS", 10_000_000)),
+                    help="read pairs per GPU per step (BASELINE configs[1]: 10M)")
+    ap.add_argument("--group-lanes", type=int, default=int(os.environ.get("BRAMBLE_AMD_GROUP_LANES", 0)))
+    ap.add_argument("--cpu-sample", type=int, default=400_000, help="alignments in the CPU-baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        dist = dist_mod
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+
+    from bramble_amd import device as brdev
+    from bramble_amd import lib, synth
+
+    t0 = time.time()
+    ann = synth.Annotation("G")
+    index = lib.Index.from_flat(ann.flat, device=local_rank)
+    ctx = lib.Context(index)
+    if args.group_lanes:
+        ctx.set_param("group_lanes", args.group_lanes)
+    cfg = lib.make_config()  # short-read defaults, unstranded (XS absent): both strands tried
+    # this rank's shard of read-name groups: its own seeded batch (weak scaling)
+    batch = ann.reads(args.pairs, "pe", seed=(synth.SEED ^ 0x51ED) + 7919 * rank)
+    n_aln = int(batch["n_aln"])
+    dbatch = brdev.upload_batch(batch, dev)
+    torch.cuda.synchronize()
+    setup_s = time.time() - t0
+
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    rows = None
+    for _ in range(args.warmup):
+        rows = ctx.project_batch_device(cfg, dbatch, stream)
+    ctx.set_profiling(True)
+    kernel_ms = {}
+    barrier()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        rows = ctx.project_batch_device(cfg, dbatch, stream)
+        for k, (ms, ln) in ctx.kernel_ms().items():
+            a = kernel_ms.setdefault(k, [0.0, 0])
+            a[0] += ms
+            a[1] += ln
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    ctx.set_profiling(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        cnt = torch.tensor([n_aln], dtype=torch.float64, device=dev)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        total_aln = float(cnt.item())
+    else:
+        total_aln = float(n_aln)
+
+    if rank == 0:
+        counters = ctx.collect_counters(dbatch, stream)
+        alg_bytes = counters["B_in"] + counters["B_idx"] + counters["B_out"]
+        # dominant kernel = largest share of device time over the timed steps
+        dom = max((k for k in kernel_ms if kernel_ms[k][1]), key=lambda k: kernel_ms[k][0])
+        launches_per_step = kernel_ms[dom][1] / args.steps
+        dom_ms = kernel_ms[dom][0] / args.steps  # device ms of that kernel per step (= per launch of the path)
+        achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("pairs") == args.pairs and tj.get("kernel") == dom:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "projected alignments/sec vs GENCODE-scale annotation",
+            "value": total_aln * args.steps / elapsed,
+            "unit": "alignments/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {
+                "workload": "%dM paired-end 2x100 short reads (name-collated, unstranded) vs GENCODE-shaped "
+                            "synthetic annotation (%d transcripts, %d transcript-exon rows, 25 refs); "
+                            "BASELINE.json configs[1]" % (args.pairs // 1_000_000, ann.n_tx, ann.n_exons)
+                if args.pairs >= 1_000_000 else
+                "%d paired-end 2x100 short reads vs GENCODE-shaped synthetic annotation (%d transcripts)" % (args.pairs, ann.n_tx),
+                "alignments_per_gpu_per_step": n_aln,
+                "pairs_per_gpu_per_step": args.pairs,
+                "sharding": "read-name groups per rank, index replicated, no collective",
+                "group_lanes": args.group_lanes or 64,
+                "seed": hex(synth.SEED),
+            },
+            "projected_records_per_step": int(rows.n_rows),
+            "matches_per_step": int(rows.n_matches),
+            "setup_seconds": round(setup_s, 1),
+            "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in kernel_ms.items()},
+            "roofline": {
+                "bound": "hbm",
+                "kernel": dom,
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "algorithmic_bytes_per_alignment": alg_bytes / n_aln,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "kernel_ms_per_launch": dom_ms,
+                "kernel_launches_per_step": launches_per_step,
+                "counters": counters,
+            },
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(ann, batch, args.cpu_sample)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(ann, batch, sample_aln):
+    """The CPU oracle (restatement of the reference algorithm; NOT the bramble binary, which
+    cannot be built here) on the first `sample_aln` alignments of the same batch, cut at a
+    read-name boundary: -p 1 and -p nproc, bundle-per-thread like src/threads.cpp."""
+    import numpy as np
+    from oracle import oracle_binding as ob
+    n = int(batch["n_aln"])
+    noff = batch["name_off"]
+    names = batch["names"]
+
+    def name(i):
+        return bytes(names[int(noff[i]):int(noff[i + 1])])
+
+    def head(cut):
+        cut = min(cut, n)
+        while cut < n and cut > 0 and name(cut) == name(cut - 1):
+            cut += 1
+        sub = {"n_aln": cut}
+        for k in ("ref_id", "ref_start", "flags", "xs", "ts", "mate_ref_id", "mate_start", "l_qseq"):
+            sub[k] = batch[k][:cut]
+        sub["cigar_off"] = batch["cigar_off"][:cut + 1]
+        sub["cigar"] = batch["cigar"][:int(sub["cigar_off"][-1])]
+        sub["name_off"] = batch["name_off"][:cut + 1]
+        sub["names"] = batch["names"][:int(sub["name_off"][-1])]
+        sub["seq_off"] = None
+        sub["seqs"] = None
+        return sub
+
+    f = ann.flat
+    oi = ob.OracleIndex.__new__(ob.OracleIndex)
+    L = ob.lib()
+    oi.h = L.orc_index_new()
+    import numpy as np  # noqa: F811
+    exs = np.stack([f["ex_start"], f["ex_end"]], axis=1).astype(np.uint32)
+    off = f["tx_exon_off"].astype(np.int64)
+    for t in range(len(f["tx_ref"])):
+        e = np.ascontiguousarray(exs[off[t]:off[t + 1]]).reshape(-1)
+        L.orc_index_add_transcript(oi.h, int(f["tx_ref"][t]), bytes([int(f["tx_strand"][t])]), b"", e.ctypes.data,
+                                   len(e) // 2, None, 0)
+    L.orc_index_finish(oi.h)
+    # the GPU box gives one GPU a 16-core CPU share
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, int(os.environ.get("BENCH_CPU_THREADS", 16))))
+    sub1 = head(sample_aln)
+    # the reference cuts bundles of >= 100000 alignments (src/bramble.cpp:362): give every worker two
+    subn = head(max(sample_aln, 2 * 100000 * cores))
+    _, _, s1 = ob.run(oi, ob.make_flags(), sub1, n_threads=1, want_matches=False)
+    _, _, sn = ob.run(oi, ob.make_flags(), subn, n_threads=cores, want_matches=False)
+    return {
+        "value": subn["n_aln"] / sn,
+        "unit": "alignments/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "first %d alignments of the same batch (cut at a read-name boundary) on %d threads, bundles of "
+                  ">=100000 alignments per worker like src/threads.cpp; CPU oracle = restatement of the reference "
+                  "algorithm (not the bramble binary); 1-thread figure on the first %d alignments"
+                  % (subn["n_aln"], cores, sub1["n_aln"]),
+        "value_1_thread": sub1["n_aln"] / s1,
+        "cores_1_thread": 1,
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -603,11 +603,37 @@ int run_device(br_ctx *c, const br_config *cfg, const br_device_batch *b, hipStr
   out->is_first = c->r_first.as<uint8_t>();
   out->mate_transcript_id = c->r_mate_tid.as<int32_t>(); out->mate_pos = c->r_mate_pos.as<int32_t>();
   out->insert_size = c->r_isize.as<int32_t>(); out->group = c->r_group.as<uint32_t>();
-  c->counters[6] = n_matches; c->counters[7] = n_out_words;
+  c->counters[6] = n_matches;
   return BR_OK;
 }
 
 }  // namespace
+
+// Exact counters of the algorithmic-bytes formula for the batch the context
+// projected last (its exon / match tables are still resident).
+extern "C" int br_ctx_collect_counters(br_ctx *c, const br_device_batch *b, void *stream) {
+  if (!c || !b) return BR_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(hipSetDevice(c->ix->device));
+  RC(c->totals.ensure(8 * 8));
+  DevBuf stats; RC(stats.ensure(8 * 8));
+  HIPCHK(hipMemsetAsync(stats.p, 0, 8 * 8, st));
+  StatsArgs T{};
+  T.ix = c->ix->dev; T.n_aln = b->n_aln; T.ref_id = b->ref_id; T.cigar_off = b->cigar_off;
+  T.seg = c->seg.as<uint2>(); T.meta = c->meta.as<AlnMeta>(); T.out = stats.as<uint64_t>();
+  int64_t nm = (int64_t)c->counters[6];
+  launch_stats(st, T, c->m_ncig.as<uint32_t>(), nm);
+  uint64_t h[8];
+  HIPCHK(hipMemcpyAsync(h, stats.p, 8 * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  stats.release();
+  uint64_t n = (uint64_t)b->n_aln;
+  c->counters[3] = h[3]; c->counters[4] = h[4]; c->counters[5] = h[5]; c->counters[7] = h[7];
+  c->counters[0] = 24ull * n + 4ull * h[3];
+  c->counters[1] = h[1];
+  c->counters[2] = 4ull * n + 24ull * (uint64_t)nm + 4ull * h[7];
+  return BR_OK;
+}
 
 extern "C" int br_project_batch_device(br_ctx *c, const br_config *cfg, const br_device_batch *b, void *stream,
                                        br_device_rows *out) {

@@ -75,6 +75,17 @@ struct RowArgs {
   uint8_t *r_paired, *r_same, *r_first;
 };
 
+struct StatsArgs {
+  DevIndex ix;
+  int64_t n_aln;
+  const int32_t *ref_id;
+  const uint32_t *cigar_off;
+  const uint2 *seg;
+  const AlnMeta *meta;
+  uint64_t *out;  // [8]
+};
+void launch_stats(hipStream_t st, const StatsArgs &T, const uint32_t *m_ncig, int64_t n_matches);
+
 void launch_segment(hipStream_t st, int64_t n_aln, const int32_t *ref_id, const int32_t *ref_start,
                     const uint16_t *flags, const int8_t *xs, const int8_t *ts, const uint32_t *cigar_off,
                     const uint32_t *cigar, const DevCfg &cfg, uint32_t n_refs, uint2 *seg, AlnMeta *meta);

@@ -941,6 +941,60 @@ __global__ void __launch_bounds__(256) k_gather(RowArgs R) {
 }
 
 // ---------------------------------------------------------------------------
+// k_stats (diagnostic, never timed): exact counters of the algorithmic-bytes
+// formula of SURVEY.md 8(d).  One lane per alignment; for every strand tried and
+// every read exon: the two key searches (8 * ceil(log2 N_slab) bytes) and 40 bytes
+// per overlapping row.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_stats(StatsArgs T) {
+  int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long b_idx = 0, hits = 0, exons = 0, ncig = 0;
+  if (a < T.n_aln) {
+    AlnMeta mt = T.meta[a];
+    uint32_t c0 = T.cigar_off[a];
+    ncig = T.cigar_off[a + 1] - c0;
+    if (mt.n_seg) {
+      const uint2 *seg = T.seg + (size_t)c0 + (size_t)a;
+      uint32_t rid = (uint32_t)T.ref_id[a];
+      exons = mt.n_seg;
+      for (int s = 0; s < 2; s++) {
+        if (!((mt.smode >> s) & 1u)) continue;
+        uint32_t sb = T.ix.slab_off[2 * rid + s], se = T.ix.slab_off[2 * rid + s + 1];
+        uint32_t N = se - sb, lg = 0;
+        while ((1u << lg) < N) lg++;
+        for (uint32_t j = 0; j < mt.n_seg; j++) {
+          uint2 q = seg[j];
+          uint32_t x = sb, y = se;
+          while (x < y) { uint32_t m = (x + y) >> 1; if (T.ix.s_start[m] < q.y) x = m + 1; else y = m; }
+          uint32_t hi = x; x = sb; y = hi;
+          while (x < y) { uint32_t m = (x + y) >> 1; if (T.ix.s_pmax[m] <= q.x) x = m + 1; else y = m; }
+          uint32_t h = 0;
+          for (uint32_t r = x; r < hi; r++) h += T.ix.s_end[r] > q.x ? 1u : 0u;
+          hits += h; b_idx += 8ull * lg + 40ull * h;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    b_idx += __shfl_down(b_idx, d, 64); hits += __shfl_down(hits, d, 64);
+    exons += __shfl_down(exons, d, 64); ncig += __shfl_down(ncig, d, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd((unsigned long long *)&T.out[1], b_idx); atomicAdd((unsigned long long *)&T.out[3], ncig);
+    atomicAdd((unsigned long long *)&T.out[4], exons); atomicAdd((unsigned long long *)&T.out[5], hits);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_sum_u32(const uint32_t *src, int64_t n, uint64_t *out) {
+  unsigned long long acc = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) acc += src[i];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) acc += __shfl_down(acc, d, 64);
+  if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long *)out, acc);
+}
+
+// ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
 static inline int grid_for(int64_t n, int per_block) { return (int)((n + per_block - 1) / per_block); }
@@ -993,6 +1047,11 @@ void launch_scan(hipStream_t st, const ScanArgs &S, int mode, void *out, bool ou
     if (out64) hipLaunchKernelGGL((k_scan_apply<2, uint64_t>), g, b, 0, st, S, (uint64_t *)out);
     else hipLaunchKernelGGL((k_scan_apply<2, uint32_t>), g, b, 0, st, S, (uint32_t *)out);
   }
+}
+
+void launch_stats(hipStream_t st, const StatsArgs &T, const uint32_t *m_ncig, int64_t n_matches) {
+  if (T.n_aln > 0) hipLaunchKernelGGL(k_stats, dim3(grid_for(T.n_aln, 256)), dim3(256), 0, st, T);
+  if (n_matches > 0) hipLaunchKernelGGL(k_sum_u32, dim3(1024), dim3(256), 0, st, m_ncig, n_matches, T.out + 7);
 }
 
 void launch_pair(hipStream_t st, const PairArgs &P, bool emit) {

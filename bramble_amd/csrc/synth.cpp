@@ -52,7 +52,7 @@ Annotation *gen_annotation(const AnnParams &P) {
     uint32_t prev_gene_start = 0, prev_gene_end = 0;
     for (int g = 0; g < genes_per_ref; g++, gene_id++) {
       // master exon chain
-      uint32_t m = 1 + rng.geometric(P.mean_exons * 1.35);
+      uint32_t m = 1 + rng.geometric(P.mean_exons * 1.05);
       if (gene_id % 4001 == 2000) m = 260 + rng.below(140);  // exercise the uint8 exon_id wrap
       if (m > (uint32_t)P.max_exons) m = P.max_exons;
       uint32_t start;

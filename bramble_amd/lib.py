@@ -89,7 +89,7 @@ EXPORTS = ["br_index_build", "br_index_build_flat", "br_index_free", "br_index_n
            "br_index_transcript_len", "br_index_num_intervals", "br_index_device_bytes", "br_config_short_read",
            "br_config_long_read", "br_config_resolve", "br_batch_prepare", "br_ctx_new", "br_ctx_free",
            "br_project_batch", "br_project_batch_device", "br_project_group", "br_ctx_set_profiling",
-           "br_ctx_set_param", "br_ctx_kernel_ms", "br_ctx_last_counters", "br_version", "br_strerror"]
+           "br_ctx_set_param", "br_ctx_kernel_ms", "br_ctx_collect_counters", "br_ctx_last_counters", "br_version", "br_strerror"]
 
 _LIB = None
 
@@ -136,6 +136,7 @@ def lib():
         L.br_ctx_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.br_ctx_set_param.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
         L.br_ctx_kernel_ms.argtypes = [C.c_void_p, C.c_int, _P(C.c_double), _P(C.c_int32)]
+        L.br_ctx_collect_counters.argtypes = [C.c_void_p, _P(BrDeviceBatch), C.c_void_p]
         L.br_ctx_last_counters.argtypes = [C.c_void_p, C.c_void_p]
         L.br_version.restype = C.c_char_p
         L.br_strerror.restype = C.c_char_p
@@ -347,9 +348,8 @@ class Context:
             rows[name] = int(getattr(r, name))
         return rows
 
-    def project_batch_device(self, cfg, dev_batch, stream=0):
-        """dev_batch: dict of torch CUDA tensors (see bramble_amd.device.upload_batch).  Returns the
-        BrDeviceRows struct (device pointers owned by the context)."""
+    @staticmethod
+    def _device_batch_struct(dev_batch):
         db = BrDeviceBatch()
         db.n_aln = dev_batch["n_aln"]
         db.n_groups = dev_batch["n_groups"]
@@ -358,6 +358,21 @@ class Context:
             setattr(db, name, dev_batch[name].data_ptr())
         db.n_cigar_words = dev_batch["n_cigar_words"]
         db.max_n_cigar = dev_batch["max_n_cigar"]
+        return db
+
+    def collect_counters(self, dev_batch, stream=0):
+        """Exact algorithmic-bytes counters of the batch projected last."""
+        db = self._device_batch_struct(dev_batch)
+        check(lib().br_ctx_collect_counters(self.h, C.byref(db), C.c_void_p(stream)), "br_ctx_collect_counters")
+        out = (C.c_uint64 * 8)()
+        check(lib().br_ctx_last_counters(self.h, out), "br_ctx_last_counters")
+        keys = ("B_in", "B_idx", "B_out", "n_cigar", "read_exons", "overlap_hits", "matches", "out_cigar_words")
+        return dict(zip(keys, [int(v) for v in out]))
+
+    def project_batch_device(self, cfg, dev_batch, stream=0):
+        """dev_batch: dict of torch CUDA tensors (see bramble_amd.device.upload_batch).  Returns the
+        BrDeviceRows struct (device pointers owned by the context)."""
+        db = self._device_batch_struct(dev_batch)
         out = BrDeviceRows()
         check(lib().br_project_batch_device(self.h, C.byref(cfg), C.byref(db), C.c_void_p(stream), C.byref(out)),
               "br_project_batch_device")

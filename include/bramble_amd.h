@@ -273,9 +273,12 @@ int br_ctx_set_param(br_ctx *, const char *key, int64_t value);
 /* Device time (ms) of kernel `which` during the last projection call, summed
  * over its launches; *launches receives the launch count. */
 int br_ctx_kernel_ms(br_ctx *, int which, double *ms, int32_t *launches);
-/* Exact algorithmic byte counters of the last call (SURVEY.md 8d formula):
+/* Diagnostic pass (never part of a timed region): computes the exact counters below
+ * for the device batch the context projected last. */
+int br_ctx_collect_counters(br_ctx *, const br_device_batch *, void *stream);
+/* Exact algorithmic byte counters (SURVEY.md 8d formula), after br_ctx_collect_counters:
  * out[0]=B_in, out[1]=B_idx, out[2]=B_out, out[3]=sum n_cigar, out[4]=read exons,
- * out[5]=overlap hits, out[6]=matches, out[7]=output cigar words. */
+ * out[5]=overlap hits, out[6]=matches, out[7]=rewritten-CIGAR words over all matches. */
 int br_ctx_last_counters(br_ctx *, uint64_t out[8]);
 
 const char *br_version(void);
