@@ -39,11 +39,11 @@ struct br_index {
   uint32_t n_refs = 0;
   bool has_seq = false;
   // host copies of the flattened tables
-  std::vector<uint32_t> slab_off, s_start, s_end, s_pmax, tx_first;
+  std::vector<uint32_t> slab_off, s_start, s_end, s_pmax, s_next, tx_first;
   std::vector<uint4> s_pay, tx_ex;
   std::vector<uint8_t> seq_pool;
   // device copies
-  void *d_slab_off = nullptr, *d_s_start = nullptr, *d_s_end = nullptr, *d_s_pmax = nullptr,
+  void *d_slab_off = nullptr, *d_s_start = nullptr, *d_s_end = nullptr, *d_s_pmax = nullptr, *d_s_next = nullptr,
        *d_s_pay = nullptr, *d_tx_ex = nullptr, *d_tx_first = nullptr, *d_seq_pool = nullptr;
   size_t device_bytes = 0;
   DevIndex dev{};
@@ -131,6 +131,7 @@ static int build_index_flat(size_t n_tx, const int32_t *tx_ref, const int8_t *tx
       m = std::max(m, r.end);
       ix->s_start.push_back(r.start); ix->s_end.push_back(r.end); ix->s_pmax.push_back(m);
       ix->s_pay.push_back(make_uint4(r.tid, r.gidx, r.pos_start, ix->tx_first[r.tid]));
+      ix->s_next.push_back(ix->tx_ex[ix->tx_first[r.tid] + r.gidx + 1].x);  // sentinel start = ~0u
     }
     ix->slab_off.push_back((uint32_t)ix->s_start.size());
   }
@@ -142,6 +143,7 @@ static int build_index_flat(size_t n_tx, const int32_t *tx_ref, const int8_t *tx
     size_t acc = 0;
     if ((rc = upload(&ix->d_slab_off, ix->slab_off, acc)) || (rc = upload(&ix->d_s_start, ix->s_start, acc)) ||
         (rc = upload(&ix->d_s_end, ix->s_end, acc)) || (rc = upload(&ix->d_s_pmax, ix->s_pmax, acc)) ||
+        (rc = upload(&ix->d_s_next, ix->s_next, acc)) ||
         (rc = upload(&ix->d_s_pay, ix->s_pay, acc)) || (rc = upload(&ix->d_tx_ex, ix->tx_ex, acc)) ||
         (rc = upload(&ix->d_tx_first, ix->tx_first, acc)) || (rc = upload(&ix->d_seq_pool, ix->seq_pool, acc))) {
       br_index_free(ix); return rc;
@@ -151,6 +153,7 @@ static int build_index_flat(size_t n_tx, const int32_t *tx_ref, const int8_t *tx
     d.n_refs = ix->n_refs; d.n_tx = (uint32_t)n_tx; d.n_rows = (uint32_t)ix->s_start.size();
     d.slab_off = (const uint32_t *)ix->d_slab_off; d.s_start = (const uint32_t *)ix->d_s_start;
     d.s_end = (const uint32_t *)ix->d_s_end; d.s_pmax = (const uint32_t *)ix->d_s_pmax;
+    d.s_next = (const uint32_t *)ix->d_s_next;
     d.s_pay = (const uint4 *)ix->d_s_pay; d.tx_ex = (const uint4 *)ix->d_tx_ex;
     d.tx_first = (const uint32_t *)ix->d_tx_first; d.seq_pool = (const uint8_t *)ix->d_seq_pool;
   }
@@ -204,7 +207,7 @@ extern "C" void br_index_free(br_index *ix) {
   if (!ix) return;
   if (ix->device >= 0) {
     (void)hipSetDevice(ix->device);
-    void *ptrs[] = {ix->d_slab_off, ix->d_s_start, ix->d_s_end, ix->d_s_pmax, ix->d_s_pay, ix->d_tx_ex,
+    void *ptrs[] = {ix->d_slab_off, ix->d_s_start, ix->d_s_end, ix->d_s_pmax, ix->d_s_next, ix->d_s_pay, ix->d_tx_ex,
                     ix->d_tx_first, ix->d_seq_pool};
     for (void *p : ptrs) if (p) (void)hipFree(p);
   }
@@ -340,9 +343,9 @@ struct br_ctx {
   double k_ms[BR_K_NUM] = {0}; int32_t k_launches[BR_K_NUM] = {0};
   uint64_t counters[8] = {0};
   // device scratch
-  DevBuf seg, meta, n_matches, ranges, mask, match_off, cig_base, tile_sums, totals, counters_d;
-  DevBuf m_tid, m_pos, m_ncig, m_aux, m_strand, m_cigoff, m_sim, m_junc, m_refc, m_clip, cig_arena;
-  DevBuf n_rows, row_off, r_input, r_match, r_nh, r_hi, r_mapq, r_group, r_flags, r_mate_tid, r_mate_pos,
+  DevBuf seg, meta, head, n_matches, ranges, mask, match_off, cig_base, tile_sums, totals, counters_d;
+  DevBuf m_tid, m_aux, m_a, m_b, m_cigoff, cig_arena;
+  DevBuf n_rows, row_off, aln_group, r_input, r_match, r_mate, r_flags, r_nh, r_hi, r_mapq, r_group, r_mate_tid, r_mate_pos,
       r_isize, r_tid, r_pos, r_ncig, r_strand, r_sim, r_clip, r_junc, r_refc, r_cigoff, cigar_out;
   DevBuf r_paired, r_same, r_first;  // unpacked flag bytes for the public row view
   // device staging of host batches (br_project_batch)
@@ -381,11 +384,11 @@ extern "C" int br_ctx_new(const br_index *ix, br_ctx **out) {
 extern "C" void br_ctx_free(br_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->ix->device);
-  DevBuf *bufs[] = {&c->seg, &c->meta, &c->n_matches, &c->ranges, &c->mask, &c->match_off, &c->cig_base,
-                    &c->tile_sums, &c->totals, &c->counters_d, &c->m_tid, &c->m_pos, &c->m_ncig, &c->m_aux,
-                    &c->m_strand, &c->m_cigoff, &c->m_sim, &c->m_junc, &c->m_refc, &c->m_clip, &c->cig_arena,
-                    &c->n_rows, &c->row_off, &c->r_input, &c->r_match, &c->r_nh, &c->r_hi, &c->r_mapq,
-                    &c->r_group, &c->r_flags, &c->r_mate_tid, &c->r_mate_pos, &c->r_isize, &c->r_tid, &c->r_pos,
+  DevBuf *bufs[] = {&c->seg, &c->meta, &c->head, &c->n_matches, &c->ranges, &c->mask, &c->match_off, &c->cig_base,
+                    &c->tile_sums, &c->totals, &c->counters_d, &c->m_tid, &c->m_aux, &c->m_a, &c->m_b,
+                    &c->m_cigoff, &c->cig_arena,
+                    &c->n_rows, &c->row_off, &c->aln_group, &c->r_input, &c->r_match, &c->r_mate, &c->r_flags, &c->r_nh, &c->r_hi, &c->r_mapq,
+                    &c->r_group, &c->r_mate_tid, &c->r_mate_pos, &c->r_isize, &c->r_tid, &c->r_pos,
                     &c->r_ncig, &c->r_strand, &c->r_sim, &c->r_clip, &c->r_junc, &c->r_refc, &c->r_cigoff,
                     &c->cigar_out, &c->r_paired, &c->r_same, &c->r_first, &c->b_ref_id, &c->b_ref_start,
                     &c->b_flags, &c->b_xs, &c->b_ts, &c->b_cigar_off, &c->b_cigar, &c->b_mate_idx,
@@ -469,7 +472,7 @@ int run_device(br_ctx *c, const br_config *cfg, const br_device_batch *b, hipStr
 
   int64_t tiles = std::max<int64_t>(scan_tiles_for(std::max<int64_t>(n, ng) + 1), 1);
   RC(c->seg.ensure((size_t)(b->n_cigar_words + n) * sizeof(uint2)));
-  RC(c->meta.ensure((size_t)n * sizeof(AlnMeta)));
+  RC(c->meta.ensure((size_t)n * sizeof(AlnMeta))); RC(c->head.ensure((size_t)n * sizeof(uint4)));
   RC(c->n_matches.ensure((size_t)n * 4)); RC(c->ranges.ensure((size_t)n * sizeof(uint4)));
   RC(c->mask.ensure((size_t)n * 8)); RC(c->match_off.ensure((size_t)(n + 1) * 4));
   RC(c->cig_base.ensure((size_t)(n + 1) * 8)); RC(c->tile_sums.ensure((size_t)tiles * 8));
@@ -479,12 +482,13 @@ int run_device(br_ctx *c, const br_config *cfg, const br_device_batch *b, hipStr
   // a1/a2/a6: CIGAR -> read exons
   RC(pf.begin(BR_K_SEGMENT));
   launch_segment(st, n, b->ref_id, b->ref_start, b->flags, b->xs, b->ts, b->cigar_off, b->cigar, dc, ix->n_refs,
-                 c->seg.as<uint2>(), c->meta.as<AlnMeta>());
+                 c->seg.as<uint2>(), c->meta.as<AlnMeta>(), c->head.as<uint4>());
   RC(pf.end());
 
   ProjectArgs A{};
   A.ix = ix->dev; A.cfg = dc; A.n_aln = n; A.ref_id = b->ref_id; A.cigar_off = b->cigar_off; A.cigar = b->cigar;
-  A.seg = c->seg.as<uint2>(); A.meta = c->meta.as<AlnMeta>(); A.n_matches = c->n_matches.as<uint32_t>();
+  A.seg = c->seg.as<uint2>(); A.meta = c->meta.as<AlnMeta>(); A.head = c->head.as<uint4>();
+  A.n_matches = c->n_matches.as<uint32_t>();
   A.ranges = c->ranges.as<uint4>(); A.mask = c->mask.as<uint64_t>();
   A.match_off = c->match_off.as<uint32_t>(); A.cig_base = c->cig_base.as<uint64_t>();
   int n_blocks = c->n_cu * c->blocks_per_cu;
@@ -493,7 +497,7 @@ int run_device(br_ctx *c, const br_config *cfg, const br_device_batch *b, hipStr
   RC(pf.end());
 
   ScanArgs S{};
-  S.n = n; S.src32 = c->n_matches.as<uint32_t>(); S.cigar_off = b->cigar_off; S.meta = c->meta.as<AlnMeta>();
+  S.n = n; S.src32 = c->n_matches.as<uint32_t>(); S.cigar_off = b->cigar_off; S.head = c->head.as<uint4>();
   S.tile_sums = c->tile_sums.as<uint64_t>();
   RC(pf.begin(BR_K_SCAN));
   launch_scan(st, S, 0, c->match_off.p, false, d_tot + 0);
@@ -506,14 +510,11 @@ int run_device(br_ctx *c, const br_config *cfg, const br_device_batch *b, hipStr
   out->n_matches = (int64_t)n_matches;
 
   size_t nm = (size_t)std::max<uint64_t>(n_matches, 1);
-  RC(c->m_tid.ensure(nm * 4)); RC(c->m_pos.ensure(nm * 4)); RC(c->m_ncig.ensure(nm * 4)); RC(c->m_aux.ensure(nm * 4));
-  RC(c->m_strand.ensure(nm)); RC(c->m_cigoff.ensure(nm * 8)); RC(c->m_sim.ensure(nm * 8));
-  RC(c->m_junc.ensure(nm * 4)); RC(c->m_refc.ensure(nm * 4)); RC(c->m_clip.ensure(nm * 4));
+  RC(c->m_tid.ensure(nm * 4)); RC(c->m_aux.ensure(nm * 4)); RC(c->m_a.ensure(nm * sizeof(uint4)));
+  RC(c->m_b.ensure(nm * sizeof(uint4))); RC(c->m_cigoff.ensure(nm * 8));
   RC(c->cig_arena.ensure((size_t)std::max<uint64_t>(n_cig_arena, 1) * 4));
-  A.m_tid = c->m_tid.as<uint32_t>(); A.m_pos = c->m_pos.as<uint32_t>(); A.m_ncig = c->m_ncig.as<uint32_t>();
-  A.m_aux = c->m_aux.as<uint32_t>(); A.m_strand = c->m_strand.as<int8_t>(); A.m_cigoff = c->m_cigoff.as<uint64_t>();
-  A.m_sim = c->m_sim.as<double>(); A.m_junc = c->m_junc.as<int32_t>(); A.m_refc = c->m_refc.as<int32_t>();
-  A.m_clip = c->m_clip.as<int32_t>(); A.cig_arena = c->cig_arena.as<uint32_t>();
+  A.m_tid = c->m_tid.as<uint32_t>(); A.m_aux = c->m_aux.as<uint32_t>(); A.m_a = c->m_a.as<uint4>();
+  A.m_b = c->m_b.as<uint4>(); A.m_cigoff = c->m_cigoff.as<uint64_t>(); A.cig_arena = c->cig_arena.as<uint32_t>();
   if (n_matches) {
     RC(pf.begin(BR_K_EMIT));
     launch_project(st, A, true, c->group_lanes, n_blocks);
@@ -521,56 +522,59 @@ int run_device(br_ctx *c, const br_config *cfg, const br_device_batch *b, hipStr
   }
 
   // a16/a17: pairing + NH
-  RC(c->n_rows.ensure((size_t)std::max<int64_t>(ng, 1) * 4)); RC(c->row_off.ensure((size_t)(ng + 1) * 8));
+  RC(c->n_rows.ensure((size_t)n * 4)); RC(c->row_off.ensure((size_t)(n + 1) * 8)); RC(c->aln_group.ensure((size_t)n * 4));
+  launch_group_ids(st, ng, b->group_off, c->aln_group.as<uint32_t>());
   HIPCHK(hipMemsetAsync(c->counters_d.p, 0, 4 * 8, st));
   PairArgs P{};
-  P.n_groups = ng; P.long_reads = dc.long_reads; P.group_off = b->group_off; P.mate_idx = b->mate_idx;
-  P.match_off = c->match_off.as<uint32_t>(); P.m_tid = A.m_tid; P.m_pos = A.m_pos; P.l_qseq = b->l_qseq;
+  P.n_groups = ng; P.n_aln = n; P.long_reads = dc.long_reads; P.group_off = b->group_off; P.mate_idx = b->mate_idx;
+  P.aln_group = c->aln_group.as<uint32_t>();
+  P.match_off = c->match_off.as<uint32_t>(); P.m_tid = A.m_tid; P.m_a = A.m_a; P.m_b = A.m_b; P.l_qseq = b->l_qseq;
   P.n_rows = c->n_rows.as<uint32_t>(); P.row_off = c->row_off.as<uint64_t>(); P.counters = c->counters_d.as<uint64_t>();
   RC(pf.begin(BR_K_PAIR_COUNT));
   launch_pair(st, P, false);
   RC(pf.end());
   ScanArgs S2{};
-  S2.n = ng; S2.src32 = c->n_rows.as<uint32_t>(); S2.tile_sums = c->tile_sums.as<uint64_t>();
+  S2.n = n; S2.src32 = c->n_rows.as<uint32_t>(); S2.tile_sums = c->tile_sums.as<uint64_t>();
   RC(pf.begin(BR_K_SCAN));
   launch_scan(st, S2, 2, c->row_off.p, true, d_tot + 2);
   RC(pf.end());
   HIPCHK(hipMemcpyAsync(c->h_totals + 2, d_tot + 2, 8, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipMemcpyAsync(c->h_totals + 4, c->counters_d.p, 4 * 8, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   uint64_t n_rows = c->h_totals[2];
   out->n_rows = (int64_t)n_rows;
-  out->total_complete = n_rows; out->total_unique = c->h_totals[5]; out->dropped_reads = c->h_totals[6];
 
   size_t nr = (size_t)std::max<uint64_t>(n_rows, 1);
-  RC(c->r_input.ensure(nr * 4)); RC(c->r_match.ensure(nr * 4)); RC(c->r_nh.ensure(nr * 4)); RC(c->r_hi.ensure(nr * 4));
-  RC(c->r_mapq.ensure(nr * 4)); RC(c->r_group.ensure(nr * 4)); RC(c->r_flags.ensure(nr));
+  RC(c->r_input.ensure(nr * 4)); RC(c->r_match.ensure(nr * 4)); RC(c->r_mate.ensure(nr * 4)); RC(c->r_flags.ensure(nr));
+  RC(c->r_nh.ensure(nr * 4)); RC(c->r_hi.ensure(nr * 4));
+  RC(c->r_mapq.ensure(nr * 4)); RC(c->r_group.ensure(nr * 4));
   RC(c->r_mate_tid.ensure(nr * 4)); RC(c->r_mate_pos.ensure(nr * 4)); RC(c->r_isize.ensure(nr * 4));
   RC(c->r_tid.ensure(nr * 4)); RC(c->r_pos.ensure(nr * 4)); RC(c->r_ncig.ensure(nr * 4)); RC(c->r_strand.ensure(nr));
   RC(c->r_sim.ensure(nr * 8)); RC(c->r_clip.ensure(nr * 4)); RC(c->r_junc.ensure(nr * 4)); RC(c->r_refc.ensure(nr * 4));
   RC(c->r_cigoff.ensure((nr + 1) * 8));
   RC(c->r_paired.ensure(nr)); RC(c->r_same.ensure(nr)); RC(c->r_first.ensure(nr));
-  P.r_input = c->r_input.as<int32_t>(); P.r_match = c->r_match.as<uint32_t>(); P.r_nh = c->r_nh.as<uint32_t>();
+  P.r_input = c->r_input.as<int32_t>(); P.r_match = c->r_match.as<uint32_t>(); P.r_mate = c->r_mate.as<uint32_t>();
+  P.r_flags = c->r_flags.as<uint8_t>(); P.r_nh = c->r_nh.as<uint32_t>();
   P.r_hi = c->r_hi.as<uint32_t>(); P.r_mapq = c->r_mapq.as<uint32_t>(); P.r_group = c->r_group.as<uint32_t>();
-  P.r_flags = c->r_flags.as<uint8_t>(); P.r_mate_tid = c->r_mate_tid.as<int32_t>();
+  P.r_mate_tid = c->r_mate_tid.as<int32_t>();
   P.r_mate_pos = c->r_mate_pos.as<int32_t>(); P.r_isize = c->r_isize.as<int32_t>();
+  P.r_tid = c->r_tid.as<uint32_t>(); P.r_pos = c->r_pos.as<uint32_t>(); P.r_ncig = c->r_ncig.as<uint32_t>();
+  P.r_strand = c->r_strand.as<int8_t>(); P.r_sim = c->r_sim.as<double>(); P.r_clip = c->r_clip.as<int32_t>();
+  P.r_junc = c->r_junc.as<int32_t>(); P.r_refc = c->r_refc.as<int32_t>(); P.r_paired = c->r_paired.as<uint8_t>();
+  P.r_same = c->r_same.as<uint8_t>(); P.r_first = c->r_first.as<uint8_t>();
   uint64_t n_out_words = 0;
   if (n_rows) {
     RC(pf.begin(BR_K_PAIR_EMIT));
     launch_pair(st, P, true);
     RC(pf.end());
+  }
+  RC(pf.begin(BR_K_GATHER));
+  launch_row_fill(st, P, (int64_t)n_rows);  // + per-group counters
+  RC(pf.end());
+  HIPCHK(hipMemcpyAsync(c->h_totals + 4, c->counters_d.p, 4 * 8, hipMemcpyDeviceToHost, st));
+  if (n_rows) {
     RowArgs R{};
-    R.n_rows = (int64_t)n_rows; R.r_match = P.r_match; R.m_tid = A.m_tid; R.m_pos = A.m_pos; R.m_ncig = A.m_ncig;
-    R.m_strand = A.m_strand; R.m_cigoff = A.m_cigoff; R.m_sim = A.m_sim; R.m_junc = A.m_junc; R.m_refc = A.m_refc;
-    R.m_clip = A.m_clip; R.cig_arena = A.cig_arena; R.r_tid = c->r_tid.as<uint32_t>(); R.r_pos = c->r_pos.as<uint32_t>();
-    R.r_ncig = c->r_ncig.as<uint32_t>(); R.r_strand = c->r_strand.as<int8_t>(); R.r_sim = c->r_sim.as<double>();
-    R.r_clip = c->r_clip.as<int32_t>(); R.r_junc = c->r_junc.as<int32_t>(); R.r_refc = c->r_refc.as<int32_t>();
-    R.r_cigoff = c->r_cigoff.as<uint64_t>();
-    R.r_flags = c->r_flags.as<uint8_t>(); R.r_paired = c->r_paired.as<uint8_t>(); R.r_same = c->r_same.as<uint8_t>();
-    R.r_first = c->r_first.as<uint8_t>();
-    RC(pf.begin(BR_K_GATHER));
-    launch_row_fill(st, R);
-    RC(pf.end());
+    R.n_rows = (int64_t)n_rows; R.r_match = P.r_match; R.r_ncig = P.r_ncig; R.m_cigoff = A.m_cigoff;
+    R.cig_arena = A.cig_arena; R.r_cigoff = c->r_cigoff.as<uint64_t>();
     ScanArgs S3{};
     S3.n = (int64_t)n_rows; S3.src32 = c->r_ncig.as<uint32_t>(); S3.tile_sums = c->tile_sums.as<uint64_t>();
     RC(c->tile_sums.ensure((size_t)std::max<int64_t>(scan_tiles_for((int64_t)n_rows + 1), 1) * 8));
@@ -591,6 +595,7 @@ int run_device(br_ctx *c, const br_config *cfg, const br_device_batch *b, hipStr
   }
   HIPCHK(hipStreamSynchronize(st));
   RC(pf.collect());
+  out->total_complete = n_rows; out->total_unique = c->h_totals[5]; out->dropped_reads = c->h_totals[6];
 
   out->n_cigar_words = (int64_t)n_out_words;
   out->input_index = c->r_input.as<int32_t>(); out->transcript_id = c->r_tid.as<uint32_t>();
@@ -622,7 +627,7 @@ extern "C" int br_ctx_collect_counters(br_ctx *c, const br_device_batch *b, void
   T.ix = c->ix->dev; T.n_aln = b->n_aln; T.ref_id = b->ref_id; T.cigar_off = b->cigar_off;
   T.seg = c->seg.as<uint2>(); T.meta = c->meta.as<AlnMeta>(); T.out = stats.as<uint64_t>();
   int64_t nm = (int64_t)c->counters[6];
-  launch_stats(st, T, c->m_ncig.as<uint32_t>(), nm);
+  launch_stats(st, T, c->m_a.as<uint4>(), nm);
   uint64_t h[8];
   HIPCHK(hipMemcpyAsync(h, stats.p, 8 * 8, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));

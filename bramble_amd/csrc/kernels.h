@@ -16,6 +16,7 @@ struct ProjectArgs {
   const uint32_t *cigar;
   const uint2 *seg;
   const AlnMeta *meta;
+  const uint4 *head;     // [n_aln] {exon0.start, exon0.end, n_seg, refid<<2|smode}
   // count pass outputs / emit pass inputs
   uint32_t *n_matches;   // [n_aln]
   uint4 *ranges;         // [n_aln] candidate row ranges (lo+,hi+,lo-,hi-)
@@ -23,11 +24,10 @@ struct ProjectArgs {
   const uint32_t *match_off;  // [n_aln + 1]
   const uint64_t *cig_base;   // [n_aln + 1]
   // match table (emit)
-  uint32_t *m_tid, *m_pos, *m_ncig, *m_aux;
-  int8_t *m_strand;
+  uint32_t *m_tid, *m_aux;
+  uint4 *m_a;            // {pos, n_cigar | minus<<31, junc_hits, ref_consumed}
+  uint4 *m_b;            // {clip_score, 0, similarity lo, similarity hi}
   uint64_t *m_cigoff;
-  double *m_sim;
-  int32_t *m_junc, *m_refc, *m_clip;
   uint32_t *cig_arena;
 };
 
@@ -35,44 +35,41 @@ struct ScanArgs {
   int64_t n;
   const uint32_t *src32;
   const uint32_t *cigar_off;  // mode 1 only
-  const AlnMeta *meta;        // mode 1 only
+  const uint4 *head;          // mode 1 only
   uint64_t *tile_sums;
 };
 
 struct PairArgs {
-  int64_t n_groups;
+  int64_t n_groups, n_aln;
   int32_t long_reads;
   const uint32_t *group_off;
+  const uint32_t *aln_group;  // [n_aln] group of each alignment (k_group_ids)
   const int32_t *mate_idx;
   const uint32_t *match_off;
-  const uint32_t *m_tid, *m_pos;
+  const uint32_t *m_tid;
+  const uint4 *m_a, *m_b;
   const int32_t *l_qseq;
-  uint32_t *n_rows;         // count pass
-  const uint64_t *row_off;  // emit pass
+  uint32_t *n_rows;         // count pass: records per leader alignment
+  const uint64_t *row_off;  // [n_aln + 1] emit pass
   int32_t *r_input;
-  uint32_t *r_match, *r_nh, *r_hi, *r_mapq, *r_group;
+  uint32_t *r_match, *r_mate, *r_nh, *r_hi, *r_mapq, *r_group;
   uint8_t *r_flags;
   int32_t *r_mate_tid, *r_mate_pos, *r_isize;
+  uint32_t *r_tid, *r_pos, *r_ncig;
+  int8_t *r_strand;
+  double *r_sim;
+  int32_t *r_clip, *r_junc, *r_refc;
+  uint8_t *r_paired, *r_same, *r_first;
   uint64_t *counters;       // [4] total_complete, total_unique, dropped_reads, total_processed
 };
 
 struct RowArgs {
   int64_t n_rows;
-  const uint32_t *r_match;
-  const uint32_t *m_tid, *m_pos, *m_ncig;
-  const int8_t *m_strand;
+  const uint32_t *r_match, *r_ncig;
   const uint64_t *m_cigoff;
-  const double *m_sim;
-  const int32_t *m_junc, *m_refc, *m_clip;
   const uint32_t *cig_arena;
-  uint32_t *r_tid, *r_pos, *r_ncig;
-  int8_t *r_strand;
-  double *r_sim;
-  int32_t *r_clip, *r_junc, *r_refc;
   const uint64_t *r_cigoff;  // [n_rows + 1]
   uint32_t *cigar_out;
-  const uint8_t *r_flags;    // packed RF_* bits from k_pair
-  uint8_t *r_paired, *r_same, *r_first;
 };
 
 struct StatsArgs {
@@ -84,17 +81,19 @@ struct StatsArgs {
   const AlnMeta *meta;
   uint64_t *out;  // [8]
 };
-void launch_stats(hipStream_t st, const StatsArgs &T, const uint32_t *m_ncig, int64_t n_matches);
+void launch_stats(hipStream_t st, const StatsArgs &T, const uint4 *m_a, int64_t n_matches);
 
 void launch_segment(hipStream_t st, int64_t n_aln, const int32_t *ref_id, const int32_t *ref_start,
                     const uint16_t *flags, const int8_t *xs, const int8_t *ts, const uint32_t *cigar_off,
-                    const uint32_t *cigar, const DevCfg &cfg, uint32_t n_refs, uint2 *seg, AlnMeta *meta);
+                    const uint32_t *cigar, const DevCfg &cfg, uint32_t n_refs, uint2 *seg, AlnMeta *meta,
+                    uint4 *head);
 void launch_project(hipStream_t st, const ProjectArgs &A, bool emit, int group_lanes, int n_blocks);
 int64_t scan_tiles_for(int64_t n);
 // mode 0: src32 as is; 1: n_matches * CIGAR slot capacity; 2: src32 as is (alias of 0)
 void launch_scan(hipStream_t st, const ScanArgs &S, int mode, void *out, bool out64, uint64_t *total_out);
+void launch_group_ids(hipStream_t st, int64_t n_groups, const uint32_t *group_off, uint32_t *aln_group);
 void launch_pair(hipStream_t st, const PairArgs &P, bool emit);
-void launch_row_fill(hipStream_t st, const RowArgs &R);
+void launch_row_fill(hipStream_t st, const PairArgs &P, int64_t n_rows);
 void launch_gather(hipStream_t st, const RowArgs &R);
 
 }  // namespace br

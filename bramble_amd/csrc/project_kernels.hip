@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(256) k_segment(int64_t n_aln, const int32_t *_
                                                  const uint32_t *__restrict__ cigar_off,
                                                  const uint32_t *__restrict__ cigar, DevCfg cfg,
                                                  uint32_t n_refs, uint2 *__restrict__ seg,
-                                                 AlnMeta *__restrict__ meta) {
+                                                 AlnMeta *__restrict__ meta, uint4 *__restrict__ head) {
   int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= n_aln) return;
   uint32_t c0 = cigar_off[a], c1 = cigar_off[a + 1];
@@ -118,6 +118,9 @@ __global__ void __launch_bounds__(256) k_segment(int64_t n_aln, const int32_t *_
   }
   AlnMeta m; m.n_seg = n; m.smode = smode; m.n_left_clip = lclip; m.n_right_clip = rclip;
   meta[a] = m;
+  // everything k_project needs for read exon 0 in one 16-byte record
+  uint2 q0 = n ? out[0] : make_uint2(0, 0);
+  head[a] = make_uint4(q0.x, q0.y, n, n ? (((uint32_t)rid << 2) | smode) : 0u);
 }
 
 // ---------------------------------------------------------------------------
@@ -274,12 +277,14 @@ __device__ uint32_t merge_cigars(const uint32_t *__restrict__ real, uint32_t n_r
 
   uint32_t ridx = 0, ri = 0, ii = 0, real_pos = 0, ideal_pos = 0;
   uint32_t last = 0;  // copy of out[ridx-1]
+  bool saw_ins = false;
 #define ADD_OP(OPV, LENV)                                                          \
   do {                                                                             \
     uint32_t _op = (OPV), _len = (LENV);                                           \
     if (_len != 0 && _op != 95u) {                                                 \
       if (ridx > 0 && CIG_OP(last) == (_op & 0xffu)) { last += (_len << 4); out[ridx - 1] = last; } \
       else { last = CIG_GEN(_len, _op); out[ridx++] = last; }                      \
+      saw_ins |= ((_op & 0xffu) == OP_I);                                          \
     }                                                                              \
   } while (0)
 
@@ -365,12 +370,18 @@ __device__ uint32_t merge_cigars(const uint32_t *__restrict__ real, uint32_t n_r
   }
 #undef ADD_OP
   // "I between clips -> clip" fix-up (bam.cpp:292-300), then re-coalesce (:302-311)
-  for (uint32_t i = 1; i + 1 < ridx; i++) {
-    uint32_t w = out[i];
-    if (CIG_OP(w) != OP_I) continue;
-    uint32_t prev = CIG_OP(out[i - 1]), next = CIG_OP(out[i + 1]);
-    if ((prev == OP_S || prev == OP_H) && (next == OP_S || next == OP_H)) out[i] = CIG_GEN(CIG_LEN(w), prev);
+  // Without an I op the fix-up is a no-op, and ADD_OP never leaves equal
+  // neighbours, so re-coalescing only matters after a fix-up rewrote an op.
+  bool changed = false;
+  if (saw_ins) {
+    for (uint32_t i = 1; i + 1 < ridx; i++) {
+      uint32_t w = out[i];
+      if (CIG_OP(w) != OP_I) continue;
+      uint32_t prev = CIG_OP(out[i - 1]), next = CIG_OP(out[i + 1]);
+      if ((prev == OP_S || prev == OP_H) && (next == OP_S || next == OP_H)) { out[i] = CIG_GEN(CIG_LEN(w), prev); changed = true; }
+    }
   }
+  if (!changed) return ridx;
   uint32_t nidx = 0, lastw = 0;
   for (uint32_t i = 0; i < ridx; i++) {
     uint32_t w = out[i];
@@ -450,31 +461,6 @@ __device__ __forceinline__ int step_exon(const DevIndex &ix, const DevCfg &cfg, 
   return STEP_HIT;
 }
 
-// G-wide cooperative lower bound: first index in [a,b) where pred fails.
-// LE=false: pred = arr[i] <  key;  LE=true: pred = arr[i] <= key.
-template <int G, bool LE>
-__device__ __forceinline__ uint32_t group_lower_bound(const uint32_t *__restrict__ arr, uint32_t a, uint32_t b,
-                                                      uint32_t key, int gl, int gbase) {
-  const uint64_t gmask = (G == 64) ? ~0ull : ((1ull << G) - 1);
-  while (b - a > (uint32_t)G) {
-    uint32_t n = b - a;
-    uint32_t p = a + (uint32_t)(((uint64_t)(gl + 1) * n) / (uint32_t)(G + 1));
-    uint32_t v = arr[p];
-    bool t = LE ? (v <= key) : (v < key);
-    uint64_t m = (__ballot(t) >> gbase) & gmask;
-    int c = __popcll(m);
-    uint32_t pa = __shfl(p, c > 0 ? c - 1 : 0, G);
-    uint32_t pb = __shfl(p, c < G ? c : G - 1, G);
-    if (c > 0) a = pa + 1;
-    if (c < G) b = pb;
-  }
-  uint32_t p = a + (uint32_t)gl;
-  bool t = false;
-  if (p < b) { uint32_t v = arr[p]; t = LE ? (v <= key) : (v < key); }
-  uint64_t m = (__ballot(t) >> gbase) & gmask;
-  return a + (uint32_t)__popcll(m);
-}
-
 // Everything one lane needs about its alignment.
 struct ReadCtx {
   const uint2 *seg;      // read exons (global)
@@ -491,10 +477,10 @@ struct CandOut {
 // Pass 1 (src/evaluate.cpp:1004-1065): survival, segment counts, fwpos/rcpos.
 __device__ __forceinline__ CandOut walk_pass1(const DevIndex &ix, const DevCfg &cfg, const ReadCtx &rd,
                                               const uint4 *E, bool minus, uint32_t sb, uint32_t se,
-                                              uint32_t i0, const Hit &h0) {
+                                              uint32_t i0, uint2 q0, const Hit &h0) {
   CandOut o; o.alive = true; o.fwpos = h0.pos; o.rcpos = h0.pos; o.n_seg = 1; o.n_gex = 1;
   uint32_t i_last = i0;
-  uint2 pq = rd.seg[0];
+  uint2 pq = q0;
   for (uint32_t j = 1; j < rd.n_seg; j++) {
     uint2 q = rd.seg[j];
     int status = (j < rd.n_seg - 1) ? ST_MIDDLE : ST_LAST;
@@ -514,13 +500,12 @@ __device__ __forceinline__ CandOut walk_pass1(const DevIndex &ix, const DevCfg &
 // Pass 2 (src/evaluate.cpp:1070-1106): ideal CIGAR + accumulators.
 __device__ __forceinline__ void walk_pass2(const DevIndex &ix, const DevCfg &cfg, const ReadCtx &rd,
                                            const uint4 *E, bool minus, uint32_t sb, uint32_t se, uint32_t i0,
-                                           const Hit &h0, const CandOut &p1, Acc &acc, IdealSink &sk) {
+                                           uint2 q0, uint32_t gs0, uint32_t ge0, const Hit &h0,
+                                           const CandOut &p1, Acc &acc, IdealSink &sk) {
   acc.init();
   uint32_t k = 0;
-  uint2 q0 = rd.seg[0];
-  uint4 e0 = E[i0];
   int st0 = (rd.n_seg == 1) ? ST_ONLY : ST_FIRST;
-  build_match(acc, sk, h0, st0, q0.x, q0.y, e0.x, e0.y, k == 0, k == p1.n_gex - 1, false, false);
+  build_match(acc, sk, h0, st0, q0.x, q0.y, gs0, ge0, k == 0, k == p1.n_gex - 1, false, false);
   k++;
   uint32_t i_last = i0;
   for (uint32_t j = 1; j < rd.n_seg; j++) {
@@ -566,9 +551,22 @@ __device__ __forceinline__ bool similarity(const DevCfg &cfg, const Acc &acc, do
 
 // ---------------------------------------------------------------------------
 // k_project<G, EMIT>: one G-lane group per alignment, grid-stride.
+//
+// Per alignment the group (1) finds the candidate row range of read exon 0 on each
+// strand to try with FOUR interleaved G-ary searches over the start-sorted slab
+// (first row with start >= qend; first row whose running max end exceeds
+// qstart), (2) gives every candidate row to one lane, which classifies it and
+// walks its own transcript, (3) counts (EMIT=false) or writes (EMIT=true) the
+// survivors.  Small ideal / rewritten CIGARs are staged in LDS.
 // ---------------------------------------------------------------------------
+#define SLAB_LDS 1025   // slab_off entries cached in LDS (<= 512 references)
+#define LDS_SLOT 33     // words of CIGAR scratch per lane (odd: conflict-free)
+#define LDS_IDEAL 10    // ideal CIGAR words kept in LDS (n_seg <= 2)
+
 template <int G, bool EMIT>
 __global__ void __launch_bounds__(256) k_project(ProjectArgs A) {
+  __shared__ uint32_t sh_slab[SLAB_LDS];
+  __shared__ uint32_t sh_cig[EMIT ? 256 * LDS_SLOT : 1];
   const int gl = threadIdx.x & (G - 1);
   const int gbase = (threadIdx.x & 63) & ~(G - 1);
   const uint64_t gmask = (G == 64) ? ~0ull : ((1ull << G) - 1);
@@ -576,55 +574,100 @@ __global__ void __launch_bounds__(256) k_project(ProjectArgs A) {
   const int64_t gid = (int64_t)blockIdx.x * (blockDim.x / G) + threadIdx.x / G;
   const DevIndex &ix = A.ix;
   const DevCfg &cfg = A.cfg;
+  const uint32_t n_slab_off = 2 * ix.n_refs + 1;
+  const bool slab_in_lds = n_slab_off <= SLAB_LDS;
+  if (slab_in_lds) {
+    for (uint32_t i = threadIdx.x; i < n_slab_off; i += blockDim.x) sh_slab[i] = ix.slab_off[i];
+    __syncthreads();
+  }
 
   for (int64_t a = gid; a < A.n_aln; a += groups_total) {
-    AlnMeta mt = A.meta[a];
-    if (mt.n_seg == 0) { if (!EMIT && gl == 0) { A.n_matches[a] = 0; A.ranges[a] = make_uint4(0, 0, 0, 0); A.mask[a] = 0; } continue; }
-    uint32_t c0 = A.cigar_off[a];
-    ReadCtx rd;
-    rd.seg = A.seg + (size_t)c0 + (size_t)a;
-    rd.n_seg = mt.n_seg;
-    rd.real = A.cigar + c0;
-    rd.n_real = A.cigar_off[a + 1] - c0;
-    uint2 q0 = rd.seg[0];
-    int st0 = (rd.n_seg == 1) ? ST_ONLY : ST_FIRST;
-    uint32_t rid = (uint32_t)A.ref_id[a];
+    uint4 hd = A.head[a];
+    uint32_t n_seg = hd.z;
+    if (n_seg == 0) { if (!EMIT && gl == 0) { A.n_matches[a] = 0; A.ranges[a] = make_uint4(0, 0, 0, 0); A.mask[a] = 0; } continue; }
+    uint2 q0 = make_uint2(hd.x, hd.y);
+    uint32_t smode = hd.w & 3u, rid = hd.w >> 2;
+    int st0 = (n_seg == 1) ? ST_ONLY : ST_FIRST;
+    uint32_t sb[2], se[2];
+    if (slab_in_lds) { sb[0] = sh_slab[2 * rid]; se[0] = sh_slab[2 * rid + 1]; se[1] = sh_slab[2 * rid + 2]; }
+    else { sb[0] = ix.slab_off[2 * rid]; se[0] = ix.slab_off[2 * rid + 1]; se[1] = ix.slab_off[2 * rid + 2]; }
+    sb[1] = se[0];
 
-    // candidate row ranges of read exon 0 on the strands to try
-    uint32_t lo[2] = {0, 0}, hi[2] = {0, 0}, sb[2], se[2];
-    sb[0] = ix.slab_off[2 * rid]; se[0] = ix.slab_off[2 * rid + 1];
-    sb[1] = se[0]; se[1] = ix.slab_off[2 * rid + 2];
+    uint32_t lo[2] = {0, 0}, hi[2] = {0, 0};
     if (EMIT) {
+      if (A.n_matches[a] == 0) continue;
       uint4 rg = A.ranges[a];
       lo[0] = rg.x; hi[0] = rg.y; lo[1] = rg.z; hi[1] = rg.w;
     } else {
+      // searches 0/1: hi/lo on '+', 2/3: hi/lo on '-'.  hi: first row with
+      // start >= qend; lo: first row with running max end > qstart.
+      uint32_t sa[4], sbn[4];
+      bool act[4];
 #pragma unroll
-      for (int s = 0; s < 2; s++) {
-        if (!((mt.smode >> s) & 1u) || sb[s] == se[s]) continue;
-        hi[s] = group_lower_bound<G, false>(ix.s_start, sb[s], se[s], q0.y, gl, gbase);
-        lo[s] = group_lower_bound<G, true>(ix.s_pmax, sb[s], hi[s], q0.x, gl, gbase);
+      for (int k = 0; k < 4; k++) {
+        int s = k >> 1;
+        act[k] = ((smode >> s) & 1u) && sb[s] != se[s];
+        sa[k] = sb[s]; sbn[k] = act[k] ? se[s] : sb[s];
       }
+      for (;;) {
+        uint32_t p[4], v[4]; bool big[4]; bool any = false;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          uint32_t n = sbn[k] - sa[k];
+          big[k] = n > (uint32_t)G;
+          p[k] = sa[k] + (uint32_t)(((uint64_t)(gl + 1) * n) / (uint32_t)(G + 1));
+          v[k] = 0;
+          if (big[k]) { v[k] = (k & 1) ? ix.s_pmax[p[k]] : ix.s_start[p[k]]; any = true; }
+        }
+        if (!any) break;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          if (!big[k]) continue;
+          bool t = (k & 1) ? (v[k] <= q0.x) : (v[k] < q0.y);
+          int c = __popcll((__ballot(t) >> gbase) & gmask);
+          uint32_t pa = __shfl(p[k], c > 0 ? c - 1 : 0, G);
+          uint32_t pb = __shfl(p[k], c < G ? c : G - 1, G);
+          if (c > 0) sa[k] = pa + 1;
+          if (c < G) sbn[k] = pb;
+        }
+      }
+      uint32_t res[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        uint32_t pp = sa[k] + (uint32_t)gl;
+        bool t = false;
+        if (pp < sbn[k]) { uint32_t vv = (k & 1) ? ix.s_pmax[pp] : ix.s_start[pp]; t = (k & 1) ? (vv <= q0.x) : (vv < q0.y); }
+        res[k] = sa[k] + (uint32_t)__popcll((__ballot(t) >> gbase) & gmask);
+      }
+      hi[0] = res[0]; lo[0] = res[1] < res[0] ? res[1] : res[0];
+      hi[1] = res[2]; lo[1] = res[3] < res[2] ? res[3] : res[2];
       if (gl == 0) A.ranges[a] = make_uint4(lo[0], hi[0], lo[1], hi[1]);
     }
     uint32_t n0 = hi[0] - lo[0], n1 = hi[1] - lo[1];
     uint32_t n_items = n0 + n1;
 
-    uint32_t total = 0;        // matches counted so far (COUNT)
-    uint64_t mask_all = 0;     // survivor bit per item (valid while n_items <= 64)
-    uint64_t mask_in = 0;
-    bool have_mask = false;
+    ReadCtx rd;
+    rd.n_seg = n_seg; rd.seg = nullptr; rd.real = nullptr; rd.n_real = 0;
     uint32_t moff = 0; uint64_t cbase = 0; uint32_t cap = 0, ideal_cap = 0;
+    bool have_mask = false; uint64_t mask_in = 0;
+    if (EMIT || n_seg > 1) {
+      uint32_t c0 = A.cigar_off[a];
+      rd.seg = A.seg + (size_t)c0 + (size_t)a;
+      rd.real = A.cigar + c0;
+      if (EMIT) rd.n_real = A.cigar_off[a + 1] - c0;
+    }
     if (EMIT) {
-      if (A.n_matches[a] == 0) continue;
       moff = A.match_off[a]; cbase = A.cig_base[a];
-      ideal_cap = 4u * rd.n_seg + 2u;
+      ideal_cap = 4u * n_seg + 2u;
       cap = rd.n_real + 2u * ideal_cap;
       have_mask = n_items <= 64;
       mask_in = A.mask[a];
     }
+    uint32_t total = 0;
+    uint64_t mask_all = 0;
 
-    // EMIT without a stored mask (n_items > 64): first sweep records every
-    // survivor's tid in aux[], second sweep ranks against that list.
+    // EMIT without a stored mask (> 64 candidate rows): sweep 0 records every
+    // survivor's tid in m_aux[], sweep 1 ranks against that list.
     const int n_sweeps = (EMIT && !have_mask) ? 2 : 1;
     uint32_t aux_n = 0;
     for (int sweep = 0; sweep < n_sweeps; sweep++) {
@@ -632,87 +675,70 @@ __global__ void __launch_bounds__(256) k_project(ProjectArgs A) {
         uint32_t item = base + (uint32_t)gl;
         bool valid = item < n_items;
         bool alive = false;
-        int s = 0; uint32_t row = 0;
-        uint4 pay = make_uint4(0, 0, 0, 0);
+        int s = 0; uint32_t row = 0, gs = 0, gend = 0, nxt = 0;
+        uint4 pay = make_uint4(0xffffffffu, 0, 0, 0);
         Hit h0; CandOut p1; const uint4 *E = nullptr; uint32_t i0 = 0;
         p1.alive = false; p1.fwpos = 0; p1.rcpos = 0; p1.n_seg = 0; p1.n_gex = 0;
         h0.pos = 0; h0.left_ins = h0.right_ins = h0.left_gap = h0.right_gap = 0;
         if (valid) {
           s = item < n0 ? 0 : 1;
           row = s == 0 ? lo[0] + item : lo[1] + (item - n0);
+          // one round trip: all four row fields are independent of each other
+          gs = ix.s_start[row]; gend = ix.s_end[row]; nxt = ix.s_next[row]; pay = ix.s_pay[row];
           bool want = true;
           if (EMIT && have_mask) want = (mask_in >> item) & 1ull;
-          if (want) {
-            uint32_t gs = ix.s_start[row], gend = ix.s_end[row];
-            if (gend > q0.x) {
-              pay = ix.s_pay[row];
-              if (classify(s == 1, st0, q0.x, q0.y, gs, gend, pay.z, cfg, h0)) {
-                E = ix.tx_ex + pay.w; i0 = pay.y;
-                // first-exon duplicate tid: the LAST passing row of the tid wins
-                // (src/evaluate.cpp:218-224); later rows of the same tid are the
-                // following exons of its table.
-                bool superseded = false;
-                for (uint32_t i = i0 + 1;; i++) {
-                  uint4 e = E[i];
-                  if (e.x >= q0.y) break;
-                  Hit hx;
-                  if (e.y > q0.x && classify(s == 1, st0, q0.x, q0.y, e.x, e.y, e.z, cfg, hx)) { superseded = true; break; }
-                }
-                if (!superseded) {
-                  p1 = walk_pass1(ix, cfg, rd, E, s == 1, sb[s], se[s], i0, h0);
-                  alive = p1.alive;
-                }
+          if (want && gend > q0.x && classify(s == 1, st0, q0.x, q0.y, gs, gend, pay.z, cfg, h0)) {
+            E = ix.tx_ex + pay.w; i0 = pay.y;
+            // first-exon duplicate tid: the LAST passing row of the tid wins
+            // (src/evaluate.cpp:218-224); later rows of the same tid are the
+            // following exons of its table.  s_next = start of the next one.
+            bool superseded = false;
+            if (nxt < q0.y) {
+              for (uint32_t i = i0 + 1;; i++) {
+                uint4 e = E[i];
+                if (e.x >= q0.y) break;
+                Hit hx;
+                if (e.y > q0.x && classify(s == 1, st0, q0.x, q0.y, e.x, e.y, e.z, cfg, hx)) { superseded = true; break; }
               }
+            }
+            if (!superseded) {
+              if (n_seg == 1) { p1.alive = true; p1.fwpos = h0.pos; p1.rcpos = h0.pos; p1.n_seg = 1; p1.n_gex = 1; }
+              else p1 = walk_pass1(ix, cfg, rd, E, s == 1, sb[s], se[s], i0, q0, h0);
+              alive = p1.alive;
             }
           }
         }
-        // similarity filter needs the pass-2 accumulators (long reads only)
         Acc acc; IdealSink sk; double score = 0.0;
-        if (!EMIT) {
+        if (!EMIT || !have_mask) {
+          // similarity filter needs the pass-2 accumulators (long reads only)
           if (alive && cfg.filter_by_similarity) {
             sk.init(nullptr);
-            walk_pass2(ix, cfg, rd, E, s == 1, sb[s], se[s], i0, h0, p1, acc, sk);
+            walk_pass2(ix, cfg, rd, E, s == 1, sb[s], se[s], i0, q0, gs, gend, h0, p1, acc, sk);
             alive = similarity(cfg, acc, score);
           }
+        }
+        uint32_t rank = 0;
+        bool do_emit = false;
+        if (!EMIT) {
           uint64_t m = (__ballot(alive) >> gbase) & gmask;
           total += (uint32_t)__popcll(m);
           if (base < 64) mask_all |= (G == 64) ? m : (m << base);
         } else if (have_mask) {
-          // rank among the read's survivors by tid: tids of the masked items
-          if (alive) {
-            uint32_t rank = 0;
-            uint64_t mm = mask_in;
-            while (mm) {
-              int b = __ffsll((long long)mm) - 1; mm &= mm - 1;
+          // rank by tid among the read's survivors (group-uniform loop over the mask):
+          // rows of this chunk come from a lane, the others from the slab.
+          uint64_t mm = mask_in;
+          while (mm) {
+            int b = __ffsll((long long)mm) - 1; mm &= mm - 1;
+            uint32_t t2;
+            if ((uint32_t)b >= base && (uint32_t)b < base + G) t2 = __shfl(pay.x, b - (int)base, G);
+            else {
               uint32_t r2 = (uint32_t)b < n0 ? lo[0] + (uint32_t)b : lo[1] + ((uint32_t)b - n0);
-              uint32_t t2 = ix.s_pay[r2].x;
-              rank += (t2 < pay.x) ? 1u : 0u;
+              t2 = ix.s_pay[r2].x;
             }
-            uint32_t *slot = A.cig_arena + cbase + (uint64_t)rank * cap;
-            uint32_t *ideal = slot + rd.n_real + ideal_cap;
-            sk.init(ideal);
-            walk_pass2(ix, cfg, rd, E, s == 1, sb[s], se[s], i0, h0, p1, acc, sk);
-            uint32_t n_ideal = sk.finish();
-            similarity(cfg, acc, score);
-            uint32_t n_out = merge_cigars(rd.real, rd.n_real, ideal, n_ideal, slot);
-            uint32_t mi = moff + rank;
-            A.m_tid[mi] = pay.x;
-            A.m_pos[mi] = (s == 0) ? p1.fwpos : p1.rcpos;
-            A.m_strand[mi] = (s == 0) ? (int8_t)'+' : (int8_t)'-';
-            A.m_ncig[mi] = n_out;
-            A.m_cigoff[mi] = cbase + (uint64_t)rank * cap;
-            A.m_sim[mi] = score;
-            A.m_junc[mi] = acc.junc_hits;
-            A.m_refc[mi] = acc.ref_consumed;
-            A.m_clip[mi] = acc.clip_score;
+            rank += (t2 < pay.x) ? 1u : 0u;
           }
+          do_emit = alive;
         } else {
-          // big alignment (> 64 candidate rows): survivors are not known yet
-          if (alive && cfg.filter_by_similarity) {
-            sk.init(nullptr);
-            walk_pass2(ix, cfg, rd, E, s == 1, sb[s], se[s], i0, h0, p1, acc, sk);
-            alive = similarity(cfg, acc, score);
-          }
           uint64_t m = (__ballot(alive) >> gbase) & gmask;
           if (sweep == 0) {
             if (alive) {
@@ -721,29 +747,33 @@ __global__ void __launch_bounds__(256) k_project(ProjectArgs A) {
             }
             aux_n += (uint32_t)__popcll(m);
           } else if (alive) {
-            uint32_t rank = 0;
             for (uint32_t k = 0; k < aux_n; k++) rank += (A.m_aux[moff + k] < pay.x) ? 1u : 0u;
-            uint32_t *slot = A.cig_arena + cbase + (uint64_t)rank * cap;
-            uint32_t *ideal = slot + rd.n_real + ideal_cap;
-            sk.init(ideal);
-            walk_pass2(ix, cfg, rd, E, s == 1, sb[s], se[s], i0, h0, p1, acc, sk);
-            uint32_t n_ideal = sk.finish();
-            similarity(cfg, acc, score);
-            uint32_t n_out = merge_cigars(rd.real, rd.n_real, ideal, n_ideal, slot);
-            uint32_t mi = moff + rank;
-            A.m_tid[mi] = pay.x;
-            A.m_pos[mi] = (s == 0) ? p1.fwpos : p1.rcpos;
-            A.m_strand[mi] = (s == 0) ? (int8_t)'+' : (int8_t)'-';
-            A.m_ncig[mi] = n_out;
-            A.m_cigoff[mi] = cbase + (uint64_t)rank * cap;
-            A.m_sim[mi] = score;
-            A.m_junc[mi] = acc.junc_hits;
-            A.m_refc[mi] = acc.ref_consumed;
-            A.m_clip[mi] = acc.clip_score;
+            do_emit = true;
           }
         }
+        if (EMIT && do_emit) {
+          uint32_t *slot = A.cig_arena + cbase + (uint64_t)rank * cap;
+          uint32_t *lds = &sh_cig[(EMIT ? threadIdx.x : 0) * LDS_SLOT];
+          bool ideal_lds = ideal_cap <= LDS_IDEAL;
+          uint32_t *ideal = ideal_lds ? lds : slot + rd.n_real + ideal_cap;
+          sk.init(ideal);
+          walk_pass2(ix, cfg, rd, E, s == 1, sb[s], se[s], i0, q0, gs, gend, h0, p1, acc, sk);
+          uint32_t n_ideal = sk.finish();
+          similarity(cfg, acc, score);
+          bool out_lds = ideal_lds && (rd.n_real + n_ideal <= LDS_SLOT - LDS_IDEAL);
+          uint32_t *outp = out_lds ? lds + LDS_IDEAL : slot;
+          uint32_t n_out = merge_cigars(rd.real, rd.n_real, ideal, n_ideal, outp);
+          if (out_lds) for (uint32_t k = 0; k < n_out; k++) slot[k] = outp[k];
+          uint32_t mi = moff + rank;
+          A.m_tid[mi] = pay.x;
+          A.m_a[mi] = make_uint4((s == 0) ? p1.fwpos : p1.rcpos, n_out | ((uint32_t)s << 31), (uint32_t)acc.junc_hits,
+                                 (uint32_t)acc.ref_consumed);
+          unsigned long long sb64 = (unsigned long long)__double_as_longlong(score);
+          A.m_b[mi] = make_uint4((uint32_t)acc.clip_score, 0u, (uint32_t)sb64, (uint32_t)(sb64 >> 32));
+          A.m_cigoff[mi] = cbase + (uint64_t)rank * cap;
+        }
       }
-      if (EMIT && !have_mask && sweep == 0) __threadfence_block();  // aux[] written above is read below
+      if (EMIT && !have_mask && sweep == 0) __threadfence_block();  // m_aux[] written above is read below
     }
     if (!EMIT && gl == 0) { A.n_matches[a] = total; A.mask[a] = mask_all; }
   }
@@ -781,7 +811,7 @@ __device__ __forceinline__ uint64_t scan_value(const ScanArgs &S, int64_t i) {
   uint32_t nm = S.src32[i];
   if (nm == 0) return 0;
   uint32_t n_real = S.cigar_off[i + 1] - S.cigar_off[i];
-  uint32_t ideal_cap = 4u * S.meta[i].n_seg + 2u;
+  uint32_t ideal_cap = 4u * S.head[i].z + 2u;
   return (uint64_t)nm * (uint64_t)(n_real + 2u * ideal_cap);
 }
 
@@ -838,95 +868,124 @@ __device__ __forceinline__ uint32_t mapq_of(uint32_t nh, bool long_reads) {  // 
   return nh > 1 ? 0u : 3u;
 }
 
+// k_group_ids: one lane per read-name group labels its alignments
+__global__ void __launch_bounds__(256) k_group_ids(int64_t n_groups, const uint32_t *__restrict__ group_off,
+                                                   uint32_t *__restrict__ aln_group) {
+  int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_groups) return;
+  for (uint32_t i = group_off[g]; i < group_off[g + 1]; i++) aln_group[i] = (uint32_t)g;
+}
+
+// k_pair<EMIT>: one lane per alignment.  A "leader" (no mate, or its mate comes
+// later in the group) emits for itself and its mate, exactly the calls
+// convert_reads makes (src/core.cpp:384-415).  EMIT=false counts the records,
+// EMIT=true writes (match, mate match, input, flags) per record at the scanned
+// offset; k_row_fill turns those into the row table.
 template <bool EMIT>
 __global__ void __launch_bounds__(256) k_pair(PairArgs P) {
-  int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= P.n_groups) return;
-  uint32_t a0 = P.group_off[g], a1 = P.group_off[g + 1];
+  int64_t i64 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i64 >= P.n_aln) return;
+  uint32_t i = (uint32_t)i64;
   uint32_t rows = 0;
-  uint64_t r0 = 0; uint32_t nh = 0, mq = 0;
-  bool any_match = false;
-  if (EMIT) { r0 = P.row_off[g]; nh = (uint32_t)(P.row_off[g + 1] - r0); mq = mapq_of(nh, P.long_reads); if (nh == 0) return; }
-  for (uint32_t i = a0; i < a1; i++) {
-    int32_t m = P.mate_idx[i];
-    uint32_t mi0 = P.match_off[i], ni = P.match_off[i + 1] - mi0;
-    if (ni) any_match = true;
-    if (m >= 0 && (uint32_t)m < i && (uint32_t)m >= a0) continue;  // handled as the mate of an earlier leader
-    if (ni == 0) continue;                    // leader without matches: pair dropped (mates.cpp:153)
+  int32_t m = P.mate_idx[i];
+  uint32_t g = P.aln_group[i];
+  uint32_t a0 = P.group_off[g], a1 = P.group_off[g + 1];
+  uint32_t mi0 = P.match_off[i], ni = P.match_off[i + 1] - mi0;
+  bool leader = !(m >= 0 && (uint32_t)m < i && (uint32_t)m >= a0);  // else: handled as the mate of an earlier leader
+  uint64_t r0 = EMIT ? P.row_off[i] : 0;
+  if (leader && ni) {                          // a leader without matches drops the pair (mates.cpp:153)
     uint32_t nm = 0, mm0 = 0;
     if (m >= 0 && (uint32_t)m > i && (uint32_t)m < a1) { mm0 = P.match_off[m]; nm = P.match_off[m + 1] - mm0; }
     if (nm == 0) {
       // unpaired emission: one record per transcript, ascending tid (mates.cpp:157-176)
-      if (EMIT) {
+      if (EMIT)
         for (uint32_t k = 0; k < ni; k++) {
-          uint64_t r = r0 + rows + k; uint32_t x = mi0 + k;
-          P.r_input[r] = (int32_t)i; P.r_match[r] = x; P.r_nh[r] = nh; P.r_hi[r] = rows + k + 1; P.r_mapq[r] = mq;
-          P.r_flags[r] = RF_FIRST; P.r_mate_tid[r] = -1; P.r_mate_pos[r] = -1; P.r_isize[r] = 0;
-          P.r_group[r] = (uint32_t)g;
+          uint64_t r = r0 + k;
+          P.r_match[r] = mi0 + k; P.r_mate[r] = 0xffffffffu; P.r_input[r] = (int32_t)i; P.r_flags[r] = RF_FIRST;
+        }
+      rows = ni;
+    } else {
+      // both mates matched: sorted-set intersection (mates.cpp:204-231)
+      uint32_t x = 0, y = 0, common = 0;
+      while (x < ni && y < nm) {
+        uint32_t tx = P.m_tid[mi0 + x], ty = P.m_tid[mm0 + y];
+        if (tx < ty) x++;
+        else if (ty < tx) y++;
+        else {
+          if (EMIT) {
+            uint64_t r = r0 + 2ull * common;
+            P.r_match[r] = mi0 + x; P.r_mate[r] = mm0 + y; P.r_input[r] = (int32_t)i;
+            P.r_flags[r] = RF_FIRST | RF_PAIRED | RF_SAME_TX;
+            P.r_match[r + 1] = mm0 + y; P.r_mate[r + 1] = mi0 + x; P.r_input[r + 1] = m;
+            P.r_flags[r + 1] = RF_PAIRED | RF_SAME_TX;
+          }
+          common++; x++; y++;
         }
       }
-      rows += ni;
-      continue;
-    }
-    // both mates matched: sorted-set intersection
-    uint32_t x = 0, y = 0, common = 0;
-    while (x < ni && y < nm) {
-      uint32_t tx = P.m_tid[mi0 + x], ty = P.m_tid[mm0 + y];
-      if (tx < ty) x++;
-      else if (ty < tx) y++;
-      else {
+      if (common) rows = 2 * common;
+      else if (ni == 1 && nm == 1) {  // one transcript each, different ones
         if (EMIT) {
-          uint64_t r = r0 + rows + 2ull * common;
-          uint32_t xr = mi0 + x, xm = mm0 + y;
-          int32_t rpos = (int32_t)P.m_pos[xr], mpos = (int32_t)P.m_pos[xm];
-          int32_t lq_r = P.l_qseq[i], lq_m = P.l_qseq[m];
-          P.r_input[r] = (int32_t)i; P.r_match[r] = xr; P.r_nh[r] = nh; P.r_hi[r] = rows + 2 * common + 1; P.r_mapq[r] = mq;
-          P.r_flags[r] = RF_FIRST | RF_PAIRED | RF_SAME_TX; P.r_mate_tid[r] = (int32_t)tx; P.r_mate_pos[r] = mpos;
-          P.r_isize[r] = (rpos <= mpos) ? (mpos + lq_r) - rpos : -((rpos + lq_r) - mpos);
-          P.r_group[r] = (uint32_t)g;
-          r++;
-          P.r_input[r] = m; P.r_match[r] = xm; P.r_nh[r] = nh; P.r_hi[r] = rows + 2 * common + 2; P.r_mapq[r] = mq;
-          P.r_flags[r] = RF_PAIRED | RF_SAME_TX; P.r_mate_tid[r] = (int32_t)tx; P.r_mate_pos[r] = rpos;
-          P.r_isize[r] = (mpos <= rpos) ? (rpos + lq_m) - mpos : -((mpos + lq_m) - rpos);
-          P.r_group[r] = (uint32_t)g;
+          P.r_match[r0] = mi0; P.r_mate[r0] = mm0; P.r_input[r0] = (int32_t)i; P.r_flags[r0] = RF_FIRST | RF_PAIRED;
+          P.r_match[r0 + 1] = mm0; P.r_mate[r0 + 1] = mi0; P.r_input[r0 + 1] = m; P.r_flags[r0 + 1] = RF_PAIRED;
         }
-        common++; x++; y++;
+        rows = 2;
       }
     }
-    if (common) { rows += 2 * common; continue; }
-    if (ni == 1 && nm == 1) {  // one transcript each, different ones (mates.cpp:227-231)
-      if (EMIT) {
-        uint64_t r = r0 + rows;
-        uint32_t xr = mi0, xm = mm0;
-        P.r_input[r] = (int32_t)i; P.r_match[r] = xr; P.r_nh[r] = nh; P.r_hi[r] = rows + 1; P.r_mapq[r] = mq;
-        P.r_flags[r] = RF_FIRST | RF_PAIRED; P.r_mate_tid[r] = (int32_t)P.m_tid[xm]; P.r_mate_pos[r] = (int32_t)P.m_pos[xm];
-        P.r_isize[r] = 0; P.r_group[r] = (uint32_t)g;
-        r++;
-        P.r_input[r] = m; P.r_match[r] = xm; P.r_nh[r] = nh; P.r_hi[r] = rows + 2; P.r_mapq[r] = mq;
-        P.r_flags[r] = RF_PAIRED; P.r_mate_tid[r] = (int32_t)P.m_tid[xr]; P.r_mate_pos[r] = (int32_t)P.m_pos[xr];
-        P.r_isize[r] = 0; P.r_group[r] = (uint32_t)g;
-      }
-      rows += 2;
-    }
   }
-  if (!EMIT) {
-    P.n_rows[g] = rows;
-    // counters of src/bramble.cpp:729-736
-    if (rows == 1) atomicAdd((unsigned long long *)&P.counters[1], 1ull);
-    if (!any_match) atomicAdd((unsigned long long *)&P.counters[2], 1ull);
-  }
+  if (!EMIT) P.n_rows[i] = rows;
 }
 
-// rows -> dense outputs: per-row fields copied from the match table, n_cigar per row
-__global__ void __launch_bounds__(256) k_row_fill(RowArgs R) {
+// k_row_fill: one lane per emitted record.  NH / HI / MAPQ of flush
+// (src/core.cpp:237-258,309-325), the match's fields, and the mate fields of
+// set_mate_info (src/bam.cpp:531-588).
+__global__ void __launch_bounds__(256) k_row_fill(PairArgs P, int64_t n_rows) {
   int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= R.n_rows) return;
-  uint32_t x = R.r_match[r];
-  R.r_tid[r] = R.m_tid[x]; R.r_pos[r] = R.m_pos[x]; R.r_strand[r] = R.m_strand[x];
-  R.r_sim[r] = R.m_sim[x]; R.r_clip[r] = R.m_clip[x]; R.r_junc[r] = R.m_junc[x]; R.r_refc[r] = R.m_refc[x];
-  R.r_ncig[r] = R.m_ncig[x];
-  uint8_t f = R.r_flags[r];
-  R.r_paired[r] = (f & RF_PAIRED) ? 1 : 0; R.r_same[r] = (f & RF_SAME_TX) ? 1 : 0; R.r_first[r] = (f & RF_FIRST) ? 1 : 0;
+  if (r >= n_rows) return;
+  uint32_t x = P.r_match[r], xm = P.r_mate[r];
+  int32_t input = P.r_input[r];
+  uint8_t flags = P.r_flags[r];
+  uint32_t g = P.aln_group[input];
+  uint64_t rs = P.row_off[P.group_off[g]], re = P.row_off[P.group_off[g + 1]];
+  uint32_t nh = (uint32_t)(re - rs);
+  uint4 ma = P.m_a[x], mb = P.m_b[x];
+  uint32_t tid = P.m_tid[x];
+  int32_t mate_tid = -1, mate_pos = -1, isize = 0;
+  if (flags & RF_PAIRED) {
+    int32_t my_pos = (int32_t)ma.x;
+    mate_pos = (int32_t)P.m_a[xm].x;
+    if (flags & RF_SAME_TX) {
+      mate_tid = (int32_t)tid;
+      int32_t lq = P.l_qseq[input];
+      isize = (my_pos <= mate_pos) ? (mate_pos + lq) - my_pos : -((my_pos + lq) - mate_pos);
+    } else {
+      mate_tid = (int32_t)P.m_tid[xm];
+    }
+  }
+  P.r_nh[r] = nh; P.r_hi[r] = (uint32_t)(r - rs) + 1u; P.r_mapq[r] = mapq_of(nh, P.long_reads);
+  P.r_mate_tid[r] = mate_tid; P.r_mate_pos[r] = mate_pos; P.r_isize[r] = isize; P.r_group[r] = g;
+  P.r_tid[r] = tid; P.r_pos[r] = ma.x; P.r_strand[r] = (ma.y >> 31) ? (int8_t)'-' : (int8_t)'+';
+  P.r_ncig[r] = ma.y & 0x7fffffffu; P.r_junc[r] = (int32_t)ma.z; P.r_refc[r] = (int32_t)ma.w;
+  P.r_clip[r] = (int32_t)mb.x;
+  P.r_sim[r] = __longlong_as_double((long long)(((unsigned long long)mb.w << 32) | mb.z));
+  P.r_paired[r] = (flags & RF_PAIRED) ? 1 : 0; P.r_same[r] = (flags & RF_SAME_TX) ? 1 : 0;
+  P.r_first[r] = (flags & RF_FIRST) ? 1 : 0;
+}
+
+// k_group_stats: counters of src/bramble.cpp:729-736 (one lane per group)
+__global__ void __launch_bounds__(256) k_group_stats(PairArgs P) {
+  int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long uniq = 0, dropped = 0;
+  if (g < P.n_groups) {
+    uint32_t a0 = P.group_off[g], a1 = P.group_off[g + 1];
+    uniq = (P.row_off[a1] - P.row_off[a0]) == 1 ? 1 : 0;
+    dropped = (P.match_off[a1] == P.match_off[a0]) ? 1 : 0;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { uniq += __shfl_down(uniq, d, 64); dropped += __shfl_down(dropped, d, 64); }
+  if ((threadIdx.x & 63) == 0) {
+    if (uniq) atomicAdd((unsigned long long *)&P.counters[1], uniq);
+    if (dropped) atomicAdd((unsigned long long *)&P.counters[2], dropped);
+  }
 }
 
 // k_gather: one lane per row copies its rewritten CIGAR to the dense pool
@@ -936,7 +995,7 @@ __global__ void __launch_bounds__(256) k_gather(RowArgs R) {
   uint32_t x = R.r_match[r];
   const uint32_t *src = R.cig_arena + R.m_cigoff[x];
   uint64_t d0 = R.r_cigoff[r];
-  uint32_t n = R.m_ncig[x];
+  uint32_t n = R.r_ncig[r];
   for (uint32_t k = 0; k < n; k++) R.cigar_out[d0 + k] = src[k];
 }
 
@@ -986,9 +1045,9 @@ __global__ void __launch_bounds__(256) k_stats(StatsArgs T) {
   }
 }
 
-__global__ void __launch_bounds__(256) k_sum_u32(const uint32_t *src, int64_t n, uint64_t *out) {
+__global__ void __launch_bounds__(256) k_sum_ncig(const uint4 *m_a, int64_t n, uint64_t *out) {
   unsigned long long acc = 0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) acc += src[i];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) acc += m_a[i].y & 0x7fffffffu;
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) acc += __shfl_down(acc, d, 64);
   if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long *)out, acc);
@@ -1001,10 +1060,11 @@ static inline int grid_for(int64_t n, int per_block) { return (int)((n + per_blo
 
 void launch_segment(hipStream_t st, int64_t n_aln, const int32_t *ref_id, const int32_t *ref_start,
                     const uint16_t *flags, const int8_t *xs, const int8_t *ts, const uint32_t *cigar_off,
-                    const uint32_t *cigar, const DevCfg &cfg, uint32_t n_refs, uint2 *seg, AlnMeta *meta) {
+                    const uint32_t *cigar, const DevCfg &cfg, uint32_t n_refs, uint2 *seg, AlnMeta *meta,
+                    uint4 *head) {
   if (n_aln <= 0) return;
   hipLaunchKernelGGL(k_segment, dim3(grid_for(n_aln, 256)), dim3(256), 0, st, n_aln, ref_id, ref_start, flags,
-                     xs, ts, cigar_off, cigar, cfg, n_refs, seg, meta);
+                     xs, ts, cigar_off, cigar, cfg, n_refs, seg, meta, head);
 }
 
 template <int G>
@@ -1049,20 +1109,25 @@ void launch_scan(hipStream_t st, const ScanArgs &S, int mode, void *out, bool ou
   }
 }
 
-void launch_stats(hipStream_t st, const StatsArgs &T, const uint32_t *m_ncig, int64_t n_matches) {
+void launch_stats(hipStream_t st, const StatsArgs &T, const uint4 *m_a, int64_t n_matches) {
   if (T.n_aln > 0) hipLaunchKernelGGL(k_stats, dim3(grid_for(T.n_aln, 256)), dim3(256), 0, st, T);
-  if (n_matches > 0) hipLaunchKernelGGL(k_sum_u32, dim3(1024), dim3(256), 0, st, m_ncig, n_matches, T.out + 7);
+  if (n_matches > 0) hipLaunchKernelGGL(k_sum_ncig, dim3(1024), dim3(256), 0, st, m_a, n_matches, T.out + 7);
+}
+
+void launch_group_ids(hipStream_t st, int64_t n_groups, const uint32_t *group_off, uint32_t *aln_group) {
+  if (n_groups <= 0) return;
+  hipLaunchKernelGGL(k_group_ids, dim3(grid_for(n_groups, 256)), dim3(256), 0, st, n_groups, group_off, aln_group);
 }
 
 void launch_pair(hipStream_t st, const PairArgs &P, bool emit) {
-  if (P.n_groups <= 0) return;
-  if (emit) hipLaunchKernelGGL((k_pair<true>), dim3(grid_for(P.n_groups, 256)), dim3(256), 0, st, P);
-  else hipLaunchKernelGGL((k_pair<false>), dim3(grid_for(P.n_groups, 256)), dim3(256), 0, st, P);
+  if (P.n_aln <= 0) return;
+  if (emit) hipLaunchKernelGGL((k_pair<true>), dim3(grid_for(P.n_aln, 256)), dim3(256), 0, st, P);
+  else hipLaunchKernelGGL((k_pair<false>), dim3(grid_for(P.n_aln, 256)), dim3(256), 0, st, P);
 }
 
-void launch_row_fill(hipStream_t st, const RowArgs &R) {
-  if (R.n_rows <= 0) return;
-  hipLaunchKernelGGL(k_row_fill, dim3(grid_for(R.n_rows, 256)), dim3(256), 0, st, R);
+void launch_row_fill(hipStream_t st, const PairArgs &P, int64_t n_rows) {
+  if (n_rows > 0) hipLaunchKernelGGL(k_row_fill, dim3(grid_for(n_rows, 256)), dim3(256), 0, st, P, n_rows);
+  if (P.n_groups > 0) hipLaunchKernelGGL(k_group_stats, dim3(grid_for(P.n_groups, 256)), dim3(256), 0, st, P);
 }
 
 void launch_gather(hipStream_t st, const RowArgs &R) {
