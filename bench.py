@@ -149,7 +149,7 @@ def main():
                 "alignments_per_gpu_per_step": n_aln,
                 "pairs_per_gpu_per_step": args.pairs,
                 "sharding": "read-name groups per rank, index replicated, no collective",
-                "group_lanes": args.group_lanes or 64,
+                "group_lanes": args.group_lanes or 8,
                 "seed": hex(synth.SEED),
             },
             "projected_records_per_step": int(rows.n_rows),

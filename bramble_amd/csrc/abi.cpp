@@ -39,11 +39,11 @@ struct br_index {
   uint32_t n_refs = 0;
   bool has_seq = false;
   // host copies of the flattened tables
-  std::vector<uint32_t> slab_off, s_start, s_end, s_pmax, s_next, tx_first;
+  std::vector<uint32_t> slab_off, s_start, s_end, s_pmax, s_next, tx_first, bin_off, t_hi, t_lo;
   std::vector<uint4> s_pay, tx_ex;
   std::vector<uint8_t> seq_pool;
   // device copies
-  void *d_slab_off = nullptr, *d_s_start = nullptr, *d_s_end = nullptr, *d_s_pmax = nullptr, *d_s_next = nullptr,
+  void *d_slab_off = nullptr, *d_s_start = nullptr, *d_s_end = nullptr, *d_s_pmax = nullptr, *d_s_next = nullptr, *d_bin_off = nullptr, *d_t_hi = nullptr, *d_t_lo = nullptr,
        *d_s_pay = nullptr, *d_tx_ex = nullptr, *d_tx_first = nullptr, *d_seq_pool = nullptr;
   size_t device_bytes = 0;
   DevIndex dev{};
@@ -135,6 +135,25 @@ static int build_index_flat(size_t n_tx, const int32_t *tx_ref, const int8_t *tx
     }
     ix->slab_off.push_back((uint32_t)ix->s_start.size());
   }
+  // bucket tables (replace the per-read binary search of the slab)
+  const uint32_t SHIFT = 11;
+  ix->bin_off.push_back(0);
+  for (size_t sl = 0; sl + 1 < ix->slab_off.size(); sl++) {
+    uint32_t sb = ix->slab_off[sl], se = ix->slab_off[sl + 1];
+    uint32_t maxc = 0;
+    if (se > sb) maxc = std::max(ix->s_start[se - 1], ix->s_pmax[se - 1]);
+    uint64_t nb = ((uint64_t)maxc >> SHIFT) + 2;
+    uint32_t rh = sb, rl = sb;
+    for (uint64_t b = 0; b < nb; b++) {
+      uint64_t edge = b << SHIFT;
+      while (rh < se && (uint64_t)ix->s_start[rh] < edge) rh++;
+      while (rl < se && (uint64_t)ix->s_pmax[rl] <= edge) rl++;
+      ix->t_hi.push_back(rh); ix->t_lo.push_back(rl);
+    }
+    ix->t_hi.push_back(se); ix->t_lo.push_back(se);
+    if (ix->t_hi.size() >= 0xfffffff0ull) { delete ix; return BR_ERR_CAPACITY; }
+    ix->bin_off.push_back((uint32_t)ix->t_hi.size());
+  }
   ix->device = device;
   if (device >= 0) {
     int rc = check_device(device);
@@ -143,7 +162,8 @@ static int build_index_flat(size_t n_tx, const int32_t *tx_ref, const int8_t *tx
     size_t acc = 0;
     if ((rc = upload(&ix->d_slab_off, ix->slab_off, acc)) || (rc = upload(&ix->d_s_start, ix->s_start, acc)) ||
         (rc = upload(&ix->d_s_end, ix->s_end, acc)) || (rc = upload(&ix->d_s_pmax, ix->s_pmax, acc)) ||
-        (rc = upload(&ix->d_s_next, ix->s_next, acc)) ||
+        (rc = upload(&ix->d_s_next, ix->s_next, acc)) || (rc = upload(&ix->d_bin_off, ix->bin_off, acc)) ||
+        (rc = upload(&ix->d_t_hi, ix->t_hi, acc)) || (rc = upload(&ix->d_t_lo, ix->t_lo, acc)) ||
         (rc = upload(&ix->d_s_pay, ix->s_pay, acc)) || (rc = upload(&ix->d_tx_ex, ix->tx_ex, acc)) ||
         (rc = upload(&ix->d_tx_first, ix->tx_first, acc)) || (rc = upload(&ix->d_seq_pool, ix->seq_pool, acc))) {
       br_index_free(ix); return rc;
@@ -154,6 +174,8 @@ static int build_index_flat(size_t n_tx, const int32_t *tx_ref, const int8_t *tx
     d.slab_off = (const uint32_t *)ix->d_slab_off; d.s_start = (const uint32_t *)ix->d_s_start;
     d.s_end = (const uint32_t *)ix->d_s_end; d.s_pmax = (const uint32_t *)ix->d_s_pmax;
     d.s_next = (const uint32_t *)ix->d_s_next;
+    d.bin_shift = SHIFT; d.bin_off = (const uint32_t *)ix->d_bin_off;
+    d.t_hi = (const uint32_t *)ix->d_t_hi; d.t_lo = (const uint32_t *)ix->d_t_lo;
     d.s_pay = (const uint4 *)ix->d_s_pay; d.tx_ex = (const uint4 *)ix->d_tx_ex;
     d.tx_first = (const uint32_t *)ix->d_tx_first; d.seq_pool = (const uint8_t *)ix->d_seq_pool;
   }
@@ -207,7 +229,7 @@ extern "C" void br_index_free(br_index *ix) {
   if (!ix) return;
   if (ix->device >= 0) {
     (void)hipSetDevice(ix->device);
-    void *ptrs[] = {ix->d_slab_off, ix->d_s_start, ix->d_s_end, ix->d_s_pmax, ix->d_s_next, ix->d_s_pay, ix->d_tx_ex,
+    void *ptrs[] = {ix->d_slab_off, ix->d_s_start, ix->d_s_end, ix->d_s_pmax, ix->d_s_next, ix->d_bin_off, ix->d_t_hi, ix->d_t_lo, ix->d_s_pay, ix->d_tx_ex,
                     ix->d_tx_first, ix->d_seq_pool};
     for (void *p : ptrs) if (p) (void)hipFree(p);
   }
@@ -335,7 +357,7 @@ struct KEvent { int which; hipEvent_t a, b; };
 
 struct br_ctx {
   const br_index *ix = nullptr;
-  int group_lanes = 64;
+  int group_lanes = 8;
   int blocks_per_cu = 8;
   int n_cu = 256;
   bool profiling = false;
@@ -344,7 +366,7 @@ struct br_ctx {
   uint64_t counters[8] = {0};
   // device scratch
   DevBuf seg, meta, head, n_matches, ranges, mask, match_off, cig_base, tile_sums, totals, counters_d;
-  DevBuf m_tid, m_aux, m_a, m_b, m_cigoff, cig_arena;
+  DevBuf m_tid, m_aux, m_a, m_b, m_cigoff, cig_arena, big_list, n_big, m_aln;
   DevBuf n_rows, row_off, aln_group, r_input, r_match, r_mate, r_flags, r_nh, r_hi, r_mapq, r_group, r_mate_tid, r_mate_pos,
       r_isize, r_tid, r_pos, r_ncig, r_strand, r_sim, r_clip, r_junc, r_refc, r_cigoff, cigar_out;
   DevBuf r_paired, r_same, r_first;  // unpacked flag bytes for the public row view
@@ -386,7 +408,7 @@ extern "C" void br_ctx_free(br_ctx *c) {
   (void)hipSetDevice(c->ix->device);
   DevBuf *bufs[] = {&c->seg, &c->meta, &c->head, &c->n_matches, &c->ranges, &c->mask, &c->match_off, &c->cig_base,
                     &c->tile_sums, &c->totals, &c->counters_d, &c->m_tid, &c->m_aux, &c->m_a, &c->m_b,
-                    &c->m_cigoff, &c->cig_arena,
+                    &c->m_cigoff, &c->cig_arena, &c->big_list, &c->n_big, &c->m_aln,
                     &c->n_rows, &c->row_off, &c->aln_group, &c->r_input, &c->r_match, &c->r_mate, &c->r_flags, &c->r_nh, &c->r_hi, &c->r_mapq,
                     &c->r_group, &c->r_mate_tid, &c->r_mate_pos, &c->r_isize, &c->r_tid, &c->r_pos,
                     &c->r_ncig, &c->r_strand, &c->r_sim, &c->r_clip, &c->r_junc, &c->r_refc, &c->r_cigoff,
@@ -491,6 +513,9 @@ int run_device(br_ctx *c, const br_config *cfg, const br_device_batch *b, hipStr
   A.n_matches = c->n_matches.as<uint32_t>();
   A.ranges = c->ranges.as<uint4>(); A.mask = c->mask.as<uint64_t>();
   A.match_off = c->match_off.as<uint32_t>(); A.cig_base = c->cig_base.as<uint64_t>();
+  RC(c->big_list.ensure((size_t)n * 4)); RC(c->n_big.ensure(16));
+  HIPCHK(hipMemsetAsync(c->n_big.p, 0, 4, st));
+  A.big_list = c->big_list.as<uint32_t>(); A.n_big = c->n_big.as<uint32_t>();
   int n_blocks = c->n_cu * c->blocks_per_cu;
   RC(pf.begin(BR_K_COUNT));
   launch_project(st, A, false, c->group_lanes, n_blocks);
@@ -511,13 +536,15 @@ int run_device(br_ctx *c, const br_config *cfg, const br_device_batch *b, hipStr
 
   size_t nm = (size_t)std::max<uint64_t>(n_matches, 1);
   RC(c->m_tid.ensure(nm * 4)); RC(c->m_aux.ensure(nm * 4)); RC(c->m_a.ensure(nm * sizeof(uint4)));
-  RC(c->m_b.ensure(nm * sizeof(uint4))); RC(c->m_cigoff.ensure(nm * 8));
+  RC(c->m_b.ensure(nm * sizeof(uint4))); RC(c->m_cigoff.ensure(nm * 8)); RC(c->m_aln.ensure(nm * 4));
+  A.m_aln = c->m_aln.as<uint32_t>();
   RC(c->cig_arena.ensure((size_t)std::max<uint64_t>(n_cig_arena, 1) * 4));
   A.m_tid = c->m_tid.as<uint32_t>(); A.m_aux = c->m_aux.as<uint32_t>(); A.m_a = c->m_a.as<uint4>();
   A.m_b = c->m_b.as<uint4>(); A.m_cigoff = c->m_cigoff.as<uint64_t>(); A.cig_arena = c->cig_arena.as<uint32_t>();
   if (n_matches) {
     RC(pf.begin(BR_K_EMIT));
-    launch_project(st, A, true, c->group_lanes, n_blocks);
+    launch_emit_dense(st, A, (int64_t)n_matches);
+    launch_project(st, A, true, 64, c->n_cu);  // alignments with > 64 candidate rows only
     RC(pf.end());
   }
 

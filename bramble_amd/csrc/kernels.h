@@ -21,6 +21,9 @@ struct ProjectArgs {
   uint32_t *n_matches;   // [n_aln]
   uint4 *ranges;         // [n_aln] candidate row ranges (lo+,hi+,lo-,hi-)
   uint64_t *mask;        // [n_aln] survivor bit per candidate row (<= 64 rows)
+  uint32_t *big_list;    // alignments with > 64 candidate rows and >= 1 match
+  uint32_t *n_big;       // their count (device counter, zeroed per batch)
+  uint32_t *m_aln;       // [n_matches] alignment of each match slot (k_expand)
   const uint32_t *match_off;  // [n_aln + 1]
   const uint64_t *cig_base;   // [n_aln + 1]
   // match table (emit)
@@ -88,6 +91,7 @@ void launch_segment(hipStream_t st, int64_t n_aln, const int32_t *ref_id, const 
                     const uint32_t *cigar, const DevCfg &cfg, uint32_t n_refs, uint2 *seg, AlnMeta *meta,
                     uint4 *head);
 void launch_project(hipStream_t st, const ProjectArgs &A, bool emit, int group_lanes, int n_blocks);
+void launch_emit_dense(hipStream_t st, const ProjectArgs &A, int64_t n_matches);
 int64_t scan_tiles_for(int64_t n);
 // mode 0: src32 as is; 1: n_matches * CIGAR slot capacity; 2: src32 as is (alias of 0)
 void launch_scan(hipStream_t st, const ScanArgs &S, int mode, void *out, bool out64, uint64_t *total_out);

@@ -566,6 +566,7 @@ __device__ __forceinline__ bool similarity(const DevCfg &cfg, const Acc &acc, do
 template <int G, bool EMIT>
 __global__ void __launch_bounds__(256) k_project(ProjectArgs A) {
   __shared__ uint32_t sh_slab[SLAB_LDS];
+  __shared__ uint32_t sh_bin[EMIT ? 1 : SLAB_LDS];
   __shared__ uint32_t sh_cig[EMIT ? 256 * LDS_SLOT : 1];
   const int gl = threadIdx.x & (G - 1);
   const int gbase = (threadIdx.x & 63) & ~(G - 1);
@@ -577,11 +578,18 @@ __global__ void __launch_bounds__(256) k_project(ProjectArgs A) {
   const uint32_t n_slab_off = 2 * ix.n_refs + 1;
   const bool slab_in_lds = n_slab_off <= SLAB_LDS;
   if (slab_in_lds) {
-    for (uint32_t i = threadIdx.x; i < n_slab_off; i += blockDim.x) sh_slab[i] = ix.slab_off[i];
+    for (uint32_t i = threadIdx.x; i < n_slab_off; i += blockDim.x) {
+      sh_slab[i] = ix.slab_off[i];
+      if (!EMIT) sh_bin[i] = ix.bin_off[i];
+    }
     __syncthreads();
   }
 
-  for (int64_t a = gid; a < A.n_aln; a += groups_total) {
+  // EMIT: only the alignments with more than 64 candidate rows come here (the
+  // rest is written by k_emit_dense); the count pass listed them in big_list.
+  const int64_t n_work = EMIT ? (int64_t)*A.n_big : A.n_aln;
+  for (int64_t w = gid; w < n_work; w += groups_total) {
+    const int64_t a = EMIT ? (int64_t)A.big_list[w] : w;
     uint4 hd = A.head[a];
     uint32_t n_seg = hd.z;
     if (n_seg == 0) { if (!EMIT && gl == 0) { A.n_matches[a] = 0; A.ranges[a] = make_uint4(0, 0, 0, 0); A.mask[a] = 0; } continue; }
@@ -599,45 +607,32 @@ __global__ void __launch_bounds__(256) k_project(ProjectArgs A) {
       uint4 rg = A.ranges[a];
       lo[0] = rg.x; hi[0] = rg.y; lo[1] = rg.z; hi[1] = rg.w;
     } else {
-      // searches 0/1: hi/lo on '+', 2/3: hi/lo on '-'.  hi: first row with
-      // start >= qend; lo: first row with running max end > qstart.
-      uint32_t sa[4], sbn[4];
-      bool act[4];
+      // Candidate rows of read exon 0 on strand s: [lo, hi) with hi = first row with
+      // start >= qend and lo = first row whose running max end exceeds qstart.  The
+      // bucket tables bound both to one coordinate bin; a G-wide count finishes.
+      uint32_t ra[4], rb[4];  // 0/1: hi/lo on '+', 2/3: hi/lo on '-'
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        int s = k >> 1;
-        act[k] = ((smode >> s) & 1u) && sb[s] != se[s];
-        sa[k] = sb[s]; sbn[k] = act[k] ? se[s] : sb[s];
-      }
-      for (;;) {
-        uint32_t p[4], v[4]; bool big[4]; bool any = false;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          uint32_t n = sbn[k] - sa[k];
-          big[k] = n > (uint32_t)G;
-          p[k] = sa[k] + (uint32_t)(((uint64_t)(gl + 1) * n) / (uint32_t)(G + 1));
-          v[k] = 0;
-          if (big[k]) { v[k] = (k & 1) ? ix.s_pmax[p[k]] : ix.s_start[p[k]]; any = true; }
-        }
-        if (!any) break;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          if (!big[k]) continue;
-          bool t = (k & 1) ? (v[k] <= q0.x) : (v[k] < q0.y);
-          int c = __popcll((__ballot(t) >> gbase) & gmask);
-          uint32_t pa = __shfl(p[k], c > 0 ? c - 1 : 0, G);
-          uint32_t pb = __shfl(p[k], c < G ? c : G - 1, G);
-          if (c > 0) sa[k] = pa + 1;
-          if (c < G) sbn[k] = pb;
-        }
+      for (int s = 0; s < 2; s++) {
+        ra[2 * s] = rb[2 * s] = ra[2 * s + 1] = rb[2 * s + 1] = sb[s];
+        if (!((smode >> s) & 1u) || sb[s] == se[s]) continue;
+        uint32_t bo = slab_in_lds ? sh_bin[2 * rid + s] : ix.bin_off[2 * rid + s];
+        uint32_t nb = (slab_in_lds ? sh_bin[2 * rid + s + 1] : ix.bin_off[2 * rid + s + 1]) - bo - 1;
+        uint32_t bh = q0.y >> ix.bin_shift, bl = q0.x >> ix.bin_shift;
+        bh = bh < nb - 1 ? bh : nb - 1; bl = bl < nb - 1 ? bl : nb - 1;
+        ra[2 * s] = ix.t_hi[bo + bh]; rb[2 * s] = ix.t_hi[bo + bh + 1];
+        ra[2 * s + 1] = ix.t_lo[bo + bl]; rb[2 * s + 1] = ix.t_lo[bo + bl + 1];
       }
       uint32_t res[4];
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        uint32_t pp = sa[k] + (uint32_t)gl;
-        bool t = false;
-        if (pp < sbn[k]) { uint32_t vv = (k & 1) ? ix.s_pmax[pp] : ix.s_start[pp]; t = (k & 1) ? (vv <= q0.x) : (vv < q0.y); }
-        res[k] = sa[k] + (uint32_t)__popcll((__ballot(t) >> gbase) & gmask);
+        uint32_t cnt = 0;
+        for (uint32_t r0 = ra[k]; r0 < rb[k]; r0 += G) {
+          uint32_t r = r0 + (uint32_t)gl;
+          bool t = false;
+          if (r < rb[k]) { uint32_t vv = (k & 1) ? ix.s_pmax[r] : ix.s_start[r]; t = (k & 1) ? (vv <= q0.x) : (vv < q0.y); }
+          cnt += (uint32_t)__popcll((__ballot(t) >> gbase) & gmask);
+        }
+        res[k] = ra[k] + cnt;
       }
       hi[0] = res[0]; lo[0] = res[1] < res[0] ? res[1] : res[0];
       hi[1] = res[2]; lo[1] = res[3] < res[2] ? res[3] : res[2];
@@ -775,8 +770,97 @@ __global__ void __launch_bounds__(256) k_project(ProjectArgs A) {
       }
       if (EMIT && !have_mask && sweep == 0) __threadfence_block();  // m_aux[] written above is read below
     }
-    if (!EMIT && gl == 0) { A.n_matches[a] = total; A.mask[a] = mask_all; }
+    if (!EMIT && gl == 0) {
+      A.n_matches[a] = total; A.mask[a] = mask_all;
+      if (n_items > 64 && total) { uint32_t k = atomicAdd(A.n_big, 1u); A.big_list[k] = (uint32_t)a; }
+    }
   }
+}
+
+// k_expand: one lane per alignment labels its match slots with the alignment
+// index (~0u for the > 64-candidate alignments, which the group kernel emits).
+__global__ void __launch_bounds__(256) k_expand(ProjectArgs A) {
+  int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= A.n_aln) return;
+  uint32_t m0 = A.match_off[a], m1 = A.match_off[a + 1];
+  if (m0 == m1) return;
+  uint4 rg = A.ranges[a];
+  uint32_t n_items = (rg.y - rg.x) + (rg.w - rg.z);
+  uint32_t v = n_items <= 64 ? (uint32_t)a : 0xffffffffu;
+  for (uint32_t k = m0; k < m1; k++) A.m_aln[k] = v;
+}
+
+// k_emit_dense: one lane per match.  Match mi of alignment a is the k-th set bit
+// (k = mi - match_off[a]) of the survivor mask the count pass stored; the lane
+// re-derives the candidate from its slab row, ranks it by tid among the read's
+// survivors, builds the ideal CIGAR, merges it with the real CIGAR and writes the
+// match record at match_off[a] + rank.
+__global__ void __launch_bounds__(256) k_emit_dense(ProjectArgs A, int64_t n_matches) {
+  __shared__ uint32_t sh_cig[256 * LDS_SLOT];
+  int64_t mi64 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (mi64 >= n_matches) return;
+  const DevIndex &ix = A.ix;
+  const DevCfg &cfg = A.cfg;
+  uint32_t a = A.m_aln[mi64];
+  if (a == 0xffffffffu) return;
+  uint4 hd = A.head[a];
+  uint4 rg = A.ranges[a];
+  uint64_t mask = A.mask[a];
+  uint32_t moff = A.match_off[a];
+  uint64_t cbase = A.cig_base[a];
+  uint32_t c0 = A.cigar_off[a], c1 = A.cigar_off[a + 1];
+  uint32_t n_seg = hd.z, rid = hd.w >> 2;
+  uint2 q0 = make_uint2(hd.x, hd.y);
+  int st0 = (n_seg == 1) ? ST_ONLY : ST_FIRST;
+  uint32_t n0 = rg.y - rg.x;
+  // k-th survivor in candidate-row order
+  uint32_t k = (uint32_t)mi64 - moff;
+  uint64_t mm = mask;
+  for (uint32_t j = 0; j < k; j++) mm &= mm - 1;
+  uint32_t item = (uint32_t)(__ffsll((long long)mm) - 1);
+  int s = item < n0 ? 0 : 1;
+  uint32_t row = s == 0 ? rg.x + item : rg.z + (item - n0);
+  uint32_t gs = ix.s_start[row], gend = ix.s_end[row];
+  uint4 pay = ix.s_pay[row];
+  // rank by tid among the survivors
+  uint32_t rank = 0;
+  for (uint64_t m2 = mask; m2; m2 &= m2 - 1) {
+    uint32_t b = (uint32_t)(__ffsll((long long)m2) - 1);
+    uint32_t r2 = b < n0 ? rg.x + b : rg.z + (b - n0);
+    rank += (ix.s_pay[r2].x < pay.x) ? 1u : 0u;
+  }
+  ReadCtx rd;
+  rd.n_seg = n_seg; rd.seg = A.seg + (size_t)c0 + (size_t)a; rd.real = A.cigar + c0; rd.n_real = c1 - c0;
+  Hit h0;
+  classify(s == 1, st0, q0.x, q0.y, gs, gend, pay.z, cfg, h0);
+  const uint4 *E = ix.tx_ex + pay.w;
+  uint32_t i0 = pay.y;
+  CandOut p1;
+  uint32_t sb = ix.slab_off[2 * rid + s], se = ix.slab_off[2 * rid + s + 1];
+  if (n_seg == 1) { p1.alive = true; p1.fwpos = h0.pos; p1.rcpos = h0.pos; p1.n_seg = 1; p1.n_gex = 1; }
+  else p1 = walk_pass1(ix, cfg, rd, E, s == 1, sb, se, i0, q0, h0);
+  uint32_t ideal_cap = 4u * n_seg + 2u;
+  uint32_t cap = rd.n_real + 2u * ideal_cap;
+  uint32_t *slot = A.cig_arena + cbase + (uint64_t)rank * cap;
+  uint32_t *lds = &sh_cig[threadIdx.x * LDS_SLOT];
+  bool ideal_lds = ideal_cap <= LDS_IDEAL;
+  uint32_t *ideal = ideal_lds ? lds : slot + rd.n_real + ideal_cap;
+  Acc acc; IdealSink sk; double score = 0.0;
+  sk.init(ideal);
+  walk_pass2(ix, cfg, rd, E, s == 1, sb, se, i0, q0, gs, gend, h0, p1, acc, sk);
+  uint32_t n_ideal = sk.finish();
+  similarity(cfg, acc, score);
+  bool out_lds = ideal_lds && (rd.n_real + n_ideal <= LDS_SLOT - LDS_IDEAL);
+  uint32_t *outp = out_lds ? lds + LDS_IDEAL : slot;
+  uint32_t n_out = merge_cigars(rd.real, rd.n_real, ideal, n_ideal, outp);
+  if (out_lds) for (uint32_t q = 0; q < n_out; q++) slot[q] = outp[q];
+  uint32_t mo = moff + rank;
+  A.m_tid[mo] = pay.x;
+  A.m_a[mo] = make_uint4((s == 0) ? p1.fwpos : p1.rcpos, n_out | ((uint32_t)s << 31), (uint32_t)acc.junc_hits,
+                         (uint32_t)acc.ref_consumed);
+  unsigned long long sb64 = (unsigned long long)__double_as_longlong(score);
+  A.m_b[mo] = make_uint4((uint32_t)acc.clip_score, 0u, (uint32_t)sb64, (uint32_t)(sb64 >> 32));
+  A.m_cigoff[mo] = cbase + (uint64_t)rank * cap;
 }
 
 // ---------------------------------------------------------------------------
@@ -1086,6 +1170,12 @@ void launch_project(hipStream_t st, const ProjectArgs &A, bool emit, int group_l
     case 32: launch_project_g<32>(st, A, emit, n_blocks); break;
     default: launch_project_g<64>(st, A, emit, n_blocks); break;
   }
+}
+
+void launch_emit_dense(hipStream_t st, const ProjectArgs &A, int64_t n_matches) {
+  if (A.n_aln <= 0 || n_matches <= 0) return;
+  hipLaunchKernelGGL(k_expand, dim3(grid_for(A.n_aln, 256)), dim3(256), 0, st, A);
+  hipLaunchKernelGGL(k_emit_dense, dim3(grid_for(n_matches, 256)), dim3(256), 0, st, A, n_matches);
 }
 
 int64_t scan_tiles_for(int64_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE; }

@@ -99,6 +99,40 @@ def test_long_read_presets_without_fasta(mode, flags):
     assert_rows_equal(prod, orc)
 
 
+def test_dense_locus_more_than_64_candidates():
+    """150 isoforms share an exon: reads there have > 64 candidate rows (the group kernel's
+    two-sweep path) next to reads that take the dense per-match path."""
+    txs = []
+    for t in range(150):
+        strand = "+" if t % 3 else "-"
+        ex = [[1000, 1200 + (t % 4)], [2000 + 5 * (t % 7), 2300], [3000, 3100 + t]]
+        if t % 5 == 0:
+            ex = ex[:2]
+        txs.append({"id": "iso%d" % t, "ref_id": 0, "strand": strand, "exons": ex})
+    txs.append({"id": "solo", "ref_id": 0, "strand": "+", "exons": [[10000, 10500]]})
+    ann = {"refnames": ["chr1"], "transcripts": txs}
+    recs = []
+    rng = np.random.RandomState(7)
+    for i in range(400):
+        kind = i % 4
+        if kind == 0:
+            recs.append({"name": "r%d" % i, "ref_id": 0, "ref_start": 1000 + int(rng.randint(0, 120)), "cigar": "80M"})
+        elif kind == 1:
+            st = 1100 + int(rng.randint(0, 50))
+            recs.append({"name": "r%d" % i, "ref_id": 0, "ref_start": st,
+                         "cigar": "%dM%dN60M" % (1200 - st, 2000 - 1200)})
+        elif kind == 2:
+            recs.append({"name": "r%d" % i, "ref_id": 0, "ref_start": 10000 + int(rng.randint(0, 400)), "cigar": "90M"})
+        else:
+            st = 2200 + int(rng.randint(0, 60))
+            recs.append({"name": "r%d" % i, "ref_id": 0, "ref_start": st, "cigar": "%dM%dN50M" % (2300 - st, 700)})
+    b = make_batch(recs)
+    for g in (64, 8):
+        prod, orc = run_both(ann, b, group_lanes=g)
+        assert orc["nh"].max() > 64
+        assert_rows_equal(prod, orc)
+
+
 def test_empty_and_degenerate_inputs():
     ann = synth.Annotation("S").as_dict()
     idx = lib.Index(ann, device=0)
