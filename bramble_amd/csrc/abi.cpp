@@ -542,9 +542,12 @@ int run_device(br_ctx *c, const br_config *cfg, const br_device_batch *b, hipStr
   A.m_tid = c->m_tid.as<uint32_t>(); A.m_aux = c->m_aux.as<uint32_t>(); A.m_a = c->m_a.as<uint4>();
   A.m_b = c->m_b.as<uint4>(); A.m_cigoff = c->m_cigoff.as<uint64_t>(); A.cig_arena = c->cig_arena.as<uint32_t>();
   if (n_matches) {
+    RC(pf.begin(BR_K_EMIT_AUX));
+    launch_expand(st, A);
+    launch_project(st, A, true, 64, c->n_cu);  // alignments with > 64 candidate rows only
+    RC(pf.end());
     RC(pf.begin(BR_K_EMIT));
     launch_emit_dense(st, A, (int64_t)n_matches);
-    launch_project(st, A, true, 64, c->n_cu);  // alignments with > 64 candidate rows only
     RC(pf.end());
   }
 

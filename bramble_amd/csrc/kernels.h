@@ -91,6 +91,7 @@ void launch_segment(hipStream_t st, int64_t n_aln, const int32_t *ref_id, const 
                     const uint32_t *cigar, const DevCfg &cfg, uint32_t n_refs, uint2 *seg, AlnMeta *meta,
                     uint4 *head);
 void launch_project(hipStream_t st, const ProjectArgs &A, bool emit, int group_lanes, int n_blocks);
+void launch_expand(hipStream_t st, const ProjectArgs &A);
 void launch_emit_dense(hipStream_t st, const ProjectArgs &A, int64_t n_matches);
 int64_t scan_tiles_for(int64_t n);
 // mode 0: src32 as is; 1: n_matches * CIGAR slot capacity; 2: src32 as is (alias of 0)

@@ -19,6 +19,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "device_types.h"
 #include "kernels.h"
 
@@ -758,14 +760,16 @@ __global__ void __launch_bounds__(256) k_project(ProjectArgs A) {
           bool out_lds = ideal_lds && (rd.n_real + n_ideal <= LDS_SLOT - LDS_IDEAL);
           uint32_t *outp = out_lds ? lds + LDS_IDEAL : slot;
           uint32_t n_out = merge_cigars(rd.real, rd.n_real, ideal, n_ideal, outp);
-          if (out_lds) for (uint32_t k = 0; k < n_out; k++) slot[k] = outp[k];
+          uint64_t cig_ref = cbase + (uint64_t)rank * cap;
+          if (n_out <= 2) cig_ref = (uint64_t)(n_out > 0 ? outp[0] : 0u) | ((uint64_t)(n_out > 1 ? outp[1] : 0u) << 32);
+          else if (out_lds) for (uint32_t k = 0; k < n_out; k++) slot[k] = outp[k];
           uint32_t mi = moff + rank;
           A.m_tid[mi] = pay.x;
           A.m_a[mi] = make_uint4((s == 0) ? p1.fwpos : p1.rcpos, n_out | ((uint32_t)s << 31), (uint32_t)acc.junc_hits,
                                  (uint32_t)acc.ref_consumed);
           unsigned long long sb64 = (unsigned long long)__double_as_longlong(score);
           A.m_b[mi] = make_uint4((uint32_t)acc.clip_score, 0u, (uint32_t)sb64, (uint32_t)(sb64 >> 32));
-          A.m_cigoff[mi] = cbase + (uint64_t)rank * cap;
+          A.m_cigoff[mi] = cig_ref;
         }
       }
       if (EMIT && !have_mask && sweep == 0) __threadfence_block();  // m_aux[] written above is read below
@@ -853,14 +857,18 @@ __global__ void __launch_bounds__(256) k_emit_dense(ProjectArgs A, int64_t n_mat
   bool out_lds = ideal_lds && (rd.n_real + n_ideal <= LDS_SLOT - LDS_IDEAL);
   uint32_t *outp = out_lds ? lds + LDS_IDEAL : slot;
   uint32_t n_out = merge_cigars(rd.real, rd.n_real, ideal, n_ideal, outp);
-  if (out_lds) for (uint32_t q = 0; q < n_out; q++) slot[q] = outp[q];
+  // rewritten CIGARs of <= 2 ops travel inside the match record (m_cigoff holds the
+  // words themselves); longer ones stay in the arena slot
+  uint64_t cig_ref = cbase + (uint64_t)rank * cap;
+  if (n_out <= 2) cig_ref = (uint64_t)(n_out > 0 ? outp[0] : 0u) | ((uint64_t)(n_out > 1 ? outp[1] : 0u) << 32);
+  else if (out_lds) for (uint32_t q = 0; q < n_out; q++) slot[q] = outp[q];
   uint32_t mo = moff + rank;
   A.m_tid[mo] = pay.x;
   A.m_a[mo] = make_uint4((s == 0) ? p1.fwpos : p1.rcpos, n_out | ((uint32_t)s << 31), (uint32_t)acc.junc_hits,
                          (uint32_t)acc.ref_consumed);
   unsigned long long sb64 = (unsigned long long)__double_as_longlong(score);
   A.m_b[mo] = make_uint4((uint32_t)acc.clip_score, 0u, (uint32_t)sb64, (uint32_t)(sb64 >> 32));
-  A.m_cigoff[mo] = cbase + (uint64_t)rank * cap;
+  A.m_cigoff[mo] = cig_ref;
 }
 
 // ---------------------------------------------------------------------------
@@ -1055,14 +1063,14 @@ __global__ void __launch_bounds__(256) k_row_fill(PairArgs P, int64_t n_rows) {
   P.r_first[r] = (flags & RF_FIRST) ? 1 : 0;
 }
 
-// k_group_stats: counters of src/bramble.cpp:729-736 (one lane per group)
+// k_group_stats: counters of src/bramble.cpp:729-736; grid-stride over groups,
+// one atomic per wave at the end.
 __global__ void __launch_bounds__(256) k_group_stats(PairArgs P) {
-  int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long uniq = 0, dropped = 0;
-  if (g < P.n_groups) {
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < P.n_groups; g += (int64_t)gridDim.x * blockDim.x) {
     uint32_t a0 = P.group_off[g], a1 = P.group_off[g + 1];
-    uniq = (P.row_off[a1] - P.row_off[a0]) == 1 ? 1 : 0;
-    dropped = (P.match_off[a1] == P.match_off[a0]) ? 1 : 0;
+    uniq += (P.row_off[a1] - P.row_off[a0]) == 1 ? 1 : 0;
+    dropped += (P.match_off[a1] == P.match_off[a0]) ? 1 : 0;
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) { uniq += __shfl_down(uniq, d, 64); dropped += __shfl_down(dropped, d, 64); }
@@ -1077,9 +1085,15 @@ __global__ void __launch_bounds__(256) k_gather(RowArgs R) {
   int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= R.n_rows) return;
   uint32_t x = R.r_match[r];
-  const uint32_t *src = R.cig_arena + R.m_cigoff[x];
+  uint64_t ref = R.m_cigoff[x];
   uint64_t d0 = R.r_cigoff[r];
   uint32_t n = R.r_ncig[r];
+  if (n <= 2) {  // inline words
+    if (n > 0) R.cigar_out[d0] = (uint32_t)ref;
+    if (n > 1) R.cigar_out[d0 + 1] = (uint32_t)(ref >> 32);
+    return;
+  }
+  const uint32_t *src = R.cig_arena + ref;
   for (uint32_t k = 0; k < n; k++) R.cigar_out[d0 + k] = src[k];
 }
 
@@ -1172,9 +1186,13 @@ void launch_project(hipStream_t st, const ProjectArgs &A, bool emit, int group_l
   }
 }
 
+void launch_expand(hipStream_t st, const ProjectArgs &A) {
+  if (A.n_aln <= 0) return;
+  hipLaunchKernelGGL(k_expand, dim3(grid_for(A.n_aln, 256)), dim3(256), 0, st, A);
+}
+
 void launch_emit_dense(hipStream_t st, const ProjectArgs &A, int64_t n_matches) {
   if (A.n_aln <= 0 || n_matches <= 0) return;
-  hipLaunchKernelGGL(k_expand, dim3(grid_for(A.n_aln, 256)), dim3(256), 0, st, A);
   hipLaunchKernelGGL(k_emit_dense, dim3(grid_for(n_matches, 256)), dim3(256), 0, st, A, n_matches);
 }
 
@@ -1217,7 +1235,7 @@ void launch_pair(hipStream_t st, const PairArgs &P, bool emit) {
 
 void launch_row_fill(hipStream_t st, const PairArgs &P, int64_t n_rows) {
   if (n_rows > 0) hipLaunchKernelGGL(k_row_fill, dim3(grid_for(n_rows, 256)), dim3(256), 0, st, P, n_rows);
-  if (P.n_groups > 0) hipLaunchKernelGGL(k_group_stats, dim3(grid_for(P.n_groups, 256)), dim3(256), 0, st, P);
+  if (P.n_groups > 0) hipLaunchKernelGGL(k_group_stats, dim3(std::min(grid_for(P.n_groups, 256), 1024)), dim3(256), 0, st, P);
 }
 
 void launch_gather(hipStream_t st, const RowArgs &R) {

@@ -257,14 +257,15 @@ int br_project_group(br_ctx *, const br_config *, const br_alignment *alns, size
 /* ---- measurement hooks ------------------------------------------------------ */
 
 /* Kernel names reported by br_ctx_kernel_ms / rocprof. */
-#define BR_K_SEGMENT 0
-#define BR_K_COUNT 1
-#define BR_K_EMIT 2
-#define BR_K_PAIR_COUNT 3
-#define BR_K_PAIR_EMIT 4
-#define BR_K_GATHER 5
-#define BR_K_SCAN 6
-#define BR_K_NUM 7
+#define BR_K_SEGMENT 0    /* k_segment */
+#define BR_K_COUNT 1      /* k_project<G,false> */
+#define BR_K_EMIT 2       /* k_emit_dense */
+#define BR_K_PAIR_COUNT 3 /* k_group_ids + k_pair<false> */
+#define BR_K_PAIR_EMIT 4  /* k_pair<true> */
+#define BR_K_GATHER 5     /* k_row_fill + k_group_stats + k_gather */
+#define BR_K_SCAN 6       /* k_scan_* */
+#define BR_K_EMIT_AUX 7   /* k_expand + k_project<64,true> (alignments with > 64 candidate rows) */
+#define BR_K_NUM 8
 /* When enabled, every launch is bracketed by hipEvents on the launch stream. */
 int br_ctx_set_profiling(br_ctx *, int enabled);
 /* Launch tuning: "group_lanes" (8|16|32|64 lanes cooperating on one alignment),
