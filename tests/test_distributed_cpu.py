@@ -1,0 +1,73 @@
+"""N>1 path on CPU: world_size-2 gloo.  Each rank takes its shard of read-name groups
+(bramble_amd.shard), projects it independently (here with the oracle standing in for
+the per-rank GPU, since this box has none) and the concatenation over ranks must equal
+the unsharded result -- the property that makes the path collective-free."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bramble_amd import shard, synth
+    from oracle import oracle_binding as ob
+    ann = synth.Annotation("S")
+    batch = ann.reads(3000, "pe")
+    sub, lo = shard.shard_batch(batch, rank, world)
+    rows, _, _ = ob.run(ob.OracleIndex(ann.as_dict()), ob.make_flags(), sub, want_matches=False)
+    # the only cross-rank traffic: counters (5 integers summed) -- never the data path
+    cnt = torch.tensor([rows["n_rows"], rows["total_unique"], rows["dropped_reads"], sub["n_aln"]], dtype=torch.int64)
+    dist.all_reduce(cnt)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), lo=lo, tid=rows["tid"], pos=rows["pos"], nh=rows["nh"],
+             input_index=rows["input_index"] + lo, cigar=rows["cigar"], total=cnt.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_equals_unsharded(tmp_path):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, ROOT)
+    from bramble_amd import synth
+    from oracle import oracle_binding as ob
+    ann = synth.Annotation("S")
+    batch = ann.reads(3000, "pe")
+    full, _, _ = ob.run(ob.OracleIndex(ann.as_dict()), ob.make_flags(), batch, want_matches=False)
+    parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    for key, fk in (("tid", "tid"), ("pos", "pos"), ("nh", "nh"), ("input_index", "input_index"), ("cigar", "cigar")):
+        assert np.array_equal(np.concatenate([p[key] for p in parts]), full[fk]), key
+    assert parts[0]["total"].tolist() == [full["n_rows"], full["total_unique"], full["dropped_reads"], batch["n_aln"]]
+
+
+def test_shards_never_split_a_name_group():
+    sys.path.insert(0, ROOT)
+    from bramble_amd import shard, synth
+    batch = synth.Annotation("S").reads(500, "pe")
+    starts = shard.group_starts(batch)
+    for world in (2, 3, 8):
+        prev = 0
+        for r in range(world):
+            lo, hi = shard.shard_bounds(starts, r, world)
+            assert lo == prev and lo in starts and hi in starts
+            prev = hi
+        assert prev == batch["n_aln"]
