@@ -336,6 +336,18 @@ extern "C" int br_batch_prepare(const br_batch *b, int32_t *mate_idx, uint32_t *
   return BR_OK;
 }
 
+extern "C" int br_batch_seq_source(const br_batch *b, const uint32_t *group_off, int64_t n_groups, int32_t *seq_src) {
+  if (!b || !group_off || !seq_src) return BR_ERR_INVALID_ARG;
+  for (int64_t g = 0; g < n_groups; g++) {
+    int32_t src = -1;
+    if (b->seq_off)
+      for (uint32_t i = group_off[g]; i < group_off[g + 1]; i++)
+        if (b->seq_off[i + 1] > b->seq_off[i]) { src = (int32_t)i; break; }
+    for (uint32_t i = group_off[g]; i < group_off[g + 1]; i++) seq_src[i] = src;
+  }
+  return BR_OK;
+}
+
 // ---------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------
@@ -367,6 +379,8 @@ struct br_ctx {
   // device scratch
   DevBuf seg, meta, head, n_matches, ranges, mask, match_off, cig_base, tile_sums, totals, counters_d;
   DevBuf m_tid, m_aux, m_a, m_b, m_cigoff, cig_arena, big_list, n_big, m_aln;
+  DevBuf fa_n_prob, fa_seq_bytes, fa_prob_off, fa_seqarena_off, fa_probs, fa_results, fa_seq_arena, fa_clip_ops,
+      fa_ideal_cap, fa_scratch, b_seq_off, b_seqs, b_seq_src;
   DevBuf n_rows, row_off, aln_group, r_input, r_match, r_mate, r_flags, r_nh, r_hi, r_mapq, r_group, r_mate_tid, r_mate_pos,
       r_isize, r_tid, r_pos, r_ncig, r_strand, r_sim, r_clip, r_junc, r_refc, r_cigoff, cigar_out;
   DevBuf r_paired, r_same, r_first;  // unpacked flag bytes for the public row view
@@ -409,6 +423,8 @@ extern "C" void br_ctx_free(br_ctx *c) {
   DevBuf *bufs[] = {&c->seg, &c->meta, &c->head, &c->n_matches, &c->ranges, &c->mask, &c->match_off, &c->cig_base,
                     &c->tile_sums, &c->totals, &c->counters_d, &c->m_tid, &c->m_aux, &c->m_a, &c->m_b,
                     &c->m_cigoff, &c->cig_arena, &c->big_list, &c->n_big, &c->m_aln,
+                    &c->fa_n_prob, &c->fa_seq_bytes, &c->fa_prob_off, &c->fa_seqarena_off, &c->fa_probs, &c->fa_results,
+                    &c->fa_seq_arena, &c->fa_clip_ops, &c->fa_ideal_cap, &c->fa_scratch, &c->b_seq_off, &c->b_seqs, &c->b_seq_src,
                     &c->n_rows, &c->row_off, &c->aln_group, &c->r_input, &c->r_match, &c->r_mate, &c->r_flags, &c->r_nh, &c->r_hi, &c->r_mapq,
                     &c->r_group, &c->r_mate_tid, &c->r_mate_pos, &c->r_isize, &c->r_tid, &c->r_pos,
                     &c->r_ncig, &c->r_strand, &c->r_sim, &c->r_clip, &c->r_junc, &c->r_refc, &c->r_cigoff,
@@ -483,7 +499,9 @@ int run_device(br_ctx *c, const br_config *cfg, const br_device_batch *b, hipStr
   memset(out, 0, sizeof(*out));
   DevCfg dc;
   RC(make_devcfg(cfg, dc));
-  if (dc.use_fasta) return BR_ERR_UNSUPPORTED;  // -S clip rescue (k_ksw2) is not built yet
+  // -S only changes long-read runs (src/evaluate.cpp:916-919,939)
+  const bool fa_mode = dc.use_fasta && dc.long_reads;
+  if (fa_mode && (!ix->has_seq || !b->seq_src || !b->seq_off || !b->seqs)) return BR_ERR_INVALID_ARG;
   int64_t n = b->n_aln, ng = b->n_groups;
   if (n < 0 || ng < 0 || n >= 0x7fffffffll || b->n_cigar_words >= 0xffffffffll - n) return BR_ERR_CAPACITY;
   HIPCHK(hipSetDevice(ix->device));
@@ -517,17 +535,77 @@ int run_device(br_ctx *c, const br_config *cfg, const br_device_batch *b, hipStr
   HIPCHK(hipMemsetAsync(c->n_big.p, 0, 4, st));
   A.big_list = c->big_list.as<uint32_t>(); A.n_big = c->n_big.as<uint32_t>();
   int n_blocks = c->n_cu * c->blocks_per_cu;
-  RC(pf.begin(BR_K_COUNT));
-  launch_project(st, A, false, c->group_lanes, n_blocks);
-  RC(pf.end());
-
   ScanArgs S{};
   S.n = n; S.src32 = c->n_matches.as<uint32_t>(); S.cigar_off = b->cigar_off; S.head = c->head.as<uint4>();
   S.tile_sums = c->tile_sums.as<uint64_t>();
-  RC(pf.begin(BR_K_SCAN));
-  launch_scan(st, S, 0, c->match_off.p, false, d_tot + 0);
-  launch_scan(st, S, 1, c->cig_base.p, true, d_tot + 1);
-  RC(pf.end());
+  FaArgs F{};
+  if (!fa_mode) {
+    RC(pf.begin(BR_K_COUNT));
+    launch_project(st, A, false, c->group_lanes, n_blocks);
+    RC(pf.end());
+    RC(pf.begin(BR_K_SCAN));
+    launch_scan(st, S, 0, c->match_off.p, false, d_tot + 0);
+    launch_scan(st, S, 1, c->cig_base.p, true, d_tot + 1);
+    RC(pf.end());
+  } else {
+    // rescue planning -> ksw2 DP -> count with the rescue results
+    RC(c->fa_n_prob.ensure((size_t)n * 4)); RC(c->fa_seq_bytes.ensure((size_t)n * 4));
+    RC(c->fa_prob_off.ensure((size_t)(n + 1) * 4)); RC(c->fa_seqarena_off.ensure((size_t)(n + 1) * 8));
+    RC(c->fa_ideal_cap.ensure((size_t)n * 4));
+    F.seq_src = b->seq_src; F.seq_off = b->seq_off; F.seqs = b->seqs;
+    F.n_prob = c->fa_n_prob.as<uint32_t>(); F.seq_bytes = c->fa_seq_bytes.as<uint32_t>();
+    F.prob_off = c->fa_prob_off.as<uint32_t>(); F.seqarena_off = c->fa_seqarena_off.as<uint64_t>();
+    F.ideal_cap = c->fa_ideal_cap.as<uint32_t>();
+    RC(pf.begin(BR_K_COUNT));
+    launch_project_fa(st, A, F, 0, n_blocks);
+    RC(pf.end());
+    ScanArgs SP{}; SP.n = n; SP.src32 = F.n_prob; SP.tile_sums = c->tile_sums.as<uint64_t>();
+    ScanArgs SB{}; SB.n = n; SB.src32 = F.seq_bytes; SB.tile_sums = c->tile_sums.as<uint64_t>();
+    RC(pf.begin(BR_K_SCAN));
+    launch_scan(st, SP, 2, c->fa_prob_off.p, false, d_tot + 4);
+    launch_scan(st, SB, 2, c->fa_seqarena_off.p, true, d_tot + 5);
+    RC(pf.end());
+    HIPCHK(hipMemcpyAsync(c->h_totals + 4, d_tot + 4, 2 * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    uint64_t n_prob = c->h_totals[4], seq_total = c->h_totals[5];
+    if (n_prob >= 0xffffffffull) return BR_ERR_CAPACITY;
+    RC(c->fa_probs.ensure(std::max<size_t>(n_prob, 1) * ksw_prob_bytes()));
+    RC(c->fa_results.ensure(std::max<size_t>(n_prob, 1) * ksw_res_bytes()));
+    RC(c->fa_seq_arena.ensure(std::max<size_t>(seq_total, 16)));
+    RC(c->fa_clip_ops.ensure((std::max<size_t>(seq_total + n_prob, 1)) * 4));
+    F.probs = (KswProb *)c->fa_probs.p; F.results = (KswRes *)c->fa_results.p;
+    F.seq_arena = c->fa_seq_arena.as<uint8_t>(); F.clip_ops = c->fa_clip_ops.as<uint32_t>();
+    if (n_prob) {
+      RC(pf.begin(BR_K_COUNT));
+      launch_project_fa(st, A, F, 1, n_blocks);
+      RC(pf.end());
+      // ksw2: per-wave scratch = direction matrix + raw traceback ops + (large targets) u/v/x/y
+      uint64_t qmax = (uint64_t)std::max(b->max_soft_clip, 0) + std::max(dc.max_clip, dc.max_junc_ins);
+      uint64_t tmax = qmax + 40;
+      KswArgs K{};
+      K.n_prob = (int64_t)n_prob; K.probs = F.probs; K.results = F.results; K.seq_arena = F.seq_arena;
+      K.clip_ops = F.clip_ops; K.tmax = (uint32_t)tmax;
+      K.pmat_bytes = (size_t)(((qmax + tmax) * tmax + 15) & ~15ull);
+      K.raw_words = (size_t)((qmax + tmax + 4 + 3) & ~3ull);
+      K.scratch_per_wave = K.pmat_bytes + K.raw_words * 4 + ((4 * tmax + 15) & ~15ull);
+      const uint64_t budget = 16ull << 30;  // HBM set aside for direction matrices
+      uint64_t waves = std::min<uint64_t>({(uint64_t)c->n_cu * 4 * 4, std::max<uint64_t>(budget / K.scratch_per_wave, 4), (n_prob + 3) / 4 * 4});
+      int kb = (int)std::max<uint64_t>(waves / 4, 1);
+      RC(c->fa_scratch.ensure((size_t)kb * 4 * K.scratch_per_wave));
+      K.scratch = c->fa_scratch.as<uint8_t>();
+      RC(pf.begin(BR_K_KSW));
+      launch_ksw(st, K, kb);
+      RC(pf.end());
+    }
+    RC(pf.begin(BR_K_COUNT));
+    launch_project_fa(st, A, F, 2, n_blocks);
+    RC(pf.end());
+    S.ideal_cap = F.ideal_cap;
+    RC(pf.begin(BR_K_SCAN));
+    launch_scan(st, S, 0, c->match_off.p, false, d_tot + 0);
+    launch_scan(st, S, 3, c->cig_base.p, true, d_tot + 1);
+    RC(pf.end());
+  }
   HIPCHK(hipMemcpyAsync(c->h_totals, d_tot, 2 * 8, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   uint64_t n_matches = c->h_totals[0], n_cig_arena = c->h_totals[1];
@@ -542,13 +620,19 @@ int run_device(br_ctx *c, const br_config *cfg, const br_device_batch *b, hipStr
   A.m_tid = c->m_tid.as<uint32_t>(); A.m_aux = c->m_aux.as<uint32_t>(); A.m_a = c->m_a.as<uint4>();
   A.m_b = c->m_b.as<uint4>(); A.m_cigoff = c->m_cigoff.as<uint64_t>(); A.cig_arena = c->cig_arena.as<uint32_t>();
   if (n_matches) {
-    RC(pf.begin(BR_K_EMIT_AUX));
-    launch_expand(st, A);
-    launch_project(st, A, true, 64, c->n_cu);  // alignments with > 64 candidate rows only
-    RC(pf.end());
-    RC(pf.begin(BR_K_EMIT));
-    launch_emit_dense(st, A, (int64_t)n_matches);
-    RC(pf.end());
+    if (fa_mode) {
+      RC(pf.begin(BR_K_EMIT));
+      launch_project_fa(st, A, F, 3, n_blocks);
+      RC(pf.end());
+    } else {
+      RC(pf.begin(BR_K_EMIT_AUX));
+      launch_expand(st, A);
+      launch_project(st, A, true, 64, c->n_cu);  // alignments with > 64 candidate rows only
+      RC(pf.end());
+      RC(pf.begin(BR_K_EMIT));
+      launch_emit_dense(st, A, (int64_t)n_matches);
+      RC(pf.end());
+    }
   }
 
   // a16/a17: pairing + NH
@@ -729,6 +813,25 @@ extern "C" int br_project_batch(br_ctx *c, const br_config *cfg, const br_batch 
   HIPCHK(hipStreamSynchronize(st));
 
   br_device_batch db{};
+  if (cfg->use_fasta && (cfg->lr || cfg->lr_hq)) {
+    if (!b->seq_off || !b->seqs) return BR_ERR_INVALID_ARG;
+    uint64_t sbytes = n ? b->seq_off[n] : 0;
+    if (sbytes >= 0xfffffff0ull) return BR_ERR_CAPACITY;
+    std::vector<uint32_t> soff((size_t)n + 1);
+    for (int64_t i = 0; i <= n; i++) soff[i] = (uint32_t)b->seq_off[i];
+    std::vector<int32_t> src((size_t)std::max<int64_t>(n, 1), -1);
+    RC(br_batch_seq_source(b, goff.data(), ng, src.data()));
+    int32_t max_clip = 0;
+    for (int64_t i = 0; i < n; i++) {
+      uint32_t a0 = coff[i], a1 = coff[i + 1];
+      for (uint32_t k = a0; k < a1; k++) if ((b->cigar[k] & 0xf) == 4) max_clip = std::max<int32_t>(max_clip, (int32_t)(b->cigar[k] >> 4));
+    }
+    RC(h2d(c->b_seq_off, soff.data(), (size_t)n + 1, st)); RC(h2d(c->b_seqs, (const uint8_t *)b->seqs, (size_t)sbytes, st));
+    RC(h2d(c->b_seq_src, src.data(), (size_t)n, st));
+    HIPCHK(hipStreamSynchronize(st));
+    db.seq_off = c->b_seq_off.as<uint32_t>(); db.seqs = c->b_seqs.as<uint8_t>(); db.seq_src = c->b_seq_src.as<int32_t>();
+    db.max_soft_clip = max_clip;
+  }
   db.n_aln = n; db.n_groups = ng; db.ref_id = c->b_ref_id.as<int32_t>(); db.ref_start = c->b_ref_start.as<int32_t>();
   db.flags = c->b_flags.as<uint16_t>(); db.xs = c->b_xs.as<int8_t>(); db.ts = c->b_ts.as<int8_t>();
   db.cigar_off = c->b_cigar_off.as<uint32_t>(); db.cigar = c->b_cigar.as<uint32_t>();

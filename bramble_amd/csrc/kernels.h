@@ -34,11 +34,42 @@ struct ProjectArgs {
   uint32_t *cig_arena;
 };
 
+struct KswProb;
+struct KswRes;
+
+// -S clip rescue (rescue_kernels.inc)
+struct FaArgs {
+  const int32_t *seq_src;      // [n_aln] alignment whose sequence the read-name group shares (-1: none)
+  const uint32_t *seq_off;     // [n_aln + 1]
+  const uint8_t *seqs;         // ASCII read sequences
+  uint32_t *n_prob;            // [n_aln] rescue problems per alignment
+  uint32_t *seq_bytes;         // [n_aln] coded sequence bytes per alignment
+  const uint32_t *prob_off;    // [n_aln + 1]
+  const uint64_t *seqarena_off;  // [n_aln + 1]
+  KswProb *probs;
+  KswRes *results;
+  uint8_t *seq_arena;          // query / target codes of every problem
+  uint32_t *clip_ops;          // clip-segment CIGARs: problem p at seq_off(p) + p
+  uint32_t *ideal_cap;         // [n_aln] ideal-CIGAR capacity incl. clip ops
+};
+
+struct KswArgs {
+  int64_t n_prob;
+  const KswProb *probs;
+  KswRes *results;
+  const uint8_t *seq_arena;
+  uint32_t *clip_ops;
+  uint8_t *scratch;
+  size_t scratch_per_wave, pmat_bytes, raw_words;
+  uint32_t tmax;
+};
+
 struct ScanArgs {
   int64_t n;
   const uint32_t *src32;
   const uint32_t *cigar_off;  // mode 1 only
   const uint4 *head;          // mode 1 only
+  const uint32_t *ideal_cap;  // mode 3 only
   uint64_t *tile_sums;
 };
 
@@ -91,10 +122,15 @@ void launch_segment(hipStream_t st, int64_t n_aln, const int32_t *ref_id, const 
                     const uint32_t *cigar, const DevCfg &cfg, uint32_t n_refs, uint2 *seg, AlnMeta *meta,
                     uint4 *head);
 void launch_project(hipStream_t st, const ProjectArgs &A, bool emit, int group_lanes, int n_blocks);
+void launch_project_fa(hipStream_t st, const ProjectArgs &A, const FaArgs &F, int mode, int n_blocks);
+void launch_ksw(hipStream_t st, const KswArgs &K, int n_blocks);
+size_t ksw_prob_bytes();
+size_t ksw_res_bytes();
 void launch_expand(hipStream_t st, const ProjectArgs &A);
 void launch_emit_dense(hipStream_t st, const ProjectArgs &A, int64_t n_matches);
 int64_t scan_tiles_for(int64_t n);
-// mode 0: src32 as is; 1: n_matches * CIGAR slot capacity; 2: src32 as is (alias of 0)
+// mode 0: src32 as is; 1: n_matches * CIGAR slot capacity; 2: src32 as is (alias of 0);
+// 3: n_matches * CIGAR slot capacity with the per-alignment ideal_cap[] of the -S path
 void launch_scan(hipStream_t st, const ScanArgs &S, int mode, void *out, bool out64, uint64_t *total_out);
 void launch_group_ids(hipStream_t st, int64_t n_groups, const uint32_t *group_off, uint32_t *aln_group);
 void launch_pair(hipStream_t st, const PairArgs &P, bool emit);

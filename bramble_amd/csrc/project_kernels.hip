@@ -474,13 +474,26 @@ struct ReadCtx {
 struct CandOut {
   bool alive;
   uint32_t fwpos, rcpos, n_seg, n_gex;
+  uint32_t i_lastm;                 // table index of the last matched guide exon
+  uint32_t last_right_ins, last_right_gap;
 };
+
+// One rescued soft clip (LEFTC_EXON / RIGHTC_EXON segment, src/evaluate.cpp:397-448,548-598)
+struct ClipSide {
+  bool ok;
+  const uint32_t *ops;   // override-op CIGAR of the segment
+  uint32_t n_ops;
+  int32_t score;         // ksw max
+  uint32_t refc;         // reference bases the rescue alignment consumed
+};
+__device__ __forceinline__ ClipSide no_clip() { ClipSide c; c.ok = false; c.ops = nullptr; c.n_ops = 0; c.score = 0; c.refc = 0; return c; }
 
 // Pass 1 (src/evaluate.cpp:1004-1065): survival, segment counts, fwpos/rcpos.
 __device__ __forceinline__ CandOut walk_pass1(const DevIndex &ix, const DevCfg &cfg, const ReadCtx &rd,
                                               const uint4 *E, bool minus, uint32_t sb, uint32_t se,
                                               uint32_t i0, uint2 q0, const Hit &h0) {
   CandOut o; o.alive = true; o.fwpos = h0.pos; o.rcpos = h0.pos; o.n_seg = 1; o.n_gex = 1;
+  o.i_lastm = i0; o.last_right_ins = h0.right_ins; o.last_right_gap = h0.right_gap;
   uint32_t i_last = i0;
   uint2 pq = q0;
   for (uint32_t j = 1; j < rd.n_seg; j++) {
@@ -495,19 +508,55 @@ __device__ __forceinline__ CandOut walk_pass1(const DevIndex &ix, const DevCfg &
     o.n_seg++; o.n_gex++;
     i_last = i_hit;
     if (minus) o.rcpos = h.pos;
+    o.i_lastm = i_hit; o.last_right_ins = h.right_ins; o.last_right_gap = h.right_gap;
   }
   return o;
 }
 
-// Pass 2 (src/evaluate.cpp:1070-1106): ideal CIGAR + accumulators.
+// Pass-1 bookkeeping of rescued clips (src/evaluate.cpp:1050-1064 with a LEFTC /
+// RIGHTC segment at either end): segment counts, fwpos from the left dummy exon,
+// rcpos from the last guide segment on '-'.
+__device__ __forceinline__ void apply_clips(CandOut &o, bool minus, uint32_t pos_start0,
+                                            uint32_t pos_start_last, const ClipSide &L, const ClipSide &R) {
+  if (L.ok) {
+    o.n_seg++; o.n_gex++;
+    uint32_t dpos = pos_start0 - L.refc;
+    o.fwpos = dpos;
+    if (!minus) o.rcpos = dpos;  // on '-' every match segment is a later guide segment and overwrites rcpos
+  }
+  if (R.ok) {
+    o.n_seg++; o.n_gex++;
+    if (minus) o.rcpos = pos_start_last - R.refc;
+  }
+}
+
+// build_cigar_clip (src/evaluate.cpp:824-841)
+__device__ __forceinline__ void build_clip(Acc &m, IdealSink &sk, const ClipSide &c) {
+  for (uint32_t i = 0; i < c.n_ops; i++) {
+    uint32_t w = c.ops[i], op = CIG_OP(w), len = CIG_LEN(w);
+    sk.add(len, op);
+    if (op == OP_MATCH_OVR || op == OP_DEL_OVR) m.ref_consumed += (int32_t)len;
+  }
+  m.clip_score += c.score;
+}
+
+// Pass 2 (src/evaluate.cpp:1070-1106): ideal CIGAR + accumulators.  L / R: rescued
+// clips (both !ok without -S): a clip segment opens / closes the chain, zeroes the
+// neighbouring match segment's left_ins / right_ins (:489-490,648) and turns on
+// td.has_left_clip / has_right_clip for build_cigar_match.
 __device__ __forceinline__ void walk_pass2(const DevIndex &ix, const DevCfg &cfg, const ReadCtx &rd,
                                            const uint4 *E, bool minus, uint32_t sb, uint32_t se, uint32_t i0,
-                                           uint2 q0, uint32_t gs0, uint32_t ge0, const Hit &h0,
-                                           const CandOut &p1, Acc &acc, IdealSink &sk) {
+                                           uint2 q0, uint32_t gs0, uint32_t ge0, const Hit &h0_in,
+                                           const CandOut &p1, Acc &acc, IdealSink &sk, const ClipSide &L,
+                                           const ClipSide &R) {
   acc.init();
   uint32_t k = 0;
+  if (L.ok) { build_clip(acc, sk, L); k++; }
+  Hit h0 = h0_in;
+  if (L.ok) h0.left_ins = 0;
+  if (R.ok && rd.n_seg == 1) h0.right_ins = 0;
   int st0 = (rd.n_seg == 1) ? ST_ONLY : ST_FIRST;
-  build_match(acc, sk, h0, st0, q0.x, q0.y, gs0, ge0, k == 0, k == p1.n_gex - 1, false, false);
+  build_match(acc, sk, h0, st0, q0.x, q0.y, gs0, ge0, k == 0, k == p1.n_gex - 1, L.ok, R.ok);
   k++;
   uint32_t i_last = i0;
   for (uint32_t j = 1; j < rd.n_seg; j++) {
@@ -531,10 +580,12 @@ __device__ __forceinline__ void walk_pass2(const DevIndex &ix, const DevCfg &cfg
       acc.junc_hits -= 2;
       k++;
     }
-    build_match(acc, sk, h, status, q.x, q.y, ge.x, ge.y, k == 0, k == p1.n_gex - 1, false, false);
+    if (R.ok && j == rd.n_seg - 1) h.right_ins = 0;
+    build_match(acc, sk, h, status, q.x, q.y, ge.x, ge.y, k == 0, k == p1.n_gex - 1, L.ok, R.ok);
     k++;
     i_last = i_hit;
   }
+  if (R.ok) { build_clip(acc, sk, R); k++; }
   if (acc.junc_hits < 0) acc.junc_hits = 0;
 }
 
@@ -699,7 +750,7 @@ __global__ void __launch_bounds__(256) k_project(ProjectArgs A) {
               }
             }
             if (!superseded) {
-              if (n_seg == 1) { p1.alive = true; p1.fwpos = h0.pos; p1.rcpos = h0.pos; p1.n_seg = 1; p1.n_gex = 1; }
+              if (n_seg == 1) { p1.alive = true; p1.fwpos = h0.pos; p1.rcpos = h0.pos; p1.n_seg = 1; p1.n_gex = 1; p1.i_lastm = i0; p1.last_right_ins = h0.right_ins; p1.last_right_gap = h0.right_gap; }
               else p1 = walk_pass1(ix, cfg, rd, E, s == 1, sb[s], se[s], i0, q0, h0);
               alive = p1.alive;
             }
@@ -710,7 +761,7 @@ __global__ void __launch_bounds__(256) k_project(ProjectArgs A) {
           // similarity filter needs the pass-2 accumulators (long reads only)
           if (alive && cfg.filter_by_similarity) {
             sk.init(nullptr);
-            walk_pass2(ix, cfg, rd, E, s == 1, sb[s], se[s], i0, q0, gs, gend, h0, p1, acc, sk);
+            walk_pass2(ix, cfg, rd, E, s == 1, sb[s], se[s], i0, q0, gs, gend, h0, p1, acc, sk, no_clip(), no_clip());
             alive = similarity(cfg, acc, score);
           }
         }
@@ -754,7 +805,7 @@ __global__ void __launch_bounds__(256) k_project(ProjectArgs A) {
           bool ideal_lds = ideal_cap <= LDS_IDEAL;
           uint32_t *ideal = ideal_lds ? lds : slot + rd.n_real + ideal_cap;
           sk.init(ideal);
-          walk_pass2(ix, cfg, rd, E, s == 1, sb[s], se[s], i0, q0, gs, gend, h0, p1, acc, sk);
+          walk_pass2(ix, cfg, rd, E, s == 1, sb[s], se[s], i0, q0, gs, gend, h0, p1, acc, sk, no_clip(), no_clip());
           uint32_t n_ideal = sk.finish();
           similarity(cfg, acc, score);
           bool out_lds = ideal_lds && (rd.n_real + n_ideal <= LDS_SLOT - LDS_IDEAL);
@@ -841,7 +892,7 @@ __global__ void __launch_bounds__(256) k_emit_dense(ProjectArgs A, int64_t n_mat
   uint32_t i0 = pay.y;
   CandOut p1;
   uint32_t sb = ix.slab_off[2 * rid + s], se = ix.slab_off[2 * rid + s + 1];
-  if (n_seg == 1) { p1.alive = true; p1.fwpos = h0.pos; p1.rcpos = h0.pos; p1.n_seg = 1; p1.n_gex = 1; }
+  if (n_seg == 1) { p1.alive = true; p1.fwpos = h0.pos; p1.rcpos = h0.pos; p1.n_seg = 1; p1.n_gex = 1; p1.i_lastm = i0; p1.last_right_ins = h0.right_ins; p1.last_right_gap = h0.right_gap; }
   else p1 = walk_pass1(ix, cfg, rd, E, s == 1, sb, se, i0, q0, h0);
   uint32_t ideal_cap = 4u * n_seg + 2u;
   uint32_t cap = rd.n_real + 2u * ideal_cap;
@@ -851,7 +902,7 @@ __global__ void __launch_bounds__(256) k_emit_dense(ProjectArgs A, int64_t n_mat
   uint32_t *ideal = ideal_lds ? lds : slot + rd.n_real + ideal_cap;
   Acc acc; IdealSink sk; double score = 0.0;
   sk.init(ideal);
-  walk_pass2(ix, cfg, rd, E, s == 1, sb, se, i0, q0, gs, gend, h0, p1, acc, sk);
+  walk_pass2(ix, cfg, rd, E, s == 1, sb, se, i0, q0, gs, gend, h0, p1, acc, sk, no_clip(), no_clip());
   uint32_t n_ideal = sk.finish();
   similarity(cfg, acc, score);
   bool out_lds = ideal_lds && (rd.n_real + n_ideal <= LDS_SLOT - LDS_IDEAL);
@@ -903,6 +954,7 @@ __device__ __forceinline__ uint64_t scan_value(const ScanArgs &S, int64_t i) {
   uint32_t nm = S.src32[i];
   if (nm == 0) return 0;
   uint32_t n_real = S.cigar_off[i + 1] - S.cigar_off[i];
+  if (MODE == 3) return (uint64_t)nm * (uint64_t)(n_real + 2u * S.ideal_cap[i]);
   uint32_t ideal_cap = 4u * S.head[i].z + 2u;
   return (uint64_t)nm * (uint64_t)(n_real + 2u * ideal_cap);
 }
@@ -1151,9 +1203,33 @@ __global__ void __launch_bounds__(256) k_sum_ncig(const uint4 *m_a, int64_t n, u
   if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long *)out, acc);
 }
 
+#include "rescue_kernels.inc"
+
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
+size_t ksw_prob_bytes() { return sizeof(KswProb); }
+size_t ksw_res_bytes() { return sizeof(KswRes); }
+
+void launch_project_fa(hipStream_t st, const ProjectArgs &A, const FaArgs &F, int mode, int n_blocks) {
+  if (A.n_aln <= 0) return;
+  int64_t need = (A.n_aln + 3) / 4;
+  if (need < n_blocks) n_blocks = (int)need;
+  if (n_blocks < 1) n_blocks = 1;
+  dim3 g(n_blocks), b(256);
+  switch (mode) {
+    case 0: hipLaunchKernelGGL((k_project_fa<0>), g, b, 0, st, A, F); break;
+    case 1: hipLaunchKernelGGL((k_project_fa<1>), g, b, 0, st, A, F); break;
+    case 2: hipLaunchKernelGGL((k_project_fa<2>), g, b, 0, st, A, F); break;
+    default: hipLaunchKernelGGL((k_project_fa<3>), g, b, 0, st, A, F); break;
+  }
+}
+
+void launch_ksw(hipStream_t st, const KswArgs &K, int n_blocks) {
+  if (K.n_prob <= 0) return;
+  hipLaunchKernelGGL(k_ksw, dim3(n_blocks), dim3(256), 0, st, K);
+}
+
 static inline int grid_for(int64_t n, int per_block) { return (int)((n + per_block - 1) / per_block); }
 
 void launch_segment(hipStream_t st, int64_t n_aln, const int32_t *ref_id, const int32_t *ref_start,
@@ -1204,6 +1280,7 @@ void launch_scan(hipStream_t st, const ScanArgs &S, int mode, void *out, bool ou
   dim3 g((unsigned)tiles), b(256);
   if (mode == 0) hipLaunchKernelGGL((k_scan_tiles<0>), g, b, 0, st, S);
   else if (mode == 1) hipLaunchKernelGGL((k_scan_tiles<1>), g, b, 0, st, S);
+  else if (mode == 3) hipLaunchKernelGGL((k_scan_tiles<3>), g, b, 0, st, S);
   else hipLaunchKernelGGL((k_scan_tiles<2>), g, b, 0, st, S);
   hipLaunchKernelGGL(k_scan_top, dim3(1), b, 0, st, S.tile_sums, tiles, total_out);
   if (mode == 0) {
@@ -1211,6 +1288,8 @@ void launch_scan(hipStream_t st, const ScanArgs &S, int mode, void *out, bool ou
     else hipLaunchKernelGGL((k_scan_apply<0, uint32_t>), g, b, 0, st, S, (uint32_t *)out);
   } else if (mode == 1) {
     hipLaunchKernelGGL((k_scan_apply<1, uint64_t>), g, b, 0, st, S, (uint64_t *)out);
+  } else if (mode == 3) {
+    hipLaunchKernelGGL((k_scan_apply<3, uint64_t>), g, b, 0, st, S, (uint64_t *)out);
   } else {
     if (out64) hipLaunchKernelGGL((k_scan_apply<2, uint64_t>), g, b, 0, st, S, (uint64_t *)out);
     else hipLaunchKernelGGL((k_scan_apply<2, uint32_t>), g, b, 0, st, S, (uint32_t *)out);

@@ -160,6 +160,52 @@ uint32_t tx_len(const Annotation &A, uint32_t tx) {
   return L;
 }
 
+// genome bases of the spliced interval [a, b) of a transcript's exon chain (genomic order)
+std::string spliced_seq(const Annotation &A, uint32_t tx, int64_t a, int64_t b) {
+  std::string out;
+  if (A.ref_seq.empty() || b <= a) return out;
+  const std::vector<char> &g = A.ref_seq[A.tx_ref[tx]];
+  int64_t acc = 0;
+  for (uint64_t k = A.tx_exon_off[tx]; k < A.tx_exon_off[tx + 1]; k++) {
+    int64_t s = A.ex_start[k], l = (int64_t)A.ex_end[k] - s;
+    int64_t lo = std::max<int64_t>(a, acc), hi = std::min<int64_t>(b, acc + l);
+    for (int64_t p = lo; p < hi; p++) out.push_back(g[(size_t)(s + (p - acc) - 1)]);
+    acc += l;
+  }
+  return out;
+}
+
+// read sequence in reference orientation for a CIGAR at `pos`: aligned bases from the
+// genome (2 % substitutions), insertions random; clips are the transcript's own
+// neighbouring bases with probability p_true (rescuable), else random
+std::string read_seq(Rng &rng, const Annotation &A, uint32_t tx, uint32_t pos, const std::vector<uint32_t> &cig,
+                     int64_t f, int64_t flen, bool lead_true, bool trail_true) {
+  std::string out;
+  const std::vector<char> &g = A.ref_seq[A.tx_ref[tx]];
+  uint64_t rp = pos;
+  auto rnd = [&](uint32_t n) { std::string s; for (uint32_t i = 0; i < n; i++) s.push_back("ACGT"[rng.next() >> 62]); return s; };
+  for (size_t i = 0; i < cig.size(); i++) {
+    uint32_t op = cig[i] & 15, len = cig[i] >> 4;
+    if (op == 0 || op == 7 || op == 8) {
+      for (uint32_t k = 0; k < len; k++) {
+        char c = (rp - 1 + k) < g.size() ? g[(size_t)(rp - 1 + k)] : 'N';
+        if (rng.chance(0.02)) c = "ACGT"[rng.next() >> 62];
+        out.push_back(c);
+      }
+      rp += len;
+    } else if (op == 1) out += rnd(len);
+    else if (op == 2 || op == 3) rp += len;
+    else if (op == 4) {
+      bool lead = (i == 0);
+      std::string t;
+      if (lead ? lead_true : trail_true) t = lead ? spliced_seq(A, tx, f - (int64_t)len, f) : spliced_seq(A, tx, f + flen, f + flen + (int64_t)len);
+      if (t.size() < len) t = lead ? rnd(len - (uint32_t)t.size()) + t : t + rnd(len - (uint32_t)t.size());
+      out += t;
+    }
+  }
+  return out;
+}
+
 void push_read(Reads &R, const std::string &name, int32_t ref, uint32_t pos, const std::vector<uint32_t> &cig,
                uint16_t flags, int32_t mref, int32_t mstart, int8_t xs, int8_t ts, uint32_t src,
                const std::string *seq) {
@@ -212,7 +258,7 @@ void short_cigar(Rng &rng, const ReadParams &P, std::vector<std::pair<uint32_t, 
 
 // long-read CIGAR: junction wobble, skipped small exons, novel small exons, in-block indels, clips
 void long_cigar(Rng &rng, const ReadParams &P, std::vector<std::pair<uint32_t, uint32_t>> blocks, uint32_t &pos,
-                std::vector<uint32_t> &cig) {
+                std::vector<uint32_t> &cig, uint32_t lead_clip, uint32_t trail_clip) {
   cig.clear();
   if (blocks.empty()) return;
   // skipped small middle exons (the read splices over an annotated exon <= 35 bp)
@@ -233,7 +279,7 @@ void long_cigar(Rng &rng, const ReadParams &P, std::vector<std::pair<uint32_t, u
     else { int64_t ns = (int64_t)blocks[k + 1].first + d; if (ns > (int64_t)blocks[k].second + 5 && ns + 5 < (int64_t)blocks[k + 1].second) blocks[k + 1].first = (uint32_t)ns; }
   }
   pos = blocks[0].first;
-  if (rng.chance(P.p_clip)) cig.push_back(cg(1 + rng.below(P.max_clip), 4));
+  if (lead_clip) cig.push_back(cg(lead_clip, 4));
   for (size_t k = 0; k < blocks.size(); k++) {
     if (k) cig.push_back(cg(blocks[k].first - blocks[k - 1].second, 3));
     uint32_t len = blocks[k].second - blocks[k].first, done = 0;
@@ -246,7 +292,7 @@ void long_cigar(Rng &rng, const ReadParams &P, std::vector<std::pair<uint32_t, u
       else if (len - done > d + 1) { cig.push_back(cg(d, 2)); done += d; }
     }
   }
-  if (rng.chance(P.p_clip)) cig.push_back(cg(1 + rng.below(P.max_clip), 4));
+  if (trail_clip) cig.push_back(cg(trail_clip, 4));
   // coalesce equal neighbours (a valid BAM CIGAR has none)
   std::vector<uint32_t> out;
   for (uint32_t w : cig) { if (!out.empty() && (out.back() & 15) == (w & 15)) out.back() += (w >> 4) << 4; else out.push_back(w); }
@@ -274,9 +320,28 @@ Reads *gen_reads(const Annotation &A, const ReadParams &P) {
         uint32_t len = (uint32_t)std::max(80.0, std::min((double)L, rng.lognormal(P.long_median, P.long_sigma)));
         uint32_t f = rng.below(L - len + 1), pos;
         splice_map(A, tx, f, len, pos, b1);
-        long_cigar(rng, P, b1, pos, c1);
+        // soft clips: an aligner that could not place a short terminal exon piece clips it,
+        // so the aligned part starts / ends exactly on an exon boundary (the rescuable case);
+        // otherwise a clip of arbitrary bases
+        uint32_t lead_clip = 0, trail_clip = 0; bool lead_true = false, trail_true = false;
+        int64_t fa = f, la = len;
+        if (rng.chance(P.p_clip)) {
+          uint32_t l0 = b1[0].second - b1[0].first;
+          if (b1.size() > 1 && l0 <= (uint32_t)P.max_clip && rng.chance(0.75)) { lead_clip = l0; lead_true = rng.chance(0.8); fa += l0; la -= l0; b1.erase(b1.begin()); }
+          else lead_clip = 1 + rng.below(P.max_clip);
+        }
+        if (rng.chance(P.p_clip)) {
+          uint32_t l1 = b1.back().second - b1.back().first;
+          if (b1.size() > 1 && l1 <= (uint32_t)P.max_clip && rng.chance(0.75)) { trail_clip = l1; trail_true = rng.chance(0.8); la -= l1; b1.pop_back(); }
+          else trail_clip = 1 + rng.below(P.max_clip);
+        }
+        long_cigar(rng, P, b1, pos, c1, lead_clip, trail_clip);
         uint16_t fl = (rng.chance(0.5) ? 0x10 : 0) | sec;
         int8_t ts = rng.chance(0.7) ? (int8_t)(A.tx_strand[tx]) : 0;
+        if (P.with_seq && !A.ref_seq.empty()) {
+          std::string sq = read_seq(rng, A, tx, pos, c1, fa, la, lead_true, trail_true);
+          push_read(*R, name, A.tx_ref[tx], pos, c1, fl, -1, 0, 0, ts, tx, &sq);
+        } else
         push_read(*R, name, A.tx_ref[tx], pos, c1, fl, -1, 0, 0, ts, tx, nullptr);
         continue;
       }
@@ -376,5 +441,7 @@ const uint32_t *synth_reads_cigar(void *h) { return ((Reads *)h)->cigar.data(); 
 const uint64_t *synth_reads_name_off(void *h) { return ((Reads *)h)->name_off.data(); }
 const char *synth_reads_names(void *h) { return ((Reads *)h)->names.data(); }
 const uint32_t *synth_reads_src_tx(void *h) { return ((Reads *)h)->src_tx.data(); }
+const uint64_t *synth_reads_seq_off(void *h) { return ((Reads *)h)->seq_off.data(); }
+const char *synth_reads_seqs(void *h) { return ((Reads *)h)->seqs.data(); }
 
 }  // extern "C"

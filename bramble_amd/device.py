@@ -34,4 +34,20 @@ def upload_batch(batch, device="cuda:0"):
         "n_cigar_words": int(coff64[-1]) if n else 0,
         "max_n_cigar": int(np.diff(coff64).max()) if n else 0,
     }
+    if batch.get("seq_off") is not None:
+        soff64 = np.asarray(batch["seq_off"], dtype=np.uint64)
+        if n and int(soff64[-1]) >= 2 ** 32 - 16:
+            raise lib.BrambleError("batch sequences exceed 32-bit device offsets; split it")
+        src = np.full(max(n, 1), -1, dtype=np.int32)
+        keep = []
+        bs = lib._batch_struct(batch, keep)
+        import ctypes as C
+        lib.check(lib.lib().br_batch_seq_source(C.byref(bs), goff.ctypes.data, len(goff) - 1, src.ctypes.data),
+                  "br_batch_seq_source")
+        cig = np.asarray(batch["cigar"], dtype=np.uint32)
+        sc = cig[(cig & 0xF) == 4] >> 4
+        d["seq_off"] = t(soff64.astype(np.uint32), np.uint32)
+        d["seqs"] = t(batch["seqs"], np.uint8)
+        d["seq_src"] = t(src[:n], np.int32)
+        d["max_soft_clip"] = int(sc.max()) if sc.size else 0
     return d

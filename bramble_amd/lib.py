@@ -12,9 +12,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbramble_amd.so")
 _P = C.POINTER
 
-K_SEGMENT, K_COUNT, K_EMIT, K_PAIR_COUNT, K_PAIR_EMIT, K_GATHER, K_SCAN, K_EMIT_AUX, K_NUM = range(9)
+K_SEGMENT, K_COUNT, K_EMIT, K_PAIR_COUNT, K_PAIR_EMIT, K_GATHER, K_SCAN, K_EMIT_AUX, K_KSW, K_NUM = range(10)
 KERNEL_NAMES = ["k_segment", "k_project<G,false>", "k_emit_dense", "k_group_ids+k_pair<false>", "k_pair<true>",
-                "k_row_fill+k_group_stats+k_gather", "k_scan_*", "k_expand+k_project<64,true>"]
+                "k_row_fill+k_group_stats+k_gather", "k_scan_*", "k_expand+k_project<64,true>", "k_ksw"]
 
 
 class BrambleError(RuntimeError):
@@ -76,7 +76,7 @@ class BrDeviceBatch(C.Structure):
                 ("flags", C.c_void_p), ("xs", C.c_void_p), ("ts", C.c_void_p), ("cigar_off", C.c_void_p),
                 ("cigar", C.c_void_p), ("mate_idx", C.c_void_p), ("group_off", C.c_void_p), ("l_qseq", C.c_void_p),
                 ("seq_off", C.c_void_p), ("seqs", C.c_void_p), ("n_cigar_words", C.c_int64),
-                ("max_n_cigar", C.c_int32)]
+                ("max_n_cigar", C.c_int32), ("seq_src", C.c_void_p), ("max_soft_clip", C.c_int32)]
 
 
 class BrDeviceRows(C.Structure):
@@ -87,7 +87,7 @@ class BrDeviceRows(C.Structure):
 # every symbol include/bramble_amd.h declares
 EXPORTS = ["br_index_build", "br_index_build_flat", "br_index_free", "br_index_num_transcripts", "br_index_transcript_name",
            "br_index_transcript_len", "br_index_num_intervals", "br_index_device_bytes", "br_config_short_read",
-           "br_config_long_read", "br_config_resolve", "br_batch_prepare", "br_ctx_new", "br_ctx_free",
+           "br_config_long_read", "br_config_resolve", "br_batch_prepare", "br_batch_seq_source", "br_ctx_new", "br_ctx_free",
            "br_project_batch", "br_project_batch_device", "br_project_group", "br_ctx_set_profiling",
            "br_ctx_set_param", "br_ctx_kernel_ms", "br_ctx_collect_counters", "br_ctx_last_counters", "br_version", "br_strerror"]
 
@@ -128,6 +128,7 @@ def lib():
         L.br_config_long_read.argtypes = [_P(BrConfig)]
         L.br_config_resolve.argtypes = [_P(BrConfig), _P(BrThresholds)]
         L.br_batch_prepare.argtypes = [_P(BrBatch), C.c_void_p, C.c_void_p, _P(C.c_int64)]
+        L.br_batch_seq_source.argtypes = [_P(BrBatch), C.c_void_p, C.c_int64, C.c_void_p]
         L.br_ctx_new.argtypes = [C.c_void_p, _P(C.c_void_p)]
         L.br_ctx_free.argtypes = [C.c_void_p]
         L.br_project_batch.argtypes = [C.c_void_p, _P(BrConfig), _P(BrBatch), _P(BrRows)]
@@ -358,6 +359,11 @@ class Context:
             setattr(db, name, dev_batch[name].data_ptr())
         db.n_cigar_words = dev_batch["n_cigar_words"]
         db.max_n_cigar = dev_batch["max_n_cigar"]
+        if dev_batch.get("seqs") is not None:
+            db.seq_off = dev_batch["seq_off"].data_ptr()
+            db.seqs = dev_batch["seqs"].data_ptr()
+            db.seq_src = dev_batch["seq_src"].data_ptr()
+            db.max_soft_clip = dev_batch["max_soft_clip"]
         return db
 
     def collect_counters(self, dev_batch, stream=0):

@@ -47,7 +47,7 @@ def lib():
         L.synth_annotation_ref_seq.restype = C.c_void_p
         L.synth_annotation_ref_seq.argtypes = [C.c_void_p, C.c_int32]
         for name in ("ref_id", "ref_start", "mate_ref_id", "mate_start", "l_qseq", "flags", "xs", "ts", "cigar_off",
-                     "cigar", "name_off", "names", "src_tx"):
+                     "cigar", "name_off", "names", "src_tx", "seq_off", "seqs"):
             f = getattr(L, "synth_reads_" + name)
             f.restype = C.c_void_p
             f.argtypes = [C.c_void_p]
@@ -142,6 +142,9 @@ class Annotation:
             b["names"] = _copy(L.synth_reads_names(h), int(b["name_off"][-1]) if n else 0, np.uint8)
             b["seq_off"] = None
             b["seqs"] = None
+            if p.with_seq:
+                b["seq_off"] = _copy(L.synth_reads_seq_off(h), n + 1, np.uint64)
+                b["seqs"] = _copy(L.synth_reads_seqs(h), int(b["seq_off"][-1]) if n else 0, np.uint8)
         finally:
             L.synth_reads_free(h)
         return b

@@ -137,6 +137,11 @@ typedef struct br_batch {
  * hold n_aln + 1 entries; *n_groups receives the group count. */
 int br_batch_prepare(const br_batch *, int32_t *mate_idx, uint32_t *group_off, int64_t *n_groups);
 
+/* With -S the clip rescue uses ONE sequence per read-name group: the first
+ * record of the group that has one (src/core.cpp:353-378).  seq_src[i] = index of
+ * that record for alignment i, or -1. */
+int br_batch_seq_source(const br_batch *, const uint32_t *group_off, int64_t n_groups, int32_t *seq_src);
+
 /* One emitted BAM record (ProjectedAlignment, bramble-rs/src/api.rs:135-176, plus
  * the fields the C++ writer sets: rewritten CIGAR, MAPQ, mate fields;
  * src/core.cpp:96-212, src/bam.cpp:531-588).  Struct-of-arrays; arrays are owned
@@ -193,6 +198,9 @@ typedef struct br_device_batch {
   const uint8_t *seqs;
   int64_t n_cigar_words;     /* total words in cigar */
   int32_t max_n_cigar;       /* longest single CIGAR in the batch */
+  /* -S clip rescue only (use_fasta with --lr / --lr-hq): */
+  const int32_t *seq_src;    /* n_aln, from br_batch_seq_source; NULL without sequences */
+  int32_t max_soft_clip;     /* longest leading / trailing S op in the batch */
 } br_device_batch;
 
 /* Rows as device pointers (same field meaning as br_rows; is_primary stays 0).
@@ -265,7 +273,8 @@ int br_project_group(br_ctx *, const br_config *, const br_alignment *alns, size
 #define BR_K_GATHER 5     /* k_row_fill + k_group_stats + k_gather */
 #define BR_K_SCAN 6       /* k_scan_* */
 #define BR_K_EMIT_AUX 7   /* k_expand + k_project<64,true> (alignments with > 64 candidate rows) */
-#define BR_K_NUM 8
+#define BR_K_KSW 8        /* k_ksw (-S clip rescue DP) */
+#define BR_K_NUM 9
 /* When enabled, every launch is bracketed by hipEvents on the launch stream. */
 int br_ctx_set_profiling(br_ctx *, int enabled);
 /* Launch tuning: "group_lanes" (8|16|32|64 lanes cooperating on one alignment),

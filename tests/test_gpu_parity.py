@@ -99,6 +99,25 @@ def test_long_read_presets_without_fasta(mode, flags):
     assert_rows_equal(prod, orc)
 
 
+@pytest.mark.parametrize("flags", [{"lr": 1, "use_fasta": 1}, {"lr_hq": 1, "use_fasta": 1},
+                                   {"lr": 1, "use_fasta": 1, "max_clip": 10, "sim_thr": 0.8}])
+def test_soft_clip_rescue_with_genome(flags):
+    """-S: ksw2 clip rescue on device (k_project_fa + k_ksw) against the oracle's scalar restatement.
+    The ksw2 piece of the oracle is 'parity unpinned' (no reference vector exists for it)."""
+    ann = synth.Annotation("G", n_genes=300, n_refs=2, with_genome=True)
+    b = ann.reads(3000, "ont", with_seq=1)
+    prod, orc = run_both(ann.as_dict(), b, **flags)
+    assert (orc["clip_score"] != 0).sum() > 500      # rescues do happen
+    assert_rows_equal(prod, orc)
+
+
+def test_fasta_flag_is_inert_for_short_reads():
+    ann = synth.Annotation("G", n_genes=300, n_refs=2, with_genome=True)
+    b = ann.reads(3000, "pe")
+    prod, orc = run_both(ann.as_dict(), b, use_fasta=1)
+    assert_rows_equal(prod, orc)
+
+
 def test_dense_locus_more_than_64_candidates():
     """150 isoforms share an exon: reads there have > 64 candidate rows (the group kernel's
     two-sweep path) next to reads that take the dense per-match path."""
