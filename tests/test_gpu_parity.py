@@ -43,6 +43,18 @@ def test_reference_known_answers(golden):
             assert ob.format_cigar(rows["cigar"][c0:c1]) == exp["out"]
 
 
+def test_hand_derived_cases():
+    """The HIP path against the hand-derived expectations (independent of the oracle)."""
+    from tests import hand_cases
+    for case in hand_cases.load():
+        idx = lib.Index(hand_cases.annotation(case), device=0)
+        ctx = lib.Context(idx)
+        rows = ctx.project_batch(lib.make_config(**case["flags"]), hand_cases.batch(case))
+        hand_cases.check(case, rows, "transcript_id")
+        ctx.close()
+        idx.close()
+
+
 @pytest.mark.parametrize("group_lanes", [64, 16])
 @pytest.mark.parametrize("mode,flags", [("se", {}), ("pe", {}), ("pe", {"strict": 1}), ("pe", {"fr": 1}),
                                         ("pe", {"rf": 1}), ("pe", {"max_clip": 2, "max_junc_ins": 3, "max_junc_gap": 3})])

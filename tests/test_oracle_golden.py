@@ -54,3 +54,13 @@ def test_index_lengths(golden):
     assert idx.num_transcripts() == len(fx["transcripts"])
     for tid, t in enumerate(fx["transcripts"]):
         assert idx.transcript_len(tid) == t["length"]
+
+
+def test_hand_derived_cases():
+    """The oracle against expectations worked out by hand from the reference's rules
+    (tests/golden/hand_derived.json): '-' strand, pairing, NH > 1, INS / GAP exons, quirks."""
+    from tests import hand_cases
+    for case in hand_cases.load():
+        idx = ob.OracleIndex(hand_cases.annotation(case))
+        rows, _, _ = ob.run(idx, ob.make_flags(**case["flags"]), hand_cases.batch(case), want_matches=False)
+        hand_cases.check(case, rows, "tid")
