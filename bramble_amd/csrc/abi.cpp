@@ -39,11 +39,11 @@ struct br_index {
   uint32_t n_refs = 0;
   bool has_seq = false;
   // host copies of the flattened tables
-  std::vector<uint32_t> slab_off, s_start, s_end, s_pmax, s_next, tx_first, bin_off, t_hi, t_lo;
+  std::vector<uint32_t> slab_off, s_start, s_end, s_pmax, s_next, s_tid, tx_first, bin_off, t_hi, t_lo;
   std::vector<uint4> s_pay, tx_ex;
   std::vector<uint8_t> seq_pool;
   // device copies
-  void *d_slab_off = nullptr, *d_s_start = nullptr, *d_s_end = nullptr, *d_s_pmax = nullptr, *d_s_next = nullptr, *d_bin_off = nullptr, *d_t_hi = nullptr, *d_t_lo = nullptr,
+  void *d_slab_off = nullptr, *d_s_start = nullptr, *d_s_end = nullptr, *d_s_pmax = nullptr, *d_s_next = nullptr, *d_bin_off = nullptr, *d_t_hi = nullptr, *d_t_lo = nullptr, *d_s_tid = nullptr,
        *d_s_pay = nullptr, *d_tx_ex = nullptr, *d_tx_first = nullptr, *d_seq_pool = nullptr;
   size_t device_bytes = 0;
   DevIndex dev{};
@@ -123,6 +123,7 @@ static int build_index_flat(size_t n_tx, const int32_t *tx_ref, const int8_t *tx
     if (ix->tx_ex.size() >= 0xfffffff0ull || ix->seq_pool.size() >= 0xfffffff0ull) { delete ix; return BR_ERR_CAPACITY; }
   }
   ix->tx_first.push_back((uint32_t)ix->tx_ex.size());
+  for (int pad = 0; pad < 4; pad++) ix->tx_ex.push_back(make_uint4(0xffffffffu, 0xffffffffu, 0, 0));  // prefetch slack
   ix->slab_off.push_back(0);
   for (auto &rows : slabs) {
     std::stable_sort(rows.begin(), rows.end(), [](const Row &a, const Row &b) { return a.start < b.start; });
@@ -132,6 +133,7 @@ static int build_index_flat(size_t n_tx, const int32_t *tx_ref, const int8_t *tx
       ix->s_start.push_back(r.start); ix->s_end.push_back(r.end); ix->s_pmax.push_back(m);
       ix->s_pay.push_back(make_uint4(r.tid, r.gidx, r.pos_start, ix->tx_first[r.tid]));
       ix->s_next.push_back(ix->tx_ex[ix->tx_first[r.tid] + r.gidx + 1].x);  // sentinel start = ~0u
+      ix->s_tid.push_back(r.tid);
     }
     ix->slab_off.push_back((uint32_t)ix->s_start.size());
   }
@@ -164,6 +166,7 @@ static int build_index_flat(size_t n_tx, const int32_t *tx_ref, const int8_t *tx
         (rc = upload(&ix->d_s_end, ix->s_end, acc)) || (rc = upload(&ix->d_s_pmax, ix->s_pmax, acc)) ||
         (rc = upload(&ix->d_s_next, ix->s_next, acc)) || (rc = upload(&ix->d_bin_off, ix->bin_off, acc)) ||
         (rc = upload(&ix->d_t_hi, ix->t_hi, acc)) || (rc = upload(&ix->d_t_lo, ix->t_lo, acc)) ||
+        (rc = upload(&ix->d_s_tid, ix->s_tid, acc)) ||
         (rc = upload(&ix->d_s_pay, ix->s_pay, acc)) || (rc = upload(&ix->d_tx_ex, ix->tx_ex, acc)) ||
         (rc = upload(&ix->d_tx_first, ix->tx_first, acc)) || (rc = upload(&ix->d_seq_pool, ix->seq_pool, acc))) {
       br_index_free(ix); return rc;
@@ -176,6 +179,7 @@ static int build_index_flat(size_t n_tx, const int32_t *tx_ref, const int8_t *tx
     d.s_next = (const uint32_t *)ix->d_s_next;
     d.bin_shift = SHIFT; d.bin_off = (const uint32_t *)ix->d_bin_off;
     d.t_hi = (const uint32_t *)ix->d_t_hi; d.t_lo = (const uint32_t *)ix->d_t_lo;
+    d.s_tid = (const uint32_t *)ix->d_s_tid;
     d.s_pay = (const uint4 *)ix->d_s_pay; d.tx_ex = (const uint4 *)ix->d_tx_ex;
     d.tx_first = (const uint32_t *)ix->d_tx_first; d.seq_pool = (const uint8_t *)ix->d_seq_pool;
   }
@@ -229,7 +233,7 @@ extern "C" void br_index_free(br_index *ix) {
   if (!ix) return;
   if (ix->device >= 0) {
     (void)hipSetDevice(ix->device);
-    void *ptrs[] = {ix->d_slab_off, ix->d_s_start, ix->d_s_end, ix->d_s_pmax, ix->d_s_next, ix->d_bin_off, ix->d_t_hi, ix->d_t_lo, ix->d_s_pay, ix->d_tx_ex,
+    void *ptrs[] = {ix->d_slab_off, ix->d_s_start, ix->d_s_end, ix->d_s_pmax, ix->d_s_next, ix->d_bin_off, ix->d_t_hi, ix->d_t_lo, ix->d_s_tid, ix->d_s_pay, ix->d_tx_ex,
                     ix->d_tx_first, ix->d_seq_pool};
     for (void *p : ptrs) if (p) (void)hipFree(p);
   }
@@ -377,7 +381,7 @@ struct br_ctx {
   double k_ms[BR_K_NUM] = {0}; int32_t k_launches[BR_K_NUM] = {0};
   uint64_t counters[8] = {0};
   // device scratch
-  DevBuf seg, meta, head, n_matches, ranges, mask, match_off, cig_base, tile_sums, totals, counters_d;
+  DevBuf seg, meta, head, head2, n_matches, ranges, mask, match_off, cig_base, tile_sums, totals, counters_d;
   DevBuf m_tid, m_aux, m_a, m_b, m_cigoff, cig_arena, big_list, n_big, m_aln;
   DevBuf fa_n_prob, fa_seq_bytes, fa_prob_off, fa_seqarena_off, fa_probs, fa_results, fa_seq_arena, fa_clip_ops,
       fa_ideal_cap, fa_scratch, b_seq_off, b_seqs, b_seq_src;
@@ -420,7 +424,7 @@ extern "C" int br_ctx_new(const br_index *ix, br_ctx **out) {
 extern "C" void br_ctx_free(br_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->ix->device);
-  DevBuf *bufs[] = {&c->seg, &c->meta, &c->head, &c->n_matches, &c->ranges, &c->mask, &c->match_off, &c->cig_base,
+  DevBuf *bufs[] = {&c->seg, &c->meta, &c->head, &c->head2, &c->n_matches, &c->ranges, &c->mask, &c->match_off, &c->cig_base,
                     &c->tile_sums, &c->totals, &c->counters_d, &c->m_tid, &c->m_aux, &c->m_a, &c->m_b,
                     &c->m_cigoff, &c->cig_arena, &c->big_list, &c->n_big, &c->m_aln,
                     &c->fa_n_prob, &c->fa_seq_bytes, &c->fa_prob_off, &c->fa_seqarena_off, &c->fa_probs, &c->fa_results,
@@ -512,7 +516,7 @@ int run_device(br_ctx *c, const br_config *cfg, const br_device_batch *b, hipStr
 
   int64_t tiles = std::max<int64_t>(scan_tiles_for(std::max<int64_t>(n, ng) + 1), 1);
   RC(c->seg.ensure((size_t)(b->n_cigar_words + n) * sizeof(uint2)));
-  RC(c->meta.ensure((size_t)n * sizeof(AlnMeta))); RC(c->head.ensure((size_t)n * sizeof(uint4)));
+  RC(c->meta.ensure((size_t)n * sizeof(AlnMeta))); RC(c->head.ensure((size_t)n * sizeof(uint4))); RC(c->head2.ensure((size_t)n * sizeof(uint4)));
   RC(c->n_matches.ensure((size_t)n * 4)); RC(c->ranges.ensure((size_t)n * sizeof(uint4)));
   RC(c->mask.ensure((size_t)n * 8)); RC(c->match_off.ensure((size_t)(n + 1) * 4));
   RC(c->cig_base.ensure((size_t)(n + 1) * 8)); RC(c->tile_sums.ensure((size_t)tiles * 8));
@@ -522,12 +526,12 @@ int run_device(br_ctx *c, const br_config *cfg, const br_device_batch *b, hipStr
   // a1/a2/a6: CIGAR -> read exons
   RC(pf.begin(BR_K_SEGMENT));
   launch_segment(st, n, b->ref_id, b->ref_start, b->flags, b->xs, b->ts, b->cigar_off, b->cigar, dc, ix->n_refs,
-                 c->seg.as<uint2>(), c->meta.as<AlnMeta>(), c->head.as<uint4>());
+                 c->seg.as<uint2>(), c->meta.as<AlnMeta>(), c->head.as<uint4>(), c->head2.as<uint4>());
   RC(pf.end());
 
   ProjectArgs A{};
   A.ix = ix->dev; A.cfg = dc; A.n_aln = n; A.ref_id = b->ref_id; A.cigar_off = b->cigar_off; A.cigar = b->cigar;
-  A.seg = c->seg.as<uint2>(); A.meta = c->meta.as<AlnMeta>(); A.head = c->head.as<uint4>();
+  A.seg = c->seg.as<uint2>(); A.meta = c->meta.as<AlnMeta>(); A.head = c->head.as<uint4>(); A.head2 = c->head2.as<uint4>();
   A.n_matches = c->n_matches.as<uint32_t>();
   A.ranges = c->ranges.as<uint4>(); A.mask = c->mask.as<uint64_t>();
   A.match_off = c->match_off.as<uint32_t>(); A.cig_base = c->cig_base.as<uint64_t>();

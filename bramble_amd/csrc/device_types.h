@@ -16,6 +16,7 @@ struct DevIndex {
   const uint32_t *s_end;       // [n_rows] exon end (exclusive)
   const uint32_t *s_pmax;      // [n_rows] running max of s_end inside the slab
   const uint32_t *s_next;      // [n_rows] start of the transcript's next exon (genomic order), ~0u if none
+  const uint32_t *s_tid;       // [n_rows] tid alone (rank lookups)
   const uint4 *s_pay;          // [n_rows] {tid, genomic exon idx, pos_start, first row of tid in tx_ex}
   const uint4 *tx_ex;          // per transcript: exons in genomic order {start, end, pos_start, seq_off},
                                // closed by a sentinel {~0u, ~0u, 0, 0}

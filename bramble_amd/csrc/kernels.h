@@ -17,6 +17,7 @@ struct ProjectArgs {
   const uint2 *seg;
   const AlnMeta *meta;
   const uint4 *head;     // [n_aln] {exon0.start, exon0.end, n_seg, refid<<2|smode}
+  const uint4 *head2;    // [n_aln] read exons 1 and 2
   // count pass outputs / emit pass inputs
   uint32_t *n_matches;   // [n_aln]
   uint4 *ranges;         // [n_aln] candidate row ranges (lo+,hi+,lo-,hi-)
@@ -120,7 +121,7 @@ void launch_stats(hipStream_t st, const StatsArgs &T, const uint4 *m_a, int64_t 
 void launch_segment(hipStream_t st, int64_t n_aln, const int32_t *ref_id, const int32_t *ref_start,
                     const uint16_t *flags, const int8_t *xs, const int8_t *ts, const uint32_t *cigar_off,
                     const uint32_t *cigar, const DevCfg &cfg, uint32_t n_refs, uint2 *seg, AlnMeta *meta,
-                    uint4 *head);
+                    uint4 *head, uint4 *head2);
 void launch_project(hipStream_t st, const ProjectArgs &A, bool emit, int group_lanes, int n_blocks);
 void launch_project_fa(hipStream_t st, const ProjectArgs &A, const FaArgs &F, int mode, int n_blocks);
 void launch_ksw(hipStream_t st, const KswArgs &K, int n_blocks);

@@ -45,7 +45,8 @@ __global__ void __launch_bounds__(256) k_segment(int64_t n_aln, const int32_t *_
                                                  const uint32_t *__restrict__ cigar_off,
                                                  const uint32_t *__restrict__ cigar, DevCfg cfg,
                                                  uint32_t n_refs, uint2 *__restrict__ seg,
-                                                 AlnMeta *__restrict__ meta, uint4 *__restrict__ head) {
+                                                 AlnMeta *__restrict__ meta, uint4 *__restrict__ head,
+                                                 uint4 *__restrict__ head2) {
   int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= n_aln) return;
   uint32_t c0 = cigar_off[a], c1 = cigar_off[a + 1];
@@ -123,6 +124,8 @@ __global__ void __launch_bounds__(256) k_segment(int64_t n_aln, const int32_t *_
   // everything k_project needs for read exon 0 in one 16-byte record
   uint2 q0 = n ? out[0] : make_uint2(0, 0);
   head[a] = make_uint4(q0.x, q0.y, n, n ? (((uint32_t)rid << 2) | smode) : 0u);
+  uint2 q1 = n > 1 ? out[1] : make_uint2(0, 0), q2 = n > 2 ? out[2] : make_uint2(0, 0);
+  head2[a] = make_uint4(q1.x, q1.y, q2.x, q2.y);
 }
 
 // ---------------------------------------------------------------------------
@@ -427,18 +430,21 @@ struct Walker {
 // last guide segment; on STEP_HIT i_hit/h/gap2 are set (gap2: a GAP_EXON segment
 // for exon i_hit-1 precedes the match segment).
 __device__ __forceinline__ int step_exon(const DevIndex &ix, const DevCfg &cfg, const uint4 *E, bool minus,
-                                         uint32_t sb, uint32_t se, uint32_t i_last, int status, uint32_t qs,
-                                         uint32_t qe, uint32_t &i_hit, Hit &h, uint4 &ge, bool &gap2) {
+                                         uint32_t sb, uint32_t se, uint32_t i_last, uint4 e_last, int status,
+                                         uint32_t qs, uint32_t qe, uint32_t &i_hit, Hit &h, uint4 &ge, bool &gap2) {
   uint32_t cnt = 0;
   Hit hh; uint4 ee;
+  // the row of the last guide segment is already in registers; the following rows are
+  // fetched two ahead so one round trip covers the usual "next exon, then stop" walk
+  // (tx_ex is padded, reading past a sentinel is harmless)
+  uint4 e = e_last, e1 = E[i_last + 1], e2 = E[i_last + 2];
   for (uint32_t i = i_last;; i++) {
-    uint4 e = E[i];
     if (e.x >= qe) break;             // start >= qend (sentinel start = ~0u)
-    if (e.y <= qs) continue;          // end <= qstart: no overlap
-    if (classify(minus, status, qs, qe, e.x, e.y, e.z, cfg, hh)) {
+    if (e.y > qs && classify(minus, status, qs, qe, e.x, e.y, e.z, cfg, hh)) {
       if (cnt == 0) { i_hit = i; h = hh; ee = e; }
       cnt++;
     }
+    e = e1; e1 = e2; e2 = E[i + 3];
   }
   gap2 = false;
   if (cnt == 0) {
@@ -469,6 +475,12 @@ struct ReadCtx {
   uint32_t n_seg;
   const uint32_t *real;  // packed real CIGAR
   uint32_t n_real;
+  uint4 q12;             // read exons 1 and 2 (from head2), so 2-3 exon reads never touch seg[]
+  __device__ __forceinline__ uint2 exon(uint32_t j) const {
+    if (j == 1) return make_uint2(q12.x, q12.y);
+    if (j == 2) return make_uint2(q12.z, q12.w);
+    return seg[j];
+  }
 };
 
 struct CandOut {
@@ -491,22 +503,23 @@ __device__ __forceinline__ ClipSide no_clip() { ClipSide c; c.ok = false; c.ops 
 // Pass 1 (src/evaluate.cpp:1004-1065): survival, segment counts, fwpos/rcpos.
 __device__ __forceinline__ CandOut walk_pass1(const DevIndex &ix, const DevCfg &cfg, const ReadCtx &rd,
                                               const uint4 *E, bool minus, uint32_t sb, uint32_t se,
-                                              uint32_t i0, uint2 q0, const Hit &h0) {
+                                              uint32_t i0, uint4 e0, uint2 q0, const Hit &h0) {
   CandOut o; o.alive = true; o.fwpos = h0.pos; o.rcpos = h0.pos; o.n_seg = 1; o.n_gex = 1;
   o.i_lastm = i0; o.last_right_ins = h0.right_ins; o.last_right_gap = h0.right_gap;
   uint32_t i_last = i0;
+  uint4 e_last = e0;
   uint2 pq = q0;
   for (uint32_t j = 1; j < rd.n_seg; j++) {
-    uint2 q = rd.seg[j];
+    uint2 q = rd.exon(j);
     int status = (j < rd.n_seg - 1) ? ST_MIDDLE : ST_LAST;
     uint32_t i_hit = 0; Hit h; uint4 ge; bool gap2;
-    int r = step_exon(ix, cfg, E, minus, sb, se, i_last, status, q.x, q.y, i_hit, h, ge, gap2);
+    int r = step_exon(ix, cfg, E, minus, sb, se, i_last, e_last, status, q.x, q.y, i_hit, h, ge, gap2);
     if (r == STEP_DEAD || (q.x == pq.x && q.y == pq.y)) { o.alive = false; break; }
     pq = q;
     if (r == STEP_INS) { o.n_seg++; continue; }
     if (gap2) { o.n_seg++; o.n_gex++; }
     o.n_seg++; o.n_gex++;
-    i_last = i_hit;
+    i_last = i_hit; e_last = ge;
     if (minus) o.rcpos = h.pos;
     o.i_lastm = i_hit; o.last_right_ins = h.right_ins; o.last_right_gap = h.right_gap;
   }
@@ -546,7 +559,7 @@ __device__ __forceinline__ void build_clip(Acc &m, IdealSink &sk, const ClipSide
 // td.has_left_clip / has_right_clip for build_cigar_match.
 __device__ __forceinline__ void walk_pass2(const DevIndex &ix, const DevCfg &cfg, const ReadCtx &rd,
                                            const uint4 *E, bool minus, uint32_t sb, uint32_t se, uint32_t i0,
-                                           uint2 q0, uint32_t gs0, uint32_t ge0, const Hit &h0_in,
+                                           uint2 q0, uint4 e0, const Hit &h0_in,
                                            const CandOut &p1, Acc &acc, IdealSink &sk, const ClipSide &L,
                                            const ClipSide &R) {
   acc.init();
@@ -556,14 +569,15 @@ __device__ __forceinline__ void walk_pass2(const DevIndex &ix, const DevCfg &cfg
   if (L.ok) h0.left_ins = 0;
   if (R.ok && rd.n_seg == 1) h0.right_ins = 0;
   int st0 = (rd.n_seg == 1) ? ST_ONLY : ST_FIRST;
-  build_match(acc, sk, h0, st0, q0.x, q0.y, gs0, ge0, k == 0, k == p1.n_gex - 1, L.ok, R.ok);
+  build_match(acc, sk, h0, st0, q0.x, q0.y, e0.x, e0.y, k == 0, k == p1.n_gex - 1, L.ok, R.ok);
   k++;
   uint32_t i_last = i0;
+  uint4 e_last = e0;
   for (uint32_t j = 1; j < rd.n_seg; j++) {
-    uint2 q = rd.seg[j];
+    uint2 q = rd.exon(j);
     int status = (j < rd.n_seg - 1) ? ST_MIDDLE : ST_LAST;
     uint32_t i_hit = 0; Hit h; uint4 ge; bool gap2;
-    int r = step_exon(ix, cfg, E, minus, sb, se, i_last, status, q.x, q.y, i_hit, h, ge, gap2);
+    int r = step_exon(ix, cfg, E, minus, sb, se, i_last, e_last, status, q.x, q.y, i_hit, h, ge, gap2);
     if (r == STEP_INS) {  // build_cigar_ins (:788-806) + junc_hits (:1089-1091)
       uint32_t len = q.y - q.x;
       bool edge = (k == 0 || k == p1.n_seg - 1);
@@ -583,7 +597,7 @@ __device__ __forceinline__ void walk_pass2(const DevIndex &ix, const DevCfg &cfg
     if (R.ok && j == rd.n_seg - 1) h.right_ins = 0;
     build_match(acc, sk, h, status, q.x, q.y, ge.x, ge.y, k == 0, k == p1.n_gex - 1, L.ok, R.ok);
     k++;
-    i_last = i_hit;
+    i_last = i_hit; e_last = ge;
   }
   if (R.ok) { build_clip(acc, sk, R); k++; }
   if (acc.junc_hits < 0) acc.junc_hits = 0;
@@ -644,6 +658,7 @@ __global__ void __launch_bounds__(256) k_project(ProjectArgs A) {
   for (int64_t w = gid; w < n_work; w += groups_total) {
     const int64_t a = EMIT ? (int64_t)A.big_list[w] : w;
     uint4 hd = A.head[a];
+    uint4 hd2 = A.head2[a];
     uint32_t n_seg = hd.z;
     if (n_seg == 0) { if (!EMIT && gl == 0) { A.n_matches[a] = 0; A.ranges[a] = make_uint4(0, 0, 0, 0); A.mask[a] = 0; } continue; }
     uint2 q0 = make_uint2(hd.x, hd.y);
@@ -675,17 +690,23 @@ __global__ void __launch_bounds__(256) k_project(ProjectArgs A) {
         ra[2 * s] = ix.t_hi[bo + bh]; rb[2 * s] = ix.t_hi[bo + bh + 1];
         ra[2 * s + 1] = ix.t_lo[bo + bl]; rb[2 * s + 1] = ix.t_lo[bo + bl + 1];
       }
-      uint32_t res[4];
+      // all four counts advance together: one round trip per G rows instead of four
+      uint32_t res[4] = {ra[0], ra[1], ra[2], ra[3]};
+      for (uint32_t it = 0;; it += G) {
+        uint32_t vv[4]; bool in[4]; bool any = false;
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        uint32_t cnt = 0;
-        for (uint32_t r0 = ra[k]; r0 < rb[k]; r0 += G) {
-          uint32_t r = r0 + (uint32_t)gl;
-          bool t = false;
-          if (r < rb[k]) { uint32_t vv = (k & 1) ? ix.s_pmax[r] : ix.s_start[r]; t = (k & 1) ? (vv <= q0.x) : (vv < q0.y); }
-          cnt += (uint32_t)__popcll((__ballot(t) >> gbase) & gmask);
+        for (int k = 0; k < 4; k++) {
+          uint32_t r = ra[k] + it + (uint32_t)gl;
+          in[k] = r < rb[k];
+          any |= (ra[k] + it) < rb[k];
+          vv[k] = in[k] ? ((k & 1) ? ix.s_pmax[r] : ix.s_start[r]) : 0u;
         }
-        res[k] = ra[k] + cnt;
+        if (!any) break;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          bool t = in[k] && ((k & 1) ? (vv[k] <= q0.x) : (vv[k] < q0.y));
+          res[k] += (uint32_t)__popcll((__ballot(t) >> gbase) & gmask);
+        }
       }
       hi[0] = res[0]; lo[0] = res[1] < res[0] ? res[1] : res[0];
       hi[1] = res[2]; lo[1] = res[3] < res[2] ? res[3] : res[2];
@@ -695,10 +716,10 @@ __global__ void __launch_bounds__(256) k_project(ProjectArgs A) {
     uint32_t n_items = n0 + n1;
 
     ReadCtx rd;
-    rd.n_seg = n_seg; rd.seg = nullptr; rd.real = nullptr; rd.n_real = 0;
+    rd.n_seg = n_seg; rd.seg = nullptr; rd.real = nullptr; rd.n_real = 0; rd.q12 = hd2;
     uint32_t moff = 0; uint64_t cbase = 0; uint32_t cap = 0, ideal_cap = 0;
     bool have_mask = false; uint64_t mask_in = 0;
-    if (EMIT || n_seg > 1) {
+    if (EMIT || n_seg > 3) {
       uint32_t c0 = A.cigar_off[a];
       rd.seg = A.seg + (size_t)c0 + (size_t)a;
       rd.real = A.cigar + c0;
@@ -751,7 +772,7 @@ __global__ void __launch_bounds__(256) k_project(ProjectArgs A) {
             }
             if (!superseded) {
               if (n_seg == 1) { p1.alive = true; p1.fwpos = h0.pos; p1.rcpos = h0.pos; p1.n_seg = 1; p1.n_gex = 1; p1.i_lastm = i0; p1.last_right_ins = h0.right_ins; p1.last_right_gap = h0.right_gap; }
-              else p1 = walk_pass1(ix, cfg, rd, E, s == 1, sb[s], se[s], i0, q0, h0);
+              else p1 = walk_pass1(ix, cfg, rd, E, s == 1, sb[s], se[s], i0, make_uint4(gs, gend, pay.z, 0), q0, h0);
               alive = p1.alive;
             }
           }
@@ -761,7 +782,7 @@ __global__ void __launch_bounds__(256) k_project(ProjectArgs A) {
           // similarity filter needs the pass-2 accumulators (long reads only)
           if (alive && cfg.filter_by_similarity) {
             sk.init(nullptr);
-            walk_pass2(ix, cfg, rd, E, s == 1, sb[s], se[s], i0, q0, gs, gend, h0, p1, acc, sk, no_clip(), no_clip());
+            walk_pass2(ix, cfg, rd, E, s == 1, sb[s], se[s], i0, q0, make_uint4(gs, gend, pay.z, 0), h0, p1, acc, sk, no_clip(), no_clip());
             alive = similarity(cfg, acc, score);
           }
         }
@@ -805,7 +826,7 @@ __global__ void __launch_bounds__(256) k_project(ProjectArgs A) {
           bool ideal_lds = ideal_cap <= LDS_IDEAL;
           uint32_t *ideal = ideal_lds ? lds : slot + rd.n_real + ideal_cap;
           sk.init(ideal);
-          walk_pass2(ix, cfg, rd, E, s == 1, sb[s], se[s], i0, q0, gs, gend, h0, p1, acc, sk, no_clip(), no_clip());
+          walk_pass2(ix, cfg, rd, E, s == 1, sb[s], se[s], i0, q0, make_uint4(gs, gend, pay.z, 0), h0, p1, acc, sk, no_clip(), no_clip());
           uint32_t n_ideal = sk.finish();
           similarity(cfg, acc, score);
           bool out_lds = ideal_lds && (rd.n_real + n_ideal <= LDS_SLOT - LDS_IDEAL);
@@ -859,6 +880,7 @@ __global__ void __launch_bounds__(256) k_emit_dense(ProjectArgs A, int64_t n_mat
   uint32_t a = A.m_aln[mi64];
   if (a == 0xffffffffu) return;
   uint4 hd = A.head[a];
+  uint4 hd2 = A.head2[a];
   uint4 rg = A.ranges[a];
   uint64_t mask = A.mask[a];
   uint32_t moff = A.match_off[a];
@@ -879,13 +901,22 @@ __global__ void __launch_bounds__(256) k_emit_dense(ProjectArgs A, int64_t n_mat
   uint4 pay = ix.s_pay[row];
   // rank by tid among the survivors
   uint32_t rank = 0;
-  for (uint64_t m2 = mask; m2; m2 &= m2 - 1) {
-    uint32_t b = (uint32_t)(__ffsll((long long)m2) - 1);
-    uint32_t r2 = b < n0 ? rg.x + b : rg.z + (b - n0);
-    rank += (ix.s_pay[r2].x < pay.x) ? 1u : 0u;
+  for (uint64_t m2 = mask; m2;) {  // four independent loads in flight per step
+    uint32_t t4[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      t4[u] = 0xffffffffu;
+      if (m2) {
+        uint32_t b = (uint32_t)(__ffsll((long long)m2) - 1);
+        m2 &= m2 - 1;
+        t4[u] = ix.s_tid[b < n0 ? rg.x + b : rg.z + (b - n0)];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) rank += (t4[u] < pay.x) ? 1u : 0u;
   }
   ReadCtx rd;
-  rd.n_seg = n_seg; rd.seg = A.seg + (size_t)c0 + (size_t)a; rd.real = A.cigar + c0; rd.n_real = c1 - c0;
+  rd.n_seg = n_seg; rd.seg = A.seg + (size_t)c0 + (size_t)a; rd.real = A.cigar + c0; rd.n_real = c1 - c0; rd.q12 = hd2;
   Hit h0;
   classify(s == 1, st0, q0.x, q0.y, gs, gend, pay.z, cfg, h0);
   const uint4 *E = ix.tx_ex + pay.w;
@@ -893,7 +924,7 @@ __global__ void __launch_bounds__(256) k_emit_dense(ProjectArgs A, int64_t n_mat
   CandOut p1;
   uint32_t sb = ix.slab_off[2 * rid + s], se = ix.slab_off[2 * rid + s + 1];
   if (n_seg == 1) { p1.alive = true; p1.fwpos = h0.pos; p1.rcpos = h0.pos; p1.n_seg = 1; p1.n_gex = 1; p1.i_lastm = i0; p1.last_right_ins = h0.right_ins; p1.last_right_gap = h0.right_gap; }
-  else p1 = walk_pass1(ix, cfg, rd, E, s == 1, sb, se, i0, q0, h0);
+  else p1 = walk_pass1(ix, cfg, rd, E, s == 1, sb, se, i0, make_uint4(gs, gend, pay.z, 0), q0, h0);
   uint32_t ideal_cap = 4u * n_seg + 2u;
   uint32_t cap = rd.n_real + 2u * ideal_cap;
   uint32_t *slot = A.cig_arena + cbase + (uint64_t)rank * cap;
@@ -902,7 +933,7 @@ __global__ void __launch_bounds__(256) k_emit_dense(ProjectArgs A, int64_t n_mat
   uint32_t *ideal = ideal_lds ? lds : slot + rd.n_real + ideal_cap;
   Acc acc; IdealSink sk; double score = 0.0;
   sk.init(ideal);
-  walk_pass2(ix, cfg, rd, E, s == 1, sb, se, i0, q0, gs, gend, h0, p1, acc, sk, no_clip(), no_clip());
+  walk_pass2(ix, cfg, rd, E, s == 1, sb, se, i0, q0, make_uint4(gs, gend, pay.z, 0), h0, p1, acc, sk, no_clip(), no_clip());
   uint32_t n_ideal = sk.finish();
   similarity(cfg, acc, score);
   bool out_lds = ideal_lds && (rd.n_real + n_ideal <= LDS_SLOT - LDS_IDEAL);
@@ -1235,10 +1266,10 @@ static inline int grid_for(int64_t n, int per_block) { return (int)((n + per_blo
 void launch_segment(hipStream_t st, int64_t n_aln, const int32_t *ref_id, const int32_t *ref_start,
                     const uint16_t *flags, const int8_t *xs, const int8_t *ts, const uint32_t *cigar_off,
                     const uint32_t *cigar, const DevCfg &cfg, uint32_t n_refs, uint2 *seg, AlnMeta *meta,
-                    uint4 *head) {
+                    uint4 *head, uint4 *head2) {
   if (n_aln <= 0) return;
   hipLaunchKernelGGL(k_segment, dim3(grid_for(n_aln, 256)), dim3(256), 0, st, n_aln, ref_id, ref_start, flags,
-                     xs, ts, cigar_off, cigar, cfg, n_refs, seg, meta, head);
+                     xs, ts, cigar_off, cigar, cfg, n_refs, seg, meta, head, head2);
 }
 
 template <int G>
