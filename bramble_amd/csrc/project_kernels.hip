@@ -627,11 +627,11 @@ __device__ __forceinline__ bool similarity(const DevCfg &cfg, const Acc &acc, do
 // survivors.  Small ideal / rewritten CIGARs are staged in LDS.
 // ---------------------------------------------------------------------------
 #define SLAB_LDS 1025   // slab_off entries cached in LDS (<= 512 references)
-#define LDS_SLOT 33     // words of CIGAR scratch per lane (odd: conflict-free)
+#define LDS_SLOT 25     // words of CIGAR scratch per lane (odd: conflict-free)
 #define LDS_IDEAL 10    // ideal CIGAR words kept in LDS (n_seg <= 2)
 
 template <int G, bool EMIT>
-__global__ void __launch_bounds__(256) k_project(ProjectArgs A) {
+__global__ void __launch_bounds__(256, EMIT ? 4 : 8) k_project(ProjectArgs A) {
   __shared__ uint32_t sh_slab[SLAB_LDS];
   __shared__ uint32_t sh_bin[EMIT ? 1 : SLAB_LDS];
   __shared__ uint32_t sh_cig[EMIT ? 256 * LDS_SLOT : 1];
@@ -871,7 +871,7 @@ __global__ void __launch_bounds__(256) k_expand(ProjectArgs A) {
 // re-derives the candidate from its slab row, ranks it by tid among the read's
 // survivors, builds the ideal CIGAR, merges it with the real CIGAR and writes the
 // match record at match_off[a] + rank.
-__global__ void __launch_bounds__(256) k_emit_dense(ProjectArgs A, int64_t n_matches) {
+__global__ void __launch_bounds__(256, 6) k_emit_dense(ProjectArgs A, int64_t n_matches) {
   __shared__ uint32_t sh_cig[256 * LDS_SLOT];
   int64_t mi64 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (mi64 >= n_matches) return;
