@@ -381,7 +381,7 @@ struct br_ctx {
   double k_ms[BR_K_NUM] = {0}; int32_t k_launches[BR_K_NUM] = {0};
   uint64_t counters[8] = {0};
   // device scratch
-  DevBuf seg, meta, head, head2, n_matches, ranges, mask, match_off, cig_base, tile_sums, totals, counters_d;
+  DevBuf seg, meta, head, head2, fast_flag, fast_pre, m_k, n_matches, ranges, mask, match_off, cig_base, tile_sums, totals, counters_d;
   DevBuf m_tid, m_aux, m_a, m_b, m_cigoff, cig_arena, big_list, n_big, m_aln;
   DevBuf fa_n_prob, fa_seq_bytes, fa_prob_off, fa_seqarena_off, fa_probs, fa_results, fa_seq_arena, fa_clip_ops,
       fa_ideal_cap, fa_scratch, b_seq_off, b_seqs, b_seq_src;
@@ -424,7 +424,7 @@ extern "C" int br_ctx_new(const br_index *ix, br_ctx **out) {
 extern "C" void br_ctx_free(br_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->ix->device);
-  DevBuf *bufs[] = {&c->seg, &c->meta, &c->head, &c->head2, &c->n_matches, &c->ranges, &c->mask, &c->match_off, &c->cig_base,
+  DevBuf *bufs[] = {&c->seg, &c->meta, &c->head, &c->head2, &c->fast_flag, &c->fast_pre, &c->m_k, &c->n_matches, &c->ranges, &c->mask, &c->match_off, &c->cig_base,
                     &c->tile_sums, &c->totals, &c->counters_d, &c->m_tid, &c->m_aux, &c->m_a, &c->m_b,
                     &c->m_cigoff, &c->cig_arena, &c->big_list, &c->n_big, &c->m_aln,
                     &c->fa_n_prob, &c->fa_seq_bytes, &c->fa_prob_off, &c->fa_seqarena_off, &c->fa_probs, &c->fa_results,
@@ -517,21 +517,23 @@ int run_device(br_ctx *c, const br_config *cfg, const br_device_batch *b, hipStr
   int64_t tiles = std::max<int64_t>(scan_tiles_for(std::max<int64_t>(n, ng) + 1), 1);
   RC(c->seg.ensure((size_t)(b->n_cigar_words + n) * sizeof(uint2)));
   RC(c->meta.ensure((size_t)n * sizeof(AlnMeta))); RC(c->head.ensure((size_t)n * sizeof(uint4))); RC(c->head2.ensure((size_t)n * sizeof(uint4)));
+  RC(c->fast_flag.ensure((size_t)n * 4)); RC(c->fast_pre.ensure((size_t)(n + 1) * 4));
   RC(c->n_matches.ensure((size_t)n * 4)); RC(c->ranges.ensure((size_t)n * sizeof(uint4)));
   RC(c->mask.ensure((size_t)n * 8)); RC(c->match_off.ensure((size_t)(n + 1) * 4));
-  RC(c->cig_base.ensure((size_t)(n + 1) * 8)); RC(c->tile_sums.ensure((size_t)tiles * 8));
+  RC(c->cig_base.ensure((size_t)(n + 1) * 8)); RC(c->tile_sums.ensure((size_t)tiles * 8 * 3));
   RC(c->totals.ensure(8 * 8)); RC(c->counters_d.ensure(4 * 8));
   uint64_t *d_tot = c->totals.as<uint64_t>();
 
   // a1/a2/a6: CIGAR -> read exons
   RC(pf.begin(BR_K_SEGMENT));
   launch_segment(st, n, b->ref_id, b->ref_start, b->flags, b->xs, b->ts, b->cigar_off, b->cigar, dc, ix->n_refs,
-                 c->seg.as<uint2>(), c->meta.as<AlnMeta>(), c->head.as<uint4>(), c->head2.as<uint4>());
+                 c->seg.as<uint2>(), c->meta.as<AlnMeta>(), c->head.as<uint4>(), c->head2.as<uint4>(),
+                 c->fast_flag.as<uint32_t>());
   RC(pf.end());
-
   ProjectArgs A{};
   A.ix = ix->dev; A.cfg = dc; A.n_aln = n; A.ref_id = b->ref_id; A.cigar_off = b->cigar_off; A.cigar = b->cigar;
   A.seg = c->seg.as<uint2>(); A.meta = c->meta.as<AlnMeta>(); A.head = c->head.as<uint4>(); A.head2 = c->head2.as<uint4>();
+  A.fast_flag = c->fast_flag.as<uint32_t>(); A.fast_pre = c->fast_pre.as<uint32_t>();
   A.n_matches = c->n_matches.as<uint32_t>();
   A.ranges = c->ranges.as<uint4>(); A.mask = c->mask.as<uint64_t>();
   A.match_off = c->match_off.as<uint32_t>(); A.cig_base = c->cig_base.as<uint64_t>();
@@ -541,15 +543,14 @@ int run_device(br_ctx *c, const br_config *cfg, const br_device_batch *b, hipStr
   int n_blocks = c->n_cu * c->blocks_per_cu;
   ScanArgs S{};
   S.n = n; S.src32 = c->n_matches.as<uint32_t>(); S.cigar_off = b->cigar_off; S.head = c->head.as<uint4>();
-  S.tile_sums = c->tile_sums.as<uint64_t>();
+  S.tile_sums = c->tile_sums.as<uint64_t>(); S.fast_flag = c->fast_flag.as<uint32_t>();
   FaArgs F{};
   if (!fa_mode) {
     RC(pf.begin(BR_K_COUNT));
     launch_project(st, A, false, c->group_lanes, n_blocks);
     RC(pf.end());
     RC(pf.begin(BR_K_SCAN));
-    launch_scan(st, S, 0, c->match_off.p, false, d_tot + 0);
-    launch_scan(st, S, 1, c->cig_base.p, true, d_tot + 1);
+    launch_scan3(st, S, c->match_off.as<uint32_t>(), c->cig_base.as<uint64_t>(), c->fast_pre.as<uint32_t>(), d_tot + 0);
     RC(pf.end());
   } else {
     // rescue planning -> ksw2 DP -> count with the rescue results
@@ -606,8 +607,7 @@ int run_device(br_ctx *c, const br_config *cfg, const br_device_batch *b, hipStr
     RC(pf.end());
     S.ideal_cap = F.ideal_cap;
     RC(pf.begin(BR_K_SCAN));
-    launch_scan(st, S, 0, c->match_off.p, false, d_tot + 0);
-    launch_scan(st, S, 3, c->cig_base.p, true, d_tot + 1);
+    launch_scan3(st, S, c->match_off.as<uint32_t>(), c->cig_base.as<uint64_t>(), c->fast_pre.as<uint32_t>(), d_tot + 0);
     RC(pf.end());
   }
   HIPCHK(hipMemcpyAsync(c->h_totals, d_tot, 2 * 8, hipMemcpyDeviceToHost, st));
@@ -618,8 +618,8 @@ int run_device(br_ctx *c, const br_config *cfg, const br_device_batch *b, hipStr
 
   size_t nm = (size_t)std::max<uint64_t>(n_matches, 1);
   RC(c->m_tid.ensure(nm * 4)); RC(c->m_aux.ensure(nm * 4)); RC(c->m_a.ensure(nm * sizeof(uint4)));
-  RC(c->m_b.ensure(nm * sizeof(uint4))); RC(c->m_cigoff.ensure(nm * 8)); RC(c->m_aln.ensure(nm * 4));
-  A.m_aln = c->m_aln.as<uint32_t>();
+  RC(c->m_b.ensure(nm * sizeof(uint4))); RC(c->m_cigoff.ensure(nm * 8)); RC(c->m_aln.ensure(nm * 4)); RC(c->m_k.ensure(nm));
+  A.m_aln = c->m_aln.as<uint32_t>(); A.m_k = c->m_k.as<uint8_t>();
   RC(c->cig_arena.ensure((size_t)std::max<uint64_t>(n_cig_arena, 1) * 4));
   A.m_tid = c->m_tid.as<uint32_t>(); A.m_aux = c->m_aux.as<uint32_t>(); A.m_a = c->m_a.as<uint4>();
   A.m_b = c->m_b.as<uint4>(); A.m_cigoff = c->m_cigoff.as<uint64_t>(); A.cig_arena = c->cig_arena.as<uint32_t>();
@@ -646,7 +646,7 @@ int run_device(br_ctx *c, const br_config *cfg, const br_device_batch *b, hipStr
   PairArgs P{};
   P.n_groups = ng; P.n_aln = n; P.long_reads = dc.long_reads; P.group_off = b->group_off; P.mate_idx = b->mate_idx;
   P.aln_group = c->aln_group.as<uint32_t>();
-  P.match_off = c->match_off.as<uint32_t>(); P.m_tid = A.m_tid; P.m_a = A.m_a; P.m_b = A.m_b; P.l_qseq = b->l_qseq;
+  P.match_off = c->match_off.as<uint32_t>(); P.n_matches = c->n_matches.as<uint32_t>(); P.m_tid = A.m_tid; P.m_a = A.m_a; P.m_b = A.m_b; P.l_qseq = b->l_qseq;
   P.n_rows = c->n_rows.as<uint32_t>(); P.row_off = c->row_off.as<uint64_t>(); P.counters = c->counters_d.as<uint64_t>();
   RC(pf.begin(BR_K_PAIR_COUNT));
   launch_pair(st, P, false);

@@ -18,6 +18,9 @@ struct ProjectArgs {
   const AlnMeta *meta;
   const uint4 *head;     // [n_aln] {exon0.start, exon0.end, n_seg, refid<<2|smode}
   const uint4 *head2;    // [n_aln] read exons 1 and 2
+  const uint32_t *fast_flag;  // [n_aln] 1: one read exon from a single M op (short-read presets)
+  const uint32_t *fast_pre;   // [n_aln + 1] exclusive prefix of the simple alignments' matches
+  uint8_t *m_k;               // [n_matches] emit work list: which survivor of m_aln[w]
   // count pass outputs / emit pass inputs
   uint32_t *n_matches;   // [n_aln]
   uint4 *ranges;         // [n_aln] candidate row ranges (lo+,hi+,lo-,hi-)
@@ -71,7 +74,9 @@ struct ScanArgs {
   const uint32_t *cigar_off;  // mode 1 only
   const uint4 *head;          // mode 1 only
   const uint32_t *ideal_cap;  // mode 3 only
+  const uint32_t *fast_flag;  // scan3 only
   uint64_t *tile_sums;
+  int64_t n_tiles;            // scan3 only (set by the launcher)
 };
 
 struct PairArgs {
@@ -81,6 +86,7 @@ struct PairArgs {
   const uint32_t *aln_group;  // [n_aln] group of each alignment (k_group_ids)
   const int32_t *mate_idx;
   const uint32_t *match_off;
+  const uint32_t *n_matches;
   const uint32_t *m_tid;
   const uint4 *m_a, *m_b;
   const int32_t *l_qseq;
@@ -121,7 +127,7 @@ void launch_stats(hipStream_t st, const StatsArgs &T, const uint4 *m_a, int64_t 
 void launch_segment(hipStream_t st, int64_t n_aln, const int32_t *ref_id, const int32_t *ref_start,
                     const uint16_t *flags, const int8_t *xs, const int8_t *ts, const uint32_t *cigar_off,
                     const uint32_t *cigar, const DevCfg &cfg, uint32_t n_refs, uint2 *seg, AlnMeta *meta,
-                    uint4 *head, uint4 *head2);
+                    uint4 *head, uint4 *head2, uint32_t *fast_flag);
 void launch_project(hipStream_t st, const ProjectArgs &A, bool emit, int group_lanes, int n_blocks);
 void launch_project_fa(hipStream_t st, const ProjectArgs &A, const FaArgs &F, int mode, int n_blocks);
 void launch_ksw(hipStream_t st, const KswArgs &K, int n_blocks);
@@ -134,6 +140,8 @@ int64_t scan_tiles_for(int64_t n);
 // 3: n_matches * CIGAR slot capacity with the per-alignment ideal_cap[] of the -S path
 void launch_scan(hipStream_t st, const ScanArgs &S, int mode, void *out, bool out64, uint64_t *total_out);
 void launch_group_ids(hipStream_t st, int64_t n_groups, const uint32_t *group_off, uint32_t *aln_group);
+void launch_scan3(hipStream_t st, ScanArgs S, uint32_t *match_off, uint64_t *cig_base, uint32_t *fast_pre,
+                  uint64_t *total_out3);
 void launch_pair(hipStream_t st, const PairArgs &P, bool emit);
 void launch_row_fill(hipStream_t st, const PairArgs &P, int64_t n_rows);
 void launch_gather(hipStream_t st, const RowArgs &R);

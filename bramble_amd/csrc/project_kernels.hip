@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(256) k_segment(int64_t n_aln, const int32_t *_
                                                  const uint32_t *__restrict__ cigar, DevCfg cfg,
                                                  uint32_t n_refs, uint2 *__restrict__ seg,
                                                  AlnMeta *__restrict__ meta, uint4 *__restrict__ head,
-                                                 uint4 *__restrict__ head2) {
+                                                 uint4 *__restrict__ head2, uint32_t *__restrict__ fast_flag) {
   int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= n_aln) return;
   uint32_t c0 = cigar_off[a], c1 = cigar_off[a + 1];
@@ -126,6 +126,9 @@ __global__ void __launch_bounds__(256) k_segment(int64_t n_aln, const int32_t *_
   head[a] = make_uint4(q0.x, q0.y, n, n ? (((uint32_t)rid << 2) | smode) : 0u);
   uint2 q1 = n > 1 ? out[1] : make_uint2(0, 0), q2 = n > 2 ? out[2] : make_uint2(0, 0);
   head2[a] = make_uint4(q1.x, q1.y, q2.x, q2.y);
+  // "simple" alignments: one read exon from a single M op, short-read presets.  They
+  // are processed first (k_perm) so that whole waves take the short code paths.
+  fast_flag[a] = (n == 1 && n_cigar == 1 && CIG_OP(cg[0]) == OP_M && !cfg.filter_by_similarity && !cfg.long_reads) ? 1u : 0u;
 }
 
 // ---------------------------------------------------------------------------
@@ -853,17 +856,21 @@ __global__ void __launch_bounds__(256, EMIT ? 4 : 8) k_project(ProjectArgs A) {
   }
 }
 
-// k_expand: one lane per alignment labels its match slots with the alignment
-// index (~0u for the > 64-candidate alignments, which the group kernel emits).
+// k_expand: one lane per alignment appends its matches to the emit work list:
+// (alignment, k-th survivor) pairs, simple alignments first so that whole waves of
+// k_emit_dense take the short path.  Alignments with > 64 candidate rows are left
+// to the group kernel (~0u entries).
 __global__ void __launch_bounds__(256) k_expand(ProjectArgs A) {
   int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= A.n_aln) return;
-  uint32_t m0 = A.match_off[a], m1 = A.match_off[a + 1];
-  if (m0 == m1) return;
+  uint32_t nm = A.n_matches[a];
+  if (nm == 0) return;
+  uint32_t fp = A.fast_pre[a];
+  uint32_t pos = A.fast_flag[a] ? fp : A.fast_pre[A.n_aln] + (A.match_off[a] - fp);
   uint4 rg = A.ranges[a];
   uint32_t n_items = (rg.y - rg.x) + (rg.w - rg.z);
   uint32_t v = n_items <= 64 ? (uint32_t)a : 0xffffffffu;
-  for (uint32_t k = m0; k < m1; k++) A.m_aln[k] = v;
+  for (uint32_t k = 0; k < nm; k++) { A.m_aln[pos + k] = v; A.m_k[pos + k] = (uint8_t)k; }
 }
 
 // k_emit_dense: one lane per match.  Match mi of alignment a is the k-th set bit
@@ -883,6 +890,7 @@ __global__ void __launch_bounds__(256, 6) k_emit_dense(ProjectArgs A, int64_t n_
   uint4 hd2 = A.head2[a];
   uint4 rg = A.ranges[a];
   uint64_t mask = A.mask[a];
+  const uint32_t is_fast = A.fast_flag[a];
   uint32_t moff = A.match_off[a];
   uint64_t cbase = A.cig_base[a];
   uint32_t c0 = A.cigar_off[a], c1 = A.cigar_off[a + 1];
@@ -891,7 +899,7 @@ __global__ void __launch_bounds__(256, 6) k_emit_dense(ProjectArgs A, int64_t n_
   int st0 = (n_seg == 1) ? ST_ONLY : ST_FIRST;
   uint32_t n0 = rg.y - rg.x;
   // k-th survivor in candidate-row order
-  uint32_t k = (uint32_t)mi64 - moff;
+  uint32_t k = A.m_k[mi64];
   uint64_t mm = mask;
   for (uint32_t j = 0; j < k; j++) mm &= mm - 1;
   uint32_t item = (uint32_t)(__ffsll((long long)mm) - 1);
@@ -915,10 +923,33 @@ __global__ void __launch_bounds__(256, 6) k_emit_dense(ProjectArgs A, int64_t n_
 #pragma unroll
     for (int u = 0; u < 4; u++) rank += (t4[u] < pay.x) ? 1u : 0u;
   }
-  ReadCtx rd;
-  rd.n_seg = n_seg; rd.seg = A.seg + (size_t)c0 + (size_t)a; rd.real = A.cigar + c0; rd.n_real = c1 - c0; rd.q12 = hd2;
   Hit h0;
   classify(s == 1, st0, q0.x, q0.y, gs, gend, pay.z, cfg, h0);
+  if (is_fast) {
+    // one read exon from a single M op (short-read presets): the ideal CIGAR is
+    // [S left_ins] M [S right_ins] (src/evaluate.cpp:699-706,739-749,752-759) and merging it
+    // with "<len>M" returns it unchanged (src/bam.cpp:85-88,96-98) -- no walk, no merge loop.
+    uint32_t os = q0.x > gs ? q0.x : gs, oe = q0.y < gend ? q0.y : gend;
+    uint32_t ml = oe - os;
+    uint32_t w0, w1 = 0, w2 = 0, n_out;
+    if (h0.left_ins) { w0 = CIG_GEN(h0.left_ins, OP_S); w1 = CIG_GEN(ml, OP_M); n_out = 2; if (h0.right_ins) { w2 = CIG_GEN(h0.right_ins, OP_S); n_out = 3; } }
+    else { w0 = CIG_GEN(ml, OP_M); n_out = 1; if (h0.right_ins) { w1 = CIG_GEN(h0.right_ins, OP_S); n_out = 2; } }
+    uint32_t junc = ((h0.left_ins == 0 && h0.left_gap == 0) ? 1u : 0u) + ((h0.right_ins == 0 && h0.right_gap == 0) ? 1u : 0u);
+    uint64_t cref = (uint64_t)w0 | ((uint64_t)w1 << 32);
+    if (n_out == 3) {
+      cref = cbase + (uint64_t)rank * (1u + 2u * 6u);
+      uint32_t *slot = A.cig_arena + cref;
+      slot[0] = w0; slot[1] = w1; slot[2] = w2;
+    }
+    uint32_t mo = moff + rank;
+    A.m_tid[mo] = pay.x;
+    A.m_a[mo] = make_uint4(h0.pos, n_out | ((uint32_t)s << 31), junc, ml);
+    A.m_b[mo] = make_uint4(0u, 0u, 0u, 0u);
+    A.m_cigoff[mo] = cref;
+    return;
+  }
+  ReadCtx rd;
+  rd.n_seg = n_seg; rd.seg = A.seg + (size_t)c0 + (size_t)a; rd.real = A.cigar + c0; rd.n_real = c1 - c0; rd.q12 = hd2;
   const uint4 *E = ix.tx_ex + pay.w;
   uint32_t i0 = pay.y;
   CandOut p1;
@@ -1032,6 +1063,68 @@ __global__ void __launch_bounds__(256) k_scan_apply(ScanArgs S, OutT *out) {
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) out[S.n] = (OutT)ex;
 }
 
+// Fused scan of the count pass: per alignment (n_matches, n_matches * CIGAR slot
+// capacity, n_matches of simple alignments) -> match_off (u32), cig_base (u64),
+// fast_pre (u32).  One read of the inputs instead of three.
+struct Scan3 { uint64_t v[3]; };
+__device__ __forceinline__ Scan3 scan3_value(const ScanArgs &S, int64_t i) {
+  Scan3 r; r.v[0] = r.v[1] = r.v[2] = 0;
+  uint32_t nm = S.src32[i];
+  if (nm) {
+    uint32_t n_real = S.cigar_off[i + 1] - S.cigar_off[i];
+    uint32_t icap = S.ideal_cap ? S.ideal_cap[i] : 4u * S.head[i].z + 2u;
+    r.v[0] = nm; r.v[1] = (uint64_t)nm * (uint64_t)(n_real + 2u * icap); r.v[2] = S.fast_flag[i] ? nm : 0;
+  }
+  return r;
+}
+__global__ void __launch_bounds__(256) k_scan3_tiles(ScanArgs S) {
+  __shared__ uint64_t sh[4];
+  int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+  uint64_t sum[3] = {0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; k++) { int64_t i = base + k; if (i < S.n) { Scan3 x = scan3_value(S, i); sum[0] += x.v[0]; sum[1] += x.v[1]; sum[2] += x.v[2]; } }
+#pragma unroll
+  for (int c = 0; c < 3; c++) { uint64_t tot; block_excl_scan_256(sum[c], sh, tot); if (threadIdx.x == 0) S.tile_sums[(int64_t)c * S.n_tiles + blockIdx.x] = tot; }
+}
+__global__ void __launch_bounds__(256) k_scan3_top(uint64_t *tile_sums, int64_t n_tiles, uint64_t *total_out) {
+  __shared__ uint64_t sh[4];
+  for (int c = 0; c < 3; c++) {
+    uint64_t carry = 0;
+    uint64_t *ts = tile_sums + (int64_t)c * n_tiles;
+    for (int64_t base = 0; base < n_tiles; base += 256) {
+      int64_t i = base + threadIdx.x;
+      uint64_t v = i < n_tiles ? ts[i] : 0, tot;
+      uint64_t ex = block_excl_scan_256(v, sh, tot);
+      if (i < n_tiles) ts[i] = carry + ex;
+      carry += tot;
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) total_out[c] = carry;
+  }
+}
+__global__ void __launch_bounds__(256) k_scan3_apply(ScanArgs S, uint32_t *match_off, uint64_t *cig_base, uint32_t *fast_pre) {
+  __shared__ uint64_t sh[4];
+  int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+  Scan3 v[SCAN_ITEMS];
+  uint64_t sum[3] = {0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; k++) {
+    int64_t i = base + k;
+    if (i < S.n) v[k] = scan3_value(S, i); else { v[k].v[0] = v[k].v[1] = v[k].v[2] = 0; }
+    sum[0] += v[k].v[0]; sum[1] += v[k].v[1]; sum[2] += v[k].v[2];
+  }
+  uint64_t ex[3];
+#pragma unroll
+  for (int c = 0; c < 3; c++) { uint64_t tot; ex[c] = block_excl_scan_256(sum[c], sh, tot) + S.tile_sums[(int64_t)c * S.n_tiles + blockIdx.x]; }
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; k++) {
+    int64_t i = base + k;
+    if (i < S.n) { match_off[i] = (uint32_t)ex[0]; cig_base[i] = ex[1]; fast_pre[i] = (uint32_t)ex[2]; }
+    ex[0] += v[k].v[0]; ex[1] += v[k].v[1]; ex[2] += v[k].v[2];
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) { match_off[S.n] = (uint32_t)ex[0]; cig_base[S.n] = ex[1]; fast_pre[S.n] = (uint32_t)ex[2]; }
+}
+
 // ---------------------------------------------------------------------------
 // k_pair<EMIT>: one lane per read-name group.
 //   src/core.cpp:343-426 (which alignments pair up), src/mates.cpp:150-261
@@ -1065,12 +1158,12 @@ __global__ void __launch_bounds__(256) k_pair(PairArgs P) {
   int32_t m = P.mate_idx[i];
   uint32_t g = P.aln_group[i];
   uint32_t a0 = P.group_off[g], a1 = P.group_off[g + 1];
-  uint32_t mi0 = P.match_off[i], ni = P.match_off[i + 1] - mi0;
+  uint32_t mi0 = P.match_off[i], ni = P.n_matches[i];
   bool leader = !(m >= 0 && (uint32_t)m < i && (uint32_t)m >= a0);  // else: handled as the mate of an earlier leader
   uint64_t r0 = EMIT ? P.row_off[i] : 0;
   if (leader && ni) {                          // a leader without matches drops the pair (mates.cpp:153)
     uint32_t nm = 0, mm0 = 0;
-    if (m >= 0 && (uint32_t)m > i && (uint32_t)m < a1) { mm0 = P.match_off[m]; nm = P.match_off[m + 1] - mm0; }
+    if (m >= 0 && (uint32_t)m > i && (uint32_t)m < a1) { mm0 = P.match_off[m]; nm = P.n_matches[m]; }
     if (nm == 0) {
       // unpaired emission: one record per transcript, ascending tid (mates.cpp:157-176)
       if (EMIT)
@@ -1153,7 +1246,9 @@ __global__ void __launch_bounds__(256) k_group_stats(PairArgs P) {
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < P.n_groups; g += (int64_t)gridDim.x * blockDim.x) {
     uint32_t a0 = P.group_off[g], a1 = P.group_off[g + 1];
     uniq += (P.row_off[a1] - P.row_off[a0]) == 1 ? 1 : 0;
-    dropped += (P.match_off[a1] == P.match_off[a0]) ? 1 : 0;
+    uint32_t any = 0;
+    for (uint32_t i = a0; i < a1; i++) any |= P.n_matches[i];
+    dropped += any ? 0 : 1;
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) { uniq += __shfl_down(uniq, d, 64); dropped += __shfl_down(dropped, d, 64); }
@@ -1266,10 +1361,10 @@ static inline int grid_for(int64_t n, int per_block) { return (int)((n + per_blo
 void launch_segment(hipStream_t st, int64_t n_aln, const int32_t *ref_id, const int32_t *ref_start,
                     const uint16_t *flags, const int8_t *xs, const int8_t *ts, const uint32_t *cigar_off,
                     const uint32_t *cigar, const DevCfg &cfg, uint32_t n_refs, uint2 *seg, AlnMeta *meta,
-                    uint4 *head, uint4 *head2) {
+                    uint4 *head, uint4 *head2, uint32_t *fast_flag) {
   if (n_aln <= 0) return;
   hipLaunchKernelGGL(k_segment, dim3(grid_for(n_aln, 256)), dim3(256), 0, st, n_aln, ref_id, ref_start, flags,
-                     xs, ts, cigar_off, cigar, cfg, n_refs, seg, meta, head, head2);
+                     xs, ts, cigar_off, cigar, cfg, n_refs, seg, meta, head, head2, fast_flag);
 }
 
 template <int G>
@@ -1325,6 +1420,17 @@ void launch_scan(hipStream_t st, const ScanArgs &S, int mode, void *out, bool ou
     if (out64) hipLaunchKernelGGL((k_scan_apply<2, uint64_t>), g, b, 0, st, S, (uint64_t *)out);
     else hipLaunchKernelGGL((k_scan_apply<2, uint32_t>), g, b, 0, st, S, (uint32_t *)out);
   }
+}
+
+void launch_scan3(hipStream_t st, ScanArgs S, uint32_t *match_off, uint64_t *cig_base, uint32_t *fast_pre,
+                  uint64_t *total_out3) {
+  int64_t tiles = scan_tiles_for(S.n);
+  if (tiles < 1) tiles = 1;
+  S.n_tiles = tiles;
+  dim3 g((unsigned)tiles), b(256);
+  hipLaunchKernelGGL(k_scan3_tiles, g, b, 0, st, S);
+  hipLaunchKernelGGL(k_scan3_top, dim3(1), b, 0, st, S.tile_sums, tiles, total_out3);
+  hipLaunchKernelGGL(k_scan3_apply, g, b, 0, st, S, match_off, cig_base, fast_pre);
 }
 
 void launch_stats(hipStream_t st, const StatsArgs &T, const uint4 *m_a, int64_t n_matches) {
