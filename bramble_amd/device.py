@@ -51,3 +51,33 @@ def upload_batch(batch, device="cuda:0"):
         d["seq_src"] = t(src[:n], np.int32)
         d["max_soft_clip"] = int(sc.max()) if sc.size else 0
     return d
+
+
+class _DevArray:
+    """Zero-copy view of context-owned device memory for torch (valid until the next projection call)."""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+_TYPESTR = {"int8": "|i1", "uint8": "|u1", "int32": "<i4", "int64": "<i8", "float64": "<f8"}
+
+
+def rows_as_tensors(rows, device="cuda:0"):
+    """BrDeviceRows -> dict of torch tensors (unsigned 32/64-bit columns are viewed as signed)."""
+    n = int(rows.n_rows)
+    spec = {"input_index": "int32", "transcript_id": "int32", "pos": "int32", "strand": "int8",
+            "similarity_score": "float64", "clip_score": "int32", "junc_hits": "int32", "aligned_len": "int32",
+            "nh": "int32", "hi": "int32", "mapq": "int32", "is_paired": "uint8", "same_transcript_as_mate": "uint8",
+            "is_first": "uint8", "mate_transcript_id": "int32", "mate_pos": "int32", "insert_size": "int32",
+            "group": "int32"}
+    out = {"n_rows": n}
+    if n == 0:
+        return out
+    for name, ty in spec.items():
+        out[name] = torch.as_tensor(_DevArray(getattr(rows, name), n, _TYPESTR[ty]), device=device)
+    out["cigar_off"] = torch.as_tensor(_DevArray(rows.cigar_off, n + 1, "<i8"), device=device)
+    nw = int(rows.n_cigar_words)
+    if nw:
+        out["cigar"] = torch.as_tensor(_DevArray(rows.cigar, nw, "<i4"), device=device)
+    return out

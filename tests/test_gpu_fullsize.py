@@ -1,0 +1,108 @@
+"""BASELINE.json's full size (configs[1]: 10M read pairs vs the GENCODE-shaped annotation) through
+size-independent properties -- the oracle cannot run 20M alignments in test time:
+
+  * every rewritten CIGAR consumes exactly the read's l_qseq query bases (merge preserves the query);
+  * NH of a read name = number of records emitted for it, HI runs 1..NH inside the name;
+  * idempotence: projecting the same batch twice gives the same checksums;
+  * shard additivity ("checksum of checksums"): the two halves of the batch, cut at a read-name boundary,
+    give exactly the rows of the whole batch (counts and per-column checksums add up);
+  * with the paired flag cleared every match is emitted: n_rows == n_matches.
+"""
+import numpy as np
+import pytest
+import torch
+
+from bramble_amd import device as brdev
+from bramble_amd import lib, shard, synth
+
+pytestmark = pytest.mark.gpu
+
+PAIRS = 10_000_000
+
+
+def _checksums(t):
+    cs = {"n_rows": t["n_rows"]}
+    for k in ("transcript_id", "pos", "nh", "hi", "mapq", "junc_hits", "aligned_len", "insert_size", "mate_pos"):
+        cs[k] = int(t[k].to(torch.int64).sum().item())
+    cs["strand"] = int(t["strand"].to(torch.int64).sum().item())
+    w = t["cigar"].to(torch.int64)
+    cs["cigar"] = int(((w & 0xFFFFFFFF) * 1315423911 % 2147483647).sum().item())
+    return cs
+
+
+@pytest.fixture(scope="module")
+def setup():
+    ann = synth.Annotation("G")
+    idx = lib.Index.from_flat(ann.flat, device=0)
+    ctx = lib.Context(idx)
+    batch = ann.reads(PAIRS, "pe")
+    return ann, idx, ctx, batch
+
+
+def test_full_size_properties(setup):
+    ann, idx, ctx, batch = setup
+    cfg = lib.make_config()
+    db = brdev.upload_batch(batch, "cuda:0")
+    rows = ctx.project_batch_device(cfg, db, 0)
+    t = brdev.rows_as_tensors(rows)
+    n = t["n_rows"]
+    assert n > 5 * PAIRS and rows.total_processed == batch["n_aln"]
+
+    # query length of every rewritten CIGAR == l_qseq of its input record
+    w = t["cigar"].to(torch.int64) & 0xFFFFFFFF
+    op = w & 0xF
+    ln = w >> 4
+    consumes = (op == 0) | (op == 1) | (op == 4) | (op == 7) | (op == 8)
+    qcum = torch.cumsum(torch.where(consumes, ln, torch.zeros_like(ln)), 0)
+    qcum = torch.cat([torch.zeros(1, dtype=torch.int64, device=qcum.device), qcum])
+    off = t["cigar_off"]
+    qlen = qcum[off[1:]] - qcum[off[:-1]]
+    lq = torch.from_numpy(batch["l_qseq"].astype(np.int64)).cuda()
+    assert bool((qlen == lq[t["input_index"].to(torch.int64)]).all())
+
+    # NH = records per read name; HI = 1..NH
+    g = t["group"].to(torch.int64)
+    ng = int(g.max().item()) + 1
+    per_group = torch.bincount(g, minlength=ng)
+    assert bool((t["nh"].to(torch.int64) == per_group[g]).all())
+    first_row = torch.cumsum(per_group, 0) - per_group
+    assert bool((t["hi"].to(torch.int64) == torch.arange(n, device=g.device) - first_row[g] + 1).all())
+    assert bool((g[1:] >= g[:-1]).all())
+
+    cs1 = _checksums(t)
+    # idempotence
+    rows2 = ctx.project_batch_device(cfg, db, 0)
+    assert _checksums(brdev.rows_as_tensors(rows2)) == cs1
+    del t, rows, rows2
+
+    # shard additivity
+    starts = shard.group_starts(batch) if batch["n_aln"] < 2_000_000 else None
+    if starts is None:  # names are "r<i>", mates adjacent: cheap group starts
+        noff = batch["name_off"].astype(np.int64)
+        ln_ = np.diff(noff)
+        names = batch["names"]
+        same = np.zeros(batch["n_aln"], dtype=bool)
+        cand = np.nonzero(ln_[1:] == ln_[:-1])[0] + 1
+        # compare fixed-width chunks only where lengths match
+        for L in np.unique(ln_[cand]):
+            idxs = cand[ln_[cand] == L]
+            a = names[(noff[idxs][:, None] + np.arange(L)[None, :])]
+            b = names[(noff[idxs - 1][:, None] + np.arange(L)[None, :])]
+            same[idxs] = (a == b).all(axis=1)
+        starts = np.concatenate([np.nonzero(~same)[0], [batch["n_aln"]]]).astype(np.int64)
+    total = {}
+    for r in range(2):
+        sub, lo = shard.shard_batch(batch, r, 2, starts=starts)
+        rs = ctx.project_batch_device(cfg, brdev.upload_batch(sub, "cuda:0"), 0)
+        cs = _checksums(brdev.rows_as_tensors(rs))
+        for k, v in cs.items():
+            total[k] = total.get(k, 0) + v
+    assert total == cs1
+
+
+def test_unpaired_emits_every_match(setup):
+    ann, idx, ctx, batch = setup
+    b2 = dict(batch)
+    b2["flags"] = (batch["flags"] & ~np.uint16(0x1)).astype(np.uint16)
+    rows = ctx.project_batch_device(lib.make_config(), brdev.upload_batch(b2, "cuda:0"), 0)
+    assert rows.n_rows == rows.n_matches and rows.n_matches > 5 * PAIRS
