@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Secondary configurations of BASELINE.json (not the bench contract line; numbers for BASELINE.md):
+
+  python bench_extra.py c5 [--reads N]   HiFi-like --lr-hq --strict --similarity-threshold 0.95 (configs[4], 1 GPU)
+  python bench_extra.py c3 [--reads N]   ONT-like --lr -S with a synthetic genome: clip rescue incl. k_ksw GCUPS (configs[2])
+
+Same protocol as bench.py: inputs resident in HBM, warmup, hipEvent kernel times, one JSON line.
+"""
+import argparse
+import json
+import sys
+import time
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("config", choices=["c3", "c5"])
+    ap.add_argument("--reads", type=int, default=0)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    args = ap.parse_args()
+    import torch
+    from bramble_amd import device as brdev
+    from bramble_amd import lib, synth
+    if args.config == "c5":
+        n = args.reads or 1_000_000
+        ann = synth.Annotation("G")
+        batch = ann.reads(n, "hifi")
+        cfg = lib.make_config(lr_hq=1, strict=1, sim_thr=0.95)
+        label = "%d HiFi-like reads (median 2 kb) --lr-hq --strict --similarity-threshold 0.95 vs GENCODE-shaped annotation" % n
+    else:
+        n = args.reads or 200_000
+        ann = synth.Annotation("G", n_genes=6000, n_refs=5, with_genome=True)
+        batch = ann.reads(n, "ont", with_seq=1)
+        cfg = lib.make_config(lr=1, use_fasta=1)
+        label = "%d ONT-like reads (median 900 bp, clips <= 300) --lr -S vs a 6000-gene annotation with synthetic genome" % n
+    idx = lib.Index.from_flat(ann.flat, device=0)
+    ctx = lib.Context(idx)
+    db = brdev.upload_batch(batch, "cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    for _ in range(args.warmup):
+        rows = ctx.project_batch_device(cfg, db, stream)
+    ctx.set_profiling(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kms = {}
+    for _ in range(args.steps):
+        rows = ctx.project_batch_device(cfg, db, stream)
+        for k, (ms, ln) in ctx.kernel_ms().items():
+            kms[k] = kms.get(k, 0.0) + ms
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    out = {"config": args.config, "workload": label, "alignments_per_step": int(batch["n_aln"]),
+           "value": batch["n_aln"] * args.steps / el, "unit": "alignments/s", "ms_per_step": 1e3 * el / args.steps,
+           "projected_records": int(rows.n_rows), "matches": int(rows.n_matches),
+           "kernel_ms_per_step": {k: round(v / args.steps, 3) for k, v in kms.items() if v}}
+    if args.config == "c3":
+        st = ctx.rescue_stats()
+        ksw_ms = kms.get("k_ksw", 0.0) / args.steps
+        out["rescue"] = st
+        out["k_ksw_GCUPS"] = st["dp_cells"] / (ksw_ms * 1e-3) / 1e9 if ksw_ms else None
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    sys.exit(main())

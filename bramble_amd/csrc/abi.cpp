@@ -380,10 +380,11 @@ struct br_ctx {
   std::vector<KEvent> events; size_t events_used = 0;
   double k_ms[BR_K_NUM] = {0}; int32_t k_launches[BR_K_NUM] = {0};
   uint64_t counters[8] = {0};
+  uint64_t rescue_stats[4] = {0};  // problems, DP cells, accepted rescues, coded sequence bytes
   // device scratch
   DevBuf seg, meta, head, head2, fast_flag, fast_pre, m_k, n_matches, ranges, mask, match_off, cig_base, tile_sums, totals, counters_d;
   DevBuf m_tid, m_aux, m_a, m_b, m_cigoff, cig_arena, big_list, n_big, m_aln;
-  DevBuf fa_n_prob, fa_seq_bytes, fa_prob_off, fa_seqarena_off, fa_probs, fa_results, fa_seq_arena, fa_clip_ops,
+  DevBuf fa_stats, fa_n_prob, fa_seq_bytes, fa_prob_off, fa_seqarena_off, fa_probs, fa_results, fa_seq_arena, fa_clip_ops,
       fa_ideal_cap, fa_scratch, b_seq_off, b_seqs, b_seq_src;
   DevBuf n_rows, row_off, aln_group, r_input, r_match, r_mate, r_flags, r_nh, r_hi, r_mapq, r_group, r_mate_tid, r_mate_pos,
       r_isize, r_tid, r_pos, r_ncig, r_strand, r_sim, r_clip, r_junc, r_refc, r_cigoff, cigar_out;
@@ -414,7 +415,7 @@ extern "C" int br_ctx_new(const br_index *ix, br_ctx **out) {
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, ix->device));
   c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  HIPCHK(hipHostMalloc((void **)&c->h_totals, 8 * sizeof(uint64_t), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void **)&c->h_totals, 16 * sizeof(uint64_t), hipHostMallocDefault));
   const char *g = getenv("BRAMBLE_AMD_GROUP_LANES");
   if (g) { int v = atoi(g); if (v == 8 || v == 16 || v == 32 || v == 64) c->group_lanes = v; }
   *out = c;
@@ -427,7 +428,7 @@ extern "C" void br_ctx_free(br_ctx *c) {
   DevBuf *bufs[] = {&c->seg, &c->meta, &c->head, &c->head2, &c->fast_flag, &c->fast_pre, &c->m_k, &c->n_matches, &c->ranges, &c->mask, &c->match_off, &c->cig_base,
                     &c->tile_sums, &c->totals, &c->counters_d, &c->m_tid, &c->m_aux, &c->m_a, &c->m_b,
                     &c->m_cigoff, &c->cig_arena, &c->big_list, &c->n_big, &c->m_aln,
-                    &c->fa_n_prob, &c->fa_seq_bytes, &c->fa_prob_off, &c->fa_seqarena_off, &c->fa_probs, &c->fa_results,
+                    &c->fa_stats, &c->fa_n_prob, &c->fa_seq_bytes, &c->fa_prob_off, &c->fa_seqarena_off, &c->fa_probs, &c->fa_results,
                     &c->fa_seq_arena, &c->fa_clip_ops, &c->fa_ideal_cap, &c->fa_scratch, &c->b_seq_off, &c->b_seqs, &c->b_seq_src,
                     &c->n_rows, &c->row_off, &c->aln_group, &c->r_input, &c->r_match, &c->r_mate, &c->r_flags, &c->r_nh, &c->r_hi, &c->r_mapq,
                     &c->r_group, &c->r_mate_tid, &c->r_mate_pos, &c->r_isize, &c->r_tid, &c->r_pos,
@@ -452,6 +453,11 @@ extern "C" int br_ctx_kernel_ms(br_ctx *c, int which, double *ms, int32_t *launc
   if (!c || which < 0 || which >= BR_K_NUM) return BR_ERR_INVALID_ARG;
   if (ms) *ms = c->k_ms[which];
   if (launches) *launches = c->k_launches[which];
+  return BR_OK;
+}
+extern "C" int br_ctx_rescue_stats(br_ctx *c, uint64_t out[4]) {
+  if (!c || !out) return BR_ERR_INVALID_ARG;
+  memcpy(out, c->rescue_stats, sizeof(c->rescue_stats));
   return BR_OK;
 }
 extern "C" int br_ctx_last_counters(br_ctx *c, uint64_t out[8]) {
@@ -573,6 +579,9 @@ int run_device(br_ctx *c, const br_config *cfg, const br_device_batch *b, hipStr
     HIPCHK(hipMemcpyAsync(c->h_totals + 4, d_tot + 4, 2 * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     uint64_t n_prob = c->h_totals[4], seq_total = c->h_totals[5];
+    RC(c->fa_stats.ensure(16));
+    HIPCHK(hipMemsetAsync(c->fa_stats.p, 0, 16, st));
+    c->rescue_stats[0] = n_prob; c->rescue_stats[1] = 0; c->rescue_stats[2] = 0; c->rescue_stats[3] = seq_total;
     if (n_prob >= 0xffffffffull) return BR_ERR_CAPACITY;
     RC(c->fa_probs.ensure(std::max<size_t>(n_prob, 1) * ksw_prob_bytes()));
     RC(c->fa_results.ensure(std::max<size_t>(n_prob, 1) * ksw_res_bytes()));
@@ -597,10 +606,11 @@ int run_device(br_ctx *c, const br_config *cfg, const br_device_batch *b, hipStr
       uint64_t waves = std::min<uint64_t>({(uint64_t)c->n_cu * 4 * 4, std::max<uint64_t>(budget / K.scratch_per_wave, 4), (n_prob + 3) / 4 * 4});
       int kb = (int)std::max<uint64_t>(waves / 4, 1);
       RC(c->fa_scratch.ensure((size_t)kb * 4 * K.scratch_per_wave));
-      K.scratch = c->fa_scratch.as<uint8_t>();
+      K.scratch = c->fa_scratch.as<uint8_t>(); K.stats = c->fa_stats.as<uint64_t>();
       RC(pf.begin(BR_K_KSW));
       launch_ksw(st, K, kb);
       RC(pf.end());
+      HIPCHK(hipMemcpyAsync(c->h_totals + 8, c->fa_stats.p, 16, hipMemcpyDeviceToHost, st));
     }
     RC(pf.begin(BR_K_COUNT));
     launch_project_fa(st, A, F, 2, n_blocks);
@@ -714,6 +724,7 @@ int run_device(br_ctx *c, const br_config *cfg, const br_device_batch *b, hipStr
   HIPCHK(hipStreamSynchronize(st));
   RC(pf.collect());
   out->total_complete = n_rows; out->total_unique = c->h_totals[5]; out->dropped_reads = c->h_totals[6];
+  if (fa_mode && c->rescue_stats[0]) { c->rescue_stats[1] = c->h_totals[8]; c->rescue_stats[2] = c->h_totals[9]; }
 
   out->n_cigar_words = (int64_t)n_out_words;
   out->input_index = c->r_input.as<int32_t>(); out->transcript_id = c->r_tid.as<uint32_t>();

@@ -66,6 +66,7 @@ struct KswArgs {
   uint8_t *scratch;
   size_t scratch_per_wave, pmat_bytes, raw_words;
   uint32_t tmax;
+  uint64_t *stats;  // [2] DP cells, accepted rescues (may be null)
 };
 
 struct ScanArgs {

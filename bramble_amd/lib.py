@@ -89,7 +89,7 @@ EXPORTS = ["br_index_build", "br_index_build_flat", "br_index_free", "br_index_n
            "br_index_transcript_len", "br_index_num_intervals", "br_index_device_bytes", "br_config_short_read",
            "br_config_long_read", "br_config_resolve", "br_batch_prepare", "br_batch_seq_source", "br_ctx_new", "br_ctx_free",
            "br_project_batch", "br_project_batch_device", "br_project_group", "br_ctx_set_profiling",
-           "br_ctx_set_param", "br_ctx_kernel_ms", "br_ctx_collect_counters", "br_ctx_last_counters", "br_version", "br_strerror"]
+           "br_ctx_set_param", "br_ctx_kernel_ms", "br_ctx_collect_counters", "br_ctx_last_counters", "br_ctx_rescue_stats", "br_version", "br_strerror"]
 
 _LIB = None
 
@@ -139,6 +139,7 @@ def lib():
         L.br_ctx_kernel_ms.argtypes = [C.c_void_p, C.c_int, _P(C.c_double), _P(C.c_int32)]
         L.br_ctx_collect_counters.argtypes = [C.c_void_p, _P(BrDeviceBatch), C.c_void_p]
         L.br_ctx_last_counters.argtypes = [C.c_void_p, C.c_void_p]
+        L.br_ctx_rescue_stats.argtypes = [C.c_void_p, C.c_void_p]
         L.br_version.restype = C.c_char_p
         L.br_strerror.restype = C.c_char_p
         L.br_strerror.argtypes = [C.c_int]
@@ -374,6 +375,11 @@ class Context:
         check(lib().br_ctx_last_counters(self.h, out), "br_ctx_last_counters")
         keys = ("B_in", "B_idx", "B_out", "n_cigar", "read_exons", "overlap_hits", "matches", "out_cigar_words")
         return dict(zip(keys, [int(v) for v in out]))
+
+    def rescue_stats(self):
+        out = (C.c_uint64 * 4)()
+        check(lib().br_ctx_rescue_stats(self.h, out), "br_ctx_rescue_stats")
+        return dict(zip(("problems", "dp_cells", "rescued", "seq_bytes"), [int(v) for v in out]))
 
     def project_batch_device(self, cfg, dev_batch, stream=0):
         """dev_batch: dict of torch CUDA tensors (see bramble_amd.device.upload_batch).  Returns the

@@ -291,6 +291,10 @@ int br_ctx_collect_counters(br_ctx *, const br_device_batch *, void *stream);
  * out[5]=overlap hits, out[6]=matches, out[7]=rewritten-CIGAR words over all matches. */
 int br_ctx_last_counters(br_ctx *, uint64_t out[8]);
 
+/* -S runs: out[0] = rescue problems of the last call, out[1] = ksw2 DP cells (sum of qlen x tlen),
+ * out[2] = accepted rescues, out[3] = coded sequence bytes. */
+int br_ctx_rescue_stats(br_ctx *, uint64_t out[4]);
+
 const char *br_version(void);
 const char *br_strerror(int code);
 
