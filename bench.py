@@ -123,8 +123,8 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("pairs") == args.pairs and tj.get("kernel") == dom:
-                    traffic = tj.get("hbm_bytes_per_launch")
+                if tj.get("pairs") == args.pairs and dom in tj.get("kernels", {}):
+                    traffic = tj["kernels"][dom]["hbm_bytes_corrected"]
             except Exception:
                 traffic = None
         out = {
