@@ -633,7 +633,7 @@ __device__ __forceinline__ bool similarity(const DevCfg &cfg, const Acc &acc, do
 #define LDS_SLOT 25     // words of CIGAR scratch per lane (odd: conflict-free)
 #define LDS_IDEAL 10    // ideal CIGAR words kept in LDS (n_seg <= 2)
 
-template <int G, bool EMIT>
+template <int G, bool EMIT, bool SIMF>
 __global__ void __launch_bounds__(256, EMIT ? 4 : 8) k_project(ProjectArgs A) {
   __shared__ uint32_t sh_slab[SLAB_LDS];
   __shared__ uint32_t sh_bin[EMIT ? 1 : SLAB_LDS];
@@ -782,8 +782,9 @@ __global__ void __launch_bounds__(256, EMIT ? 4 : 8) k_project(ProjectArgs A) {
         }
         Acc acc; IdealSink sk; double score = 0.0;
         if (!EMIT || !have_mask) {
-          // similarity filter needs the pass-2 accumulators (long reads only)
-          if (alive && cfg.filter_by_similarity) {
+          // similarity filter needs the pass-2 accumulators (long reads only; SIMF is
+          // cfg.filter_by_similarity lifted to compile time so the short-read kernel drops this code)
+          if (SIMF && alive) {
             sk.init(nullptr);
             walk_pass2(ix, cfg, rd, E, s == 1, sb[s], se[s], i0, q0, make_uint4(gs, gend, pay.z, 0), h0, p1, acc, sk, no_clip(), no_clip());
             alive = similarity(cfg, acc, score);
@@ -1369,8 +1370,14 @@ void launch_segment(hipStream_t st, int64_t n_aln, const int32_t *ref_id, const 
 
 template <int G>
 static void launch_project_g(hipStream_t st, const ProjectArgs &A, bool emit, int n_blocks) {
-  if (emit) hipLaunchKernelGGL((k_project<G, true>), dim3(n_blocks), dim3(256), 0, st, A);
-  else hipLaunchKernelGGL((k_project<G, false>), dim3(n_blocks), dim3(256), 0, st, A);
+  bool simf = A.cfg.filter_by_similarity != 0;
+  if (emit) {
+    if (simf) hipLaunchKernelGGL((k_project<G, true, true>), dim3(n_blocks), dim3(256), 0, st, A);
+    else hipLaunchKernelGGL((k_project<G, true, false>), dim3(n_blocks), dim3(256), 0, st, A);
+  } else {
+    if (simf) hipLaunchKernelGGL((k_project<G, false, true>), dim3(n_blocks), dim3(256), 0, st, A);
+    else hipLaunchKernelGGL((k_project<G, false, false>), dim3(n_blocks), dim3(256), 0, st, A);
+  }
 }
 
 void launch_project(hipStream_t st, const ProjectArgs &A, bool emit, int group_lanes, int n_blocks) {
