@@ -386,7 +386,7 @@ struct br_ctx {
   DevBuf m_tid, m_aux, m_a, m_b, m_cigoff, cig_arena, big_list, n_big, m_aln;
   DevBuf fa_stats, fa_n_prob, fa_seq_bytes, fa_prob_off, fa_seqarena_off, fa_probs, fa_results, fa_seq_arena, fa_clip_ops,
       fa_ideal_cap, fa_scratch, b_seq_off, b_seqs, b_seq_src;
-  DevBuf n_rows, row_off, aln_group, r_input, r_match, r_mate, r_flags, r_nh, r_hi, r_mapq, r_group, r_mate_tid, r_mate_pos,
+  DevBuf n_rows, row_off, aln_group, r_input, r_rec, r_nh, r_hi, r_mapq, r_group, r_mate_tid, r_mate_pos,
       r_isize, r_tid, r_pos, r_ncig, r_strand, r_sim, r_clip, r_junc, r_refc, r_cigoff, cigar_out;
   DevBuf r_paired, r_same, r_first;  // unpacked flag bytes for the public row view
   // device staging of host batches (br_project_batch)
@@ -430,7 +430,7 @@ extern "C" void br_ctx_free(br_ctx *c) {
                     &c->m_cigoff, &c->cig_arena, &c->big_list, &c->n_big, &c->m_aln,
                     &c->fa_stats, &c->fa_n_prob, &c->fa_seq_bytes, &c->fa_prob_off, &c->fa_seqarena_off, &c->fa_probs, &c->fa_results,
                     &c->fa_seq_arena, &c->fa_clip_ops, &c->fa_ideal_cap, &c->fa_scratch, &c->b_seq_off, &c->b_seqs, &c->b_seq_src,
-                    &c->n_rows, &c->row_off, &c->aln_group, &c->r_input, &c->r_match, &c->r_mate, &c->r_flags, &c->r_nh, &c->r_hi, &c->r_mapq,
+                    &c->n_rows, &c->row_off, &c->aln_group, &c->r_input, &c->r_rec, &c->r_nh, &c->r_hi, &c->r_mapq,
                     &c->r_group, &c->r_mate_tid, &c->r_mate_pos, &c->r_isize, &c->r_tid, &c->r_pos,
                     &c->r_ncig, &c->r_strand, &c->r_sim, &c->r_clip, &c->r_junc, &c->r_refc, &c->r_cigoff,
                     &c->cigar_out, &c->r_paired, &c->r_same, &c->r_first, &c->b_ref_id, &c->b_ref_start,
@@ -672,7 +672,7 @@ int run_device(br_ctx *c, const br_config *cfg, const br_device_batch *b, hipStr
   out->n_rows = (int64_t)n_rows;
 
   size_t nr = (size_t)std::max<uint64_t>(n_rows, 1);
-  RC(c->r_input.ensure(nr * 4)); RC(c->r_match.ensure(nr * 4)); RC(c->r_mate.ensure(nr * 4)); RC(c->r_flags.ensure(nr));
+  RC(c->r_input.ensure(nr * 4)); RC(c->r_rec.ensure(nr * sizeof(uint4)));
   RC(c->r_nh.ensure(nr * 4)); RC(c->r_hi.ensure(nr * 4));
   RC(c->r_mapq.ensure(nr * 4)); RC(c->r_group.ensure(nr * 4));
   RC(c->r_mate_tid.ensure(nr * 4)); RC(c->r_mate_pos.ensure(nr * 4)); RC(c->r_isize.ensure(nr * 4));
@@ -680,8 +680,7 @@ int run_device(br_ctx *c, const br_config *cfg, const br_device_batch *b, hipStr
   RC(c->r_sim.ensure(nr * 8)); RC(c->r_clip.ensure(nr * 4)); RC(c->r_junc.ensure(nr * 4)); RC(c->r_refc.ensure(nr * 4));
   RC(c->r_cigoff.ensure((nr + 1) * 8));
   RC(c->r_paired.ensure(nr)); RC(c->r_same.ensure(nr)); RC(c->r_first.ensure(nr));
-  P.r_input = c->r_input.as<int32_t>(); P.r_match = c->r_match.as<uint32_t>(); P.r_mate = c->r_mate.as<uint32_t>();
-  P.r_flags = c->r_flags.as<uint8_t>(); P.r_nh = c->r_nh.as<uint32_t>();
+  P.r_input = c->r_input.as<int32_t>(); P.r_rec = c->r_rec.as<uint4>(); P.r_nh = c->r_nh.as<uint32_t>();
   P.r_hi = c->r_hi.as<uint32_t>(); P.r_mapq = c->r_mapq.as<uint32_t>(); P.r_group = c->r_group.as<uint32_t>();
   P.r_mate_tid = c->r_mate_tid.as<int32_t>();
   P.r_mate_pos = c->r_mate_pos.as<int32_t>(); P.r_isize = c->r_isize.as<int32_t>();
@@ -701,7 +700,7 @@ int run_device(br_ctx *c, const br_config *cfg, const br_device_batch *b, hipStr
   HIPCHK(hipMemcpyAsync(c->h_totals + 4, c->counters_d.p, 4 * 8, hipMemcpyDeviceToHost, st));
   if (n_rows) {
     RowArgs R{};
-    R.n_rows = (int64_t)n_rows; R.r_match = P.r_match; R.r_ncig = P.r_ncig; R.m_cigoff = A.m_cigoff;
+    R.n_rows = (int64_t)n_rows; R.r_rec = P.r_rec; R.r_ncig = P.r_ncig; R.m_cigoff = A.m_cigoff;
     R.cig_arena = A.cig_arena; R.r_cigoff = c->r_cigoff.as<uint64_t>();
     ScanArgs S3{};
     S3.n = (int64_t)n_rows; S3.src32 = c->r_ncig.as<uint32_t>(); S3.tile_sums = c->tile_sums.as<uint64_t>();

@@ -94,8 +94,8 @@ struct PairArgs {
   uint32_t *n_rows;         // count pass: records per leader alignment
   const uint64_t *row_off;  // [n_aln + 1] emit pass
   int32_t *r_input;
-  uint32_t *r_match, *r_mate, *r_nh, *r_hi, *r_mapq, *r_group;
-  uint8_t *r_flags;
+  uint4 *r_rec;             // per record {match, mate match or ~0u, input alignment, RF_* flags}
+  uint32_t *r_nh, *r_hi, *r_mapq, *r_group;
   int32_t *r_mate_tid, *r_mate_pos, *r_isize;
   uint32_t *r_tid, *r_pos, *r_ncig;
   int8_t *r_strand;
@@ -107,7 +107,8 @@ struct PairArgs {
 
 struct RowArgs {
   int64_t n_rows;
-  const uint32_t *r_match, *r_ncig;
+  const uint4 *r_rec;
+  const uint32_t *r_ncig;
   const uint64_t *m_cigoff;
   const uint32_t *cig_arena;
   const uint64_t *r_cigoff;  // [n_rows + 1]

@@ -128,7 +128,9 @@ __global__ void __launch_bounds__(256) k_segment(int64_t n_aln, const int32_t *_
   head2[a] = make_uint4(q1.x, q1.y, q2.x, q2.y);
   // "simple" alignments: one read exon from a single M op, short-read presets.  They
   // are processed first (k_perm) so that whole waves take the short code paths.
-  fast_flag[a] = (n == 1 && n_cigar == 1 && CIG_OP(cg[0]) == OP_M && !cfg.filter_by_similarity && !cfg.long_reads) ? 1u : 0u;
+  uint32_t fast = (n == 1 && n_cigar == 1 && CIG_OP(cg[0]) == OP_M && !cfg.filter_by_similarity && !cfg.long_reads) ? 1u : 0u;
+  // bit 31: simple; bits 0..30: CIGAR slot capacity of one match = n_real + 2 * (4 * n_seg + 2)
+  fast_flag[a] = (fast << 31) | ((n_cigar + 2u * (4u * n + 2u)) & 0x7fffffffu);
 }
 
 // ---------------------------------------------------------------------------
@@ -867,7 +869,7 @@ __global__ void __launch_bounds__(256) k_expand(ProjectArgs A) {
   uint32_t nm = A.n_matches[a];
   if (nm == 0) return;
   uint32_t fp = A.fast_pre[a];
-  uint32_t pos = A.fast_flag[a] ? fp : A.fast_pre[A.n_aln] + (A.match_off[a] - fp);
+  uint32_t pos = (A.fast_flag[a] >> 31) ? fp : A.fast_pre[A.n_aln] + (A.match_off[a] - fp);
   uint4 rg = A.ranges[a];
   uint32_t n_items = (rg.y - rg.x) + (rg.w - rg.z);
   uint32_t v = n_items <= 64 ? (uint32_t)a : 0xffffffffu;
@@ -879,7 +881,8 @@ __global__ void __launch_bounds__(256) k_expand(ProjectArgs A) {
 // re-derives the candidate from its slab row, ranks it by tid among the read's
 // survivors, builds the ideal CIGAR, merges it with the real CIGAR and writes the
 // match record at match_off[a] + rank.
-__global__ void __launch_bounds__(256, 6) k_emit_dense(ProjectArgs A, int64_t n_matches) {
+template <bool SIMF>
+__global__ void __launch_bounds__(256, SIMF ? 6 : 8) k_emit_dense(ProjectArgs A, int64_t n_matches) {
   __shared__ uint32_t sh_cig[256 * LDS_SLOT];
   int64_t mi64 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (mi64 >= n_matches) return;
@@ -891,7 +894,7 @@ __global__ void __launch_bounds__(256, 6) k_emit_dense(ProjectArgs A, int64_t n_
   uint4 hd2 = A.head2[a];
   uint4 rg = A.ranges[a];
   uint64_t mask = A.mask[a];
-  const uint32_t is_fast = A.fast_flag[a];
+  const uint32_t is_fast = A.fast_flag[a] >> 31;
   uint32_t moff = A.match_off[a];
   uint64_t cbase = A.cig_base[a];
   uint32_t c0 = A.cigar_off[a], c1 = A.cigar_off[a + 1];
@@ -967,7 +970,7 @@ __global__ void __launch_bounds__(256, 6) k_emit_dense(ProjectArgs A, int64_t n_
   sk.init(ideal);
   walk_pass2(ix, cfg, rd, E, s == 1, sb, se, i0, q0, make_uint4(gs, gend, pay.z, 0), h0, p1, acc, sk, no_clip(), no_clip());
   uint32_t n_ideal = sk.finish();
-  similarity(cfg, acc, score);
+  if (SIMF) similarity(cfg, acc, score);
   bool out_lds = ideal_lds && (rd.n_real + n_ideal <= LDS_SLOT - LDS_IDEAL);
   uint32_t *outp = out_lds ? lds + LDS_IDEAL : slot;
   uint32_t n_out = merge_cigars(rd.real, rd.n_real, ideal, n_ideal, outp);
@@ -1072,9 +1075,10 @@ __device__ __forceinline__ Scan3 scan3_value(const ScanArgs &S, int64_t i) {
   Scan3 r; r.v[0] = r.v[1] = r.v[2] = 0;
   uint32_t nm = S.src32[i];
   if (nm) {
-    uint32_t n_real = S.cigar_off[i + 1] - S.cigar_off[i];
-    uint32_t icap = S.ideal_cap ? S.ideal_cap[i] : 4u * S.head[i].z + 2u;
-    r.v[0] = nm; r.v[1] = (uint64_t)nm * (uint64_t)(n_real + 2u * icap); r.v[2] = S.fast_flag[i] ? nm : 0;
+    uint32_t cf = S.fast_flag[i];
+    uint32_t cap = cf & 0x7fffffffu;
+    if (S.ideal_cap) cap = (S.cigar_off[i + 1] - S.cigar_off[i]) + 2u * S.ideal_cap[i];  // -S path: clip ops included
+    r.v[0] = nm; r.v[1] = (uint64_t)nm * (uint64_t)cap; r.v[2] = (cf >> 31) ? nm : 0;
   }
   return r;
 }
@@ -1169,8 +1173,7 @@ __global__ void __launch_bounds__(256) k_pair(PairArgs P) {
       // unpaired emission: one record per transcript, ascending tid (mates.cpp:157-176)
       if (EMIT)
         for (uint32_t k = 0; k < ni; k++) {
-          uint64_t r = r0 + k;
-          P.r_match[r] = mi0 + k; P.r_mate[r] = 0xffffffffu; P.r_input[r] = (int32_t)i; P.r_flags[r] = RF_FIRST;
+          P.r_rec[r0 + k] = make_uint4(mi0 + k, 0xffffffffu, i, RF_FIRST);
         }
       rows = ni;
     } else {
@@ -1183,10 +1186,8 @@ __global__ void __launch_bounds__(256) k_pair(PairArgs P) {
         else {
           if (EMIT) {
             uint64_t r = r0 + 2ull * common;
-            P.r_match[r] = mi0 + x; P.r_mate[r] = mm0 + y; P.r_input[r] = (int32_t)i;
-            P.r_flags[r] = RF_FIRST | RF_PAIRED | RF_SAME_TX;
-            P.r_match[r + 1] = mm0 + y; P.r_mate[r + 1] = mi0 + x; P.r_input[r + 1] = m;
-            P.r_flags[r + 1] = RF_PAIRED | RF_SAME_TX;
+            P.r_rec[r] = make_uint4(mi0 + x, mm0 + y, i, RF_FIRST | RF_PAIRED | RF_SAME_TX);
+            P.r_rec[r + 1] = make_uint4(mm0 + y, mi0 + x, (uint32_t)m, RF_PAIRED | RF_SAME_TX);
           }
           common++; x++; y++;
         }
@@ -1194,8 +1195,8 @@ __global__ void __launch_bounds__(256) k_pair(PairArgs P) {
       if (common) rows = 2 * common;
       else if (ni == 1 && nm == 1) {  // one transcript each, different ones
         if (EMIT) {
-          P.r_match[r0] = mi0; P.r_mate[r0] = mm0; P.r_input[r0] = (int32_t)i; P.r_flags[r0] = RF_FIRST | RF_PAIRED;
-          P.r_match[r0 + 1] = mm0; P.r_mate[r0 + 1] = mi0; P.r_input[r0 + 1] = m; P.r_flags[r0 + 1] = RF_PAIRED;
+          P.r_rec[r0] = make_uint4(mi0, mm0, i, RF_FIRST | RF_PAIRED);
+          P.r_rec[r0 + 1] = make_uint4(mm0, mi0, (uint32_t)m, RF_PAIRED);
         }
         rows = 2;
       }
@@ -1210,9 +1211,11 @@ __global__ void __launch_bounds__(256) k_pair(PairArgs P) {
 __global__ void __launch_bounds__(256) k_row_fill(PairArgs P, int64_t n_rows) {
   int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n_rows) return;
-  uint32_t x = P.r_match[r], xm = P.r_mate[r];
-  int32_t input = P.r_input[r];
-  uint8_t flags = P.r_flags[r];
+  uint4 rec = P.r_rec[r];
+  uint32_t x = rec.x, xm = rec.y;
+  int32_t input = (int32_t)rec.z;
+  uint8_t flags = (uint8_t)rec.w;
+  P.r_input[r] = input;
   uint32_t g = P.aln_group[input];
   uint64_t rs = P.row_off[P.group_off[g]], re = P.row_off[P.group_off[g + 1]];
   uint32_t nh = (uint32_t)(re - rs);
@@ -1263,7 +1266,7 @@ __global__ void __launch_bounds__(256) k_group_stats(PairArgs P) {
 __global__ void __launch_bounds__(256) k_gather(RowArgs R) {
   int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= R.n_rows) return;
-  uint32_t x = R.r_match[r];
+  uint32_t x = R.r_rec[r].x;
   uint64_t ref = R.m_cigoff[x];
   uint64_t d0 = R.r_cigoff[r];
   uint32_t n = R.r_ncig[r];
@@ -1402,7 +1405,8 @@ void launch_expand(hipStream_t st, const ProjectArgs &A) {
 
 void launch_emit_dense(hipStream_t st, const ProjectArgs &A, int64_t n_matches) {
   if (A.n_aln <= 0 || n_matches <= 0) return;
-  hipLaunchKernelGGL(k_emit_dense, dim3(grid_for(n_matches, 256)), dim3(256), 0, st, A, n_matches);
+  if (A.cfg.filter_by_similarity) hipLaunchKernelGGL((k_emit_dense<true>), dim3(grid_for(n_matches, 256)), dim3(256), 0, st, A, n_matches);
+  else hipLaunchKernelGGL((k_emit_dense<false>), dim3(grid_for(n_matches, 256)), dim3(256), 0, st, A, n_matches);
 }
 
 int64_t scan_tiles_for(int64_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE; }
