@@ -16,6 +16,7 @@
 #include "../../include/bramble_amd.h"
 #include "device_types.h"
 #include "kernels.h"
+#include "primary_pick.h"
 
 using namespace br;
 
@@ -388,7 +389,8 @@ struct br_ctx {
       fa_ideal_cap, fa_scratch, b_seq_off, b_seqs, b_seq_src;
   DevBuf n_rows, row_off, aln_group, r_input, r_rec, r_nh, r_hi, r_mapq, r_group, r_mate_tid, r_mate_pos,
       r_isize, r_tid, r_pos, r_ncig, r_strand, r_sim, r_clip, r_junc, r_refc, r_cigoff, cigar_out;
-  DevBuf r_paired, r_same, r_first;  // unpacked flag bytes for the public row view
+  DevBuf r_paired, r_same, r_first, r_primary;  // unpacked flag bytes for the public row view
+  DevBuf b_name_off, b_names;
   // device staging of host batches (br_project_batch)
   DevBuf b_ref_id, b_ref_start, b_flags, b_xs, b_ts, b_cigar_off, b_cigar, b_mate_idx, b_group_off, b_lqseq;
   uint64_t *h_totals = nullptr;  // pinned, 8 words
@@ -433,7 +435,7 @@ extern "C" void br_ctx_free(br_ctx *c) {
                     &c->n_rows, &c->row_off, &c->aln_group, &c->r_input, &c->r_rec, &c->r_nh, &c->r_hi, &c->r_mapq,
                     &c->r_group, &c->r_mate_tid, &c->r_mate_pos, &c->r_isize, &c->r_tid, &c->r_pos,
                     &c->r_ncig, &c->r_strand, &c->r_sim, &c->r_clip, &c->r_junc, &c->r_refc, &c->r_cigoff,
-                    &c->cigar_out, &c->r_paired, &c->r_same, &c->r_first, &c->b_ref_id, &c->b_ref_start,
+                    &c->cigar_out, &c->r_paired, &c->r_same, &c->r_first, &c->r_primary, &c->b_name_off, &c->b_names, &c->b_ref_id, &c->b_ref_start,
                     &c->b_flags, &c->b_xs, &c->b_ts, &c->b_cigar_off, &c->b_cigar, &c->b_mate_idx,
                     &c->b_group_off, &c->b_lqseq};
   for (DevBuf *b : bufs) b->release();
@@ -679,7 +681,8 @@ int run_device(br_ctx *c, const br_config *cfg, const br_device_batch *b, hipStr
   RC(c->r_tid.ensure(nr * 4)); RC(c->r_pos.ensure(nr * 4)); RC(c->r_ncig.ensure(nr * 4)); RC(c->r_strand.ensure(nr));
   RC(c->r_sim.ensure(nr * 8)); RC(c->r_clip.ensure(nr * 4)); RC(c->r_junc.ensure(nr * 4)); RC(c->r_refc.ensure(nr * 4));
   RC(c->r_cigoff.ensure((nr + 1) * 8));
-  RC(c->r_paired.ensure(nr)); RC(c->r_same.ensure(nr)); RC(c->r_first.ensure(nr));
+  RC(c->r_paired.ensure(nr)); RC(c->r_same.ensure(nr)); RC(c->r_first.ensure(nr)); RC(c->r_primary.ensure(nr));
+  HIPCHK(hipMemsetAsync(c->r_primary.p, 0, nr, st));
   P.r_input = c->r_input.as<int32_t>(); P.r_rec = c->r_rec.as<uint4>(); P.r_nh = c->r_nh.as<uint32_t>();
   P.r_hi = c->r_hi.as<uint32_t>(); P.r_mapq = c->r_mapq.as<uint32_t>(); P.r_group = c->r_group.as<uint32_t>();
   P.r_mate_tid = c->r_mate_tid.as<int32_t>();
@@ -697,6 +700,11 @@ int run_device(br_ctx *c, const br_config *cfg, const br_device_batch *b, hipStr
   RC(pf.begin(BR_K_GATHER));
   launch_row_fill(st, P, (int64_t)n_rows);  // + per-group counters
   RC(pf.end());
+  if (n_rows && b->names && b->name_off) {
+    RC(pf.begin(BR_K_GATHER));
+    launch_primary(st, P, b->name_off, b->names, c->r_primary.as<uint8_t>());
+    RC(pf.end());
+  }
   HIPCHK(hipMemcpyAsync(c->h_totals + 4, c->counters_d.p, 4 * 8, hipMemcpyDeviceToHost, st));
   if (n_rows) {
     RowArgs R{};
@@ -736,6 +744,7 @@ int run_device(br_ctx *c, const br_config *cfg, const br_device_batch *b, hipStr
   out->is_first = c->r_first.as<uint8_t>();
   out->mate_transcript_id = c->r_mate_tid.as<int32_t>(); out->mate_pos = c->r_mate_pos.as<int32_t>();
   out->insert_size = c->r_isize.as<int32_t>(); out->group = c->r_group.as<uint32_t>();
+  out->is_primary = c->r_primary.as<uint8_t>();
   c->counters[6] = n_matches;
   return BR_OK;
 }
@@ -790,13 +799,6 @@ static int d2h(std::vector<T> &dst, const void *src, size_t n, hipStream_t st) {
   return BR_OK;
 }
 
-// src/core.cpp:214-218
-static int32_t get_rand(uint32_t x, uint64_t seed_key) {
-  std::mt19937_64 gen(seed_key);
-  std::uniform_int_distribution<uint32_t> dis(0, x - 1);
-  return (int32_t)dis(gen);
-}
-
 extern "C" int br_project_batch(br_ctx *c, const br_config *cfg, const br_batch *b, br_rows *out) {
   if (!c || !cfg || !b || !out) return BR_ERR_INVALID_ARG;
   memset(out, 0, sizeof(*out));
@@ -846,6 +848,15 @@ extern "C" int br_project_batch(br_ctx *c, const br_config *cfg, const br_batch 
     db.seq_off = c->b_seq_off.as<uint32_t>(); db.seqs = c->b_seqs.as<uint8_t>(); db.seq_src = c->b_seq_src.as<int32_t>();
     db.max_soft_clip = max_clip;
   }
+  {
+    uint64_t nbytes = n ? b->name_off[n] : 0;
+    if (nbytes >= 0xfffffff0ull) return BR_ERR_CAPACITY;
+    std::vector<uint32_t> noff((size_t)n + 1);
+    for (int64_t i = 0; i <= n; i++) noff[i] = (uint32_t)(n ? b->name_off[i] : 0);
+    RC(h2d(c->b_name_off, noff.data(), (size_t)n + 1, st)); RC(h2d(c->b_names, (const uint8_t *)b->names, (size_t)nbytes, st));
+    HIPCHK(hipStreamSynchronize(st));
+    db.name_off = c->b_name_off.as<uint32_t>(); db.names = c->b_names.as<uint8_t>();
+  }
   db.n_aln = n; db.n_groups = ng; db.ref_id = c->b_ref_id.as<int32_t>(); db.ref_start = c->b_ref_start.as<int32_t>();
   db.flags = c->b_flags.as<uint16_t>(); db.xs = c->b_xs.as<int8_t>(); db.ts = c->b_ts.as<int8_t>();
   db.cigar_off = c->b_cigar_off.as<uint32_t>(); db.cigar = c->b_cigar.as<uint32_t>();
@@ -868,40 +879,8 @@ extern "C" int br_project_batch(br_ctx *c, const br_config *cfg, const br_batch 
   HIPCHK(hipStreamSynchronize(st));
   if (nr == 0) c->h_cigoff.assign(1, 0);
 
-  // primary / secondary per read name (src/core.cpp:243-307); an emitted pair is
-  // two consecutive rows (read1 side first).
-  c->h_primary.assign(nr, 0);
-  for (size_t r0 = 0; r0 < nr;) {
-    size_t r1 = r0;
-    while (r1 < nr && c->h_group[r1] == c->h_group[r0]) r1++;
-    std::vector<size_t> units;
-    for (size_t r = r0; r < r1; r += c->h_paired[r] ? 2 : 1) units.push_back(r);
-    double best = -std::numeric_limits<double>::infinity(); size_t best_u = 0; int at_best = 0;
-    auto score_of = [&](size_t r) {
-      double s = c->h_sim[r];
-      if (c->h_paired[r]) s = std::max(s, c->h_sim[r + 1]);
-      return s;
-    };
-    for (size_t u = 0; u < units.size(); u++) {
-      double s = score_of(units[u]);
-      if (s > best) { best = s; best_u = u; at_best = 1; } else if (s == best) at_best++;
-    }
-    if (!units.empty()) {
-      size_t pick = units[best_u];
-      if (at_best > 1) {
-        std::vector<size_t> tied;
-        for (size_t u = 0; u < units.size(); u++) if (score_of(units[u]) == best) tied.push_back(units[u]);
-        uint32_t g = c->h_group[r0];
-        uint32_t a0 = goff[g];
-        std::string name(b->names + b->name_off[a0], b->names + b->name_off[a0 + 1]);
-        uint64_t seed_key = std::hash<std::string>{}(name);
-        pick = tied[(size_t)get_rand((uint32_t)tied.size(), seed_key)];
-      }
-      c->h_primary[pick] = 1;
-      if (c->h_paired[pick]) c->h_primary[pick + 1] = 1;
-    }
-    r0 = r1;
-  }
+  RC(d2h(c->h_primary, dr.is_primary, nr, st));
+  HIPCHK(hipStreamSynchronize(st));
 
   out->n_rows = (int64_t)nr;
   out->input_index = c->h_input.data(); out->transcript_id = c->h_tid.data(); out->pos = c->h_pos.data();
@@ -972,6 +951,10 @@ extern "C" int br_project_group(br_ctx *c, const br_config *cfg, const br_alignm
   }
   *out = c->h_proj.data(); *n_out = c->h_proj.size();
   return BR_OK;
+}
+
+extern "C" uint32_t br_primary_pick(const char *name, size_t len, uint32_t n_tied) {
+  return n_tied ? br::primary_pick((const uint8_t *)name, len, n_tied) : 0;
 }
 
 extern "C" const char *br_version(void) { return "bramble_amd 0.1.0 (gfx950)"; }

@@ -146,6 +146,7 @@ void launch_scan3(hipStream_t st, ScanArgs S, uint32_t *match_off, uint64_t *cig
                   uint64_t *total_out3);
 void launch_pair(hipStream_t st, const PairArgs &P, bool emit);
 void launch_row_fill(hipStream_t st, const PairArgs &P, int64_t n_rows);
+void launch_primary(hipStream_t st, const PairArgs &P, const uint32_t *name_off, const uint8_t *names, uint8_t *r_primary);
 void launch_gather(hipStream_t st, const RowArgs &R);
 
 }  // namespace br

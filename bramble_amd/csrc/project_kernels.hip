@@ -23,6 +23,7 @@
 
 #include "device_types.h"
 #include "kernels.h"
+#include "primary_pick.h"
 
 namespace br {
 
@@ -1262,6 +1263,40 @@ __global__ void __launch_bounds__(256) k_group_stats(PairArgs P) {
   }
 }
 
+// k_primary: one lane per read name.  Primary = the emitted record (pair) with the
+// best similarity score; ties are broken by get_rand(n_tied, std::hash(name))
+// (src/core.cpp:243-307), restated in primary_pick.h.
+__global__ void __launch_bounds__(256) k_primary(PairArgs P, const uint32_t *__restrict__ name_off,
+                                                 const uint8_t *__restrict__ names, uint8_t *__restrict__ r_primary) {
+  int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= P.n_groups) return;
+  uint32_t a0 = P.group_off[g], a1 = P.group_off[g + 1];
+  uint64_t rs = P.row_off[a0], re = P.row_off[a1];
+  if (rs == re) return;
+  double best = -__builtin_inf(); uint64_t best_r = rs; uint32_t at_best = 0;
+  for (uint64_t r = rs; r < re;) {
+    bool paired = P.r_paired[r];
+    double sc = P.r_sim[r];
+    if (paired) { double s2 = P.r_sim[r + 1]; sc = sc > s2 ? sc : s2; }   // std::max(pair_score, m_align score)
+    if (sc > best) { best = sc; best_r = r; at_best = 1; } else if (sc == best) at_best++;
+    r += paired ? 2 : 1;
+  }
+  uint64_t pick = best_r;
+  if (at_best > 1) {
+    uint32_t idx = primary_pick(names + name_off[a0], name_off[a0 + 1] - name_off[a0], at_best);
+    uint32_t seen = 0;
+    for (uint64_t r = rs; r < re;) {
+      bool paired = P.r_paired[r];
+      double sc = P.r_sim[r];
+      if (paired) { double s2 = P.r_sim[r + 1]; sc = sc > s2 ? sc : s2; }
+      if (sc == best) { if (seen == idx) { pick = r; break; } seen++; }
+      r += paired ? 2 : 1;
+    }
+  }
+  r_primary[pick] = 1;
+  if (P.r_paired[pick]) r_primary[pick + 1] = 1;
+}
+
 // k_gather: one lane per row copies its rewritten CIGAR to the dense pool
 __global__ void __launch_bounds__(256) k_gather(RowArgs R) {
   int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1463,6 +1498,11 @@ void launch_pair(hipStream_t st, const PairArgs &P, bool emit) {
 void launch_row_fill(hipStream_t st, const PairArgs &P, int64_t n_rows) {
   if (n_rows > 0) hipLaunchKernelGGL(k_row_fill, dim3(grid_for(n_rows, 256)), dim3(256), 0, st, P, n_rows);
   if (P.n_groups > 0) hipLaunchKernelGGL(k_group_stats, dim3(std::min(grid_for(P.n_groups, 256), 1024)), dim3(256), 0, st, P);
+}
+
+void launch_primary(hipStream_t st, const PairArgs &P, const uint32_t *name_off, const uint8_t *names, uint8_t *r_primary) {
+  if (P.n_groups <= 0) return;
+  hipLaunchKernelGGL(k_primary, dim3(grid_for(P.n_groups, 256)), dim3(256), 0, st, P, name_off, names, r_primary);
 }
 
 void launch_gather(hipStream_t st, const RowArgs &R) {

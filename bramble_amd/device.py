@@ -7,7 +7,7 @@ import torch
 from . import lib
 
 
-def upload_batch(batch, device="cuda:0"):
+def upload_batch(batch, device="cuda:0", with_names=True):
     """Host SoA batch -> torch tensors on `device`, plus the host-side input contract
     (read-name groups, mate index; br_batch_prepare)."""
     mate, goff = lib.prepare_batch(batch)
@@ -34,6 +34,12 @@ def upload_batch(batch, device="cuda:0"):
         "n_cigar_words": int(coff64[-1]) if n else 0,
         "max_n_cigar": int(np.diff(coff64).max()) if n else 0,
     }
+    if with_names:
+        noff64 = np.asarray(batch["name_off"], dtype=np.uint64)
+        if n and int(noff64[-1]) >= 2 ** 32 - 16:
+            raise lib.BrambleError("read names exceed 32-bit device offsets; split the batch")
+        d["name_off"] = t(noff64.astype(np.uint32), np.uint32)
+        d["names"] = t(batch["names"], np.uint8)
     if batch.get("seq_off") is not None:
         soff64 = np.asarray(batch["seq_off"], dtype=np.uint64)
         if n and int(soff64[-1]) >= 2 ** 32 - 16:
@@ -70,7 +76,7 @@ def rows_as_tensors(rows, device="cuda:0"):
             "similarity_score": "float64", "clip_score": "int32", "junc_hits": "int32", "aligned_len": "int32",
             "nh": "int32", "hi": "int32", "mapq": "int32", "is_paired": "uint8", "same_transcript_as_mate": "uint8",
             "is_first": "uint8", "mate_transcript_id": "int32", "mate_pos": "int32", "insert_size": "int32",
-            "group": "int32"}
+            "group": "int32", "is_primary": "uint8"}
     out = {"n_rows": n}
     if n == 0:
         return out

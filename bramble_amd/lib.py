@@ -76,12 +76,14 @@ class BrDeviceBatch(C.Structure):
                 ("flags", C.c_void_p), ("xs", C.c_void_p), ("ts", C.c_void_p), ("cigar_off", C.c_void_p),
                 ("cigar", C.c_void_p), ("mate_idx", C.c_void_p), ("group_off", C.c_void_p), ("l_qseq", C.c_void_p),
                 ("seq_off", C.c_void_p), ("seqs", C.c_void_p), ("n_cigar_words", C.c_int64),
-                ("max_n_cigar", C.c_int32), ("seq_src", C.c_void_p), ("max_soft_clip", C.c_int32)]
+                ("max_n_cigar", C.c_int32), ("seq_src", C.c_void_p), ("max_soft_clip", C.c_int32),
+                ("name_off", C.c_void_p), ("names", C.c_void_p)]
 
 
 class BrDeviceRows(C.Structure):
     _fields_ = [("n_rows", C.c_int64), ("n_matches", C.c_int64), ("n_cigar_words", C.c_int64)] + \
-               [(n, C.c_void_p) for n, _ in _ROW_FIELDS] + [(n, C.c_void_p) for n, _ in _ROW_TAIL] + _COUNTERS
+               [(n, C.c_void_p) for n, _ in _ROW_FIELDS] + [(n, C.c_void_p) for n, _ in _ROW_TAIL] + _COUNTERS + \
+               [("is_primary", C.c_void_p)]
 
 
 # every symbol include/bramble_amd.h declares
@@ -89,7 +91,7 @@ EXPORTS = ["br_index_build", "br_index_build_flat", "br_index_free", "br_index_n
            "br_index_transcript_len", "br_index_num_intervals", "br_index_device_bytes", "br_config_short_read",
            "br_config_long_read", "br_config_resolve", "br_batch_prepare", "br_batch_seq_source", "br_ctx_new", "br_ctx_free",
            "br_project_batch", "br_project_batch_device", "br_project_group", "br_ctx_set_profiling",
-           "br_ctx_set_param", "br_ctx_kernel_ms", "br_ctx_collect_counters", "br_ctx_last_counters", "br_ctx_rescue_stats", "br_version", "br_strerror"]
+           "br_ctx_set_param", "br_ctx_kernel_ms", "br_ctx_collect_counters", "br_ctx_last_counters", "br_ctx_rescue_stats", "br_primary_pick", "br_version", "br_strerror"]
 
 _LIB = None
 
@@ -140,6 +142,8 @@ def lib():
         L.br_ctx_collect_counters.argtypes = [C.c_void_p, _P(BrDeviceBatch), C.c_void_p]
         L.br_ctx_last_counters.argtypes = [C.c_void_p, C.c_void_p]
         L.br_ctx_rescue_stats.argtypes = [C.c_void_p, C.c_void_p]
+        L.br_primary_pick.restype = C.c_uint32
+        L.br_primary_pick.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32]
         L.br_version.restype = C.c_char_p
         L.br_strerror.restype = C.c_char_p
         L.br_strerror.argtypes = [C.c_int]
@@ -365,6 +369,9 @@ class Context:
             db.seqs = dev_batch["seqs"].data_ptr()
             db.seq_src = dev_batch["seq_src"].data_ptr()
             db.max_soft_clip = dev_batch["max_soft_clip"]
+        if dev_batch.get("names") is not None:
+            db.name_off = dev_batch["name_off"].data_ptr()
+            db.names = dev_batch["names"].data_ptr()
         return db
 
     def collect_counters(self, dev_batch, stream=0):

@@ -159,7 +159,7 @@ typedef struct br_rows {
   const int32_t *junc_hits;
   const int32_t *aligned_len;     /* ref_consumed: transcript bases spanned */
   const uint32_t *nh, *hi, *mapq;
-  const uint8_t *is_primary;      /* host API only (needs read names; src/core.cpp:243-307) */
+  const uint8_t *is_primary;      /* best similarity score per read name, libstdc++-exact tie-break (src/core.cpp:243-307) */
   const uint8_t *is_paired;       /* emitted together with its mate */
   const uint8_t *same_transcript_as_mate;
   const uint8_t *is_first;        /* read1 side of the emitted pair */
@@ -201,9 +201,13 @@ typedef struct br_device_batch {
   /* -S clip rescue only (use_fasta with --lr / --lr-hq): */
   const int32_t *seq_src;    /* n_aln, from br_batch_seq_source; NULL without sequences */
   int32_t max_soft_clip;     /* longest leading / trailing S op in the batch */
+  /* optional read names (primary / secondary choice needs them; NULL: is_primary stays 0) */
+  const uint32_t *name_off;  /* n_aln + 1 */
+  const uint8_t *names;
 } br_device_batch;
 
-/* Rows as device pointers (same field meaning as br_rows; is_primary stays 0).
+/* Rows as device pointers (same field meaning as br_rows; is_primary is filled
+ * when the batch carries read names).
  * Valid until the next projection call on the context. */
 typedef struct br_device_rows {
   int64_t n_rows, n_matches, n_cigar_words;
@@ -219,6 +223,7 @@ typedef struct br_device_rows {
   const int32_t *mate_transcript_id, *mate_pos, *insert_size;
   const uint32_t *group;
   uint64_t total_complete, total_unique, dropped_reads, total_processed;
+  const uint8_t *is_primary;
 } br_device_rows;
 
 int br_project_batch_device(br_ctx *, const br_config *, const br_device_batch *, void *stream,
@@ -294,6 +299,11 @@ int br_ctx_last_counters(br_ctx *, uint64_t out[8]);
 /* -S runs: out[0] = rescue problems of the last call, out[1] = ksw2 DP cells (sum of qlen x tlen),
  * out[2] = accepted rescues, out[3] = coded sequence bytes. */
 int br_ctx_rescue_stats(br_ctx *, uint64_t out[4]);
+
+/* The reference's primary tie-break (src/core.cpp:214-218,298-299):
+ * uniform_int_distribution<uint32_t>(0, n_tied-1)(mt19937_64(std::hash<std::string>(name))),
+ * restated bit-exactly for libstdc++ (GCC 11, x86-64). */
+uint32_t br_primary_pick(const char *name, size_t len, uint32_t n_tied);
 
 const char *br_version(void);
 const char *br_strerror(int code);

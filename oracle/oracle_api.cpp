@@ -433,6 +433,12 @@ int32_t orc_resolve_config(const orc_flags *cf, uint32_t *out5, float *thr_out) 
   return c.filter_by_similarity;
 }
 
+uint32_t orc_primary_pick(const char *name, int64_t len, uint32_t n_tied) {
+  // src/core.cpp:298-299 with the real libstdc++ facilities
+  uint64_t seed_key = std::hash<std::string>{}(std::string(name, name + len));
+  return (uint32_t)get_rand(n_tied, seed_key);
+}
+
 int32_t orc_ksw_align(const char *tseq, const char *qseq, int32_t *score, int32_t *max, uint32_t *cigar,
                       int32_t cap) {
   Evaluator::KswResult r = Evaluator::align(tseq, qseq, 1, -4, 4, 1, 40);

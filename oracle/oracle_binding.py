@@ -123,6 +123,8 @@ def lib():
         L.orc_resolve_config.argtypes = [_P(OrcFlags), C.c_void_p, _P(C.c_float)]
         L.orc_ksw_align.restype = C.c_int32
         L.orc_ksw_align.argtypes = [C.c_char_p, C.c_char_p, _P(C.c_int32), _P(C.c_int32), C.c_void_p, C.c_int32]
+        L.orc_primary_pick.restype = C.c_uint32
+        L.orc_primary_pick.argtypes = [C.c_char_p, C.c_int64, C.c_uint32]
         _LIB = L
     return _LIB
 
@@ -268,3 +270,8 @@ def ksw_align(tseq, qseq):
     score, mx = C.c_int32(), C.c_int32()
     n = lib().orc_ksw_align(tseq.encode(), qseq.encode(), C.byref(score), C.byref(mx), out.ctypes.data, cap)
     return out[:n], score.value, mx.value
+
+
+def primary_pick(name, n_tied):
+    b = name if isinstance(name, bytes) else name.encode()
+    return lib().orc_primary_pick(b, len(b), n_tied)

@@ -97,3 +97,15 @@ def test_prepare_pairing_rules():
     mate, goff = lib.prepare_batch(b)
     assert mate.tolist() == [-1, 2, 1, -1, -1]
     assert goff.tolist() == [0, 4, 5]
+
+
+def test_primary_tie_break_matches_libstdcxx():
+    """br_primary_pick (murmur hash + lazy mt19937_64 + Lemire, restated for host and device)
+    against the oracle's call of the real std::hash / std::mt19937_64 / uniform_int_distribution."""
+    rng = np.random.RandomState(11)
+    L = lib.lib()
+    for it in range(5000):
+        ln = int(rng.randint(0, 40))
+        name = bytes(rng.randint(33, 126, size=ln).astype(np.uint8))
+        n = int(rng.randint(1, 9)) if it % 2 else int(rng.randint(1, 10 ** 6))
+        assert L.br_primary_pick(name, len(name), n) == ob.primary_pick(name, n), (name, n)
