@@ -53,9 +53,17 @@ def main():
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
+        # RCCL (backend "nccl") in production; BENCH_DIST_BACKEND=gloo rehearses the N>1 path on a box
+        # with fewer GPUs than ranks (ranks then share devices)
+        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+        ndev = max(torch.cuda.device_count(), 1)
+        if backend == "nccl":
+            dist_mod.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                        device_id=torch.device("cuda", local_rank % ndev))
+        else:
+            dist_mod.init_process_group(backend=backend, rank=rank, world_size=world)
         dist = dist_mod
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
 
@@ -101,10 +109,11 @@ def main():
     elapsed = time.perf_counter() - t_start
     ctx.set_profiling(False)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        rdev = dev if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        cnt = torch.tensor([n_aln], dtype=torch.float64, device=dev)
+        cnt = torch.tensor([n_aln], dtype=torch.float64, device=rdev)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         total_aln = float(cnt.item())
     else:
