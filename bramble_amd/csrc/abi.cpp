@@ -385,6 +385,8 @@ struct br_ctx {
   // device scratch
   DevBuf seg, meta, head, head2, fast_flag, fast_pre, m_k, n_matches, ranges, mask, match_off, cig_base, tile_sums, totals, counters_d;
   DevBuf m_tid, m_aux, m_a, m_b, m_cigoff, cig_arena, big_list, n_big, m_aln;
+  DevBuf bam_aux, bam_len, bam_off, bam_out;
+  int64_t last_n_rows = 0, last_n_aln = 0;
   DevBuf fa_stats, fa_n_prob, fa_seq_bytes, fa_prob_off, fa_seqarena_off, fa_probs, fa_results, fa_seq_arena, fa_clip_ops,
       fa_ideal_cap, fa_scratch, b_seq_off, b_seqs, b_seq_src;
   DevBuf n_rows, row_off, aln_group, r_input, r_rec, r_nh, r_hi, r_mapq, r_group, r_mate_tid, r_mate_pos,
@@ -430,7 +432,7 @@ extern "C" void br_ctx_free(br_ctx *c) {
   DevBuf *bufs[] = {&c->seg, &c->meta, &c->head, &c->head2, &c->fast_flag, &c->fast_pre, &c->m_k, &c->n_matches, &c->ranges, &c->mask, &c->match_off, &c->cig_base,
                     &c->tile_sums, &c->totals, &c->counters_d, &c->m_tid, &c->m_aux, &c->m_a, &c->m_b,
                     &c->m_cigoff, &c->cig_arena, &c->big_list, &c->n_big, &c->m_aln,
-                    &c->fa_stats, &c->fa_n_prob, &c->fa_seq_bytes, &c->fa_prob_off, &c->fa_seqarena_off, &c->fa_probs, &c->fa_results,
+                    &c->bam_aux, &c->bam_len, &c->bam_off, &c->bam_out, &c->fa_stats, &c->fa_n_prob, &c->fa_seq_bytes, &c->fa_prob_off, &c->fa_seqarena_off, &c->fa_probs, &c->fa_results,
                     &c->fa_seq_arena, &c->fa_clip_ops, &c->fa_ideal_cap, &c->fa_scratch, &c->b_seq_off, &c->b_seqs, &c->b_seq_src,
                     &c->n_rows, &c->row_off, &c->aln_group, &c->r_input, &c->r_rec, &c->r_nh, &c->r_hi, &c->r_mapq,
                     &c->r_group, &c->r_mate_tid, &c->r_mate_pos, &c->r_isize, &c->r_tid, &c->r_pos,
@@ -746,6 +748,7 @@ int run_device(br_ctx *c, const br_config *cfg, const br_device_batch *b, hipStr
   out->insert_size = c->r_isize.as<int32_t>(); out->group = c->r_group.as<uint32_t>();
   out->is_primary = c->r_primary.as<uint8_t>();
   c->counters[6] = n_matches;
+  c->last_n_rows = (int64_t)n_rows; c->last_n_aln = n;
   return BR_OK;
 }
 
@@ -774,6 +777,54 @@ extern "C" int br_ctx_collect_counters(br_ctx *c, const br_device_batch *b, void
   c->counters[0] = 24ull * n + 4ull * h[3];
   c->counters[1] = h[1];
   c->counters[2] = 4ull * n + 24ull * (uint64_t)nm + 4ull * h[7];
+  return BR_OK;
+}
+
+extern "C" int br_bam_encode_device(br_ctx *c, const br_config *cfg, const br_device_records *recs, void *stream,
+                                    br_device_bam *out) {
+  if (!c || !cfg || !recs || !out) return BR_ERR_INVALID_ARG;
+  memset(out, 0, sizeof(*out));
+  if (recs->n_aln != c->last_n_aln) return BR_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(hipSetDevice(c->ix->device));
+  int64_t nr = c->last_n_rows, n = recs->n_aln;
+  out->n_rows = nr;
+  Prof pf{c, st};
+  c->events_used = 0;
+  BamArgs B{};
+  B.n_aln = n; B.n_rows = nr; B.long_reads = (cfg->lr || cfg->lr_hq) ? 1 : 0;
+  B.blob = recs->blob; B.rec_off = recs->rec_off;
+  RC(c->bam_aux.ensure(std::max<size_t>((size_t)n, 1) * sizeof(BamAux)));
+  RC(c->bam_len.ensure(std::max<size_t>((size_t)nr, 1) * 4)); RC(c->bam_off.ensure(((size_t)nr + 1) * 8));
+  B.aux = (BamAux *)c->bam_aux.p;
+  B.r_input = c->r_input.as<int32_t>(); B.r_tid = c->r_tid.as<uint32_t>(); B.r_pos = c->r_pos.as<uint32_t>();
+  B.r_ncig = c->r_ncig.as<uint32_t>(); B.r_nh = c->r_nh.as<uint32_t>(); B.r_hi = c->r_hi.as<uint32_t>();
+  B.r_mapq = c->r_mapq.as<uint32_t>(); B.r_strand = c->r_strand.as<int8_t>(); B.r_paired = c->r_paired.as<uint8_t>();
+  B.r_same = c->r_same.as<uint8_t>(); B.r_primary = c->r_primary.as<uint8_t>();
+  B.r_mate_tid = c->r_mate_tid.as<int32_t>(); B.r_mate_pos = c->r_mate_pos.as<int32_t>(); B.r_isize = c->r_isize.as<int32_t>();
+  B.r_clip = c->r_clip.as<int32_t>(); B.r_sim = c->r_sim.as<double>(); B.r_cigoff = c->r_cigoff.as<uint64_t>();
+  B.cigar = c->cigar_out.as<uint32_t>(); B.out_len = c->bam_len.as<uint32_t>(); B.out_off = c->bam_off.as<uint64_t>();
+  RC(c->tile_sums.ensure((size_t)std::max<int64_t>(scan_tiles_for(nr + 1), 1) * 8 * 3));
+  RC(c->totals.ensure(8 * 8));
+  RC(pf.begin(BR_K_BAM));
+  launch_bam_scan(st, B);
+  launch_bam_size(st, B);
+  RC(pf.end());
+  ScanArgs S{}; S.n = nr; S.src32 = B.out_len; S.tile_sums = c->tile_sums.as<uint64_t>();
+  RC(pf.begin(BR_K_SCAN));
+  launch_scan(st, S, 2, c->bam_off.p, true, c->totals.as<uint64_t>() + 7);
+  RC(pf.end());
+  HIPCHK(hipMemcpyAsync(c->h_totals + 10, c->totals.as<uint64_t>() + 7, 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  uint64_t total = nr ? c->h_totals[10] : 0;
+  RC(c->bam_out.ensure(std::max<size_t>(total, 16)));
+  B.out = c->bam_out.as<uint8_t>();
+  RC(pf.begin(BR_K_BAM));
+  launch_bam_encode(st, B);
+  RC(pf.end());
+  HIPCHK(hipStreamSynchronize(st));
+  RC(pf.collect());
+  out->data = c->bam_out.as<uint8_t>(); out->n_bytes = total; out->row_off = c->bam_off.as<uint64_t>();
   return BR_OK;
 }
 

@@ -126,6 +126,34 @@ struct StatsArgs {
 };
 void launch_stats(hipStream_t st, const StatsArgs &T, const uint4 *m_a, int64_t n_matches);
 
+// BAM re-encoding (bam_kernels.hip)
+struct BamAux {
+  uint32_t off[4], len[4];  // removal intervals inside the aux area, sorted by offset (~0u: none)
+  int32_t as_val;           // input AS value (long reads)
+  uint32_t aux_start, aux_len;
+};
+struct BamArgs {
+  int64_t n_aln, n_rows;
+  int32_t long_reads;
+  const uint8_t *blob;       // original records, BAM layout from refID on
+  const uint64_t *rec_off;   // [n_aln + 1]
+  BamAux *aux;               // [n_aln]
+  const int32_t *r_input;
+  const uint32_t *r_tid, *r_pos, *r_ncig, *r_nh, *r_hi, *r_mapq;
+  const int8_t *r_strand;
+  const uint8_t *r_paired, *r_same, *r_primary;
+  const int32_t *r_mate_tid, *r_mate_pos, *r_isize, *r_clip;
+  const double *r_sim;
+  const uint64_t *r_cigoff;
+  const uint32_t *cigar;
+  uint32_t *out_len;         // [n_rows]
+  const uint64_t *out_off;   // [n_rows + 1]
+  uint8_t *out;
+};
+void launch_bam_scan(hipStream_t st, const BamArgs &B);
+void launch_bam_size(hipStream_t st, const BamArgs &B);
+void launch_bam_encode(hipStream_t st, const BamArgs &B);
+
 void launch_segment(hipStream_t st, int64_t n_aln, const int32_t *ref_id, const int32_t *ref_start,
                     const uint16_t *flags, const int8_t *xs, const int8_t *ts, const uint32_t *cigar_off,
                     const uint32_t *cigar, const DevCfg &cfg, uint32_t n_refs, uint2 *seg, AlnMeta *meta,

@@ -125,6 +125,7 @@ struct ReadParams {
   double p_softclip, p_indel, p_junc_shift, p_intergenic, p_multimap;
   double long_median, long_sigma; int32_t wobble; double p_wobble, p_skip_small, p_novel_small, p_clip;
   int32_t max_clip; int32_t with_seq; int32_t xs_tag;  // xs_tag: emit XS strand tag (stranded)
+  int32_t with_records;
 };
 
 struct Reads {
@@ -133,6 +134,10 @@ struct Reads {
   std::vector<uint64_t> cigar_off{0}, name_off{0}, seq_off{0};
   std::vector<uint32_t> cigar; std::vector<char> names, seqs;
   std::vector<uint32_t> src_tx;  // transcript the template was drawn from (0xffffffff: none)
+  // optional: full BAM alignment records (file layout from refID on), for the re-encoding stage
+  bool with_records = false;
+  std::vector<uint8_t> rec_blob; std::vector<uint64_t> rec_off{0};
+  uint64_t rec_rng = 0x243f6a8885a308d3ull;
 };
 
 inline uint32_t cg(uint32_t len, uint32_t op) { return (len << 4) | op; }
@@ -219,6 +224,47 @@ void push_read(Reads &R, const std::string &name, int32_t ref, uint32_t pos, con
   if (seq) R.seqs.insert(R.seqs.end(), seq->begin(), seq->end());
   R.seq_off.push_back(R.seqs.size());
   R.src_tx.push_back(src);
+  if (R.with_records) {
+    // a plausible aligner record: name, CIGAR, 4-bit sequence, qualities and a mix of aux tags in
+    // varying order / integer widths (NH, HI, AS, XS|ts, NM, MD:Z, a B array)
+    auto rnd = [&]() { uint64_t z = (R.rec_rng += 0x9e3779b97f4a7c15ull); z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull; return z ^ (z >> 31); };
+    std::vector<uint8_t> &o = R.rec_blob;
+    auto p32 = [&](uint32_t v) { for (int k = 0; k < 4; k++) o.push_back((uint8_t)(v >> (8 * k))); };
+    auto p16 = [&](uint32_t v) { o.push_back((uint8_t)v); o.push_back((uint8_t)(v >> 8)); };
+    uint32_t lq = ql;
+    if (flags & 0x100) { if (rnd() % 3 == 0) lq = 0; }  // secondary records often carry no SEQ
+    p32((uint32_t)ref); p32(pos - 1);
+    o.push_back((uint8_t)(name.size() + 1)); o.push_back((uint8_t)(rnd() % 61));
+    p16((uint32_t)(4681 + (pos >> 14))); p16((uint32_t)cig.size()); p16(flags);
+    p32(lq); p32((uint32_t)mref); p32((uint32_t)(mstart - 1)); p32(0);
+    o.insert(o.end(), name.begin(), name.end()); o.push_back(0);
+    for (uint32_t w : cig) p32(w);
+    for (uint32_t i = 0; i < lq; i += 2) {
+      auto code = [&](uint32_t k) -> uint8_t { if (k >= lq) return 0; char c = seq ? (*seq)[k] : "ACGT"[rnd() >> 62]; if (rnd() % 97 == 0) c = 'N'; return c == 'A' ? 1 : c == 'C' ? 2 : c == 'G' ? 4 : c == 'T' ? 8 : 15; };
+      o.push_back((uint8_t)(code(i) << 4 | code(i + 1)));
+    }
+    bool noqual = rnd() % 50 == 0;
+    for (uint32_t i = 0; i < lq; i++) o.push_back(noqual ? 0xff : (uint8_t)(2 + rnd() % 39));
+    // aux tags
+    int order = (int)(rnd() % 4);
+    auto tagC = [&](const char *t, uint32_t v) { o.push_back(t[0]); o.push_back(t[1]); o.push_back('C'); o.push_back((uint8_t)v); };
+    auto tagInt = [&](const char *t, int32_t v) {
+      o.push_back(t[0]); o.push_back(t[1]);
+      switch (rnd() % 4) { case 0: if (v >= 0 && v < 256) { o.push_back('C'); o.push_back((uint8_t)v); break; }
+                           case 1: if (v >= -32768 && v < 32768) { o.push_back('s'); p16((uint32_t)(uint16_t)(int16_t)v); break; }
+                           case 2: if (v >= 0 && v < 65536) { o.push_back('S'); p16((uint32_t)v); break; }
+                           default: o.push_back('i'); p32((uint32_t)v); }
+    };
+    auto tagA = [&](const char *t, char v) { o.push_back(t[0]); o.push_back(t[1]); o.push_back('A'); o.push_back((uint8_t)v); };
+    auto md = [&]() { o.push_back('M'); o.push_back('D'); o.push_back('Z'); uint32_t n = 1 + rnd() % 12; for (uint32_t i = 0; i < n; i++) o.push_back((uint8_t)("0123456789ACGT^"[rnd() % 15])); o.push_back(0); };
+    auto barr = [&]() { o.push_back('Z'); o.push_back('B'); o.push_back('B'); o.push_back('S'); uint32_t n = rnd() % 4; p32(n); for (uint32_t i = 0; i < n; i++) p16((uint32_t)(rnd() & 0xffff)); };
+    bool has_nh = rnd() % 8 != 0, has_hi = rnd() % 3 == 0, has_as = rnd() % 8 != 0, has_md = rnd() % 2 == 0, has_b = rnd() % 16 == 0;
+    if (order == 0) { if (has_as) tagInt("AS", (int32_t)(rnd() % 200)); if (xs) tagA("XS", (char)xs); tagC("NM", rnd() % 5); if (has_nh) tagC("NH", 1 + rnd() % 3); if (has_hi) tagC("HI", 1); if (has_md) md(); }
+    else if (order == 1) { if (has_nh) tagInt("NH", 1); if (has_hi) tagInt("HI", 1 + (int32_t)(rnd() % 3)); if (has_md) md(); if (xs) tagA("XS", (char)xs); if (has_as) tagInt("AS", (int32_t)(rnd() % 30000) - 100); }
+    else if (order == 2) { if (has_b) barr(); if (ts) tagA("ts", (char)ts); if (has_as) tagInt("AS", (int32_t)(rnd() % 4000)); if (has_nh) tagInt("NH", 2); tagC("NM", rnd() % 9); }
+    else { if (has_md) md(); if (has_hi) tagInt("HI", 0); if (ts) tagA("ts", (char)ts); if (xs) tagA("XS", (char)xs); if (has_b) barr(); if (has_nh) tagC("NH", 1); if (has_as) tagInt("AS", 77); if (rnd() % 9 == 0) tagC("NH", 5); }
+    R.rec_off.push_back(o.size());
+  }
 }
 
 // blocks -> CIGAR with optional perturbations (short reads)
@@ -301,6 +347,7 @@ void long_cigar(Rng &rng, const ReadParams &P, std::vector<std::pair<uint32_t, u
 
 Reads *gen_reads(const Annotation &A, const ReadParams &P) {
   Reads *R = new Reads();
+  R->with_records = P.with_records != 0;
   Rng rng(P.seed);
   size_t ntx = A.n_tx();
   std::vector<uint32_t> tlen(ntx);
@@ -417,13 +464,13 @@ struct synth_read_params {
   uint64_t seed; int64_t n_templates; int32_t mode; int32_t read_len; double frag_mean, frag_sd;
   double p_softclip, p_indel, p_junc_shift, p_intergenic, p_multimap;
   double long_median, long_sigma; int32_t wobble; double p_wobble, p_skip_small, p_novel_small, p_clip;
-  int32_t max_clip; int32_t with_seq; int32_t xs_tag;
+  int32_t max_clip; int32_t with_seq; int32_t xs_tag; int32_t with_records;
 };
 
 void *synth_reads_new(void *ann, const synth_read_params *p) {
   ReadParams P{p->seed, p->n_templates, p->mode, p->read_len, p->frag_mean, p->frag_sd, p->p_softclip, p->p_indel,
                p->p_junc_shift, p->p_intergenic, p->p_multimap, p->long_median, p->long_sigma, p->wobble,
-               p->p_wobble, p->p_skip_small, p->p_novel_small, p->p_clip, p->max_clip, p->with_seq, p->xs_tag};
+               p->p_wobble, p->p_skip_small, p->p_novel_small, p->p_clip, p->max_clip, p->with_seq, p->xs_tag, p->with_records};
   return gen_reads(*(Annotation *)ann, P);
 }
 void synth_reads_free(void *h) { delete (Reads *)h; }
@@ -441,6 +488,8 @@ const uint32_t *synth_reads_cigar(void *h) { return ((Reads *)h)->cigar.data(); 
 const uint64_t *synth_reads_name_off(void *h) { return ((Reads *)h)->name_off.data(); }
 const char *synth_reads_names(void *h) { return ((Reads *)h)->names.data(); }
 const uint32_t *synth_reads_src_tx(void *h) { return ((Reads *)h)->src_tx.data(); }
+const uint64_t *synth_reads_rec_off(void *h) { return ((Reads *)h)->rec_off.data(); }
+const uint8_t *synth_reads_rec_blob(void *h) { return ((Reads *)h)->rec_blob.data(); }
 const uint64_t *synth_reads_seq_off(void *h) { return ((Reads *)h)->seq_off.data(); }
 const char *synth_reads_seqs(void *h) { return ((Reads *)h)->seqs.data(); }
 

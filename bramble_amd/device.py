@@ -87,3 +87,18 @@ def rows_as_tensors(rows, device="cuda:0"):
     if nw:
         out["cigar"] = torch.as_tensor(_DevArray(rows.cigar, nw, "<i4"), device=device)
     return out
+
+
+def upload_records(batch, device="cuda:0"):
+    """Original BAM records of the batch (batch['rec_blob'], batch['rec_off']) -> (blob, rec_off) CUDA tensors."""
+    blob = np.ascontiguousarray(batch["rec_blob"], dtype=np.uint8)
+    off = np.ascontiguousarray(batch["rec_off"], dtype=np.uint64).view(np.int64)
+    return torch.from_numpy(blob).to(device), torch.from_numpy(off).to(device)
+
+
+def bam_stream_to_host(bam, device="cuda:0"):
+    """BrDeviceBam -> numpy uint8 array with the uncompressed BAM record stream."""
+    n = int(bam.n_bytes)
+    if n == 0:
+        return np.zeros(0, dtype=np.uint8)
+    return torch.as_tensor(_DevArray(bam.data, n, "|u1"), device=device).cpu().numpy().copy()

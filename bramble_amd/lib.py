@@ -86,11 +86,19 @@ class BrDeviceRows(C.Structure):
                [("is_primary", C.c_void_p)]
 
 
+class BrDeviceRecords(C.Structure):
+    _fields_ = [("blob", C.c_void_p), ("rec_off", C.c_void_p), ("n_aln", C.c_int64)]
+
+
+class BrDeviceBam(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("n_bytes", C.c_uint64), ("row_off", C.c_void_p), ("n_rows", C.c_int64)]
+
+
 # every symbol include/bramble_amd.h declares
 EXPORTS = ["br_index_build", "br_index_build_flat", "br_index_free", "br_index_num_transcripts", "br_index_transcript_name",
            "br_index_transcript_len", "br_index_num_intervals", "br_index_device_bytes", "br_config_short_read",
            "br_config_long_read", "br_config_resolve", "br_batch_prepare", "br_batch_seq_source", "br_ctx_new", "br_ctx_free",
-           "br_project_batch", "br_project_batch_device", "br_project_group", "br_ctx_set_profiling",
+           "br_project_batch", "br_project_batch_device", "br_project_group", "br_bam_encode_device", "br_ctx_set_profiling",
            "br_ctx_set_param", "br_ctx_kernel_ms", "br_ctx_collect_counters", "br_ctx_last_counters", "br_ctx_rescue_stats", "br_primary_pick", "br_version", "br_strerror"]
 
 _LIB = None
@@ -136,6 +144,7 @@ def lib():
         L.br_project_batch.argtypes = [C.c_void_p, _P(BrConfig), _P(BrBatch), _P(BrRows)]
         L.br_project_batch_device.argtypes = [C.c_void_p, _P(BrConfig), _P(BrDeviceBatch), C.c_void_p,
                                               _P(BrDeviceRows)]
+        L.br_bam_encode_device.argtypes = [C.c_void_p, _P(BrConfig), _P(BrDeviceRecords), C.c_void_p, _P(BrDeviceBam)]
         L.br_ctx_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.br_ctx_set_param.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
         L.br_ctx_kernel_ms.argtypes = [C.c_void_p, C.c_int, _P(C.c_double), _P(C.c_int32)]
@@ -382,6 +391,18 @@ class Context:
         check(lib().br_ctx_last_counters(self.h, out), "br_ctx_last_counters")
         keys = ("B_in", "B_idx", "B_out", "n_cigar", "read_exons", "overlap_hits", "matches", "out_cigar_words")
         return dict(zip(keys, [int(v) for v in out]))
+
+    def bam_encode_device(self, cfg, blob, rec_off, stream=0):
+        """Re-encode every row of the last project_batch_device call as BAM records.
+        blob / rec_off: torch CUDA tensors (uint8 record bytes, int64 offsets n_aln+1)."""
+        recs = BrDeviceRecords()
+        recs.blob = blob.data_ptr()
+        recs.rec_off = rec_off.data_ptr()
+        recs.n_aln = rec_off.numel() - 1
+        out = BrDeviceBam()
+        check(lib().br_bam_encode_device(self.h, C.byref(cfg), C.byref(recs), C.c_void_p(stream), C.byref(out)),
+              "br_bam_encode_device")
+        return out
 
     def rescue_stats(self):
         out = (C.c_uint64 * 4)()

@@ -21,7 +21,7 @@ class ReadParams(C.Structure):
                 ("p_multimap", C.c_double), ("long_median", C.c_double), ("long_sigma", C.c_double),
                 ("wobble", C.c_int32), ("p_wobble", C.c_double), ("p_skip_small", C.c_double),
                 ("p_novel_small", C.c_double), ("p_clip", C.c_double), ("max_clip", C.c_int32),
-                ("with_seq", C.c_int32), ("xs_tag", C.c_int32)]
+                ("with_seq", C.c_int32), ("xs_tag", C.c_int32), ("with_records", C.c_int32)]
 
 
 def lib():
@@ -47,7 +47,7 @@ def lib():
         L.synth_annotation_ref_seq.restype = C.c_void_p
         L.synth_annotation_ref_seq.argtypes = [C.c_void_p, C.c_int32]
         for name in ("ref_id", "ref_start", "mate_ref_id", "mate_start", "l_qseq", "flags", "xs", "ts", "cigar_off",
-                     "cigar", "name_off", "names", "src_tx", "seq_off", "seqs"):
+                     "cigar", "name_off", "names", "src_tx", "seq_off", "seqs", "rec_off", "rec_blob"):
             f = getattr(L, "synth_reads_" + name)
             f.restype = C.c_void_p
             f.argtypes = [C.c_void_p]
@@ -142,6 +142,9 @@ class Annotation:
             b["names"] = _copy(L.synth_reads_names(h), int(b["name_off"][-1]) if n else 0, np.uint8)
             b["seq_off"] = None
             b["seqs"] = None
+            if p.with_records:
+                b["rec_off"] = _copy(L.synth_reads_rec_off(h), n + 1, np.uint64)
+                b["rec_blob"] = _copy(L.synth_reads_rec_blob(h), int(b["rec_off"][-1]) if n else 0, np.uint8)
             if p.with_seq:
                 b["seq_off"] = _copy(L.synth_reads_seq_off(h), n + 1, np.uint64)
                 b["seqs"] = _copy(L.synth_reads_seqs(h), int(b["seq_off"][-1]) if n else 0, np.uint8)

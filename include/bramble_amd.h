@@ -267,6 +267,31 @@ typedef struct br_projected { /* ProjectedAlignment, api.rs:135-176 */
 int br_project_group(br_ctx *, const br_config *, const br_alignment *alns, size_t n,
                      const br_projected **out, size_t *n_out);
 
+/* ---- BAM record re-encoding (next row of the scope table: the data format after the path) -- */
+
+/* The batch's original alignment records in HBM: BAM file layout starting at refID
+ * (without the 4-byte block_size), record i = blob[rec_off[i] .. rec_off[i+1]). */
+typedef struct br_device_records {
+  const uint8_t *blob;
+  const uint64_t *rec_off; /* n_aln + 1 */
+  int64_t n_aln;
+} br_device_records;
+
+typedef struct br_device_bam {
+  const uint8_t *data;     /* [block_size][record] per emitted row, concatenated (uncompressed BAM stream) */
+  uint64_t n_bytes;
+  const uint64_t *row_off; /* n_rows + 1 */
+  int64_t n_rows;
+} br_device_bam;
+
+/* Replaces the per-record byte work of write_to_bam (src/core.cpp:96-212: update_cigar,
+ * NH/HI/AS tags, XS/ts deletion, reverse_complement_bam, set_mate_info; src/bam.cpp:474-702)
+ * for every row of the LAST br_project_batch_device call on this context.  The rows must have
+ * been produced with read names (is_primary decides the secondary flag).  CIGARs longer than
+ * 65535 ops are not supported (BR_ERR_UNSUPPORTED). */
+int br_bam_encode_device(br_ctx *, const br_config *, const br_device_records *, void *stream,
+                         br_device_bam *out);
+
 /* ---- measurement hooks ------------------------------------------------------ */
 
 /* Kernel names reported by br_ctx_kernel_ms / rocprof. */
@@ -279,7 +304,8 @@ int br_project_group(br_ctx *, const br_config *, const br_alignment *alns, size
 #define BR_K_SCAN 6       /* k_scan_* */
 #define BR_K_EMIT_AUX 7   /* k_expand + k_project<64,true> (alignments with > 64 candidate rows) */
 #define BR_K_KSW 8        /* k_ksw (-S clip rescue DP) */
-#define BR_K_NUM 9
+#define BR_K_BAM 9        /* k_bam_scan + k_bam_size + k_bam_encode */
+#define BR_K_NUM 10
 /* When enabled, every launch is bracketed by hipEvents on the launch stream. */
 int br_ctx_set_profiling(br_ctx *, int enabled);
 /* Launch tuning: "group_lanes" (8|16|32|64 lanes cooperating on one alignment),

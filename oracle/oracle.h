@@ -109,6 +109,11 @@ int32_t orc_segments(int32_t ref_start, const uint32_t *cigar, int32_t n_cigar, 
 /* resolved presets: out[0..4] = max_clip, max_junc_ins, max_junc_gap, max_error_exon,
  * ignore_small_exons; thr_out = threshold; returns filter_by_similarity */
 int32_t orc_resolve_config(const orc_flags *, uint32_t *out5, float *thr_out);
+/* write_to_bam over the rows of a finished run (records: BAM layout from refID on); returns the
+ * byte count of the uncompressed BAM stream placed in *out (free with orc_free_buffer) */
+int64_t orc_bam_encode(const orc_result *, const uint8_t *blob, const uint64_t *rec_off, int64_t n_aln,
+                       int32_t long_reads, uint8_t **out);
+void orc_free_buffer(uint8_t *);
 /* primary tie-break: get_rand(n_tied, std::hash<std::string>(name)), src/core.cpp:214-218,298-299 */
 uint32_t orc_primary_pick(const char *name, int64_t len, uint32_t n_tied);
 /* ksw2 extension as bramble calls it (ASCII in): returns n_cigar, fills score/max */

@@ -7,6 +7,7 @@
 // ============================================================================
 #include "oracle.h"
 #include "oracle_eval.hpp"
+#include "oracle_bam.hpp"
 
 #include <atomic>
 #include <chrono>
@@ -432,6 +433,41 @@ int32_t orc_resolve_config(const orc_flags *cf, uint32_t *out5, float *thr_out) 
   *thr_out = c.similarity_threshold;
   return c.filter_by_similarity;
 }
+
+// write_to_bam (src/core.cpp:96-212) over the rows of a finished run: returns the
+// uncompressed BAM stream ([block_size][record] per row) in a malloc'd buffer.
+int64_t orc_bam_encode(const orc_result *res, const uint8_t *blob, const uint64_t *rec_off, int64_t n_aln,
+                       int32_t long_reads, uint8_t **out) {
+  const RowStore &R = res->rows;
+  std::vector<Bam1> old((size_t)n_aln);
+  std::vector<bool> seen((size_t)n_aln, false);
+  std::vector<uint8_t> stream;
+  for (size_t r = 0; r < R.tid.size(); r++) {
+    size_t i = (size_t)R.input_index[r];
+    if (!seen[i]) {  // first use of this read: tags go onto the ORIGINAL record (core.cpp:115-124)
+      seen[i] = true;
+      old[i] = bam_parse(blob + rec_off[i], (size_t)(rec_off[i + 1] - rec_off[i]));
+      set_int_tag(old[i], "NH", (int32_t)R.nh[r]);
+      del_tag(old[i], long_reads ? "ts" : "XS");
+    }
+    Bam1 b = old[i];  // bam_dup1
+    update_cigar(b, R.cigar.data() + R.cigar_off[r], (uint32_t)(R.cigar_off[r + 1] - R.cigar_off[r]));
+    b.qual = (uint8_t)R.mapq[r];
+    b.tid = (int32_t)R.tid[r];
+    if (R.primary[r]) b.flag &= ~0x100; else b.flag |= 0x100;
+    char strand = (char)R.strand[r];
+    if (strand == '-') reverse_complement_bam(b);
+    b.pos = (int32_t)R.pos[r];
+    if (long_reads) set_as_tag(b, R.sim[r], R.clip_score[r]);
+    set_int_tag(b, "HI", (int32_t)R.hi[r]);
+    set_mate_info(b, R.is_paired[r], R.same_transcript[r], strand, R.mate_tid[r], R.mate_pos[r], R.isize[r]);
+    bam_serialize(b, stream);
+  }
+  *out = (uint8_t *)malloc(stream.size() ? stream.size() : 1);
+  memcpy(*out, stream.data(), stream.size());
+  return (int64_t)stream.size();
+}
+void orc_free_buffer(uint8_t *p) { free(p); }
 
 uint32_t orc_primary_pick(const char *name, int64_t len, uint32_t n_tied) {
   // src/core.cpp:298-299 with the real libstdc++ facilities

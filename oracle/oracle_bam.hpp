@@ -1,0 +1,163 @@
+// ============================================================================
+// TEST INFRASTRUCTURE ONLY -- CPU restatement of the reference's BAM record
+// mutation (write_to_bam and helpers), see oracle_core.hpp for the oracle's role.
+//
+// Follows src/core.cpp:96-212 (write_to_bam), src/bam.cpp:474-528 (update_cigar /
+// copy_cigar_memory), :531-588 (set_mate_info), :590-634 (tag setters), :636-702
+// (reverse_complement_bam) as in-place edits of one record, the way the reference
+// drives htslib.  htslib itself (1.22, subprojects/htslib.wrap) is absent from the
+// reference tree: bam_aux_get / bam_aux_del / bam_aux_append / bam_aux2i / bam_dup1 and the
+// record layout are restated from the SAM/BAM specification and htslib's published
+// behaviour -> "parity unpinned" for those primitives.
+// ============================================================================
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+namespace orc {
+
+struct Bam1 {  // bam1_t: core + data (qname | cigar | seq | qual | aux)
+  int32_t tid = -1, pos = -1; uint16_t bin = 0; uint8_t qual = 0, l_qname = 0; uint16_t flag = 0;
+  uint32_t n_cigar = 0; int32_t l_qseq = 0, mtid = -1, mpos = -1, isize = 0;
+  std::vector<uint8_t> data;
+  size_t cigar_at() const { return l_qname; }
+  size_t seq_at() const { return l_qname + 4u * n_cigar; }
+  size_t qual_at() const { return seq_at() + (size_t)((l_qseq > 0 ? l_qseq : 0) + 1) / 2; }
+  size_t aux_at() const { return qual_at() + (size_t)(l_qseq > 0 ? l_qseq : 0); }
+};
+
+static inline uint32_t rd32(const uint8_t *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
+static inline void wr32(std::vector<uint8_t> &o, uint32_t v) { for (int k = 0; k < 4; k++) o.push_back((uint8_t)(v >> (8 * k))); }
+
+static inline Bam1 bam_parse(const uint8_t *r, size_t len) {  // BAM record from refID on
+  Bam1 b;
+  b.tid = (int32_t)rd32(r); b.pos = (int32_t)rd32(r + 4); b.l_qname = r[8]; b.qual = r[9];
+  b.bin = (uint16_t)(r[10] | r[11] << 8); b.n_cigar = (uint32_t)(r[12] | r[13] << 8); b.flag = (uint16_t)(r[14] | r[15] << 8);
+  b.l_qseq = (int32_t)rd32(r + 16); b.mtid = (int32_t)rd32(r + 20); b.mpos = (int32_t)rd32(r + 24); b.isize = (int32_t)rd32(r + 28);
+  b.data.assign(r + 32, r + len);
+  return b;
+}
+static inline void bam_serialize(const Bam1 &b, std::vector<uint8_t> &o) {  // [block_size][record]
+  wr32(o, (uint32_t)(32 + b.data.size()));
+  wr32(o, (uint32_t)b.tid); wr32(o, (uint32_t)b.pos);
+  o.push_back(b.l_qname); o.push_back(b.qual); o.push_back((uint8_t)b.bin); o.push_back((uint8_t)(b.bin >> 8));
+  o.push_back((uint8_t)b.n_cigar); o.push_back((uint8_t)(b.n_cigar >> 8)); o.push_back((uint8_t)b.flag); o.push_back((uint8_t)(b.flag >> 8));
+  wr32(o, (uint32_t)b.l_qseq); wr32(o, (uint32_t)b.mtid); wr32(o, (uint32_t)b.mpos); wr32(o, (uint32_t)b.isize);
+  o.insert(o.end(), b.data.begin(), b.data.end());
+}
+
+// htslib skip_aux: bytes of the value after the type byte, -1 when malformed
+static inline long aux_skip(const std::vector<uint8_t> &d, size_t p) {
+  if (p >= d.size()) return -1;
+  uint8_t ty = d[p]; size_t v = p + 1, end = d.size();
+  switch (ty) {
+    case 'A': case 'c': case 'C': return v + 1 <= end ? 1 : -1;
+    case 's': case 'S': return v + 2 <= end ? 2 : -1;
+    case 'i': case 'I': case 'f': return v + 4 <= end ? 4 : -1;
+    case 'd': return v + 8 <= end ? 8 : -1;
+    case 'Z': case 'H': { size_t q = v; while (q < end && d[q]) q++; return q < end ? (long)(q - v + 1) : -1; }
+    case 'B': {
+      if (v + 5 > end) return -1;
+      uint8_t st = d[v]; uint32_t n = rd32(&d[v + 1]);
+      int sz = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : (st == 'i' || st == 'I' || st == 'f') ? 4 : 0;
+      if (!sz) return -1;
+      uint64_t tot = 5 + (uint64_t)n * sz;
+      return v + tot <= end ? (long)tot : -1;
+    }
+    default: return -1;
+  }
+}
+// bam_aux_get: index of the TYPE byte of the first occurrence of tag, or -1
+static inline long aux_get(const Bam1 &b, const char tag[2]) {
+  size_t s = b.aux_at();
+  while (s + 3 <= b.data.size()) {
+    long vl = aux_skip(b.data, s + 2);
+    if (vl < 0) return -1;
+    if (b.data[s] == (uint8_t)tag[0] && b.data[s + 1] == (uint8_t)tag[1]) return (long)(s + 2);
+    s += 3 + (size_t)vl;
+  }
+  return -1;
+}
+static inline void aux_del(Bam1 &b, long type_at) {
+  long vl = aux_skip(b.data, (size_t)type_at);
+  b.data.erase(b.data.begin() + (type_at - 2), b.data.begin() + (type_at + 1 + vl));
+}
+static inline void aux_append(Bam1 &b, const char tag[2], char type, int len, const uint8_t *data) {
+  b.data.push_back((uint8_t)tag[0]); b.data.push_back((uint8_t)tag[1]); b.data.push_back((uint8_t)type);
+  b.data.insert(b.data.end(), data, data + len);
+}
+static inline int64_t aux2i(const Bam1 &b, long type_at) {
+  const uint8_t *v = &b.data[(size_t)type_at + 1];
+  switch (b.data[(size_t)type_at]) {
+    case 'c': return (int8_t)v[0]; case 'C': return v[0];
+    case 's': return (int16_t)(v[0] | v[1] << 8); case 'S': return (uint16_t)(v[0] | v[1] << 8);
+    case 'i': return (int32_t)rd32(v); case 'I': return rd32(v);
+    default: return 0;
+  }
+}
+
+// src/bam.cpp:590-634
+static inline void set_int_tag(Bam1 &b, const char tag[2], int32_t v) {
+  long at = aux_get(b, tag);
+  if (at >= 0) aux_del(b, at);
+  uint8_t raw[4]; memcpy(raw, &v, 4);
+  aux_append(b, tag, 'i', 4, raw);
+}
+static inline void del_tag(Bam1 &b, const char tag[2]) { long at = aux_get(b, tag); if (at >= 0) aux_del(b, at); }
+static inline void set_as_tag(Bam1 &b, double similarity_score, int clip_score) {
+  long at = aux_get(b, "AS");
+  int32_t gn_as = 0;
+  if (at >= 0) gn_as = (int32_t)aux2i(b, at);
+  if (at >= 0) aux_del(b, at);
+  double score = (static_cast<double>(gn_as) + static_cast<double>(clip_score)) * similarity_score;
+  int32_t new_as = static_cast<int32_t>(score);
+  uint8_t raw[4]; memcpy(raw, &new_as, 4);
+  aux_append(b, "AS", 'i', 4, raw);
+}
+
+// src/bam.cpp:474-528 (update_cigar + copy_cigar_memory): swap the CIGAR bytes
+static inline void update_cigar(Bam1 &b, const uint32_t *cig, uint32_t n) {
+  std::vector<uint8_t> nd(b.data.begin(), b.data.begin() + b.l_qname);
+  for (uint32_t k = 0; k < n; k++) wr32(nd, cig[k]);
+  nd.insert(nd.end(), b.data.begin() + b.seq_at(), b.data.end());
+  b.data.swap(nd);
+  b.n_cigar = n;
+}
+
+// src/bam.cpp:636-702
+static inline void reverse_complement_bam(Bam1 &b) {
+  auto rev_cigar = [&]() {
+    uint8_t *c = &b.data[b.cigar_at()];
+    for (uint32_t i = 0; i < b.n_cigar / 2; i++)
+      for (int k = 0; k < 4; k++) std::swap(c[4 * i + k], c[4 * (b.n_cigar - 1 - i) + k]);
+  };
+  if (b.l_qseq <= 0) { rev_cigar(); b.flag ^= 0x10; return; }
+  int len = b.l_qseq;
+  uint8_t *seq = &b.data[b.seq_at()], *qual = &b.data[b.qual_at()];
+  static const uint8_t comp_table[16] = {15, 8, 4, 15, 2, 15, 15, 15, 1, 15, 15, 15, 15, 15, 15, 15};
+  std::vector<uint8_t> tmp((len + 1) / 2);
+  for (int i = 0; i < len; ++i) {
+    int j = len - 1 - i;
+    uint8_t nt = (seq[j >> 1] >> ((~j & 1) << 2)) & 0xf;                       // bam_seqi
+    uint8_t c = comp_table[nt];
+    tmp[i >> 1] = (uint8_t)((tmp[i >> 1] & (0xf0 >> ((~i & 1) << 2))) | (c << ((~i & 1) << 2)));  // bam_set_seqi
+  }
+  memcpy(seq, tmp.data(), (len + 1) / 2);
+  if (qual[0] != 0xff) for (int i = 0; i < len / 2; ++i) std::swap(qual[i], qual[len - 1 - i]);
+  rev_cigar();
+  b.flag ^= 0x10;
+}
+
+// src/bam.cpp:531-588; own_strand: the strand this record's transcript lies on (both
+// branches at :551-555 end up testing it)
+static inline void set_mate_info(Bam1 &b, bool is_paired, bool same_transcript, char own_strand, int32_t mate_tid,
+                                 int32_t mate_pos, int32_t isize) {
+  if (!is_paired) { b.flag &= ~(0x1 | 0x2 | 0x20); b.mtid = -1; b.mpos = -1; b.isize = 0; return; }
+  b.flag |= 0x1;
+  if (own_strand == '-') b.flag |= 0x20;
+  if (same_transcript) { b.mtid = b.tid; b.mpos = mate_pos; b.flag |= 0x2; b.isize = isize; }
+  else { b.mtid = mate_tid; b.mpos = mate_pos; b.isize = 0; b.flag &= ~0x2; }
+}
+
+}  // namespace orc

@@ -123,6 +123,9 @@ def lib():
         L.orc_resolve_config.argtypes = [_P(OrcFlags), C.c_void_p, _P(C.c_float)]
         L.orc_ksw_align.restype = C.c_int32
         L.orc_ksw_align.argtypes = [C.c_char_p, C.c_char_p, _P(C.c_int32), _P(C.c_int32), C.c_void_p, C.c_int32]
+        L.orc_bam_encode.restype = C.c_int64
+        L.orc_bam_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, _P(C.c_void_p)]
+        L.orc_free_buffer.argtypes = [C.c_void_p]
         L.orc_primary_pick.restype = C.c_uint32
         L.orc_primary_pick.argtypes = [C.c_char_p, C.c_int64, C.c_uint32]
         _LIB = L
@@ -167,7 +170,7 @@ class OracleIndex:
             pass
 
 
-def run(index, flags, batch, n_threads=1, want_matches=True):
+def run(index, flags, batch, n_threads=1, want_matches=True, bam_records=None):
     """batch: dict of numpy arrays in the shared SoA layout (see bramble_amd.batch).
     Returns (rows dict, matches dict or None, seconds)."""
     L = lib()
@@ -233,6 +236,16 @@ def run(index, flags, batch, n_threads=1, want_matches=True):
             matches["n_exons"] = _arr(m.n_exons, n, np.int32)
             matches["mate_idx"] = _arr(m.mate_idx, n, np.int32)
         secs = L.orc_result_seconds(h)
+        if bam_records is not None:
+            # write_to_bam over the rows: bam_records = (blob uint8[], rec_off uint64[n+1])
+            blob = np.ascontiguousarray(bam_records[0], dtype=np.uint8)
+            roff = np.ascontiguousarray(bam_records[1], dtype=np.uint64)
+            outp = C.c_void_p()
+            nb = L.orc_bam_encode(h, blob.ctypes.data, roff.ctypes.data, n, 1 if (flags.lr or flags.lr_hq) else 0,
+                                  C.byref(outp))
+            buf = (C.c_char * max(nb, 1)).from_address(outp.value)
+            rows["bam_stream"] = np.frombuffer(buf, dtype=np.uint8, count=nb).copy()
+            L.orc_free_buffer(outp)
     finally:
         L.orc_result_free(h)
     return rows, matches, secs

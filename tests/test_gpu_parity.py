@@ -130,6 +130,36 @@ def test_fasta_flag_is_inert_for_short_reads():
     assert_rows_equal(prod, orc)
 
 
+@pytest.mark.parametrize("mode,flags,kw", [("pe", {}, {"xs_tag": True}), ("pe", {}, {}), ("se", {"strict": 1}, {}),
+                                           ("hifi", {"lr_hq": 1}, {}), ("ont", {"lr": 1}, {})])
+def test_bam_reencode_matches_oracle(mode, flags, kw):
+    """k_bam_scan / k_bam_size / k_bam_encode against the oracle's restatement of write_to_bam
+    (update_cigar, NH/HI/AS tags, XS/ts deletion, reverse_complement_bam, set_mate_info): the whole
+    uncompressed BAM record stream must be byte-identical."""
+    import torch
+    from bramble_amd import device as brdev
+    ann = synth.Annotation("G", n_genes=1500, n_refs=3)
+    b = ann.reads(8000, mode, with_records=1, **kw)
+    idx = lib.Index(ann.as_dict(), device=0)
+    ctx = lib.Context(idx)
+    cfg = lib.make_config(**flags)
+    db = brdev.upload_batch(b, "cuda:0")
+    rows = ctx.project_batch_device(cfg, db, 0)
+    blob, roff = brdev.upload_records(b, "cuda:0")
+    bam = ctx.bam_encode_device(cfg, blob, roff, 0)
+    got = brdev.bam_stream_to_host(bam)
+    orc, _, _ = ob.run(ob.OracleIndex(ann.as_dict()), ob.make_flags(**flags), b, want_matches=False,
+                       bam_records=(b["rec_blob"], b["rec_off"]))
+    assert bam.n_rows == orc["n_rows"] and orc["n_rows"] > 5000
+    exp = orc["bam_stream"]
+    assert len(got) == len(exp)
+    if not np.array_equal(got, exp):
+        bad = int(np.nonzero(got != exp)[0][0])
+        raise AssertionError("BAM streams differ first at byte %d of %d" % (bad, len(exp)))
+    ctx.close()
+    idx.close()
+
+
 def test_dense_locus_more_than_64_candidates():
     """150 isoforms share an exon: reads there have > 64 candidate rows (the group kernel's
     two-sweep path) next to reads that take the dense per-match path."""
