@@ -14,7 +14,7 @@ import time
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("config", choices=["c3", "c5"])
+    ap.add_argument("config", choices=["c3", "c5", "bam"])
     ap.add_argument("--reads", type=int, default=0)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
@@ -22,6 +22,42 @@ def main():
     import torch
     from bramble_amd import device as brdev
     from bramble_amd import lib, synth
+    if args.config == "bam":
+        # re-encode the rows of configs[1] as BAM records: HBM-bound byte streaming
+        n = args.reads or 10_000_000
+        ann = synth.Annotation("G")
+        batch = ann.reads(n, "pe", with_records=1)
+        cfg = lib.make_config()
+        idx = lib.Index.from_flat(ann.flat, device=0)
+        ctx = lib.Context(idx)
+        import os
+        if os.environ.get("BAM_LANES"):
+            ctx.set_param("bam_lanes", int(os.environ["BAM_LANES"]))
+        db = brdev.upload_batch(batch, "cuda:0")
+        blob, roff = brdev.upload_records(batch, "cuda:0")
+        stream = torch.cuda.current_stream().cuda_stream
+        rows = ctx.project_batch_device(cfg, db, stream)
+        n_rows = int(rows.n_rows)
+        bam = ctx.bam_encode_device(cfg, blob, roff, stream)
+        ctx.set_profiling(True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        kms = {}
+        for _ in range(args.steps):
+            bam = ctx.bam_encode_device(cfg, blob, roff, stream)
+            for k, (ms, ln) in ctx.kernel_ms().items():
+                kms[k] = kms.get(k, 0.0) + ms
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / args.steps
+        out_bytes = int(bam.n_bytes)
+        in_bytes_per_row = out_bytes  # every output byte is copied from (or computed next to) one input byte
+        k_ms = kms.get("k_bam_scan+k_bam_size+k_bam_encode", 0.0) / args.steps
+        print(json.dumps({"config": "bam", "workload": "re-encode the %d rows of %d paired-end alignments as BAM records" % (n_rows, batch["n_aln"]),
+                          "rows_per_s": n_rows / el, "ms_per_step": el * 1e3, "output_bytes": out_bytes,
+                          "input_record_bytes": int(len(batch["rec_blob"])), "kernel_ms_per_step": {k: round(v / args.steps, 3) for k, v in kms.items() if v},
+                          "bam_kernels_GBps_read_plus_write": (out_bytes + in_bytes_per_row) / (k_ms * 1e-3) / 1e9 if k_ms else None,
+                          "hbm_peak_GBps": 8000.0}))
+        return
     if args.config == "c5":
         n = args.reads or 1_000_000
         ann = synth.Annotation("G")

@@ -375,6 +375,7 @@ struct KEvent { int which; hipEvent_t a, b; };
 struct br_ctx {
   const br_index *ix = nullptr;
   int group_lanes = 8;
+  int bam_lanes = 8;
   int blocks_per_cu = 8;
   int n_cu = 256;
   bool profiling = false;
@@ -450,6 +451,7 @@ extern "C" int br_ctx_set_profiling(br_ctx *c, int enabled) { if (!c) return BR_
 extern "C" int br_ctx_set_param(br_ctx *c, const char *key, int64_t v) {
   if (!c || !key) return BR_ERR_INVALID_ARG;
   if (!strcmp(key, "group_lanes")) { if (v != 8 && v != 16 && v != 32 && v != 64) return BR_ERR_INVALID_ARG; c->group_lanes = (int)v; return BR_OK; }
+  if (!strcmp(key, "bam_lanes")) { if (v != 4 && v != 8 && v != 16 && v != 32 && v != 64) return BR_ERR_INVALID_ARG; c->bam_lanes = (int)v; return BR_OK; }
   if (!strcmp(key, "blocks_per_cu")) { if (v < 1 || v > 64) return BR_ERR_INVALID_ARG; c->blocks_per_cu = (int)v; return BR_OK; }
   return BR_ERR_INVALID_ARG;
 }
@@ -806,6 +808,8 @@ extern "C" int br_bam_encode_device(br_ctx *c, const br_config *cfg, const br_de
   B.cigar = c->cigar_out.as<uint32_t>(); B.out_len = c->bam_len.as<uint32_t>(); B.out_off = c->bam_off.as<uint64_t>();
   RC(c->tile_sums.ensure((size_t)std::max<int64_t>(scan_tiles_for(nr + 1), 1) * 8 * 3));
   RC(c->totals.ensure(8 * 8));
+  B.too_long = c->totals.as<uint64_t>() + 6;
+  HIPCHK(hipMemsetAsync(B.too_long, 0, 8, st));
   RC(pf.begin(BR_K_BAM));
   launch_bam_scan(st, B);
   launch_bam_size(st, B);
@@ -814,13 +818,14 @@ extern "C" int br_bam_encode_device(br_ctx *c, const br_config *cfg, const br_de
   RC(pf.begin(BR_K_SCAN));
   launch_scan(st, S, 2, c->bam_off.p, true, c->totals.as<uint64_t>() + 7);
   RC(pf.end());
-  HIPCHK(hipMemcpyAsync(c->h_totals + 10, c->totals.as<uint64_t>() + 7, 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(c->h_totals + 10, c->totals.as<uint64_t>() + 6, 16, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
-  uint64_t total = nr ? c->h_totals[10] : 0;
+  if (nr && c->h_totals[10]) return BR_ERR_UNSUPPORTED;  // > 65535 CIGAR ops in one record
+  uint64_t total = nr ? c->h_totals[11] : 0;
   RC(c->bam_out.ensure(std::max<size_t>(total, 16)));
   B.out = c->bam_out.as<uint8_t>();
   RC(pf.begin(BR_K_BAM));
-  launch_bam_encode(st, B);
+  launch_bam_encode(st, B, c->bam_lanes);
   RC(pf.end());
   HIPCHK(hipStreamSynchronize(st));
   RC(pf.collect());

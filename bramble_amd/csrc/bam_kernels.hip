@@ -116,14 +116,51 @@ __global__ void __launch_bounds__(256) k_bam_size(BamArgs B) {
   int32_t a = B.r_input[r];
   const uint8_t *rec = B.blob + B.rec_off[a];
   B.out_len[r] = row_out_len(B, r, rec, B.aux[a]);
+  if (B.r_ncig[r] > 65535u) *B.too_long = 1;  // would need htslib's CG:B,I spill-over; refused by the host
 }
 
 // 4-bit base complement of reverse_complement_bam (src/bam.cpp:658-667)
 __device__ __forceinline__ uint8_t comp4(uint8_t nt) { return nt == 1 ? 8 : nt == 2 ? 4 : nt == 4 ? 2 : nt == 8 ? 1 : 15; }
 
+// Unaligned wide accesses: gfx950 global loads / stores need no alignment, so byte
+// regions are moved 16 bytes per lane-instruction.
+struct __attribute__((packed, aligned(1))) W4 { uint32_t a, b, c, d; };
+typedef uint32_t u32u __attribute__((aligned(1)));
+
+template <int G>
+__device__ __forceinline__ void copy_fwd(uint8_t *dst, const uint8_t *src, uint32_t n, int lane) {
+  uint32_t n16 = n & ~15u;
+  for (uint32_t i = 16u * lane; i < n16; i += 16u * G) *(W4 *)(dst + i) = *(const W4 *)(src + i);
+  for (uint32_t i = n16 + lane; i < n; i += G) dst[i] = src[i];
+}
+// dst[i] = src[n-1-i]
+template <int G>
+__device__ __forceinline__ void copy_rev(uint8_t *dst, const uint8_t *src, uint32_t n, int lane) {
+  uint32_t n16 = n & ~15u;
+  for (uint32_t i = 16u * lane; i < n16; i += 16u * G) {
+    W4 w = *(const W4 *)(src + (n - 16u - i));
+    W4 o; o.a = __builtin_bswap32(w.d); o.b = __builtin_bswap32(w.c); o.c = __builtin_bswap32(w.b); o.d = __builtin_bswap32(w.a);
+    *(W4 *)(dst + i) = o;
+  }
+  for (uint32_t i = n16 + lane; i < n; i += G) dst[i] = src[n - 1 - i];
+}
+// reverse-complement of 8 packed 4-bit bases (one dword of BAM SEQ): reversing all 32 bits
+// reverses the base order AND maps A(1)<->T(8), C(2)<->G(4); every other code becomes N(15)
+// (comp_table of src/bam.cpp:658-667)
+__device__ __forceinline__ uint32_t revcomp8(uint32_t v) {
+  uint32_t x = __builtin_bitreverse32(v);
+  uint32_t pop = (x & 0x11111111u) + ((x >> 1) & 0x11111111u) + ((x >> 2) & 0x11111111u) + ((x >> 3) & 0x11111111u);
+  uint32_t y = pop ^ 0x11111111u;                       // zero nibble <=> exactly one bit set
+  uint32_t bad = (y | (y >> 1) | (y >> 2) | (y >> 3)) & 0x11111111u;
+  return x | (bad * 15u);
+}
+
+// G lanes cooperate on one row (records are ~200-300 bytes: a full wave per row would
+// leave most lanes idle in every region loop)
+template <int G>
 __global__ void __launch_bounds__(256) k_bam_encode(BamArgs B) {
-  const int lane = threadIdx.x & 63;
-  int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & (G - 1);
+  int64_t r = (int64_t)blockIdx.x * (256 / G) + (threadIdx.x / G);
   if (r >= B.n_rows) return;
   int32_t a = B.r_input[r];
   const uint8_t *rec = B.blob + B.rec_off[a];
@@ -131,11 +168,12 @@ __global__ void __launch_bounds__(256) k_bam_encode(BamArgs B) {
   uint8_t *out = B.out + B.out_off[r];
   uint32_t total = (uint32_t)(B.out_off[r + 1] - B.out_off[r]);
 
-  uint32_t l_qname = rec[8];
-  uint32_t flag = ld_u16(rec + 14);
-  int32_t l_seq = (int32_t)ld_u32(rec + 16);
+  W4 c0 = *(const W4 *)(rec + 8);   // l_qname|mapq|bin, n_cigar|flag, l_seq, next_refID
+  uint32_t l_qname = c0.a & 0xffu;
+  uint32_t bin = c0.a >> 16;
+  uint32_t n_cig_in = c0.b & 0xffffu, flag = c0.b >> 16;
+  int32_t l_seq = (int32_t)c0.c;
   uint32_t ls = l_seq > 0 ? (uint32_t)l_seq : 0;
-  uint32_t n_cig_in = ld_u16(rec + 12);
   uint32_t n_cig = B.r_ncig[r];
   bool minus = B.r_strand[r] == '-';
   bool paired = B.r_paired[r], same = B.r_same[r];
@@ -150,69 +188,66 @@ __global__ void __launch_bounds__(256) k_bam_encode(BamArgs B) {
     mtid = B.r_mate_tid[r]; mpos = B.r_mate_pos[r];
     if (same) { flag |= 0x2u; tlen = B.r_isize[r]; } else flag &= ~0x2u;
   }
-  // header: block_size + the 32 fixed bytes, one word per lane 0..8
-  if (lane < 9) {
-    uint32_t w;
-    switch (lane) {
-      case 0: w = total - 4u; break;
-      case 1: w = B.r_tid[r]; break;
-      case 2: w = B.r_pos[r]; break;
-      case 3: w = l_qname | ((B.r_mapq[r] & 0xffu) << 8) | (ld_u16(rec + 10) << 16); break;   // l_read_name, mapq, bin (kept)
-      case 4: w = (n_cig & 0xffffu) | (flag << 16); break;
-      case 5: w = (uint32_t)l_seq; break;
-      case 6: w = (uint32_t)mtid; break;
-      case 7: w = (uint32_t)mpos; break;
-      default: w = (uint32_t)tlen; break;
-    }
-    uint8_t *o = out + 4 * lane;
-    o[0] = (uint8_t)w; o[1] = (uint8_t)(w >> 8); o[2] = (uint8_t)(w >> 16); o[3] = (uint8_t)(w >> 24);
+  // block_size + the 32 fixed bytes: nine dwords
+  if (lane == 0) {
+    W4 h0; h0.a = total - 4u; h0.b = B.r_tid[r]; h0.c = B.r_pos[r];
+    h0.d = l_qname | ((B.r_mapq[r] & 0xffu) << 8) | (bin << 16);             // l_read_name, mapq, bin (kept)
+    *(W4 *)out = h0;
+  } else if (lane == 1) {
+    W4 h1; h1.a = (n_cig & 0xffffu) | (flag << 16); h1.b = (uint32_t)l_seq; h1.c = (uint32_t)mtid; h1.d = (uint32_t)mpos;
+    *(W4 *)(out + 16) = h1;
+  } else if (lane == 2) {
+    *(u32u *)(out + 32) = (uint32_t)tlen;
   }
   uint32_t o = 36;
-  // read name
-  for (uint32_t i = lane; i < l_qname; i += 64) out[o + i] = rec[32 + i];
+  copy_fwd<G>(out + o, rec + 32, l_qname, lane);                            // read name
   o += l_qname;
   // rewritten CIGAR (op order reversed on '-', bam.cpp:688-695)
   const uint32_t *cg = B.cigar + B.r_cigoff[r];
-  for (uint32_t i = lane; i < 4 * n_cig; i += 64) {
-    uint32_t k = i >> 2, w = cg[minus ? n_cig - 1 - k : k];
-    out[o + i] = (uint8_t)(w >> (8 * (i & 3)));
-  }
+  for (uint32_t k = lane; k < n_cig; k += G) *(u32u *)(out + o + 4 * k) = cg[minus ? n_cig - 1 - k : k];
   o += 4 * n_cig;
   // sequence: reverse-complemented nibbles on '-' (bam.cpp:671-678; the pad nibble of an odd length stays 0)
   const uint8_t *seq = rec + 32 + l_qname + 4 * n_cig_in;
   uint32_t sb = (ls + 1) / 2;
-  for (uint32_t i = lane; i < sb; i += 64) {
-    uint8_t v;
-    if (!minus) v = seq[i];
-    else {
+  if (!minus) copy_fwd<G>(out + o, seq, sb, lane);
+  else if ((ls & 1u) == 0) {
+    uint32_t n4 = sb & ~3u;
+    for (uint32_t i = 4u * lane; i < n4; i += 4u * G) *(u32u *)(out + o + i) = revcomp8(*(const u32u *)(seq + (sb - 4u - i)));
+    for (uint32_t i = n4 + lane; i < sb; i += G) {  // tail: one byte = two bases
+      uint8_t v = seq[sb - 1 - i];
+      out[o + i] = (uint8_t)((comp4(v & 0xf) << 4) | comp4(v >> 4));
+    }
+  } else {
+    for (uint32_t i = lane; i < sb; i += G) {
       uint32_t p0 = 2 * i, p1 = 2 * i + 1;
       uint32_t s0 = ls - 1 - p0;
-      uint8_t n0 = (seq[s0 >> 1] >> ((~s0 & 1) << 2)) & 0xf, n1 = 0;
-      v = (uint8_t)(comp4(n0) << 4);
-      if (p1 < ls) { uint32_t s1 = ls - 1 - p1; n1 = (seq[s1 >> 1] >> ((~s1 & 1) << 2)) & 0xf; v |= comp4(n1); }
+      uint8_t n0 = (seq[s0 >> 1] >> ((~s0 & 1) << 2)) & 0xf;
+      uint8_t v = (uint8_t)(comp4(n0) << 4);
+      if (p1 < ls) { uint32_t s1 = ls - 1 - p1; uint8_t n1 = (seq[s1 >> 1] >> ((~s1 & 1) << 2)) & 0xf; v |= comp4(n1); }
+      out[o + i] = v;
     }
-    out[o + i] = v;
   }
   o += sb;
   // qualities: reversed on '-' unless absent (0xff) (bam.cpp:680-686)
   const uint8_t *qual = seq + sb;
   bool rev_q = minus && ls > 0 && qual[0] != 0xff;
-  for (uint32_t i = lane; i < ls; i += 64) out[o + i] = qual[rev_q ? ls - 1 - i : i];
+  if (rev_q) copy_rev<G>(out + o, qual, ls, lane); else copy_fwd<G>(out + o, qual, ls, lane);
   o += ls;
-  // aux: original minus the first NH, XS|ts, HI (and AS for long reads) ...
+  // aux: original minus the first NH, XS|ts, HI (and AS for long reads): up to five kept pieces ...
   const uint8_t *aux = rec + x.aux_start;
-  uint32_t removed = x.len[0] + x.len[1] + x.len[2] + x.len[3];
-  uint32_t keep = x.aux_len - removed;
-  for (uint32_t i = lane; i < keep; i += 64) {
-    uint32_t src = i;
+  uint32_t src = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) if (x.off[k] != 0xffffffffu && x.off[k] <= src) src += x.len[k];
-    out[o + i] = aux[src];
+  for (int k = 0; k < 4; k++) {
+    if (x.off[k] == 0xffffffffu) break;
+    uint32_t piece = x.off[k] - src;
+    copy_fwd<G>(out + o, aux + src, piece, lane);
+    o += piece; src = x.off[k] + x.len[k];
   }
-  o += keep;
+  copy_fwd<G>(out + o, aux + src, x.aux_len - src, lane);
+  o += x.aux_len - src;
   // ... plus NH:i, (AS:i,) HI:i appended in that order (bam.cpp:590-634, core.cpp:118-161)
-  if (lane < 21) {
-    int which = lane / 7, k = lane % 7;
+  for (int tb = lane; tb < 21; tb += G) {
+    int which = tb / 7, k = tb % 7;
     bool lr = B.long_reads != 0;
     if (which < (lr ? 3 : 2)) {
       int kind = which == 0 ? 0 : (lr ? (which == 1 ? 1 : 2) : 2);  // 0 NH, 1 AS, 2 HI
@@ -236,8 +271,13 @@ void launch_bam_scan(hipStream_t st, const BamArgs &B) {
 void launch_bam_size(hipStream_t st, const BamArgs &B) {
   if (B.n_rows > 0) hipLaunchKernelGGL(k_bam_size, dim3((unsigned)((B.n_rows + 255) / 256)), dim3(256), 0, st, B);
 }
-void launch_bam_encode(hipStream_t st, const BamArgs &B) {
-  if (B.n_rows > 0) hipLaunchKernelGGL(k_bam_encode, dim3((unsigned)((B.n_rows + 3) / 4)), dim3(256), 0, st, B);
+void launch_bam_encode(hipStream_t st, const BamArgs &B, int lanes) {
+  if (B.n_rows <= 0) return;
+  if (lanes == 4) hipLaunchKernelGGL((k_bam_encode<4>), dim3((unsigned)((B.n_rows + 63) / 64)), dim3(256), 0, st, B);
+  else if (lanes == 8) hipLaunchKernelGGL((k_bam_encode<8>), dim3((unsigned)((B.n_rows + 31) / 32)), dim3(256), 0, st, B);
+  else if (lanes == 32) hipLaunchKernelGGL((k_bam_encode<32>), dim3((unsigned)((B.n_rows + 7) / 8)), dim3(256), 0, st, B);
+  else if (lanes == 64) hipLaunchKernelGGL((k_bam_encode<64>), dim3((unsigned)((B.n_rows + 3) / 4)), dim3(256), 0, st, B);
+  else hipLaunchKernelGGL((k_bam_encode<16>), dim3((unsigned)((B.n_rows + 15) / 16)), dim3(256), 0, st, B);
 }
 size_t bam_aux_bytes() { return sizeof(BamAux); }
 

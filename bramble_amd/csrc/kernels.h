@@ -149,10 +149,11 @@ struct BamArgs {
   uint32_t *out_len;         // [n_rows]
   const uint64_t *out_off;   // [n_rows + 1]
   uint8_t *out;
+  uint64_t *too_long;        // set when a row's CIGAR exceeds the 16-bit n_cigar_op field
 };
 void launch_bam_scan(hipStream_t st, const BamArgs &B);
 void launch_bam_size(hipStream_t st, const BamArgs &B);
-void launch_bam_encode(hipStream_t st, const BamArgs &B);
+void launch_bam_encode(hipStream_t st, const BamArgs &B, int lanes);
 
 void launch_segment(hipStream_t st, int64_t n_aln, const int32_t *ref_id, const int32_t *ref_start,
                     const uint16_t *flags, const int8_t *xs, const int8_t *ts, const uint32_t *cigar_off,
