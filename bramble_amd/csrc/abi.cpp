@@ -247,6 +247,7 @@ extern "C" const char *br_index_transcript_name(const br_index *ix, uint32_t tid
 extern "C" int64_t br_index_transcript_len(const br_index *ix, uint32_t tid) {
   return (ix && tid < ix->lengths.size()) ? (int64_t)ix->lengths[tid] : -1;
 }
+extern "C" size_t br_index_num_refs(const br_index *ix) { return ix ? ix->n_refs : 0; }
 extern "C" size_t br_index_num_intervals(const br_index *ix) { return ix ? ix->s_start.size() : 0; }
 extern "C" size_t br_index_device_bytes(const br_index *ix) { return ix ? ix->device_bytes : 0; }
 
@@ -387,6 +388,8 @@ struct br_ctx {
   DevBuf seg, meta, head, head2, fast_flag, fast_pre, m_k, n_matches, ranges, mask, match_off, cig_base, tile_sums, totals, counters_d;
   DevBuf m_tid, m_aux, m_a, m_b, m_cigoff, cig_arena, big_list, n_big, m_aln;
   DevBuf bam_aux, bam_len, bam_off, bam_out;
+  DevBuf p_ncig, p_name_len, p_isnew, p_group_pre, p_small, p_big, p_seq_len, p_ref_map, p_blob, p_rec_off, p_rec_len;
+  uint8_t *h_bam = nullptr; size_t h_bam_cap = 0;  // pinned download buffer of br_project_bam_bundle
   int64_t last_n_rows = 0, last_n_aln = 0;
   DevBuf fa_stats, fa_n_prob, fa_seq_bytes, fa_prob_off, fa_seqarena_off, fa_probs, fa_results, fa_seq_arena, fa_clip_ops,
       fa_ideal_cap, fa_scratch, b_seq_off, b_seqs, b_seq_src;
@@ -420,7 +423,7 @@ extern "C" int br_ctx_new(const br_index *ix, br_ctx **out) {
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, ix->device));
   c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  HIPCHK(hipHostMalloc((void **)&c->h_totals, 16 * sizeof(uint64_t), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void **)&c->h_totals, 32 * sizeof(uint64_t), hipHostMallocDefault));
   const char *g = getenv("BRAMBLE_AMD_GROUP_LANES");
   if (g) { int v = atoi(g); if (v == 8 || v == 16 || v == 32 || v == 64) c->group_lanes = v; }
   *out = c;
@@ -433,7 +436,7 @@ extern "C" void br_ctx_free(br_ctx *c) {
   DevBuf *bufs[] = {&c->seg, &c->meta, &c->head, &c->head2, &c->fast_flag, &c->fast_pre, &c->m_k, &c->n_matches, &c->ranges, &c->mask, &c->match_off, &c->cig_base,
                     &c->tile_sums, &c->totals, &c->counters_d, &c->m_tid, &c->m_aux, &c->m_a, &c->m_b,
                     &c->m_cigoff, &c->cig_arena, &c->big_list, &c->n_big, &c->m_aln,
-                    &c->bam_aux, &c->bam_len, &c->bam_off, &c->bam_out, &c->fa_stats, &c->fa_n_prob, &c->fa_seq_bytes, &c->fa_prob_off, &c->fa_seqarena_off, &c->fa_probs, &c->fa_results,
+                    &c->bam_aux, &c->bam_len, &c->bam_off, &c->bam_out, &c->p_ncig, &c->p_name_len, &c->p_isnew, &c->p_group_pre, &c->p_small, &c->p_big, &c->p_seq_len, &c->p_ref_map, &c->p_blob, &c->p_rec_off, &c->p_rec_len, &c->fa_stats, &c->fa_n_prob, &c->fa_seq_bytes, &c->fa_prob_off, &c->fa_seqarena_off, &c->fa_probs, &c->fa_results,
                     &c->fa_seq_arena, &c->fa_clip_ops, &c->fa_ideal_cap, &c->fa_scratch, &c->b_seq_off, &c->b_seqs, &c->b_seq_src,
                     &c->n_rows, &c->row_off, &c->aln_group, &c->r_input, &c->r_rec, &c->r_nh, &c->r_hi, &c->r_mapq,
                     &c->r_group, &c->r_mate_tid, &c->r_mate_pos, &c->r_isize, &c->r_tid, &c->r_pos,
@@ -444,6 +447,7 @@ extern "C" void br_ctx_free(br_ctx *c) {
   for (DevBuf *b : bufs) b->release();
   for (auto &e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if (c->h_totals) (void)hipHostFree(c->h_totals);
+  if (c->h_bam) (void)hipHostFree(c->h_bam);
   delete c;
 }
 
@@ -510,7 +514,13 @@ struct Prof {
 #define RC(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 
 // The HIP pipeline over a device-resident batch.
+static int run_device_impl(br_ctx *c, const br_config *cfg, const br_device_batch *b, hipStream_t st, br_device_rows *out,
+                           bool keep_events);
 int run_device(br_ctx *c, const br_config *cfg, const br_device_batch *b, hipStream_t st, br_device_rows *out) {
+  return run_device_impl(c, cfg, b, st, out, false);
+}
+static int run_device_impl(br_ctx *c, const br_config *cfg, const br_device_batch *b, hipStream_t st, br_device_rows *out,
+                           bool keep_events) {
   const br_index *ix = c->ix;
   memset(out, 0, sizeof(*out));
   DevCfg dc;
@@ -522,7 +532,7 @@ int run_device(br_ctx *c, const br_config *cfg, const br_device_batch *b, hipStr
   if (n < 0 || ng < 0 || n >= 0x7fffffffll || b->n_cigar_words >= 0xffffffffll - n) return BR_ERR_CAPACITY;
   HIPCHK(hipSetDevice(ix->device));
   Prof pf{c, st};
-  c->events_used = 0;
+  if (!keep_events) c->events_used = 0;
   out->total_processed = (uint64_t)n;
   if (n == 0) { pf.collect(); return BR_OK; }
 
@@ -733,7 +743,7 @@ int run_device(br_ctx *c, const br_config *cfg, const br_device_batch *b, hipStr
     HIPCHK(hipMemsetAsync(c->r_cigoff.p, 0, 8, st));
   }
   HIPCHK(hipStreamSynchronize(st));
-  RC(pf.collect());
+  if (!keep_events) RC(pf.collect());
   out->total_complete = n_rows; out->total_unique = c->h_totals[5]; out->dropped_reads = c->h_totals[6];
   if (fa_mode && c->rescue_stats[0]) { c->rescue_stats[1] = c->h_totals[8]; c->rescue_stats[2] = c->h_totals[9]; }
 
@@ -782,20 +792,20 @@ extern "C" int br_ctx_collect_counters(br_ctx *c, const br_device_batch *b, void
   return BR_OK;
 }
 
-extern "C" int br_bam_encode_device(br_ctx *c, const br_config *cfg, const br_device_records *recs, void *stream,
-                                    br_device_bam *out) {
-  if (!c || !cfg || !recs || !out) return BR_ERR_INVALID_ARG;
+// aux_done: k_bam_scan already ran over these records with the same configuration
+// (br_project_bam_device); keep_events: append to the running event list instead of restarting it
+static int bam_encode_impl(br_ctx *c, const br_config *cfg, const br_device_records *recs, hipStream_t st,
+                           br_device_bam *out, bool aux_done, bool keep_events) {
   memset(out, 0, sizeof(*out));
   if (recs->n_aln != c->last_n_aln) return BR_ERR_INVALID_ARG;
-  hipStream_t st = (hipStream_t)stream;
   HIPCHK(hipSetDevice(c->ix->device));
   int64_t nr = c->last_n_rows, n = recs->n_aln;
   out->n_rows = nr;
   Prof pf{c, st};
-  c->events_used = 0;
+  if (!keep_events) c->events_used = 0;
   BamArgs B{};
   B.n_aln = n; B.n_rows = nr; B.long_reads = (cfg->lr || cfg->lr_hq) ? 1 : 0;
-  B.blob = recs->blob; B.rec_off = recs->rec_off;
+  B.blob = recs->blob; B.rec_off = recs->rec_off; B.rec_len = recs->rec_len;
   RC(c->bam_aux.ensure(std::max<size_t>((size_t)n, 1) * sizeof(BamAux)));
   RC(c->bam_len.ensure(std::max<size_t>((size_t)nr, 1) * 4)); RC(c->bam_off.ensure(((size_t)nr + 1) * 8));
   B.aux = (BamAux *)c->bam_aux.p;
@@ -811,7 +821,7 @@ extern "C" int br_bam_encode_device(br_ctx *c, const br_config *cfg, const br_de
   B.too_long = c->totals.as<uint64_t>() + 6;
   HIPCHK(hipMemsetAsync(B.too_long, 0, 8, st));
   RC(pf.begin(BR_K_BAM));
-  launch_bam_scan(st, B);
+  if (!aux_done) launch_bam_scan(st, B);
   launch_bam_size(st, B);
   RC(pf.end());
   ScanArgs S{}; S.n = nr; S.src32 = B.out_len; S.tile_sums = c->tile_sums.as<uint64_t>();
@@ -820,7 +830,7 @@ extern "C" int br_bam_encode_device(br_ctx *c, const br_config *cfg, const br_de
   RC(pf.end());
   HIPCHK(hipMemcpyAsync(c->h_totals + 10, c->totals.as<uint64_t>() + 6, 16, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
-  if (nr && c->h_totals[10]) return BR_ERR_UNSUPPORTED;  // > 65535 CIGAR ops in one record
+  if (nr && c->h_totals[10]) { pf.collect(); return BR_ERR_UNSUPPORTED; }  // > 65535 CIGAR ops in one record
   uint64_t total = nr ? c->h_totals[11] : 0;
   RC(c->bam_out.ensure(std::max<size_t>(total, 16)));
   B.out = c->bam_out.as<uint8_t>();
@@ -830,6 +840,180 @@ extern "C" int br_bam_encode_device(br_ctx *c, const br_config *cfg, const br_de
   HIPCHK(hipStreamSynchronize(st));
   RC(pf.collect());
   out->data = c->bam_out.as<uint8_t>(); out->n_bytes = total; out->row_off = c->bam_off.as<uint64_t>();
+  return BR_OK;
+}
+
+extern "C" int br_bam_encode_device(br_ctx *c, const br_config *cfg, const br_device_records *recs, void *stream,
+                                    br_device_bam *out) {
+  if (!c || !cfg || !recs || !out) return BR_ERR_INVALID_ARG;
+  return bam_encode_impl(c, cfg, recs, (hipStream_t)stream, out, false, false);
+}
+
+// ---------------------------------------------------------------------------
+// BAM bundle entry: records -> input tables -> projection -> records
+// ---------------------------------------------------------------------------
+extern "C" int br_project_bam_device(br_ctx *c, const br_config *cfg, const br_device_records *recs,
+                                     const int32_t *ref_map, int32_t n_ref_map, void *stream,
+                                     br_device_rows *rows_out, br_device_bam *out) {
+  if (!c || !cfg || !recs || !out || n_ref_map < 0 || (n_ref_map && !ref_map)) return BR_ERR_INVALID_ARG;
+  if (recs->n_aln && (!recs->blob || !recs->rec_off)) return BR_ERR_INVALID_ARG;
+  memset(out, 0, sizeof(*out));
+  br_device_rows local_rows;
+  br_device_rows *rows = rows_out ? rows_out : &local_rows;
+  memset(rows, 0, sizeof(*rows));
+  hipStream_t st = (hipStream_t)stream;
+  const br_index *ix = c->ix;
+  DevCfg dc;
+  RC(make_devcfg(cfg, dc));
+  const bool fa_mode = dc.use_fasta && dc.long_reads;
+  int64_t n = recs->n_aln;
+  if (n < 0 || n >= 0x7fffffffll) return BR_ERR_CAPACITY;
+  HIPCHK(hipSetDevice(ix->device));
+  c->last_n_aln = n; c->last_n_rows = 0;
+  c->events_used = 0;
+  Prof pf{c, st};
+  if (n == 0) { pf.collect(); return BR_OK; }
+
+  size_t nn = (size_t)n;
+  RC(c->b_ref_id.ensure(nn * 4)); RC(c->b_ref_start.ensure(nn * 4)); RC(c->b_flags.ensure(nn * 2));
+  RC(c->b_xs.ensure(nn)); RC(c->b_ts.ensure(nn)); RC(c->b_lqseq.ensure(nn * 4));
+  RC(c->b_cigar_off.ensure((nn + 1) * 4)); RC(c->b_name_off.ensure((nn + 1) * 4)); RC(c->b_mate_idx.ensure(nn * 4));
+  RC(c->p_ncig.ensure(nn * 4)); RC(c->p_name_len.ensure(nn * 4)); RC(c->p_isnew.ensure(nn * 4));
+  RC(c->p_group_pre.ensure((nn + 1) * 4)); RC(c->p_small.ensure(64)); RC(c->p_big.ensure((nn / 96 + 2) * 4));
+  RC(c->p_ref_map.ensure(std::max<size_t>((size_t)n_ref_map, 1) * 4));
+  RC(c->bam_aux.ensure(nn * sizeof(BamAux)));
+  RC(c->tile_sums.ensure((size_t)std::max<int64_t>(scan_tiles_for(n + 1), 1) * 8 * 3));
+  RC(c->totals.ensure(8 * 8));
+  if (n_ref_map) HIPCHK(hipMemcpyAsync(c->p_ref_map.p, ref_map, (size_t)n_ref_map * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemsetAsync(c->p_small.p, 0, 64, st));  // [0] max n_cigar, [1] max soft clip, [2] big-group count
+
+  ParseArgs P{};
+  P.n = n; P.blob = recs->blob; P.rec_off = recs->rec_off; P.rec_len = recs->rec_len;
+  P.ref_map = c->p_ref_map.as<int32_t>(); P.n_ref_map = n_ref_map;
+  P.ref_id = c->b_ref_id.as<int32_t>(); P.ref_start = c->b_ref_start.as<int32_t>(); P.l_qseq = c->b_lqseq.as<int32_t>();
+  P.flags = c->b_flags.as<uint16_t>(); P.ncig = c->p_ncig.as<uint32_t>(); P.name_len = c->p_name_len.as<uint32_t>();
+  P.isnew = c->p_isnew.as<uint32_t>(); P.maxima = c->p_small.as<uint32_t>(); P.n_big_groups = c->p_small.as<uint32_t>() + 2;
+  P.big_groups = c->p_big.as<uint32_t>(); P.group_pre = c->p_group_pre.as<uint32_t>();
+  P.cigar_off = c->b_cigar_off.as<uint32_t>(); P.name_off = c->b_name_off.as<uint32_t>(); P.mate_idx = c->b_mate_idx.as<int32_t>();
+
+  BamArgs B{};
+  B.n_aln = n; B.long_reads = dc.long_reads ? 1 : 0; B.blob = recs->blob; B.rec_off = recs->rec_off; B.rec_len = recs->rec_len;
+  B.aux = (BamAux *)c->bam_aux.p; B.xs_out = c->b_xs.as<int8_t>(); B.ts_out = c->b_ts.as<int8_t>();
+
+  RC(pf.begin(BR_K_PARSE));
+  launch_rec_fields(st, P);
+  RC(pf.end());
+  RC(pf.begin(BR_K_BAM));
+  launch_bam_scan(st, B);
+  RC(pf.end());
+  uint64_t *d_tot = c->totals.as<uint64_t>();
+  ScanArgs S{}; S.n = n; S.tile_sums = c->tile_sums.as<uint64_t>();
+  RC(pf.begin(BR_K_SCAN));
+  S.src32 = P.ncig;     launch_scan(st, S, 2, c->b_cigar_off.p, false, d_tot + 0);
+  S.src32 = P.name_len; launch_scan(st, S, 2, c->b_name_off.p, false, d_tot + 1);
+  S.src32 = P.isnew;    launch_scan(st, S, 2, c->p_group_pre.p, false, d_tot + 2);
+  RC(pf.end());
+  HIPCHK(hipMemcpyAsync(c->h_totals + 16, d_tot, 3 * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(c->h_totals + 20, c->p_small.p, 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  uint64_t n_words = c->h_totals[16], name_bytes = c->h_totals[17], ng = c->h_totals[18];
+  uint32_t max_nc = (uint32_t)(c->h_totals[20] & 0xffffffffu), max_clip = (uint32_t)(c->h_totals[20] >> 32);
+  if (n_words >= 0xffffffffull - (uint64_t)n || name_bytes >= 0xfffffff0ull) { pf.collect(); return BR_ERR_CAPACITY; }
+  RC(c->b_cigar.ensure(std::max<size_t>((size_t)n_words, 1) * 4)); RC(c->b_names.ensure(std::max<size_t>((size_t)name_bytes, 1)));
+  RC(c->b_group_off.ensure(((size_t)ng + 1) * 4));
+  P.n_groups = (int64_t)ng; P.group_off = c->b_group_off.as<uint32_t>();
+  P.cigar = c->b_cigar.as<uint32_t>(); P.names = c->b_names.as<uint8_t>();
+  RC(pf.begin(BR_K_PARSE));
+  launch_group_off(st, P);
+  launch_rec_copy(st, P);
+  launch_mates(st, P);
+  RC(pf.end());
+
+  br_device_batch db{};
+  if (fa_mode) {
+    RC(c->b_seq_src.ensure(nn * 4)); RC(c->p_seq_len.ensure(nn * 4)); RC(c->b_seq_off.ensure((nn + 1) * 4));
+    P.seq_src = c->b_seq_src.as<int32_t>(); P.seq_len = c->p_seq_len.as<uint32_t>(); P.seq_off = c->b_seq_off.as<uint32_t>();
+    RC(pf.begin(BR_K_PARSE));
+    launch_seq_src(st, P);
+    RC(pf.end());
+    RC(pf.begin(BR_K_SCAN));
+    S.src32 = P.seq_len; launch_scan(st, S, 2, c->b_seq_off.p, false, d_tot + 3);
+    RC(pf.end());
+    HIPCHK(hipMemcpyAsync(c->h_totals + 19, d_tot + 3, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    uint64_t sbytes = c->h_totals[19];
+    if (sbytes >= 0xfffffff0ull) { pf.collect(); return BR_ERR_CAPACITY; }
+    RC(c->b_seqs.ensure(std::max<size_t>((size_t)sbytes, 1)));
+    P.seqs = c->b_seqs.as<uint8_t>();
+    RC(pf.begin(BR_K_PARSE));
+    launch_seq_ascii(st, P);
+    RC(pf.end());
+    db.seq_off = P.seq_off; db.seqs = P.seqs; db.seq_src = P.seq_src; db.max_soft_clip = (int32_t)max_clip;
+  }
+  db.n_aln = n; db.n_groups = (int64_t)ng; db.ref_id = P.ref_id; db.ref_start = P.ref_start; db.flags = P.flags;
+  db.xs = c->b_xs.as<int8_t>(); db.ts = c->b_ts.as<int8_t>(); db.cigar_off = P.cigar_off; db.cigar = P.cigar;
+  db.mate_idx = P.mate_idx; db.group_off = P.group_off; db.l_qseq = P.l_qseq;
+  db.n_cigar_words = (int64_t)n_words; db.max_n_cigar = (int32_t)max_nc;
+  db.name_off = P.name_off; db.names = P.names;
+  RC(run_device_impl(c, cfg, &db, st, rows, true));
+  RC(bam_encode_impl(c, cfg, recs, st, out, true, true));
+  return BR_OK;
+}
+
+extern "C" int br_bam_split(const uint8_t *data, uint64_t n_bytes, int64_t cap, uint64_t *rec_off, uint32_t *rec_len,
+                            int64_t *n_records, int64_t *n_unmapped, uint64_t *consumed) {
+  if ((!data && n_bytes) || !rec_off || !rec_len || !n_records || !consumed || cap < 0) return BR_ERR_INVALID_ARG;
+  uint64_t p = 0; int64_t n = 0, un = 0;
+  while (n < cap && p + 4 <= n_bytes) {
+    uint32_t bs; memcpy(&bs, data + p, 4);
+    if (bs < 32) return BR_ERR_INVALID_ARG;
+    if (p + 4 + (uint64_t)bs > n_bytes) break;  // partial record: next call
+    const uint8_t *r = data + p + 4;
+    uint32_t l_qname = r[8]; uint16_t ncig, flag; int32_t l_seq;
+    memcpy(&ncig, r + 12, 2); memcpy(&flag, r + 14, 2); memcpy(&l_seq, r + 16, 4);
+    uint64_t ls = l_seq > 0 ? (uint64_t)l_seq : 0;
+    if (32ull + l_qname + 4ull * ncig + (ls + 1) / 2 + ls > bs || l_qname == 0) return BR_ERR_INVALID_ARG;
+    if (flag & 0x4) un++;
+    else { rec_off[n] = p + 4; rec_len[n] = bs; n++; }
+    p += 4 + (uint64_t)bs;
+  }
+  *n_records = n; if (n_unmapped) *n_unmapped = un; *consumed = p;
+  return BR_OK;
+}
+
+extern "C" int br_project_bam_bundle(br_ctx *c, const br_config *cfg, const br_bam_bundle *bb, br_host_bam *out) {
+  if (!c || !cfg || !bb || !out) return BR_ERR_INVALID_ARG;
+  memset(out, 0, sizeof(*out));
+  int64_t n = bb->n_records;
+  if (n < 0 || (n && (!bb->blob || !bb->rec_off || !bb->rec_len))) return BR_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(c->ix->device));
+  hipStream_t st = nullptr;
+  out->total_processed = (uint64_t)n;
+  if (n == 0) return BR_OK;
+  // upload only the span the records cover
+  uint64_t lo = bb->rec_off[0], hi = bb->rec_off[n - 1] + bb->rec_len[n - 1];
+  if (hi > bb->n_bytes || lo > hi) return BR_ERR_INVALID_ARG;
+  RC(c->p_blob.ensure((size_t)(hi - lo) + 16)); RC(c->p_rec_off.ensure((size_t)n * 8)); RC(c->p_rec_len.ensure((size_t)n * 4));
+  HIPCHK(hipMemcpyAsync(c->p_blob.p, bb->blob + lo, (size_t)(hi - lo), hipMemcpyHostToDevice, st));
+  std::vector<uint64_t> off((size_t)n);
+  for (int64_t i = 0; i < n; i++) off[(size_t)i] = bb->rec_off[i] - lo;
+  HIPCHK(hipMemcpyAsync(c->p_rec_off.p, off.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(c->p_rec_len.p, bb->rec_len, (size_t)n * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));
+  br_device_records dr{c->p_blob.as<uint8_t>(), c->p_rec_off.as<uint64_t>(), n, c->p_rec_len.as<uint32_t>()};
+  br_device_rows rows; br_device_bam db;
+  RC(br_project_bam_device(c, cfg, &dr, bb->ref_map, bb->n_ref_map, st, &rows, &db));
+  if (db.n_bytes > c->h_bam_cap) {
+    if (c->h_bam) { HIPCHK(hipHostFree(c->h_bam)); c->h_bam = nullptr; c->h_bam_cap = 0; }
+    size_t want = (size_t)db.n_bytes + (size_t)db.n_bytes / 4 + 4096;
+    HIPCHK(hipHostMalloc((void **)&c->h_bam, want, hipHostMallocDefault));
+    c->h_bam_cap = want;
+  }
+  if (db.n_bytes) HIPCHK(hipMemcpyAsync(c->h_bam, db.data, (size_t)db.n_bytes, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  out->data = c->h_bam; out->n_bytes = db.n_bytes; out->n_rows = db.n_rows;
+  out->total_complete = rows.total_complete; out->total_unique = rows.total_unique;
+  out->dropped_reads = rows.dropped_reads; out->total_processed = rows.total_processed;
   return BR_OK;
 }
 

@@ -48,8 +48,10 @@ __global__ void __launch_bounds__(256) k_bam_scan(BamArgs B) {
   int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= B.n_aln) return;
   const uint8_t *rec = B.blob + B.rec_off[a];
-  uint64_t rlen = B.rec_off[a + 1] - B.rec_off[a];
+  uint64_t rlen = B.rec_len ? (uint64_t)B.rec_len[a] : B.rec_off[a + 1] - B.rec_off[a];
   BamAux x;
+  int8_t xs_c = 0, ts_c = 0;
+  bool have_xs = false, have_ts = false;
   for (int k = 0; k < 4; k++) { x.off[k] = 0xffffffffu; x.len[k] = 0; }
   x.as_val = 0; x.aux_start = 0; x.aux_len = 0;
   if (rlen >= 32) {
@@ -66,6 +68,9 @@ __global__ void __launch_bounds__(256) k_bam_scan(BamArgs B) {
         uint8_t t0 = s[0], t1 = s[1], ty = s[2];
         int64_t vl = aux_value_len(ty, s + 3, end);
         if (vl < 0 || s + 3 + vl > end) break;  // malformed: htslib stops here too
+        // tag_char1 (gclib/GSam.cpp:310-318): first value byte of the first XS / ts tag when A or Z
+        if (t0 == 'X' && t1 == 'S' && !have_xs) { have_xs = true; if (ty == 'A' || ty == 'Z') xs_c = (int8_t)s[3]; }
+        if (t0 == 't' && t1 == 's' && !have_ts) { have_ts = true; if (ty == 'A' || ty == 'Z') ts_c = (int8_t)s[3]; }
         int slot = -1;
         if (t0 == 'N' && t1 == 'H') slot = 0;
         else if (!B.long_reads && t0 == 'X' && t1 == 'S') slot = 1;
@@ -99,6 +104,7 @@ __global__ void __launch_bounds__(256) k_bam_scan(BamArgs B) {
     }
   }
   B.aux[a] = x;
+  if (B.xs_out) { B.xs_out[a] = xs_c; B.ts_out[a] = ts_c; }
 }
 
 __device__ __forceinline__ uint32_t row_out_len(const BamArgs &B, int64_t r, const uint8_t *rec, const BamAux &x) {

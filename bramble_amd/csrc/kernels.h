@@ -136,7 +136,9 @@ struct BamArgs {
   int64_t n_aln, n_rows;
   int32_t long_reads;
   const uint8_t *blob;       // original records, BAM layout from refID on
-  const uint64_t *rec_off;   // [n_aln + 1]
+  const uint64_t *rec_off;   // [n_aln + 1] (or [n_aln] with rec_len)
+  const uint32_t *rec_len;   // [n_aln] or null: rec_off[i + 1] - rec_off[i]
+  int8_t *xs_out, *ts_out;   // [n_aln] or null: tag_char1("XS") / tag_char1("ts") of every record
   BamAux *aux;               // [n_aln]
   const int32_t *r_input;
   const uint32_t *r_tid, *r_pos, *r_ncig, *r_nh, *r_hi, *r_mapq;
@@ -152,6 +154,37 @@ struct BamArgs {
   uint64_t *too_long;        // set when a row's CIGAR exceeds the 16-bit n_cigar_op field
 };
 void launch_bam_scan(hipStream_t st, const BamArgs &B);
+
+// BAM records -> input tables (parse_kernels.hip)
+struct ParseArgs {
+  int64_t n, n_groups;
+  const uint8_t *blob;
+  const uint64_t *rec_off;
+  const uint32_t *rec_len;     // or null
+  const int32_t *ref_map;      // BAM refID -> annotation reference index
+  int32_t n_ref_map;
+  int32_t *ref_id, *ref_start, *l_qseq;
+  uint16_t *flags;
+  uint32_t *ncig, *name_len, *isnew;
+  uint32_t *maxima;            // [2] longest CIGAR, longest soft clip
+  const uint32_t *group_pre;   // [n + 1] exclusive scan of isnew
+  uint32_t *group_off;         // [n_groups + 1]
+  const uint32_t *cigar_off, *name_off;  // [n + 1]
+  uint32_t *cigar;
+  uint8_t *names;
+  int32_t *mate_idx;
+  uint32_t *n_big_groups, *big_groups;
+  int32_t *seq_src;
+  uint32_t *seq_len;
+  const uint32_t *seq_off;
+  uint8_t *seqs;
+};
+void launch_rec_fields(hipStream_t st, const ParseArgs &P);
+void launch_group_off(hipStream_t st, const ParseArgs &P);
+void launch_rec_copy(hipStream_t st, const ParseArgs &P);
+void launch_mates(hipStream_t st, const ParseArgs &P);
+void launch_seq_src(hipStream_t st, const ParseArgs &P);
+void launch_seq_ascii(hipStream_t st, const ParseArgs &P);
 void launch_bam_size(hipStream_t st, const BamArgs &B);
 void launch_bam_encode(hipStream_t st, const BamArgs &B, int lanes);
 

@@ -233,6 +233,7 @@ void push_read(Reads &R, const std::string &name, int32_t ref, uint32_t pos, con
     auto p16 = [&](uint32_t v) { o.push_back((uint8_t)v); o.push_back((uint8_t)(v >> 8)); };
     uint32_t lq = ql;
     if (flags & 0x100) { if (rnd() % 3 == 0) lq = 0; }  // secondary records often carry no SEQ
+    R.l_qseq.back() = (int32_t)lq;                       // the flat table says what the record says
     p32((uint32_t)ref); p32(pos - 1);
     o.push_back((uint8_t)(name.size() + 1)); o.push_back((uint8_t)(rnd() % 61));
     p16((uint32_t)(4681 + (pos >> 14))); p16((uint32_t)cig.size()); p16(flags);
@@ -259,9 +260,9 @@ void push_read(Reads &R, const std::string &name, int32_t ref, uint32_t pos, con
     auto md = [&]() { o.push_back('M'); o.push_back('D'); o.push_back('Z'); uint32_t n = 1 + rnd() % 12; for (uint32_t i = 0; i < n; i++) o.push_back((uint8_t)("0123456789ACGT^"[rnd() % 15])); o.push_back(0); };
     auto barr = [&]() { o.push_back('Z'); o.push_back('B'); o.push_back('B'); o.push_back('S'); uint32_t n = rnd() % 4; p32(n); for (uint32_t i = 0; i < n; i++) p16((uint32_t)(rnd() & 0xffff)); };
     bool has_nh = rnd() % 8 != 0, has_hi = rnd() % 3 == 0, has_as = rnd() % 8 != 0, has_md = rnd() % 2 == 0, has_b = rnd() % 16 == 0;
-    if (order == 0) { if (has_as) tagInt("AS", (int32_t)(rnd() % 200)); if (xs) tagA("XS", (char)xs); tagC("NM", rnd() % 5); if (has_nh) tagC("NH", 1 + rnd() % 3); if (has_hi) tagC("HI", 1); if (has_md) md(); }
-    else if (order == 1) { if (has_nh) tagInt("NH", 1); if (has_hi) tagInt("HI", 1 + (int32_t)(rnd() % 3)); if (has_md) md(); if (xs) tagA("XS", (char)xs); if (has_as) tagInt("AS", (int32_t)(rnd() % 30000) - 100); }
-    else if (order == 2) { if (has_b) barr(); if (ts) tagA("ts", (char)ts); if (has_as) tagInt("AS", (int32_t)(rnd() % 4000)); if (has_nh) tagInt("NH", 2); tagC("NM", rnd() % 9); }
+    if (order == 0) { if (has_as) tagInt("AS", (int32_t)(rnd() % 200)); if (xs) tagA("XS", (char)xs); tagC("NM", rnd() % 5); if (has_nh) tagC("NH", 1 + rnd() % 3); if (ts) tagA("ts", (char)ts); if (has_hi) tagC("HI", 1); if (has_md) md(); }
+    else if (order == 1) { if (has_nh) tagInt("NH", 1); if (has_hi) tagInt("HI", 1 + (int32_t)(rnd() % 3)); if (has_md) md(); if (xs) tagA("XS", (char)xs); if (ts) tagA("ts", (char)ts); if (has_as) tagInt("AS", (int32_t)(rnd() % 30000) - 100); }
+    else if (order == 2) { if (has_b) barr(); if (ts) tagA("ts", (char)ts); if (xs) tagA("XS", (char)xs); if (has_as) tagInt("AS", (int32_t)(rnd() % 4000)); if (has_nh) tagInt("NH", 2); tagC("NM", rnd() % 9); }
     else { if (has_md) md(); if (has_hi) tagInt("HI", 0); if (ts) tagA("ts", (char)ts); if (xs) tagA("XS", (char)xs); if (has_b) barr(); if (has_nh) tagC("NH", 1); if (has_as) tagInt("AS", 77); if (rnd() % 9 == 0) tagC("NH", 5); }
     R.rec_off.push_back(o.size());
   }

@@ -12,9 +12,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbramble_amd.so")
 _P = C.POINTER
 
-K_SEGMENT, K_COUNT, K_EMIT, K_PAIR_COUNT, K_PAIR_EMIT, K_GATHER, K_SCAN, K_EMIT_AUX, K_KSW, K_BAM, K_NUM = range(11)
+K_SEGMENT, K_COUNT, K_EMIT, K_PAIR_COUNT, K_PAIR_EMIT, K_GATHER, K_SCAN, K_EMIT_AUX, K_KSW, K_BAM, K_PARSE, K_NUM = range(12)
 KERNEL_NAMES = ["k_segment", "k_project<G,false>", "k_emit_dense", "k_group_ids+k_pair<false>", "k_pair<true>",
-                "k_row_fill+k_group_stats+k_gather", "k_scan_*", "k_expand+k_project<64,true>", "k_ksw", "k_bam_scan+k_bam_size+k_bam_encode"]
+                "k_row_fill+k_group_stats+k_gather", "k_scan_*", "k_expand+k_project<64,true>", "k_ksw", "k_bam_scan+k_bam_size+k_bam_encode",
+                "k_rec_fields+k_group_off+k_rec_copy+k_mates+k_seq_*"]
 
 
 class BrambleError(RuntimeError):
@@ -87,7 +88,16 @@ class BrDeviceRows(C.Structure):
 
 
 class BrDeviceRecords(C.Structure):
-    _fields_ = [("blob", C.c_void_p), ("rec_off", C.c_void_p), ("n_aln", C.c_int64)]
+    _fields_ = [("blob", C.c_void_p), ("rec_off", C.c_void_p), ("n_aln", C.c_int64), ("rec_len", C.c_void_p)]
+
+
+class BrBamBundle(C.Structure):
+    _fields_ = [("blob", C.c_void_p), ("n_bytes", C.c_uint64), ("rec_off", C.c_void_p), ("rec_len", C.c_void_p),
+                ("n_records", C.c_int64), ("ref_map", C.c_void_p), ("n_ref_map", C.c_int32)]
+
+
+class BrHostBam(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("n_bytes", C.c_uint64), ("n_rows", C.c_int64)] + _COUNTERS
 
 
 class BrDeviceBam(C.Structure):
@@ -96,12 +106,25 @@ class BrDeviceBam(C.Structure):
 
 # every symbol include/bramble_amd.h declares
 EXPORTS = ["br_index_build", "br_index_build_flat", "br_index_free", "br_index_num_transcripts", "br_index_transcript_name",
-           "br_index_transcript_len", "br_index_num_intervals", "br_index_device_bytes", "br_config_short_read",
+           "br_index_transcript_len", "br_index_num_refs", "br_index_num_intervals", "br_index_device_bytes", "br_config_short_read",
            "br_config_long_read", "br_config_resolve", "br_batch_prepare", "br_batch_seq_source", "br_ctx_new", "br_ctx_free",
-           "br_project_batch", "br_project_batch_device", "br_project_group", "br_bam_encode_device", "br_ctx_set_profiling",
+           "br_project_batch", "br_project_batch_device", "br_project_group", "br_bam_encode_device", "br_project_bam_device", "br_project_bam_bundle", "br_bam_split", "br_ctx_set_profiling",
            "br_ctx_set_param", "br_ctx_kernel_ms", "br_ctx_collect_counters", "br_ctx_last_counters", "br_ctx_rescue_stats", "br_primary_pick", "br_version", "br_strerror"]
 
 _LIB = None
+
+
+def bam_split(data, cap=None):
+    """Host walk of the block_size chain: numpy uint8 alignment section -> (rec_off uint64[n], rec_len uint32[n],
+    n_unmapped, consumed bytes); unmapped records are skipped."""
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    cap = int(cap if cap is not None else max(data.size // 36 + 1, 1))
+    off = np.zeros(cap, dtype=np.uint64)
+    ln = np.zeros(cap, dtype=np.uint32)
+    n, un, used = C.c_int64(), C.c_int64(), C.c_uint64()
+    check(lib().br_bam_split(data.ctypes.data, data.size, cap, off.ctypes.data, ln.ctypes.data, C.byref(n), C.byref(un),
+                             C.byref(used)), "br_bam_split")
+    return off[:n.value].copy(), ln[:n.value].copy(), un.value, used.value
 
 
 def lib():
@@ -145,6 +168,13 @@ def lib():
         L.br_project_batch_device.argtypes = [C.c_void_p, _P(BrConfig), _P(BrDeviceBatch), C.c_void_p,
                                               _P(BrDeviceRows)]
         L.br_bam_encode_device.argtypes = [C.c_void_p, _P(BrConfig), _P(BrDeviceRecords), C.c_void_p, _P(BrDeviceBam)]
+        L.br_project_bam_device.argtypes = [C.c_void_p, _P(BrConfig), _P(BrDeviceRecords), C.c_void_p, C.c_int32, C.c_void_p,
+                                            _P(BrDeviceRows), _P(BrDeviceBam)]
+        L.br_project_bam_bundle.argtypes = [C.c_void_p, _P(BrConfig), _P(BrBamBundle), _P(BrHostBam)]
+        L.br_bam_split.argtypes = [C.c_void_p, C.c_uint64, C.c_int64, C.c_void_p, C.c_void_p, _P(C.c_int64), _P(C.c_int64),
+                                   _P(C.c_uint64)]
+        L.br_index_num_refs.restype = C.c_size_t
+        L.br_index_num_refs.argtypes = [C.c_void_p]
         L.br_ctx_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.br_ctx_set_param.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
         L.br_ctx_kernel_ms.argtypes = [C.c_void_p, C.c_int, _P(C.c_double), _P(C.c_int32)]
@@ -392,6 +422,37 @@ class Context:
         keys = ("B_in", "B_idx", "B_out", "n_cigar", "read_exons", "overlap_hits", "matches", "out_cigar_words")
         return dict(zip(keys, [int(v) for v in out]))
 
+    def project_bam_device(self, cfg, blob, rec_off, rec_len, ref_map, stream=0):
+        """Raw mapped BAM records resident in HBM -> (BrDeviceRows, BrDeviceBam): reader side, projection and
+        record re-encoding, all on the device.  blob uint8 / rec_off int64 [n] / rec_len int32 [n] are torch CUDA
+        tensors; ref_map is a host int32 array (input refID -> annotation reference index)."""
+        recs = BrDeviceRecords()
+        recs.blob = blob.data_ptr()
+        recs.rec_off = rec_off.data_ptr()
+        recs.n_aln = rec_len.numel()
+        recs.rec_len = rec_len.data_ptr()
+        rm = np.ascontiguousarray(ref_map, dtype=np.int32)
+        rows, out = BrDeviceRows(), BrDeviceBam()
+        check(lib().br_project_bam_device(self.h, C.byref(cfg), C.byref(recs), rm.ctypes.data, len(rm), C.c_void_p(stream),
+                                          C.byref(rows), C.byref(out)), "br_project_bam_device")
+        return rows, out
+
+    def project_bam_bundle(self, cfg, blob, rec_off, rec_len, ref_map):
+        """Host form: numpy blob / rec_off (uint64) / rec_len (uint32) in, (stream uint8[], counters dict) out."""
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        rec_off = np.ascontiguousarray(rec_off, dtype=np.uint64)
+        rec_len = np.ascontiguousarray(rec_len, dtype=np.uint32)
+        rm = np.ascontiguousarray(ref_map, dtype=np.int32)
+        bb = BrBamBundle(blob.ctypes.data, blob.size, rec_off.ctypes.data, rec_len.ctypes.data, len(rec_len),
+                         rm.ctypes.data, len(rm))
+        out = BrHostBam()
+        check(lib().br_project_bam_bundle(self.h, C.byref(cfg), C.byref(bb), C.byref(out)), "br_project_bam_bundle")
+        n = int(out.n_bytes)
+        data = np.ctypeslib.as_array(C.cast(out.data, _P(C.c_uint8)), shape=(n,)).copy() if n else np.zeros(0, np.uint8)
+        return data, {"n_rows": int(out.n_rows), "total_complete": int(out.total_complete),
+                      "total_unique": int(out.total_unique), "dropped_reads": int(out.dropped_reads),
+                      "total_processed": int(out.total_processed)}
+
     def bam_encode_device(self, cfg, blob, rec_off, stream=0):
         """Re-encode every row of the last project_batch_device call as BAM records.
         blob / rec_off: torch CUDA tensors (uint8 record bytes, int64 offsets n_aln+1)."""
@@ -399,6 +460,7 @@ class Context:
         recs.blob = blob.data_ptr()
         recs.rec_off = rec_off.data_ptr()
         recs.n_aln = rec_off.numel() - 1
+        recs.rec_len = None
         out = BrDeviceBam()
         check(lib().br_bam_encode_device(self.h, C.byref(cfg), C.byref(recs), C.c_void_p(stream), C.byref(out)),
               "br_bam_encode_device")

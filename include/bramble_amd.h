@@ -80,6 +80,7 @@ void br_index_free(br_index *);
 size_t br_index_num_transcripts(const br_index *);
 const char *br_index_transcript_name(const br_index *, uint32_t tid); /* NULL if out of range */
 int64_t br_index_transcript_len(const br_index *, uint32_t tid);      /* -1 if out of range */
+size_t br_index_num_refs(const br_index *);
 size_t br_index_num_intervals(const br_index *);                      /* transcript-exon rows */
 size_t br_index_device_bytes(const br_index *);
 
@@ -273,8 +274,9 @@ int br_project_group(br_ctx *, const br_config *, const br_alignment *alns, size
  * (without the 4-byte block_size), record i = blob[rec_off[i] .. rec_off[i+1]). */
 typedef struct br_device_records {
   const uint8_t *blob;
-  const uint64_t *rec_off; /* n_aln + 1 */
+  const uint64_t *rec_off; /* n_aln + 1 (n_aln suffices when rec_len is given) */
   int64_t n_aln;
+  const uint32_t *rec_len; /* n_aln record lengths (the BAM block_size), or NULL: rec_off[i+1]-rec_off[i] */
 } br_device_records;
 
 typedef struct br_device_bam {
@@ -292,6 +294,48 @@ typedef struct br_device_bam {
 int br_bam_encode_device(br_ctx *, const br_config *, const br_device_records *, void *stream,
                          br_device_bam *out);
 
+/* ---- BAM bundle entry: raw alignment records in, raw projected records out ---------------- */
+
+/* Replaces the reader side of process_reads / process_read_in (src/bramble.cpp:313-441: start,
+ * refid, XS/ts strand inputs via GSamRecord::tag_char1, gclib/GSam.cpp:310-318; process_pairs,
+ * src/bramble.cpp:272-311; the name group's shared sequence, src/core.cpp:353-378), then
+ * convert_reads and write_to_bam, for one bundle of raw BAM records that is resident in HBM:
+ * every field is extracted from the records on the device.  Records must be mapped
+ * (process_reads skips unmapped ones, bramble.cpp:376-379), name-collated, and the bundle must
+ * end at a read-name boundary.  ref_map (HOST memory) maps the input header's refID to the
+ * annotation's reference index (position in br_index_build's `refnames`), -1 or any id >= br_index_num_refs for names
+ * the annotation lacks.  rows_out may be NULL. */
+int br_project_bam_device(br_ctx *, const br_config *, const br_device_records *, const int32_t *ref_map,
+                          int32_t n_ref_map, void *stream, br_device_rows *rows_out, br_device_bam *out);
+
+/* Host-memory form of the same call (uploads the records, downloads the stream). */
+typedef struct br_bam_bundle {
+  const uint8_t *blob;      /* uncompressed BAM alignment section */
+  uint64_t n_bytes;
+  const uint64_t *rec_off;  /* n_records: offset of each record's refID word (just after its block_size) */
+  const uint32_t *rec_len;  /* n_records: its block_size */
+  int64_t n_records;
+  const int32_t *ref_map;
+  int32_t n_ref_map;
+} br_bam_bundle;
+
+typedef struct br_host_bam {
+  const uint8_t *data;      /* [block_size][record]... ready for BGZF framing; owned by the context */
+  uint64_t n_bytes;
+  int64_t n_rows;
+  uint64_t total_complete, total_unique, dropped_reads, total_processed;
+} br_host_bam;
+
+int br_project_bam_bundle(br_ctx *, const br_config *, const br_bam_bundle *, br_host_bam *out);
+
+/* Walks the block_size chain of an uncompressed BAM alignment section (host): fills rec_off /
+ * rec_len for up to `cap` MAPPED records (unmapped ones are counted and skipped like
+ * bramble.cpp:376-379) and reports how many bytes were consumed (a trailing partial record is
+ * left for the next call).  BR_ERR_INVALID_ARG on a record whose fixed fields overrun its
+ * block_size. */
+int br_bam_split(const uint8_t *data, uint64_t n_bytes, int64_t cap, uint64_t *rec_off, uint32_t *rec_len,
+                 int64_t *n_records, int64_t *n_unmapped, uint64_t *consumed);
+
 /* ---- measurement hooks ------------------------------------------------------ */
 
 /* Kernel names reported by br_ctx_kernel_ms / rocprof. */
@@ -305,7 +349,8 @@ int br_bam_encode_device(br_ctx *, const br_config *, const br_device_records *,
 #define BR_K_EMIT_AUX 7   /* k_expand + k_project<64,true> (alignments with > 64 candidate rows) */
 #define BR_K_KSW 8        /* k_ksw (-S clip rescue DP) */
 #define BR_K_BAM 9        /* k_bam_scan + k_bam_size + k_bam_encode */
-#define BR_K_NUM 10
+#define BR_K_PARSE 10     /* k_rec_fields + k_group_off + k_rec_copy + k_mates* + k_seq_* */
+#define BR_K_NUM 11
 /* When enabled, every launch is bracketed by hipEvents on the launch stream. */
 int br_ctx_set_profiling(br_ctx *, int enabled);
 /* Launch tuning: "group_lanes" (8|16|32|64 lanes cooperating on one alignment),

@@ -111,8 +111,15 @@ int32_t orc_segments(int32_t ref_start, const uint32_t *cigar, int32_t n_cigar, 
 int32_t orc_resolve_config(const orc_flags *, uint32_t *out5, float *thr_out);
 /* write_to_bam over the rows of a finished run (records: BAM layout from refID on); returns the
  * byte count of the uncompressed BAM stream placed in *out (free with orc_free_buffer) */
-int64_t orc_bam_encode(const orc_result *, const uint8_t *blob, const uint64_t *rec_off, int64_t n_aln,
-                       int32_t long_reads, uint8_t **out);
+int64_t orc_bam_encode(const orc_result *, const uint8_t *blob, const uint64_t *rec_off, const uint32_t *rec_len,
+                       int64_t n_aln, int32_t long_reads, uint8_t **out);
+/* reader side (process_reads / process_read_in, src/bramble.cpp:313-441): raw mapped BAM records ->
+ * the batch orc_run takes.  rec_len may be NULL (records contiguous: rec_off has n + 1 entries). */
+typedef struct orc_parsed orc_parsed;
+orc_parsed *orc_bam_parse(const uint8_t *blob, const uint64_t *rec_off, const uint32_t *rec_len, int64_t n,
+                          const int32_t *ref_map, int32_t n_ref_map);
+const orc_batch *orc_parsed_batch(const orc_parsed *);
+void orc_parsed_free(orc_parsed *);
 void orc_free_buffer(uint8_t *);
 /* primary tie-break: get_rand(n_tied, std::hash<std::string>(name)), src/core.cpp:214-218,298-299 */
 uint32_t orc_primary_pick(const char *name, int64_t len, uint32_t n_tied);

@@ -436,8 +436,24 @@ int32_t orc_resolve_config(const orc_flags *cf, uint32_t *out5, float *thr_out) 
 
 // write_to_bam (src/core.cpp:96-212) over the rows of a finished run: returns the
 // uncompressed BAM stream ([block_size][record] per row) in a malloc'd buffer.
-int64_t orc_bam_encode(const orc_result *res, const uint8_t *blob, const uint64_t *rec_off, int64_t n_aln,
-                       int32_t long_reads, uint8_t **out) {
+struct orc_parsed { ParsedBatch pb; orc_batch view; };
+
+orc_parsed *orc_bam_parse(const uint8_t *blob, const uint64_t *rec_off, const uint32_t *rec_len, int64_t n,
+                          const int32_t *ref_map, int32_t n_ref_map) {
+  orc_parsed *p = new orc_parsed();
+  parse_records(blob, rec_off, rec_len, n, ref_map, n_ref_map, p->pb);
+  ParsedBatch &b = p->pb; orc_batch &v = p->view;
+  v.n_aln = n; v.ref_id = b.ref_id.data(); v.ref_start = b.ref_start.data(); v.flags = b.flags.data();
+  v.xs = b.xs.data(); v.ts = b.ts.data(); v.cigar_off = b.cigar_off.data(); v.cigar = b.cigar.data();
+  v.mate_ref_id = b.mate_ref_id.data(); v.mate_start = b.mate_start.data(); v.name_off = b.name_off.data();
+  v.names = b.names.data(); v.seq_off = b.seq_off.data(); v.seqs = b.seqs.data(); v.l_qseq = b.l_qseq.data();
+  return p;
+}
+const orc_batch *orc_parsed_batch(const orc_parsed *p) { return &p->view; }
+void orc_parsed_free(orc_parsed *p) { delete p; }
+
+int64_t orc_bam_encode(const orc_result *res, const uint8_t *blob, const uint64_t *rec_off, const uint32_t *rec_len,
+                       int64_t n_aln, int32_t long_reads, uint8_t **out) {
   const RowStore &R = res->rows;
   std::vector<Bam1> old((size_t)n_aln);
   std::vector<bool> seen((size_t)n_aln, false);
@@ -446,7 +462,7 @@ int64_t orc_bam_encode(const orc_result *res, const uint8_t *blob, const uint64_
     size_t i = (size_t)R.input_index[r];
     if (!seen[i]) {  // first use of this read: tags go onto the ORIGINAL record (core.cpp:115-124)
       seen[i] = true;
-      old[i] = bam_parse(blob + rec_off[i], (size_t)(rec_off[i + 1] - rec_off[i]));
+      old[i] = bam_parse(blob + rec_off[i], rec_len ? (size_t)rec_len[i] : (size_t)(rec_off[i + 1] - rec_off[i]));
       set_int_tag(old[i], "NH", (int32_t)R.nh[r]);
       del_tag(old[i], long_reads ? "ts" : "XS");
     }

@@ -13,6 +13,7 @@
 #pragma once
 #include <cstdint>
 #include <cstring>
+#include <string>
 #include <vector>
 
 namespace orc {
@@ -158,6 +159,60 @@ static inline void set_mate_info(Bam1 &b, bool is_paired, bool same_transcript, 
   if (own_strand == '-') b.flag |= 0x20;
   if (same_transcript) { b.mtid = b.tid; b.mpos = mate_pos; b.flag |= 0x2; b.isize = isize; }
   else { b.mtid = mate_tid; b.mpos = mate_pos; b.isize = 0; b.flag &= ~0x2; }
+}
+
+
+// ---- reader side: what process_reads / process_read_in take from each record ------------
+// (src/bramble.cpp:313-441; gclib/GSam.h:310-344; tag_char1 gclib/GSam.cpp:310-318).
+// Unmapped records are expected to have been dropped already (bramble.cpp:376-379).
+struct ParsedBatch {
+  std::vector<int32_t> ref_id, ref_start, mate_ref_id, mate_start, l_qseq;
+  std::vector<uint16_t> flags;
+  std::vector<int8_t> xs, ts;
+  std::vector<uint64_t> cigar_off, name_off, seq_off;
+  std::vector<uint32_t> cigar;
+  std::string names, seqs;
+};
+
+static inline char tag_char1(const Bam1 &b, const char tag[2]) {
+  long at = aux_get(b, tag);          // bam_aux_get: the type byte of the first such tag
+  if (at < 0) return 0;
+  char type = (char)b.data[(size_t)at];
+  if (type == 'A' || type == 'Z') return (char)b.data[(size_t)at + 1];
+  return 0;
+}
+
+static inline void parse_records(const uint8_t *blob, const uint64_t *rec_off, const uint32_t *rec_len, int64_t n,
+                                 const int32_t *ref_map, int32_t n_ref_map, ParsedBatch &out) {
+  static const char nt16[] = "=ACMGRSVTWYHKDBN";  // htslib seq_nt16_str
+  out.cigar_off.push_back(0); out.name_off.push_back(0); out.seq_off.push_back(0);
+  for (int64_t i = 0; i < n; i++) {
+    size_t len = rec_len ? rec_len[i] : (size_t)(rec_off[i + 1] - rec_off[i]);
+    Bam1 b = bam_parse(blob + rec_off[i], len);
+    // refid: index of the reference NAME in the annotation's name table (gseqs.addName), handed in as ref_map
+    int32_t ref = (b.tid >= 0 && b.tid < n_ref_map) ? ref_map[b.tid] : -1;
+    int32_t mref = (b.mtid >= 0 && b.mtid < n_ref_map) ? ref_map[b.mtid] : -1;
+    // process_pairs compares the raw header ids (refId() != mate_refId()): keep distinct raw ids distinct
+    if (b.tid != b.mtid && ref == mref) mref = -2 - (b.mtid < 0 ? 0 : b.mtid);
+    out.ref_id.push_back(ref);
+    out.ref_start.push_back(b.pos + 1);                 // GSamRecord::start (1-based)
+    out.mate_ref_id.push_back(mref);
+    out.mate_start.push_back(b.mpos < 0 ? 0 : b.mpos + 1);  // GSam.h:344
+    out.flags.push_back(b.flag);
+    out.l_qseq.push_back(b.l_qseq);
+    out.xs.push_back((int8_t)tag_char1(b, "XS"));
+    out.ts.push_back((int8_t)tag_char1(b, "ts"));
+    for (uint32_t k = 0; k < b.n_cigar; k++) out.cigar.push_back(rd32(b.data.data() + b.cigar_at() + 4 * k));
+    out.cigar_off.push_back(out.cigar.size());
+    out.names.append((const char *)b.data.data(), strnlen((const char *)b.data.data(), b.l_qname));  // bam_get_qname: C string
+    out.name_off.push_back(out.names.size());
+    int32_t ls = b.l_qseq > 0 ? b.l_qseq : 0;
+    for (int32_t k = 0; k < ls; k++) {
+      uint8_t byte = b.data[b.seq_at() + (size_t)(k >> 1)];
+      out.seqs.push_back(nt16[(k & 1) ? (byte & 0xf) : (byte >> 4)]);  // bam_seqi
+    }
+    out.seq_off.push_back(out.seqs.size());
+  }
 }
 
 }  // namespace orc

@@ -124,7 +124,12 @@ def lib():
         L.orc_ksw_align.restype = C.c_int32
         L.orc_ksw_align.argtypes = [C.c_char_p, C.c_char_p, _P(C.c_int32), _P(C.c_int32), C.c_void_p, C.c_int32]
         L.orc_bam_encode.restype = C.c_int64
-        L.orc_bam_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, _P(C.c_void_p)]
+        L.orc_bam_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, _P(C.c_void_p)]
+        L.orc_bam_parse.restype = C.c_void_p
+        L.orc_bam_parse.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32]
+        L.orc_parsed_batch.restype = _P(OrcBatch)
+        L.orc_parsed_batch.argtypes = [C.c_void_p]
+        L.orc_parsed_free.argtypes = [C.c_void_p]
         L.orc_free_buffer.argtypes = [C.c_void_p]
         L.orc_primary_pick.restype = C.c_uint32
         L.orc_primary_pick.argtypes = [C.c_char_p, C.c_int64, C.c_uint32]
@@ -203,7 +208,38 @@ def run(index, flags, batch, n_threads=1, want_matches=True, bam_records=None):
         keep["seqs"] = seqs
         b.seqs = seqs
     b.l_qseq = _ptr(get("l_qseq", np.int32), C.c_int32)
-    h = L.orc_run(index.h, C.byref(flags), C.byref(b), n_threads, 1 if want_matches else 0)
+    return _run_struct(index, flags, C.byref(b), n, n_threads, want_matches, bam_records)
+
+
+def run_bam(index, flags, blob, rec_off, rec_len, ref_map, n_threads=1, want_matches=False):
+    """Reader side + projection + write_to_bam over raw mapped BAM records (blob uint8[], rec_off uint64[n]
+    pointing at each record's refID word, rec_len uint32[n]).  Returns (rows incl. bam_stream, matches, seconds,
+    parsed) where parsed holds the reader-side tables (mate pairing is reported through matches['mate_idx'])."""
+    L = lib()
+    blob = np.ascontiguousarray(blob, dtype=np.uint8)
+    rec_off = np.ascontiguousarray(rec_off, dtype=np.uint64)
+    rec_len = np.ascontiguousarray(rec_len, dtype=np.uint32)
+    ref_map = np.ascontiguousarray(ref_map, dtype=np.int32)
+    n = len(rec_len)
+    ph = L.orc_bam_parse(blob.ctypes.data, rec_off.ctypes.data, rec_len.ctypes.data, n, ref_map.ctypes.data, len(ref_map))
+    try:
+        bp = L.orc_parsed_batch(ph)
+        v = bp.contents
+        parsed = {"n_aln": n}
+        for name, dt in (("ref_id", np.int32), ("ref_start", np.int32), ("flags", np.uint16), ("xs", np.int8),
+                         ("ts", np.int8), ("mate_ref_id", np.int32), ("mate_start", np.int32), ("l_qseq", np.int32)):
+            parsed[name] = _arr(getattr(v, name), n, dt)
+        parsed["cigar_off"] = _arr(v.cigar_off, n + 1, np.uint64)
+        parsed["name_off"] = _arr(v.name_off, n + 1, np.uint64)
+        rows, matches, secs = _run_struct(index, flags, bp, n, n_threads, want_matches, (blob, rec_off, rec_len))
+    finally:
+        L.orc_parsed_free(ph)
+    return rows, matches, secs, parsed
+
+
+def _run_struct(index, flags, bref, n, n_threads, want_matches, bam_records):
+    L = lib()
+    h = L.orc_run(index.h, flags if isinstance(flags, C._Pointer) else C.byref(flags), bref, n_threads, 1 if want_matches else 0)
     try:
         r = L.orc_result_rows(h).contents
         nr = r.n_rows
@@ -241,8 +277,11 @@ def run(index, flags, batch, n_threads=1, want_matches=True, bam_records=None):
             blob = np.ascontiguousarray(bam_records[0], dtype=np.uint8)
             roff = np.ascontiguousarray(bam_records[1], dtype=np.uint64)
             outp = C.c_void_p()
-            nb = L.orc_bam_encode(h, blob.ctypes.data, roff.ctypes.data, n, 1 if (flags.lr or flags.lr_hq) else 0,
-                                  C.byref(outp))
+            rlen = None
+            if len(bam_records) > 2 and bam_records[2] is not None:
+                rlen = np.ascontiguousarray(bam_records[2], dtype=np.uint32)
+            nb = L.orc_bam_encode(h, blob.ctypes.data, roff.ctypes.data, rlen.ctypes.data if rlen is not None else None,
+                                  n, 1 if (flags.lr or flags.lr_hq) else 0, C.byref(outp))
             buf = (C.c_char * max(nb, 1)).from_address(outp.value)
             rows["bam_stream"] = np.frombuffer(buf, dtype=np.uint8, count=nb).copy()
             L.orc_free_buffer(outp)

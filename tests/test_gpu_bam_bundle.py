@@ -1,0 +1,181 @@
+"""Scope-table row f-1 (BAM bundle entry): raw BAM records in, raw projected records out, everything between on
+the device -- against the oracle's restatement of the reader side (process_reads / process_read_in /
+process_pairs), convert_reads and write_to_bam.  Streams must be byte-identical."""
+import numpy as np
+import pytest
+
+from bramble_amd import lib, synth
+from oracle import oracle_binding as ob
+
+pytestmark = pytest.mark.gpu
+
+
+def framed_stream(b, unmapped_every=0):
+    """synth records (BAM layout from refID on, contiguous) -> uncompressed BAM alignment section
+    [block_size][record]..., optionally with unmapped copies sprinkled in (process_reads skips those)."""
+    blob = np.asarray(b["rec_blob"], dtype=np.uint8)
+    off = np.asarray(b["rec_off"], dtype=np.uint64)
+    out = bytearray()
+    n = len(off) - 1
+    for i in range(n):
+        rec = blob[int(off[i]):int(off[i + 1])].tobytes()
+        if unmapped_every and i % unmapped_every == 0:
+            un = bytearray(rec)
+            flag = un[14] | (un[15] << 8) | 0x4
+            un[14], un[15] = flag & 0xff, flag >> 8
+            out += len(un).to_bytes(4, "little") + bytes(un)
+        out += len(rec).to_bytes(4, "little") + rec
+    return np.frombuffer(bytes(out), dtype=np.uint8)
+
+
+def run_both_bam(ann, stream, ref_map, **flags):
+    roff, rlen, n_un, used = lib.bam_split(stream)
+    assert used == stream.size
+    idx = lib.Index(ann, device=0)
+    ctx = lib.Context(idx)
+    got, counters = ctx.project_bam_bundle(lib.make_config(**flags), stream, roff, rlen, ref_map)
+    ctx.close()
+    idx.close()
+    orc, _, _, parsed = ob.run_bam(ob.OracleIndex(ann), ob.make_flags(**flags), stream, roff, rlen, ref_map)
+    return got, counters, orc, n_un
+
+
+def assert_streams_equal(got, exp):
+    assert len(got) == len(exp)
+    if not np.array_equal(got, exp):
+        bad = int(np.nonzero(got != exp)[0][0])
+        raise AssertionError("BAM streams differ first at byte %d of %d" % (bad, len(exp)))
+
+
+@pytest.mark.parametrize("mode,flags,kw", [("pe", {}, {"xs_tag": True}), ("pe", {}, {}), ("pe", {"fr": 1}, {}),
+                                           ("se", {"strict": 1}, {}), ("hifi", {"lr_hq": 1}, {}), ("ont", {"lr": 1}, {})])
+def test_bam_bundle_matches_oracle(mode, flags, kw):
+    ann = synth.Annotation("G", n_genes=1500, n_refs=3)
+    b = ann.reads(8000, mode, with_records=1, **kw)
+    stream = framed_stream(b, unmapped_every=97)
+    got, counters, orc, n_un = run_both_bam(ann.as_dict(), stream, np.arange(3, dtype=np.int32), **flags)
+    assert n_un > 0 and orc["n_rows"] > 5000
+    assert counters["n_rows"] == orc["n_rows"]
+    for k in ("total_complete", "total_unique", "dropped_reads", "total_processed"):
+        assert counters[k] == orc[k], k
+    assert_streams_equal(got, orc["bam_stream"])
+
+
+def test_bam_bundle_reader_side_equals_flat_batch():
+    """The oracle fed with raw records and the oracle fed with the generator's flat batch agree: the synthetic
+    records carry the same alignments as the SoA tables the other parity tests use."""
+    ann = synth.Annotation("G", n_genes=800, n_refs=3)
+    b = ann.reads(4000, "pe", with_records=1, xs_tag=True)
+    stream = framed_stream(b)
+    roff, rlen, _, _ = lib.bam_split(stream)
+    oi = ob.OracleIndex(ann.as_dict())
+    r1, _, _, _ = ob.run_bam(oi, ob.make_flags(), stream, roff, rlen, np.arange(3, dtype=np.int32))
+    r2, _, _ = ob.run(oi, ob.make_flags(), b, want_matches=False, bam_records=(b["rec_blob"], b["rec_off"]))
+    assert np.array_equal(r1["bam_stream"], r2["bam_stream"])
+
+
+def test_bam_bundle_clip_rescue_reads_sequence_from_records():
+    """-S: the query bases come from the records' 4-bit SEQ (k_seq_src / k_seq_ascii)."""
+    ann = synth.Annotation("G", n_genes=300, n_refs=2, with_genome=True)
+    b = ann.reads(3000, "ont", with_seq=1, with_records=1)
+    stream = framed_stream(b)
+    got, counters, orc, _ = run_both_bam(ann.as_dict(), stream, np.arange(2, dtype=np.int32), lr=1, use_fasta=1)
+    assert (orc["clip_score"] != 0).sum() > 500
+    assert_streams_equal(got, orc["bam_stream"])
+
+
+def test_bam_bundle_reference_names_the_annotation_lacks():
+    """Input references that are not in the annotation map to ids without intervals: their records vanish
+    (g2tTree::getGuideExons returns false for an unknown refid, src/g2t.cpp:334-344)."""
+    ann = synth.Annotation("G", n_genes=800, n_refs=3)
+    b = ann.reads(3000, "pe", with_records=1)
+    stream = framed_stream(b)
+    ref_map = np.array([0, -1, 7], dtype=np.int32)   # ref 1 unknown, ref 2 -> id past the annotation's table
+    got, counters, orc, _ = run_both_bam(ann.as_dict(), stream, ref_map)
+    assert 0 < orc["n_rows"]
+    assert_streams_equal(got, orc["bam_stream"])
+
+
+def _record(name, ref, pos0, flag, cigar, mref, mpos0, seq_len):
+    ops = "MIDNSHP=X"
+    cg = []
+    num = ""
+    for ch in cigar:
+        if ch.isdigit():
+            num += ch
+        else:
+            cg.append((int(num) << 4) | ops.index(ch))
+            num = ""
+    nm = name.encode() + b"\0"
+    body = bytearray()
+    body += int(ref).to_bytes(4, "little", signed=True) + int(pos0).to_bytes(4, "little", signed=True)
+    body += bytes([len(nm), 60]) + (4680).to_bytes(2, "little") + len(cg).to_bytes(2, "little") + int(flag).to_bytes(2, "little")
+    body += int(seq_len).to_bytes(4, "little") + int(mref).to_bytes(4, "little", signed=True)
+    body += int(mpos0).to_bytes(4, "little", signed=True) + (0).to_bytes(4, "little")
+    body += nm
+    for w in cg:
+        body += int(w).to_bytes(4, "little")
+    body += bytes([0x12] * ((seq_len + 1) // 2)) + bytes([30] * seq_len)
+    body += b"NMC\x00"
+    return len(body).to_bytes(4, "little") + bytes(body)
+
+
+def test_bam_bundle_large_name_group_pairs_like_the_hash_map():
+    """One read name with several hundred multi-mapping pair records (k_mates_big: wave-wide open-set search) next to
+    small groups, including duplicate positions (a later record overwrites the map entry of an earlier one)."""
+    txs = [{"id": "t%d" % t, "ref_id": 0, "strand": "+", "exons": [[1000 + 7 * t, 1400 + 7 * t], [2000, 2300]]}
+           for t in range(40)]
+    ann = {"refnames": ["chr1"], "transcripts": txs}
+    rng = np.random.RandomState(11)
+    out = bytearray()
+    # big group: 150 pairs, mates listed in a shuffled order, some positions duplicated
+    pairs = []
+    for k in range(150):
+        p1 = 1000 + int(rng.randint(0, 60))
+        p2 = 1200 + int(rng.randint(0, 60))
+        pairs.append((p1, p2))
+    recs = []
+    for p1, p2 in pairs:
+        recs.append(("big", p1, 0x1 | 0x40 | 0x20, p2))
+        recs.append(("big", p2, 0x1 | 0x80 | 0x10, p1))
+    order = rng.permutation(len(recs))
+    for i in order:
+        name, pos, flag, mpos = recs[int(i)]
+        out += _record(name, 0, pos, flag, "50M", 0, mpos, 50)
+    # small groups
+    for g in range(200):
+        p1 = 1000 + int(rng.randint(0, 100))
+        p2 = 1150 + int(rng.randint(0, 100))
+        out += _record("s%d" % g, 0, p1, 0x1 | 0x40 | 0x20, "50M", 0, p2, 50)
+        if g % 9 == 0:   # duplicate of read1 at the same position: overwrites the map entry
+            out += _record("s%d" % g, 0, p1, 0x1 | 0x40 | 0x20 | 0x100, "50M", 0, p2, 50)
+        out += _record("s%d" % g, 0, p2, 0x1 | 0x80 | 0x10, "50M", 0, p1, 50)
+    stream = np.frombuffer(bytes(out), dtype=np.uint8)
+    got, counters, orc, _ = run_both_bam(ann, stream, np.array([0], dtype=np.int32))
+    assert orc["n_rows"] > 1000
+    assert_streams_equal(got, orc["bam_stream"])
+
+
+def test_bam_split_stops_at_partial_record_and_rejects_garbage():
+    ann = synth.Annotation("G", n_genes=200, n_refs=2)
+    b = ann.reads(500, "pe", with_records=1)
+    stream = framed_stream(b)
+    roff, rlen, _, used = lib.bam_split(stream[:-5])
+    full_off, full_len, _, full_used = lib.bam_split(stream)
+    assert len(roff) == len(full_off) - 1 and used == int(full_off[-1]) - 4
+    assert full_used == stream.size
+    bad = stream.copy()
+    bad[0:4] = np.frombuffer((7).to_bytes(4, "little"), dtype=np.uint8)   # block_size < 32
+    with pytest.raises(lib.BrambleError):
+        lib.bam_split(bad)
+
+
+def test_bam_bundle_empty():
+    idx = lib.Index({"refnames": ["chr1"], "transcripts": [{"id": "t", "ref_id": 0, "strand": "+", "exons": [[10, 50]]}]},
+                    device=0)
+    ctx = lib.Context(idx)
+    got, counters = ctx.project_bam_bundle(lib.make_config(), np.zeros(0, np.uint8), np.zeros(0, np.uint64),
+                                           np.zeros(0, np.uint32), np.array([0], np.int32))
+    assert got.size == 0 and counters["n_rows"] == 0
+    ctx.close()
+    idx.close()
