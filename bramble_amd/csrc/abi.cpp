@@ -389,7 +389,7 @@ struct br_ctx {
   DevBuf m_tid, m_aux, m_a, m_b, m_cigoff, cig_arena, big_list, n_big, m_aln;
   DevBuf bam_aux, bam_len, bam_off, bam_out;
   DevBuf p_ncig, p_name_len, p_isnew, p_group_pre, p_small, p_big, p_seq_len, p_ref_map, p_blob, p_rec_off, p_rec_len;
-  uint8_t *h_bam = nullptr; size_t h_bam_cap = 0;  // pinned download buffer of br_project_bam_bundle
+  uint8_t *h_bam[2] = {nullptr, nullptr}; size_t h_bam_cap[2] = {0, 0}; int h_bam_next = 0;  // pinned download buffers of br_project_bam_bundle (alternating)
   int64_t last_n_rows = 0, last_n_aln = 0;
   DevBuf fa_stats, fa_n_prob, fa_seq_bytes, fa_prob_off, fa_seqarena_off, fa_probs, fa_results, fa_seq_arena, fa_clip_ops,
       fa_ideal_cap, fa_scratch, b_seq_off, b_seqs, b_seq_src;
@@ -447,7 +447,7 @@ extern "C" void br_ctx_free(br_ctx *c) {
   for (DevBuf *b : bufs) b->release();
   for (auto &e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if (c->h_totals) (void)hipHostFree(c->h_totals);
-  if (c->h_bam) (void)hipHostFree(c->h_bam);
+  for (int k = 0; k < 2; k++) if (c->h_bam[k]) (void)hipHostFree(c->h_bam[k]);
   delete c;
 }
 
@@ -1003,15 +1003,16 @@ extern "C" int br_project_bam_bundle(br_ctx *c, const br_config *cfg, const br_b
   br_device_records dr{c->p_blob.as<uint8_t>(), c->p_rec_off.as<uint64_t>(), n, c->p_rec_len.as<uint32_t>()};
   br_device_rows rows; br_device_bam db;
   RC(br_project_bam_device(c, cfg, &dr, bb->ref_map, bb->n_ref_map, st, &rows, &db));
-  if (db.n_bytes > c->h_bam_cap) {
-    if (c->h_bam) { HIPCHK(hipHostFree(c->h_bam)); c->h_bam = nullptr; c->h_bam_cap = 0; }
+  int slot = c->h_bam_next; c->h_bam_next ^= 1;
+  if (db.n_bytes > c->h_bam_cap[slot]) {
+    if (c->h_bam[slot]) { HIPCHK(hipHostFree(c->h_bam[slot])); c->h_bam[slot] = nullptr; c->h_bam_cap[slot] = 0; }
     size_t want = (size_t)db.n_bytes + (size_t)db.n_bytes / 4 + 4096;
-    HIPCHK(hipHostMalloc((void **)&c->h_bam, want, hipHostMallocDefault));
-    c->h_bam_cap = want;
+    HIPCHK(hipHostMalloc((void **)&c->h_bam[slot], want, hipHostMallocDefault));
+    c->h_bam_cap[slot] = want;
   }
-  if (db.n_bytes) HIPCHK(hipMemcpyAsync(c->h_bam, db.data, (size_t)db.n_bytes, hipMemcpyDeviceToHost, st));
+  if (db.n_bytes) HIPCHK(hipMemcpyAsync(c->h_bam[slot], db.data, (size_t)db.n_bytes, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
-  out->data = c->h_bam; out->n_bytes = db.n_bytes; out->n_rows = db.n_rows;
+  out->data = c->h_bam[slot]; out->n_bytes = db.n_bytes; out->n_rows = db.n_rows;
   out->total_complete = rows.total_complete; out->total_unique = rows.total_unique;
   out->dropped_reads = rows.dropped_reads; out->total_processed = rows.total_processed;
   return BR_OK;

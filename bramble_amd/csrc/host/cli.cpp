@@ -1,0 +1,379 @@
+// The bramble command line on top of the C ABI (scope table rows f-1 / f-3 / f-4): same flags as the
+// reference's CLI11 front-end (src/bramble.cpp:443-485), same output header layout
+// (src/bramble.cpp:513-623), same final report (src/bramble.cpp:727-736).
+//
+//   reader thread : BGZF inflate (threaded) -> record boundaries -> bundles cut at a read-name change
+//                   (process_reads, src/bramble.cpp:330-441; a bundle here is millions of records, the
+//                   result does not depend on where a name-collated stream is cut)
+//   main thread   : br_project_bam_bundle (everything between the raw records on the device)
+//   writer thread : BGZF deflate (threaded) -> output file
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <zlib.h>
+
+#include <chrono>
+#include <condition_variable>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "../../../include/bramble_amd.h"
+#include "bgzf.h"
+
+#define BRAMBLE_REF_VERSION "0.1.6"  // src/bramble.cpp:35
+
+namespace {
+
+using brio::BgzfReader;
+using brio::BgzfWriter;
+
+struct Options {
+  std::string in_bam, out_bam, gff, fasta;
+  br_config cfg;
+  int threads = 1, level = 6, device = 0;
+  int64_t bundle_records = 2000000;
+  bool quiet = false;
+};
+
+void usage(FILE *f) {
+  fprintf(f,
+          "bramble (MI355X) usage:\n\n"
+          "bramble <in.bam> -G <annotation.gtf> -o <out.bam> [-p <cpus>] [-S <genome.fa>]\n"
+          " [--help] [--version] [--quiet] [--fr] [--rf] [--lr] [--lr-hq] [--strict]\n"
+          " [--max-soft-clip N] [--max-junction-insertion N] [--max-junction-deletion N]\n"
+          " [--max-error-exon N] [--similarity-threshold X]\n"
+          " [--compression-level 0-9] [--bundle-size N] [--device N]\n\n"
+          "Project spliced genomic alignments into transcriptomic space.\n");
+}
+
+bool parse_u32(const char *s, uint32_t &v) { char *e; unsigned long x = strtoul(s, &e, 10); if (e == s || *e) return false; v = (uint32_t)x; return true; }
+
+// returns 0 to continue, 1 to exit(0), <0 on error
+int parse_args(int argc, char **argv, Options &o) {
+  memset(&o.cfg, 0, sizeof(o.cfg));
+  o.cfg.junc_miss_discount = 1.0;
+  auto need = [&](int &i) -> const char * { if (i + 1 >= argc) { fprintf(stderr, "%s: missing value\n", argv[i]); return nullptr; } return argv[++i]; };
+  for (int i = 1; i < argc; i++) {
+    std::string a = argv[i];
+    std::string val; bool has_eq = false;
+    if (a.rfind("--", 0) == 0) { size_t eq = a.find('='); if (eq != std::string::npos) { val = a.substr(eq + 1); a = a.substr(0, eq); has_eq = true; } }
+    auto value = [&]() -> const char * { if (has_eq) return val.c_str(); return need(i); };
+    if (a == "--help" || a == "-h") { usage(stdout); return 1; }
+    else if (a == "--version" || a == "-V") { printf("version: %s (bramble_amd %s)\n", BRAMBLE_REF_VERSION, br_version()); return 1; }
+    else if (a == "--quiet") o.quiet = true;
+    else if (a == "--fr") o.cfg.fr = 1;
+    else if (a == "--rf") o.cfg.rf = 1;
+    else if (a == "--lr") o.cfg.lr = 1;
+    else if (a == "--lr-hq") o.cfg.lr_hq = 1;
+    else if (a == "--strict") o.cfg.strict = 1;
+    else if (a == "--max-soft-clip") { const char *v = value(); if (!v || !parse_u32(v, o.cfg.max_clip)) return -1; o.cfg.has_max_clip = 1; }
+    else if (a == "--max-junction-insertion") { const char *v = value(); if (!v || !parse_u32(v, o.cfg.max_junc_ins)) return -1; o.cfg.has_max_junc_ins = 1; }
+    else if (a == "--max-junction-deletion") { const char *v = value(); if (!v || !parse_u32(v, o.cfg.max_junc_gap)) return -1; o.cfg.has_max_junc_gap = 1; }
+    else if (a == "--max-error-exon") { const char *v = value(); if (!v || !parse_u32(v, o.cfg.max_error_exon)) return -1; o.cfg.has_max_error_exon = 1; }
+    else if (a == "--similarity-threshold") { const char *v = value(); if (!v) return -1; o.cfg.sim_thr = strtof(v, nullptr); o.cfg.has_sim_thr = 1; }
+    else if (a == "-G" || a == "--guide") { const char *v = value(); if (!v) return -1; o.gff = v; }
+    else if (a == "-S" || a == "--genome") { const char *v = value(); if (!v) return -1; o.fasta = v; }
+    else if (a == "-o" || a == "--out") { const char *v = value(); if (!v) return -1; o.out_bam = v; }
+    else if (a == "-p") { const char *v = value(); if (!v) return -1; o.threads = atoi(v); if (o.threads < 1) o.threads = 1; }
+    else if (a == "--compression-level") { const char *v = value(); if (!v) return -1; o.level = atoi(v); if (o.level < 0 || o.level > 9) return -1; }
+    else if (a == "--bundle-size") { const char *v = value(); if (!v) return -1; o.bundle_records = atoll(v); if (o.bundle_records < 1) return -1; }
+    else if (a == "--device") { const char *v = value(); if (!v) return -1; o.device = atoi(v); }
+    else if (!a.empty() && a[0] == '-' && a != "-") { fprintf(stderr, "unknown option %s\n", a.c_str()); return -1; }
+    else if (o.in_bam.empty()) o.in_bam = a;
+    else { fprintf(stderr, "unexpected argument %s\n", a.c_str()); return -1; }
+  }
+  if (o.in_bam.empty()) { fprintf(stderr, "in.bam is required\n"); return -1; }
+  if (o.out_bam.empty()) { fprintf(stderr, "--out is required\n"); return -1; }
+  if (o.gff.empty()) { fprintf(stderr, "--guide is required\n"); return -1; }
+  if (!o.fasta.empty()) o.cfg.use_fasta = 1;
+  return 0;
+}
+
+// ---- FASTA (plain or gzip): name = first word of the '>' line ---------------------------------
+struct Fasta { std::vector<std::string> names, seqs; };
+bool load_fasta(const char *path, Fasta &fa) {
+  gzFile f = gzopen(path, "rb");
+  if (!f) return false;
+  gzbuffer(f, 1 << 20);
+  std::vector<char> buf(1 << 16);
+  while (gzgets(f, buf.data(), (int)buf.size())) {
+    char *s = buf.data();
+    size_t n = strlen(s);
+    bool full = n && s[n - 1] == '\n';
+    while (n && (s[n - 1] == '\n' || s[n - 1] == '\r')) n--;
+    if (s[0] == '>') {
+      size_t e = 1; while (e < n && s[e] != ' ' && s[e] != '\t') e++;
+      fa.names.emplace_back(s + 1, e - 1); fa.seqs.emplace_back();
+      while (!full && gzgets(f, buf.data(), (int)buf.size())) { size_t m = strlen(buf.data()); full = m && buf[m - 1] == '\n'; }
+    } else if (!fa.seqs.empty()) fa.seqs.back().append(s, n);
+  }
+  gzclose(f);
+  return true;
+}
+
+// ---- BAM header ---------------------------------------------------------------------------------
+struct BamHeader { std::string text; std::vector<std::string> ref_names; std::vector<uint32_t> ref_lens; };
+
+// consumes the header from the front of `buf` (reading more as needed); false on a malformed file
+bool read_header(BgzfReader &rd, std::vector<uint8_t> &buf, size_t &pos, BamHeader &h, std::string &err) {
+  auto need = [&](size_t n) -> bool {
+    while (buf.size() - pos < n) { int64_t got = rd.read(buf, 1 << 20); if (got < 0) { err = rd.error(); return false; } if (got == 0) { err = "truncated BAM header"; return false; } }
+    return true;
+  };
+  auto u32 = [&](size_t at) { uint32_t v; memcpy(&v, buf.data() + at, 4); return v; };
+  if (!need(12)) return false;
+  if (memcmp(buf.data() + pos, "BAM\1", 4) != 0) { err = "not a BAM file (bad magic)"; return false; }
+  uint32_t l_text = u32(pos + 4);
+  if (!need(12 + (size_t)l_text)) return false;
+  h.text.assign((const char *)buf.data() + pos + 8, l_text);
+  while (!h.text.empty() && h.text.back() == '\0') h.text.pop_back();
+  size_t p = pos + 8 + l_text;
+  uint32_t n_ref = u32(p); p += 4;
+  for (uint32_t r = 0; r < n_ref; r++) {
+    if (!need(p - pos + 4)) return false;
+    uint32_t l_name = u32(p); p += 4;
+    if (!need(p - pos + l_name + 4)) return false;
+    h.ref_names.emplace_back((const char *)buf.data() + p, l_name ? l_name - 1 : 0); p += l_name;
+    h.ref_lens.push_back(u32(p)); p += 4;
+  }
+  pos = p;
+  return true;
+}
+
+// src/bramble.cpp:513-623: @HD first, one @SQ per transcript in guide order, then every other input
+// line except @SQ / @HD (with the new @PG appended the way sam_hdr_add_pg chains it), then the @CO line.
+std::string make_header_text(const std::string &in_text, const br_index *ix, const std::string &cl, const std::string &gff) {
+  std::vector<std::string> lines;
+  for (size_t a = 0; a < in_text.size();) { size_t b = in_text.find('\n', a); if (b == std::string::npos) b = in_text.size(); if (b > a) lines.emplace_back(in_text, a, b - a); a = b + 1; }
+  std::string out;
+  for (auto &l : lines) if (l.compare(0, 3, "@HD") == 0) { out += l; out += '\n'; }
+  size_t nt = br_index_num_transcripts(ix);
+  for (size_t t = 0; t < nt; t++) {
+    int64_t len = br_index_transcript_len(ix, (uint32_t)t);
+    if (len > 0) { out += "@SQ\tSN:"; out += br_index_transcript_name(ix, (uint32_t)t); out += "\tLN:"; out += std::to_string(len); out += '\n'; }
+  }
+  // @PG chain ends: ids no other @PG names as its PP (htslib sam_hdr_add_pg links the new record to each)
+  std::vector<std::string> pg_ids, pg_pp;
+  auto field = [](const std::string &l, const char *key) -> std::string {
+    size_t p = 0;
+    while ((p = l.find('\t', p)) != std::string::npos) { p++; if (l.compare(p, 3, key) == 0) { size_t e = l.find('\t', p); return l.substr(p + 3, e == std::string::npos ? std::string::npos : e - p - 3); } }
+    return "";
+  };
+  for (auto &l : lines) if (l.compare(0, 3, "@PG") == 0) { pg_ids.push_back(field(l, "ID:")); pg_pp.push_back(field(l, "PP:")); }
+  std::vector<std::string> ends;
+  for (auto &id : pg_ids) { bool used = false; for (auto &pp : pg_pp) if (pp == id) used = true; if (!used && !id.empty()) ends.push_back(id); }
+  for (auto &l : lines) if (l.compare(0, 3, "@SQ") != 0 && l.compare(0, 3, "@HD") != 0) { out += l; out += '\n'; }
+  auto unique_id = [&](int &serial) { for (;;) { std::string id = serial ? "bramble." + std::to_string(serial) : "bramble"; serial++; bool clash = false; for (auto &x : pg_ids) if (x == id) clash = true; if (!clash) { pg_ids.push_back(id); return id; } } };
+  int serial = 0;
+  auto pg_line = [&](const std::string &pp) {
+    std::string l = "@PG\tID:" + unique_id(serial) + "\tPN:bramble";
+    if (!pp.empty()) l += "\tPP:" + pp;
+    l += "\tVN:" BRAMBLE_REF_VERSION "+amd." + std::string(br_version()) + "\tCL:" + cl + "\n";
+    return l;
+  };
+  if (ends.empty()) out += pg_line("");
+  else for (auto &e : ends) out += pg_line(e);
+  out += "@CO\tGenerated from GTF: " + gff + "\n";
+  return out;
+}
+
+std::vector<uint8_t> make_bam_header(const std::string &text, const br_index *ix) {
+  std::vector<uint8_t> o;
+  auto p32 = [&](uint32_t v) { for (int k = 0; k < 4; k++) o.push_back((uint8_t)(v >> (8 * k))); };
+  o.insert(o.end(), {'B', 'A', 'M', 1});
+  p32((uint32_t)text.size()); o.insert(o.end(), text.begin(), text.end());
+  size_t nt = br_index_num_transcripts(ix);
+  uint32_t n_sq = 0;
+  for (size_t t = 0; t < nt; t++) if (br_index_transcript_len(ix, (uint32_t)t) > 0) n_sq++;
+  p32(n_sq);
+  for (size_t t = 0; t < nt; t++) {
+    int64_t len = br_index_transcript_len(ix, (uint32_t)t);
+    if (len <= 0) continue;
+    const char *nm = br_index_transcript_name(ix, (uint32_t)t);
+    uint32_t l = (uint32_t)strlen(nm) + 1;
+    p32(l); o.insert(o.end(), nm, nm + l); p32((uint32_t)len);
+  }
+  return o;
+}
+
+// ---- bounded single-slot hand-off between pipeline stages ---------------------------------------
+template <typename T>
+struct Slot {
+  std::mutex m; std::condition_variable cv; std::unique_ptr<T> item; bool done = false;
+  void put(std::unique_ptr<T> v) { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return !item; }); item = std::move(v); cv.notify_all(); }
+  void finish() { std::unique_lock<std::mutex> l(m); done = true; cv.notify_all(); }
+  std::unique_ptr<T> take() { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return item || done; }); auto v = std::move(item); cv.notify_all(); return v; }
+  // consumer that keeps the slot occupied while it works on the item: put() of the next one waits for release()
+  T *hold() { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return item || done; }); return item.get(); }
+  void release() { std::unique_lock<std::mutex> l(m); item.reset(); cv.notify_all(); }
+};
+
+struct Bundle { std::vector<uint8_t> blob; std::vector<uint64_t> off; std::vector<uint32_t> len; };
+struct OutChunk { const uint8_t *data; uint64_t n; };
+
+const uint8_t *rec_name(const std::vector<uint8_t> &b, uint64_t off, uint32_t &l) { l = b[off + 8]; return b.data() + off + 32; }
+
+}  // namespace
+
+extern "C" int br_cli_main(int argc, char **argv) {
+  Options o;
+  int prc = parse_args(argc, argv, o);
+  if (prc > 0) return 0;
+  if (prc < 0) { usage(stderr); return 2; }
+  std::string cl;
+  for (int i = 0; i < argc; i++) { if (i) cl += ' '; cl += argv[i]; }
+  auto t_start = std::chrono::steady_clock::now();
+  auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
+  if (!o.quiet) { printf("\n[bramble] starting version: %s (bramble_amd %s)\n", BRAMBLE_REF_VERSION, br_version()); printf("[bramble] loading reference annotation...\n"); }
+
+  br_annotation *ann = nullptr;
+  int rc = br_annotation_load(o.gff.c_str(), &ann);
+  if (rc) { fprintf(stderr, "error: could not load reference annotation %s: %s\n", o.gff.c_str(), br_strerror(rc)); return 1; }
+  size_t n_tx = br_annotation_num_transcripts(ann), n_refs = br_annotation_num_refs(ann);
+  const char *const *refnames = br_annotation_refnames(ann);
+  Fasta fa;
+  std::vector<br_fasta_seq> fseqs;
+  if (o.cfg.use_fasta) {
+    if (!load_fasta(o.fasta.c_str(), fa)) { fprintf(stderr, "error: could not open genome %s\n", o.fasta.c_str()); return 1; }
+    for (size_t i = 0; i < fa.names.size(); i++) fseqs.push_back({fa.names[i].c_str(), fa.seqs[i].data(), fa.seqs[i].size()});
+  }
+  if (!o.quiet) {
+    printf("[bramble] reference annotation loaded! %zu unique transcripts were found (%.1fs)\n", n_tx, since());
+    if (o.cfg.lr) printf("[bramble] using long-read mode (--lr)\n");
+    else if (o.cfg.lr_hq) printf("[bramble] using long-read mode (--lr-hq)\n");
+    else printf("[bramble] using short-read mode (have long reads? try running with --lr or --lr-hq)\n");
+    printf("[bramble] building g2t index\n");
+  }
+  br_index *ix = nullptr;
+  rc = br_index_build(br_annotation_transcripts(ann), n_tx, refnames, n_refs, fseqs.empty() ? nullptr : fseqs.data(), fseqs.size(),
+                      o.device, &ix);
+  if (rc) { fprintf(stderr, "error: index build failed: %s\n", br_strerror(rc)); br_annotation_free(ann); return 1; }
+  fa = Fasta();  // the index holds the exon sequences now
+  br_ctx *ctx = nullptr;
+  rc = br_ctx_new(ix, &ctx);
+  if (rc) { fprintf(stderr, "error: %s\n", br_strerror(rc)); br_index_free(ix); br_annotation_free(ann); return 1; }
+
+  BgzfReader rd;
+  if (!rd.open(o.in_bam.c_str(), o.threads)) { fprintf(stderr, "error: %s\n", rd.error().c_str()); return 1; }
+  std::vector<uint8_t> buf; size_t pos = 0;
+  BamHeader hdr; std::string err;
+  if (!read_header(rd, buf, pos, hdr, err)) { fprintf(stderr, "error: %s: %s\n", o.in_bam.c_str(), err.c_str()); return 1; }
+  // input refID -> annotation reference index; names the annotation lacks get ids past its table
+  // (gseqs.addName, src/bramble.cpp:384: a new id with no interval tree behind it)
+  std::unordered_map<std::string, int32_t> ref_of;
+  for (size_t r = 0; r < n_refs; r++) ref_of.emplace(refnames[r], (int32_t)r);
+  std::vector<int32_t> ref_map(hdr.ref_names.size());
+  int32_t extra = (int32_t)n_refs;
+  for (size_t r = 0; r < hdr.ref_names.size(); r++) { auto it = ref_of.find(hdr.ref_names[r]); ref_map[r] = it != ref_of.end() ? it->second : extra++; }
+
+  BgzfWriter wr;
+  if (!wr.open(o.out_bam.c_str(), o.threads, o.level)) { fprintf(stderr, "error: %s\n", wr.error().c_str()); return 1; }
+  {
+    std::vector<uint8_t> h = make_bam_header(make_header_text(hdr.text, ix, cl, o.gff), ix);
+    if (!wr.write(h.data(), h.size()) ) { fprintf(stderr, "error: %s\n", wr.error().c_str()); return 1; }
+  }
+  if (!o.quiet) printf("[bramble] processing alignments :-)\n");
+
+  Slot<Bundle> to_gpu; Slot<OutChunk> to_writer;
+  uint64_t total_reads = 0, unmapped_reads = 0;
+  std::string reader_err, writer_err;
+
+  std::thread reader([&]() {
+    buf.erase(buf.begin(), buf.begin() + (ptrdiff_t)pos); pos = 0;
+    std::vector<uint64_t> off; std::vector<uint32_t> len;
+    bool eof = false;
+    size_t scanned = 0;  // bytes of buf already split into off/len
+    for (;;) {
+      // split what is there; read more until a cut point exists
+      int64_t cut = -1;
+      size_t searched = std::max<size_t>((size_t)o.bundle_records, 1);  // records below this index cannot be a cut
+      for (;;) {
+        size_t cap = (size_t)(buf.size() - scanned) / 36 + 1;
+        size_t base = off.size();
+        off.resize(base + cap); len.resize(base + cap);
+        int64_t n = 0, un = 0; uint64_t used = 0;
+        int r = br_bam_split(buf.data() + scanned, buf.size() - scanned, (int64_t)cap, off.data() + base, len.data() + base, &n, &un, &used);
+        if (r) { reader_err = "malformed BAM record"; to_gpu.finish(); return; }
+        for (int64_t i = 0; i < n; i++) off[base + (size_t)i] += scanned;
+        off.resize(base + (size_t)n); len.resize(base + (size_t)n);
+        total_reads += (uint64_t)(n + un); unmapped_reads += (uint64_t)un;
+        scanned += used;
+        // cut: first record >= bundle_records whose name differs from its predecessor's
+        for (size_t i = searched; i < off.size(); i++) {
+          uint32_t la, lb; const uint8_t *a = rec_name(buf, off[i - 1], la), *b = rec_name(buf, off[i], lb);
+          if (la != lb || memcmp(a, b, la) != 0) { cut = (int64_t)i; break; }
+        }
+        searched = std::max(searched, off.size());
+        if (cut >= 0 || eof) break;
+        int64_t got = rd.read(buf, 256u << 20);
+        if (got < 0) { reader_err = rd.error(); to_gpu.finish(); return; }
+        if (got == 0) { eof = true; if (scanned != buf.size()) { reader_err = "truncated BAM record at end of file"; to_gpu.finish(); return; } }
+      }
+      size_t n_take = cut >= 0 ? (size_t)cut : off.size();
+      if (n_take) {
+        auto b = std::make_unique<Bundle>();
+        size_t byte_end = (n_take < off.size()) ? (size_t)off[n_take] - 4 : scanned;
+        b->off.assign(off.begin(), off.begin() + (ptrdiff_t)n_take); b->len.assign(len.begin(), len.begin() + (ptrdiff_t)n_take);
+        b->blob.assign(buf.begin(), buf.begin() + (ptrdiff_t)byte_end);
+        // keep the tail for the next bundle
+        buf.erase(buf.begin(), buf.begin() + (ptrdiff_t)byte_end);
+        scanned -= byte_end;
+        std::vector<uint64_t> noff(off.begin() + (ptrdiff_t)n_take, off.end()); std::vector<uint32_t> nlen(len.begin() + (ptrdiff_t)n_take, len.end());
+        for (auto &x : noff) x -= byte_end;
+        off.swap(noff); len.swap(nlen);
+        to_gpu.put(std::move(b));
+      }
+      if (cut < 0 && eof) break;
+    }
+    to_gpu.finish();
+  });
+
+  std::thread writer([&]() {
+    for (;;) {
+      OutChunk *c = to_writer.hold();
+      if (!c) break;
+      if (writer_err.empty() && c->n && !wr.write(c->data, (size_t)c->n)) writer_err = wr.error();
+      to_writer.release();
+    }
+  });
+
+  uint64_t total_complete = 0, total_unique = 0, dropped = 0, n_bundles = 0;
+  double gpu_seconds = 0;
+  int fail = 0;
+  for (;;) {
+    auto b = to_gpu.take();
+    if (!b) break;
+    if (fail) continue;  // drain
+    br_bam_bundle bb{b->blob.data(), b->blob.size(), b->off.data(), b->len.data(), (int64_t)b->off.size(), ref_map.data(), (int32_t)ref_map.size()};
+    br_host_bam hb;
+    auto t0 = std::chrono::steady_clock::now();
+    rc = br_project_bam_bundle(ctx, &o.cfg, &bb, &hb);
+    gpu_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (rc) { fprintf(stderr, "error: projection failed: %s\n", br_strerror(rc)); fail = 1; continue; }
+    total_complete += hb.total_complete; total_unique += hb.total_unique; dropped += hb.dropped_reads; n_bundles++;
+    auto c = std::make_unique<OutChunk>(); c->data = hb.data; c->n = hb.n_bytes;
+    to_writer.put(std::move(c));  // returns once the writer has FINISHED the previous chunk: the two pinned buffers alternate
+  }
+  to_writer.finish();
+  reader.join(); writer.join();
+  if (!reader_err.empty()) { fprintf(stderr, "error: %s: %s\n", o.in_bam.c_str(), reader_err.c_str()); fail = 1; }
+  if (!writer_err.empty()) { fprintf(stderr, "error: %s: %s\n", o.out_bam.c_str(), writer_err.c_str()); fail = 1; }
+  if (!wr.close()) { fprintf(stderr, "error: %s: %s\n", o.out_bam.c_str(), wr.error().c_str()); fail = 1; }
+  br_ctx_free(ctx); br_index_free(ix); br_annotation_free(ann);
+  if (!o.quiet) {  // src/bramble.cpp:727-736
+    printf("\n[bramble] final report:\n");
+    printf("# input alignments:   %llu\n", (unsigned long long)total_reads);
+    printf("# unmapped reads:     %llu\n", (unsigned long long)unmapped_reads);
+    printf("# dropped alignments: %llu\n", (unsigned long long)dropped);
+    printf("# total alignments:   %llu\n", (unsigned long long)total_complete);
+    printf("# unique alignments:  %llu\n\n", (unsigned long long)total_unique);
+    printf("[bramble] %llu bundles, %.2fs on the device path (upload + kernels + download), %.2fs wall\n",
+           (unsigned long long)n_bundles, gpu_seconds, since());
+  }
+  return fail;
+}

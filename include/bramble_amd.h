@@ -320,7 +320,9 @@ typedef struct br_bam_bundle {
 } br_bam_bundle;
 
 typedef struct br_host_bam {
-  const uint8_t *data;      /* [block_size][record]... ready for BGZF framing; owned by the context */
+  const uint8_t *data;      /* [block_size][record]... ready for BGZF framing; owned by the context, valid until
+                             * the SECOND next br_project_bam_bundle call (two pinned buffers alternate, so a
+                             * writer thread can compress bundle k while bundle k+1 is projected) */
   uint64_t n_bytes;
   int64_t n_rows;
   uint64_t total_complete, total_unique, dropped_reads, total_processed;
@@ -335,6 +337,27 @@ int br_project_bam_bundle(br_ctx *, const br_config *, const br_bam_bundle *, br
  * block_size. */
 int br_bam_split(const uint8_t *data, uint64_t n_bytes, int64_t cap, uint64_t *rec_off, uint32_t *rec_len,
                  int64_t *n_records, int64_t *n_unmapped, uint64_t *consumed);
+
+/* ---- annotation loading and the command line (scope table rows f-1 / f-3) ----------------- */
+
+/* GTF / GFF3 (plain or gzip) -> transcripts in the reference's guide order: gclib GffReader with
+ * transcripts only, sorted by location, reference names compared lexicographically
+ * (src/bramble.cpp:497-512; gfo_cmpByLoc, gclib/gff.cpp:75-90), so that position = the tid the
+ * reference assigns through its output header (src/bramble.cpp:559-596).  Exons are 1-based
+ * half-open [start, end+1) like src/bramble.cpp:164-165.  The arrays stay owned by the handle and
+ * feed br_index_build directly. */
+typedef struct br_annotation br_annotation;
+int br_annotation_load(const char *path, br_annotation **out);
+void br_annotation_free(br_annotation *);
+size_t br_annotation_num_transcripts(const br_annotation *);
+const br_transcript *br_annotation_transcripts(const br_annotation *);
+size_t br_annotation_num_refs(const br_annotation *);            /* reference names in order of first appearance */
+const char *const *br_annotation_refnames(const br_annotation *);
+
+/* The reference's command line (src/bramble.cpp:443-485): in.bam -G -o [-S] [-p] [--fr|--rf]
+ * [--lr|--lr-hq] [--strict] [--max-*] [--similarity-threshold] [--quiet], plus --compression-level,
+ * --bundle-size and --device.  Returns the process exit code. */
+int br_cli_main(int argc, char **argv);
 
 /* ---- measurement hooks ------------------------------------------------------ */
 

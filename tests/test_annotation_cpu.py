@@ -1,0 +1,131 @@
+"""GTF / GFF3 guide loader (host only): transcript order, exon merging and the cases the reference's
+gclib reader handles that matter for tid identity (scope table row f-3)."""
+import ctypes as C
+import gzip
+
+import numpy as np
+import pytest
+
+from bramble_amd import lib, synth
+from tests import bamio
+
+
+class BrExon(C.Structure):
+    _fields_ = [("start", C.c_uint32), ("end", C.c_uint32)]
+
+
+class BrTranscript(C.Structure):
+    _fields_ = [("id", C.c_char_p), ("seqname", C.c_char_p), ("strand", C.c_char), ("exons", C.POINTER(BrExon)),
+                ("n_exons", C.c_uint32)]
+
+
+def load(path):
+    L = lib.lib()
+    L.br_annotation_load.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+    L.br_annotation_transcripts.restype = C.POINTER(BrTranscript)
+    L.br_annotation_transcripts.argtypes = [C.c_void_p]
+    L.br_annotation_num_transcripts.restype = C.c_size_t
+    L.br_annotation_num_transcripts.argtypes = [C.c_void_p]
+    L.br_annotation_num_refs.restype = C.c_size_t
+    L.br_annotation_num_refs.argtypes = [C.c_void_p]
+    L.br_annotation_refnames.restype = C.POINTER(C.c_char_p)
+    L.br_annotation_refnames.argtypes = [C.c_void_p]
+    L.br_annotation_free.argtypes = [C.c_void_p]
+    h = C.c_void_p()
+    rc = L.br_annotation_load(str(path).encode(), C.byref(h))
+    if rc:
+        raise lib.BrambleError("br_annotation_load: %d" % rc)
+    n = L.br_annotation_num_transcripts(h)
+    t = L.br_annotation_transcripts(h)
+    out = []
+    for i in range(n):
+        out.append((t[i].id.decode(), t[i].seqname.decode(), t[i].strand.decode(),
+                    [(t[i].exons[k].start, t[i].exons[k].end) for k in range(t[i].n_exons)]))
+    nr = L.br_annotation_num_refs(h)
+    rn = L.br_annotation_refnames(h)
+    refs = [rn[i].decode() for i in range(nr)]
+    L.br_annotation_free(h)
+    return out, refs
+
+
+def test_gtf_order_is_refname_start_end_id(tmp_path):
+    gtf = tmp_path / "a.gtf"
+    rows = [
+        ("chr2", "t_b", "+", [(100, 200), (300, 400)]),
+        ("chr10", "t_z", "-", [(50, 80)]),
+        ("chr10", "t_a", "-", [(50, 80)]),          # same span: id decides
+        ("chr10", "t_long", "+", [(50, 90)]),       # same start, larger end
+        ("chr1", "t_c", "+", [(500, 600)]),
+        ("chr2", "t_early", "+", [(10, 20)]),
+    ]
+    with open(gtf, "w") as f:
+        for ref, tid, strand, exons in rows:
+            for s, e in exons:
+                f.write("%s\tx\texon\t%d\t%d\t.\t%s\t.\tgene_id \"g\"; transcript_id \"%s\";\n" % (ref, s, e, strand, tid))
+    txs, refs = load(gtf)
+    assert [t[0] for t in txs] == ["t_c", "t_a", "t_z", "t_long", "t_early", "t_b"]   # chr1 < chr10 < chr2 (strcmp)
+    assert refs == ["chr2", "chr10", "chr1"]                                        # order of first appearance
+    assert txs[-1][3] == [(100, 201), (300, 401)]                                    # 1-based half-open
+
+
+def test_exon_like_features_merge_when_overlapping_or_adjacent(tmp_path):
+    gtf = tmp_path / "m.gtf"
+    a = 'gene_id "g"; transcript_id "t1";'
+    with open(gtf, "w") as f:
+        f.write("chr1\tx\ttranscript\t100\t900\t.\t+\t.\t%s\n" % a)
+        f.write("chr1\tx\texon\t100\t200\t.\t+\t.\t%s\n" % a)
+        f.write("chr1\tx\texon\t201\t250\t.\t+\t.\t%s\n" % a)          # adjacent: merged (gff.cpp:963-1079)
+        f.write("chr1\tx\tCDS\t240\t300\t.\t+\t0\t%s\n" % a)           # CDS reaching past the exon: merged in
+        f.write("chr1\tx\tfive_prime_UTR\t500\t520\t.\t+\t.\t%s\n" % a)
+        f.write("chr1\tx\texon\t800\t900\t.\t+\t.\t%s\n" % a)
+        f.write("chr1\tx\tstop_codon\t901\t903\t.\t+\t0\t%s\n" % a)    # adjacent to the last exon
+        f.write("chr1\tx\tgene\t100\t900\t.\t+\t.\tgene_id \"g\";\n")   # genes are not transcripts
+        f.write("chr1\tx\ttranscript\t2000\t2100\t.\t-\t.\tgene_id \"g2\"; transcript_id \"lonely\";\n")  # exonless
+    txs, _ = load(gtf)
+    assert txs[0] == ("t1", "chr1", "+", [(100, 301), (500, 521), (800, 904)])
+    assert txs[1] == ("lonely", "chr1", "-", [(2000, 2101)])
+    assert len(txs) == 2
+
+
+def test_gff3_parents_and_gzip(tmp_path):
+    gff = tmp_path / "a.gff3.gz"
+    body = "\n".join([
+        "##gff-version 3",
+        "chrA\tx\tgene\t1\t1000\t.\t+\t.\tID=gene1",
+        "chrA\tx\tmRNA\t10\t500\t.\t+\t.\tID=rna2;Parent=gene1",
+        "chrA\tx\tmRNA\t10\t300\t.\t+\t.\tID=rna1;Parent=gene1",
+        "chrA\tx\texon\t10\t100\t.\t+\t.\tID=e1;Parent=rna1,rna2",
+        "chrA\tx\texon\t200\t300\t.\t+\t.\tParent=rna1",
+        "chrA\tx\texon\t400\t500\t.\t+\t.\tParent=rna2",
+        "chrA\tx\tlnc_RNA\t700\t800\t.\t-\t.\tID=lnc1",
+        "chrA\tx\tcDNA_match\t1\t50\t.\t+\t.\tID=m1",
+    ]) + "\n"
+    with gzip.open(gff, "wb") as f:
+        f.write(body.encode())
+    txs, refs = load(gff)
+    assert [t[0] for t in txs] == ["rna1", "rna2", "lnc1"]
+    assert txs[0][3] == [(10, 101), (200, 301)] and txs[1][3] == [(10, 101), (400, 501)]
+    assert txs[2] == ("lnc1", "chrA", "-", [(700, 801)])
+
+
+def test_loader_matches_synthetic_annotation_in_guide_order(tmp_path):
+    ann = synth.Annotation("G", n_genes=400, n_refs=12).as_dict()
+    rng = np.random.RandomState(3)
+    gtf = tmp_path / "s.gtf"
+    bamio.write_gtf(gtf, ann, order=rng.permutation(len(ann["transcripts"])), with_transcript_lines=False)
+    txs, refs = load(gtf)
+    exp = bamio.guide_order(ann)
+    assert len(txs) == len(exp)
+    for got, t in zip(txs, exp):
+        tx = ann["transcripts"][t]
+        assert got[0] == tx["id"] and got[1] == ann["refnames"][tx["ref_id"]] and got[2] == tx["strand"]
+        assert got[3] == [tuple(e) for e in sorted(tx["exons"])]
+
+
+def test_missing_file_and_empty_annotation(tmp_path):
+    with pytest.raises(lib.BrambleError):
+        load(tmp_path / "nope.gtf")
+    p = tmp_path / "empty.gtf"
+    p.write_text("# nothing\n")
+    with pytest.raises(lib.BrambleError):
+        load(p)

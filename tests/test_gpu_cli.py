@@ -1,0 +1,153 @@
+"""The command line end to end on the GPU box (scope table rows f-1 / f-3 / f-4): BGZF/BAM in, GTF (and FASTA)
+in, BAM out -- header layout of src/bramble.cpp:513-623 and a record stream byte-identical to the oracle's."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from bramble_amd import lib, synth
+from oracle import oracle_binding as ob
+from tests import bamio
+from tests.test_gpu_bam_bundle import framed_stream
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "bramble_amd", "bin", "bramble")
+
+
+def remap_refs(stream, perm):
+    """Rewrite refID / next_refID of every record: new = perm[old]."""
+    s = bytearray(stream.tobytes())
+    p = 0
+    while p < len(s):
+        bs = struct.unpack_from("<I", s, p)[0]
+        for at in (p + 4, p + 4 + 20):
+            v = struct.unpack_from("<i", s, at)[0]
+            if v >= 0:
+                struct.pack_into("<i", s, at, int(perm[v]))
+        p += 4 + bs
+    return np.frombuffer(bytes(s), dtype=np.uint8)
+
+
+def run_cli(tmp_path, annd, stream_in_bam_ids, bam_refs, flags_cli, flags_cfg, in_header, fasta=None, bundle=2500):
+    order = bamio.guide_order(annd)
+    rng = np.random.RandomState(5)
+    gtf = str(tmp_path / "guides.gtf")
+    bamio.write_gtf(gtf, annd, order=rng.permutation(len(annd["transcripts"])))
+    in_bam, out_bam = str(tmp_path / "in.bam"), str(tmp_path / "out.bam")
+    bamio.write_bam(in_bam, in_header, bam_refs, stream_in_bam_ids.tobytes(), block=40000)
+    cmd = [BIN, in_bam, "-G", gtf, "-o", out_bam, "-p", "4", "--bundle-size", str(bundle), "--compression-level", "1"] + flags_cli
+    if fasta:
+        cmd += ["-S", fasta]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr + r.stdout
+    text, refs, got = bamio.read_bam(out_bam)
+    # oracle: transcripts in guide order (tid = @SQ position), records with annotation reference ids
+    sorted_ann = dict(annd)
+    sorted_ann["transcripts"] = [annd["transcripts"][t] for t in order]
+    name_to_ann = {n: i for i, n in enumerate(annd["refnames"])}
+    ref_map = np.array([name_to_ann.get(n, -1) for n, _ in bam_refs], dtype=np.int32)
+    roff, rlen, n_un, used = lib.bam_split(stream_in_bam_ids)
+    orc, _, _, _ = ob.run_bam(ob.OracleIndex(sorted_ann), ob.make_flags(**flags_cfg), stream_in_bam_ids, roff, rlen, ref_map)
+    return text, refs, got, orc, sorted_ann, r.stdout, gtf, n_un, len(rlen)
+
+
+def tx_len(tx):
+    return sum(e - s for s, e in tx["exons"])
+
+
+def test_cli_short_reads_header_and_records(tmp_path):
+    ann = synth.Annotation("G", n_genes=1200, n_refs=5)
+    annd = ann.as_dict()
+    b = ann.reads(8000, "pe", with_records=1, xs_tag=True)
+    stream = framed_stream(b, unmapped_every=101)
+    # the BAM lists the references in another order and has one the annotation lacks
+    perm = np.array([3, 0, 4, 1, 2])
+    bam_refs = [None] * 6
+    for old, new in enumerate(perm):
+        bam_refs[new] = (annd["refnames"][old], 1000000)
+    bam_refs[5] = ("chrUn_extra", 500)
+    in_header = "@HD\tVN:1.6\tSO:unsorted\tGO:query\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % r for r in bam_refs) + \
+        "@RG\tID:rg1\tSM:s\n@PG\tID:aligner\tPN:aligner\tVN:2.1\n@PG\tID:sorter\tPN:sorter\tPP:aligner\n@CO\tuser comment\n"
+    text, refs, got, orc, sorted_ann, out, gtf, n_un, n_rec = run_cli(tmp_path, annd, remap_refs(stream, perm), bam_refs, [], {}, in_header)
+    # header: @HD first, one @SQ per transcript in guide order, the other input lines, the chained @PG, the @CO
+    lines = text.rstrip("\n").split("\n")
+    assert lines[0] == "@HD\tVN:1.6\tSO:unsorted\tGO:query"
+    ntx = len(sorted_ann["transcripts"])
+    assert lines[1:1 + ntx] == ["@SQ\tSN:%s\tLN:%d" % (t["id"], tx_len(t)) for t in sorted_ann["transcripts"]]
+    rest = lines[1 + ntx:]
+    assert rest[:4] == ["@RG\tID:rg1\tSM:s", "@PG\tID:aligner\tPN:aligner\tVN:2.1", "@PG\tID:sorter\tPN:sorter\tPP:aligner", "@CO\tuser comment"]
+    assert rest[4].startswith("@PG\tID:bramble\tPN:bramble\tPP:sorter\tVN:") and "\tCL:" in rest[4] and "-G" in rest[4]
+    assert rest[5] == "@CO\tGenerated from GTF: " + gtf and len(rest) == 6
+    assert refs == [(t["id"], tx_len(t)) for t in sorted_ann["transcripts"]]
+    # records
+    assert orc["n_rows"] > 5000
+    assert len(got) == len(orc["bam_stream"]) and np.array_equal(got, orc["bam_stream"])
+    # final report (src/bramble.cpp:727-736)
+    assert "# input alignments:   %d" % (n_rec + n_un) in out and "# unmapped reads:     %d" % n_un in out
+    assert "# total alignments:   %d" % orc["total_complete"] in out and "# unique alignments:  %d" % orc["total_unique"] in out
+    assert "# dropped alignments: %d" % orc["dropped_reads"] in out
+
+
+def test_cli_long_reads_with_genome(tmp_path):
+    ann = synth.Annotation("G", n_genes=300, n_refs=2, with_genome=True)
+    annd = ann.as_dict()
+    b = ann.reads(3000, "ont", with_seq=1, with_records=1)
+    stream = framed_stream(b)
+    fasta = str(tmp_path / "genome.fa")
+    with open(fasta, "w") as f:
+        for rid, name in enumerate(annd["refnames"]):
+            seq = annd["ref_seqs"][rid]
+            if isinstance(seq, (bytes, bytearray)):
+                seq = bytes(seq).decode()
+            f.write(">%s some description\n" % name)
+            for a in range(0, len(seq), 70):
+                f.write(seq[a:a + 70] + "\n")
+    bam_refs = [(n, len(annd["ref_seqs"][i])) for i, n in enumerate(annd["refnames"])]
+    in_header = "".join("@SQ\tSN:%s\tLN:%d\n" % r for r in bam_refs)   # no @HD, no @PG
+    text, refs, got, orc, sorted_ann, out, gtf, _, _ = run_cli(tmp_path, annd, stream, bam_refs, ["--lr"], {"lr": 1, "use_fasta": 1},
+                                                             in_header, fasta=fasta, bundle=700)
+    lines = text.rstrip("\n").split("\n")
+    assert lines[0].startswith("@SQ\tSN:") and lines[-2].startswith("@PG\tID:bramble\tPN:bramble\tVN:") and lines[-1].startswith("@CO\t")
+    assert (orc["clip_score"] != 0).sum() > 300
+    assert len(got) == len(orc["bam_stream"]) and np.array_equal(got, orc["bam_stream"])
+
+
+def test_cli_result_does_not_depend_on_bundle_size(tmp_path):
+    ann = synth.Annotation("G", n_genes=600, n_refs=3)
+    annd = ann.as_dict()
+    b = ann.reads(5000, "pe", with_records=1)
+    stream = framed_stream(b)
+    bam_refs = [(n, 1000000) for n in annd["refnames"]]
+    gtf = str(tmp_path / "g.gtf")
+    bamio.write_gtf(gtf, annd)
+    in_bam = str(tmp_path / "in.bam")
+    bamio.write_bam(in_bam, "@HD\tVN:1.6\n", bam_refs, stream.tobytes())
+    outs = []
+    for k, bundle in enumerate((1, 777, 10 ** 7)):
+        out_bam = str(tmp_path / ("o%d.bam" % k))
+        r = subprocess.run([BIN, in_bam, "-G", gtf, "-o", out_bam, "-p", "2", "--bundle-size", str(bundle), "--quiet",
+                            "--strict", "--max-soft-clip", "3"], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        outs.append(bamio.read_bam(out_bam)[2])
+        sizes = bamio.bgzf_block_sizes(out_bam)
+        assert max(sizes) <= 65536 and sizes[-1] == 28
+    assert len(outs[0]) > 100000
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
+def test_cli_errors(tmp_path):
+    r = subprocess.run([BIN, "--version"], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.startswith("version: ")
+    r = subprocess.run([BIN, str(tmp_path / "missing.bam"), "-G", str(tmp_path / "x.gtf"), "-o", str(tmp_path / "o.bam")],
+                       capture_output=True, text=True)
+    assert r.returncode != 0
+    notbam = tmp_path / "n.bam"
+    notbam.write_bytes(b"this is not a bam file")
+    gtf = tmp_path / "g.gtf"
+    gtf.write_text('chr1\tx\texon\t10\t50\t.\t+\t.\tgene_id "g"; transcript_id "t";\n')
+    r = subprocess.run([BIN, str(notbam), "-G", str(gtf), "-o", str(tmp_path / "o.bam")], capture_output=True, text=True)
+    assert r.returncode != 0 and "BGZF" in r.stderr
