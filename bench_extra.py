@@ -3,18 +3,24 @@
 
   python bench_extra.py c5 [--reads N]   HiFi-like --lr-hq --strict --similarity-threshold 0.95 (configs[4], 1 GPU)
   python bench_extra.py c3 [--reads N]   ONT-like --lr -S with a synthetic genome: clip rescue incl. k_ksw GCUPS (configs[2])
+  python bench_extra.py bam [--reads N]  re-encode the rows of configs[1] as BAM records (device part)
+  python bench_extra.py bundle [--reads N]  raw BAM records resident in HBM -> projected BAM records (br_project_bam_device)
+  python bench_extra.py cli [--reads N] [--threads T]  the command line file to file (BGZF inflate, device path, BGZF deflate)
 
 Same protocol as bench.py: inputs resident in HBM, warmup, hipEvent kernel times, one JSON line.
 """
 import argparse
 import json
+
+import numpy as np
 import sys
 import time
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("config", choices=["c3", "c5", "bam"])
+    ap.add_argument("config", choices=["c3", "c5", "bam", "bundle", "cli"])
+    ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--reads", type=int, default=0)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
@@ -57,6 +63,82 @@ def main():
                           "input_record_bytes": int(len(batch["rec_blob"])), "kernel_ms_per_step": {k: round(v / args.steps, 3) for k, v in kms.items() if v},
                           "bam_kernels_GBps_read_plus_write": (out_bytes + in_bytes_per_row) / (k_ms * 1e-3) / 1e9 if k_ms else None,
                           "hbm_peak_GBps": 8000.0}))
+        return
+    if args.config == "bundle":
+        n = args.reads or 10_000_000
+        ann = synth.Annotation("G")
+        batch = ann.reads(n, "pe", with_records=1)
+        stream_h, roff, rlen = synth.Annotation.frame_records(batch)
+        cfg = lib.make_config()
+        idx = lib.Index.from_flat(ann.flat, device=0)
+        ctx = lib.Context(idx)
+        blob = torch.from_numpy(stream_h).to("cuda:0")
+        off_d = torch.from_numpy(roff.view(np.int64)).to("cuda:0")
+        len_d = torch.from_numpy(rlen.view(np.int32)).to("cuda:0")
+        ref_map = np.arange(ann.flat["n_refs"], dtype=np.int32)
+        st = torch.cuda.current_stream().cuda_stream
+        for _ in range(args.warmup):
+            rows, bam = ctx.project_bam_device(cfg, blob, off_d, len_d, ref_map, st)
+        ctx.set_profiling(True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        kms = {}
+        for _ in range(args.steps):
+            rows, bam = ctx.project_bam_device(cfg, blob, off_d, len_d, ref_map, st)
+            for k, (ms, ln) in ctx.kernel_ms().items():
+                kms[k] = kms.get(k, 0.0) + ms
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / args.steps
+        print(json.dumps({"config": "bundle", "workload": "%d raw paired-end BAM records resident in HBM -> %d projected BAM records (reader side, projection and re-encoding on the device)" % (len(rlen), int(bam.n_rows)),
+                          "alignments_per_s": len(rlen) / el, "ms_per_step": el * 1e3, "input_bytes": int(stream_h.size),
+                          "output_bytes": int(bam.n_bytes), "kernel_ms_per_step": {k: round(v / args.steps, 3) for k, v in kms.items() if v}}))
+        return
+    if args.config == "cli":
+        import os
+        import subprocess
+        import tempfile
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from tests import bamio
+        from oracle import oracle_binding as ob
+        n = args.reads or 2_000_000
+        ann = synth.Annotation("G")
+        annd = ann.as_dict()
+        batch = ann.reads(n, "pe", with_records=1)
+        stream_h, roff, rlen = synth.Annotation.frame_records(batch)
+        tmp = tempfile.mkdtemp(prefix="bramble_cli_")
+        gtf, in_bam = os.path.join(tmp, "guides.gtf"), os.path.join(tmp, "in.bam")
+        bamio.write_gtf(gtf, annd)
+        refs = [(r, 250_000_000) for r in annd["refnames"]]
+        t0 = time.perf_counter()
+        bamio.write_bam(in_bam, "@HD\tVN:1.6\tSO:unsorted\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % r for r in refs), refs, stream_h.tobytes(), level=1)
+        prep = time.perf_counter() - t0
+        exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bramble_amd", "bin", "bramble")
+        res = {}
+        for level in (1, 6):
+            out_bam = os.path.join(tmp, "out%d.bam" % level)
+            t0 = time.perf_counter()
+            r = subprocess.run([exe, in_bam, "-G", gtf, "-o", out_bam, "-p", str(args.threads), "--compression-level", str(level)],
+                               capture_output=True, text=True)
+            wall = time.perf_counter() - t0
+            if r.returncode != 0:
+                print(r.stderr, file=sys.stderr)
+                sys.exit(1)
+            tail = [l for l in r.stdout.splitlines() if "bundles" in l]
+            res["level%d" % level] = {"wall_s": round(wall, 2), "alignments_per_s": len(rlen) / wall, "out_bam_bytes": os.path.getsize(out_bam),
+                                       "report": tail[-1] if tail else ""}
+        # CPU beside it: the oracle's reader side + projection + write_to_bam on a sample, one thread, no (de)compression
+        m = min(len(rlen), 200_000)
+        while m < len(rlen) and batch["name_off"][m + 1] - batch["name_off"][m] == batch["name_off"][m] - batch["name_off"][m - 1] and \
+                bytes(batch["names"][int(batch["name_off"][m]):int(batch["name_off"][m + 1])]) == bytes(batch["names"][int(batch["name_off"][m - 1]):int(batch["name_off"][m])]):
+            m += 1
+        oi = ob.OracleIndex(annd)
+        order = bamio.guide_order(annd)
+        t0 = time.perf_counter()
+        ob.run_bam(oi, ob.make_flags(), stream_h, roff[:m], rlen[:m], np.arange(len(refs), dtype=np.int32))
+        cpu = time.perf_counter() - t0
+        print(json.dumps({"config": "cli", "workload": "%d paired-end alignments, BAM file -> BAM file, -p %d, GENCODE-shaped GTF (%d transcripts)" % (len(rlen), args.threads, len(order)),
+                          "in_bam_bytes": os.path.getsize(in_bam), "uncompressed_in_bytes": int(stream_h.size), "results": res,
+                          "cpu_oracle_1_thread_alignments_per_s_no_codec": m / cpu, "input_prep_s": round(prep, 1)}))
         return
     if args.config == "c5":
         n = args.reads or 1_000_000

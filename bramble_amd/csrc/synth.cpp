@@ -491,6 +491,16 @@ const char *synth_reads_names(void *h) { return ((Reads *)h)->names.data(); }
 const uint32_t *synth_reads_src_tx(void *h) { return ((Reads *)h)->src_tx.data(); }
 const uint64_t *synth_reads_rec_off(void *h) { return ((Reads *)h)->rec_off.data(); }
 const uint8_t *synth_reads_rec_blob(void *h) { return ((Reads *)h)->rec_blob.data(); }
+// contiguous records -> an uncompressed BAM alignment section: [block_size][record]...; out holds total + 4 n bytes
+void synth_frame_records(const uint8_t *blob, const uint64_t *off, int64_t n, uint8_t *out) {
+  uint64_t o = 0;
+  for (int64_t i = 0; i < n; i++) {
+    uint32_t len = (uint32_t)(off[i + 1] - off[i]);
+    memcpy(out + o, &len, 4);
+    memcpy(out + o + 4, blob + off[i], len);
+    o += 4 + (uint64_t)len;
+  }
+}
 const uint64_t *synth_reads_seq_off(void *h) { return ((Reads *)h)->seq_off.data(); }
 const char *synth_reads_seqs(void *h) { return ((Reads *)h)->seqs.data(); }
 

@@ -152,6 +152,22 @@ class Annotation:
             L.synth_reads_free(h)
         return b
 
+    @staticmethod
+    def frame_records(b):
+        """Records of a batch made with with_records=1 -> (stream uint8[] of [block_size][record]..., rec_off uint64[n]
+        of each record's refID word, rec_len uint32[n]): an uncompressed BAM alignment section."""
+        off = np.ascontiguousarray(b["rec_off"], dtype=np.uint64)
+        blob = np.ascontiguousarray(b["rec_blob"], dtype=np.uint8)
+        n = len(off) - 1
+        out = np.empty(int(off[-1]) + 4 * n, dtype=np.uint8)
+        L = lib()
+        L.synth_frame_records.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.synth_frame_records.restype = None
+        L.synth_frame_records(blob.ctypes.data, off.ctypes.data, n, out.ctypes.data)
+        rec_len = np.diff(off).astype(np.uint32)
+        rec_off = off[:-1] + np.uint64(4) * np.arange(1, n + 1, dtype=np.uint64)
+        return out, rec_off, rec_len
+
     def __del__(self):
         try:
             lib().synth_annotation_free(self.h)
