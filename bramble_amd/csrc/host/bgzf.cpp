@@ -3,10 +3,53 @@
 #include <string.h>
 #include <zlib.h>
 
+#include <dlfcn.h>
+#include <stdlib.h>
+
 #include <atomic>
 #include <thread>
 
 namespace brio {
+
+// libdeflate (2-3x zlib's speed on 64 KiB blocks) when the shared object is on the box; the image ships
+// libdeflate.so.0 without headers, so the five entry points are bound by name.  zlib otherwise.
+namespace {
+struct LibDeflate {
+  void *(*alloc_c)(int) = nullptr;
+  size_t (*compress)(void *, const void *, size_t, void *, size_t) = nullptr;
+  void (*free_c)(void *) = nullptr;
+  void *(*alloc_d)(void) = nullptr;
+  int (*decompress)(void *, const void *, size_t, void *, size_t, size_t *) = nullptr;
+  void (*free_d)(void *) = nullptr;
+  uint32_t (*crc)(uint32_t, const void *, size_t) = nullptr;
+  bool ok = false;
+  LibDeflate() {
+    if (getenv("BRAMBLE_AMD_NO_LIBDEFLATE")) return;
+    void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("libdeflate.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) return;
+    alloc_c = (void *(*)(int))dlsym(h, "libdeflate_alloc_compressor");
+    compress = (size_t(*)(void *, const void *, size_t, void *, size_t))dlsym(h, "libdeflate_deflate_compress");
+    free_c = (void (*)(void *))dlsym(h, "libdeflate_free_compressor");
+    alloc_d = (void *(*)(void))dlsym(h, "libdeflate_alloc_decompressor");
+    decompress = (int (*)(void *, const void *, size_t, void *, size_t, size_t *))dlsym(h, "libdeflate_deflate_decompress");
+    free_d = (void (*)(void *))dlsym(h, "libdeflate_free_decompressor");
+    crc = (uint32_t(*)(uint32_t, const void *, size_t))dlsym(h, "libdeflate_crc32");
+    ok = alloc_c && compress && free_c && alloc_d && decompress && free_d && crc;
+  }
+};
+const LibDeflate &ld() { static LibDeflate l; return l; }
+// one codec object per worker thread and level (libdeflate objects are not shareable)
+struct TlsCodec {
+  void *c = nullptr, *d = nullptr; int level = -100;
+  ~TlsCodec() { if (c) ld().free_c(c); if (d) ld().free_d(d); }
+  void *comp(int lv) { if (!c || lv != level) { if (c) ld().free_c(c); c = ld().alloc_c(lv); level = lv; } return c; }
+  void *decomp() { if (!d) d = ld().alloc_d(); return d; }
+};
+thread_local TlsCodec tls_codec;
+}  // namespace
+
+const char *codec_name() { return ld().ok ? "libdeflate" : "zlib"; }
 
 void parallel_for(size_t n, int threads, void (*fn)(size_t, void *), void *arg) {
   if (n == 0) return;
@@ -59,6 +102,12 @@ static void inflate_one(size_t i, void *arg) {
   InflateCtx *c = (InflateCtx *)arg;
   InflateJob &j = (*c->jobs)[i];
   if (j.ulen == 0) return;
+  if (ld().ok) {
+    size_t got = 0;
+    int rc = ld().decompress(tls_codec.decomp(), j.src, j.clen, j.dst, j.ulen, &got);
+    if (rc != 0 || got != j.ulen || ld().crc(0, j.dst, j.ulen) != j.crc) c->bad = 1;
+    return;
+  }
   z_stream zs; memset(&zs, 0, sizeof(zs));
   if (inflateInit2(&zs, -15) != Z_OK) { c->bad = 1; return; }
   zs.next_in = (Bytef *)j.src; zs.avail_in = j.clen; zs.next_out = j.dst; zs.avail_out = j.ulen;
@@ -146,7 +195,12 @@ static void deflate_one(size_t i, void *arg) {
   z_stream zs; memset(&zs, 0, sizeof(zs));
   uint32_t clen = 0;
   int level = c->level;
-  for (;;) {
+  bool done = false;
+  if (ld().ok && level > 0) {
+    size_t got = ld().compress(tls_codec.comp(level), src, len, o + 18, 0x10000 - 18 - 8);
+    if (got) { clen = (uint32_t)got; done = true; } else level = 0;  // did not fit: stored block below
+  }
+  while (!done) {
     if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { c->bad = 1; return; }
     zs.next_in = (Bytef *)src; zs.avail_in = (uInt)len; zs.next_out = o + 18; zs.avail_out = 0x10000 - 18 - 8;
     int rc = deflate(&zs, Z_FINISH);
@@ -158,7 +212,7 @@ static void deflate_one(size_t i, void *arg) {
   }
   uint32_t bsize = 18 + clen + 8 - 1;
   o[16] = (uint8_t)bsize; o[17] = (uint8_t)(bsize >> 8);
-  uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), src, (uInt)len);
+  uint32_t crc = ld().ok ? ld().crc(0, src, len) : (uint32_t)crc32(crc32(0L, Z_NULL, 0), src, (uInt)len);
   uint8_t *t = o + 18 + clen;
   for (int k = 0; k < 4; k++) t[k] = (uint8_t)(crc >> (8 * k));
   for (int k = 0; k < 4; k++) t[4 + k] = (uint8_t)((uint32_t)len >> (8 * k));

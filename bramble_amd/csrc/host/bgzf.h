@@ -52,6 +52,8 @@ class BgzfWriter {
   uint64_t bytes_out_ = 0;
 };
 
+const char *codec_name();  // "libdeflate" or "zlib"
+
 // runs fn(i) for i in [0, n) on up to `threads` threads
 void parallel_for(size_t n, int threads, void (*fn)(size_t, void *), void *arg);
 

@@ -278,6 +278,7 @@ extern "C" int br_cli_main(int argc, char **argv) {
     if (!wr.write(h.data(), h.size()) ) { fprintf(stderr, "error: %s\n", wr.error().c_str()); return 1; }
   }
   if (!o.quiet) printf("[bramble] processing alignments :-)\n");
+  double t_setup = since();
 
   Slot<Bundle> to_gpu; Slot<OutChunk> to_writer;
   uint64_t total_reads = 0, unmapped_reads = 0;
@@ -372,8 +373,34 @@ extern "C" int br_cli_main(int argc, char **argv) {
     printf("# dropped alignments: %llu\n", (unsigned long long)dropped);
     printf("# total alignments:   %llu\n", (unsigned long long)total_complete);
     printf("# unique alignments:  %llu\n\n", (unsigned long long)total_unique);
-    printf("[bramble] %llu bundles, %.2fs on the device path (upload + kernels + download), %.2fs wall\n",
-           (unsigned long long)n_bundles, gpu_seconds, since());
+    printf("[bramble] %llu bundles, %.2fs on the device path (upload + kernels + download), %.2fs wall (setup %.2fs, codec %s)\n",
+           (unsigned long long)n_bundles, gpu_seconds, since(), t_setup, brio::codec_name());
   }
   return fail;
 }
+
+// ---- BGZF utilities (host only) -------------------------------------------------------------------
+extern "C" int br_bgzf_write_file(const char *path, const uint8_t *data, uint64_t n, int threads, int level) {
+  if (!path || (!data && n)) return BR_ERR_INVALID_ARG;
+  BgzfWriter wr;
+  if (!wr.open(path, threads, level)) return BR_ERR_INVALID_ARG;
+  if (n && !wr.write(data, (size_t)n)) return BR_ERR_INVALID_ARG;
+  return wr.close() ? BR_OK : BR_ERR_INVALID_ARG;
+}
+
+extern "C" int br_bgzf_read_file(const char *path, int threads, uint8_t **out, uint64_t *n) {
+  if (!path || !out || !n) return BR_ERR_INVALID_ARG;
+  *out = nullptr; *n = 0;
+  BgzfReader rd;
+  if (!rd.open(path, threads)) return BR_ERR_INVALID_ARG;
+  std::vector<uint8_t> buf;
+  for (;;) { int64_t got = rd.read(buf, 64u << 20); if (got < 0) return BR_ERR_INVALID_ARG; if (got == 0) break; }
+  uint8_t *p = (uint8_t *)malloc(buf.size() ? buf.size() : 1);
+  if (!p) return BR_ERR_CAPACITY;
+  memcpy(p, buf.data(), buf.size());
+  *out = p; *n = buf.size();
+  return BR_OK;
+}
+
+extern "C" void br_free_buffer(uint8_t *p) { free(p); }
+extern "C" const char *br_bgzf_codec(void) { return brio::codec_name(); }

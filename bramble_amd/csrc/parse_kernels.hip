@@ -31,6 +31,14 @@ __device__ __forceinline__ uint32_t rec_length(const ParseArgs &P, int64_t i) {
   return P.rec_len ? P.rec_len[i] : (uint32_t)(P.rec_off[i + 1] - P.rec_off[i]);
 }
 
+// names compared four bytes at a time (unaligned dword loads), tail bytewise
+__device__ __forceinline__ bool same_bytes(const uint8_t *a, const uint8_t *b, uint32_t n) {
+  uint32_t k = 0;
+  for (; k + 4 <= n; k += 4) if (*(const u32u *)(a + k) != *(const u32u *)(b + k)) return false;
+  for (; k < n; k++) if (a[k] != b[k]) return false;
+  return true;
+}
+
 __global__ void __launch_bounds__(256) k_rec_fields(ParseArgs P) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t ncig = 0, max_s = 0;
@@ -51,23 +59,25 @@ __global__ void __launch_bounds__(256) k_rec_fields(ParseArgs P) {
       nlen = l_qname ? l_qname - 1 : 0;  // without the NUL
       lq = l_seq;
       const uint8_t *nm = rec + 32;
-      // leading / trailing soft clips (sizing of the rescue buffers)
+      // leading / trailing soft clips (sizing of the rescue buffers): S is only legal next to the ends (after H)
       const uint8_t *cg = rec + 32 + l_qname;
-      for (uint32_t k = 0; k < ncig; k++) {
-        uint32_t w = *(const u32u *)(cg + 4 * k);
+      if (ncig) {
+        uint32_t w = *(const u32u *)cg;
+        if ((w & 0xfu) == 5u && ncig > 1) w = *(const u32u *)(cg + 4);
+        if ((w & 0xfu) == 4u) max_s = w >> 4;
+        w = *(const u32u *)(cg + 4 * (ncig - 1));
+        if ((w & 0xfu) == 5u && ncig > 1) w = *(const u32u *)(cg + 4 * (ncig - 2));
         if ((w & 0xfu) == 4u) max_s = max(max_s, w >> 4);
       }
       if (i > 0) {
         const uint8_t *prev = P.blob + P.rec_off[i - 1];
         uint32_t plen = rec_length(P, i - 1);
-        uint32_t pl = plen >= 32 ? prev[8] : 0;
-        if (plen >= 32 && 32ull + pl + 4ull * *(const u16u *)(prev + 12) > plen) pl = 0;
-        uint32_t pn = pl ? pl - 1 : 0;
-        if (pn == nlen && plen >= 32) {
-          bool same = true;
-          const uint8_t *pm = prev + 32;
-          for (uint32_t k = 0; k < nlen; k++) if (pm[k] != nm[k]) { same = false; break; }
-          if (same) isnew = 0;
+        if (plen >= 32) {
+          uint32_t pw = *(const u32u *)(prev + 8), pc = *(const u16u *)(prev + 12);
+          uint32_t pl = pw & 0xffu;
+          if (32ull + pl + 4ull * pc > plen) pl = 0;
+          uint32_t pn = pl ? pl - 1 : 0;
+          if (pn == nlen && (nlen == 0 || same_bytes(prev + 32, nm, nlen))) isnew = 0;
         }
       }
     }

@@ -359,6 +359,14 @@ const char *const *br_annotation_refnames(const br_annotation *);
  * --bundle-size and --device.  Returns the process exit code. */
 int br_cli_main(int argc, char **argv);
 
+/* BGZF container utilities (host only; what the reference gets from htslib's bgzf layer behind
+ * GSamReader / GSamWriter): whole-file inflate / deflate on `threads` host threads.  The reader
+ * verifies each block's CRC32; the writer emits 0xff00-byte payload blocks and the EOF marker. */
+int br_bgzf_write_file(const char *path, const uint8_t *data, uint64_t n, int threads, int level);
+int br_bgzf_read_file(const char *path, int threads, uint8_t **out, uint64_t *n); /* free with br_free_buffer */
+void br_free_buffer(uint8_t *);
+const char *br_bgzf_codec(void); /* "libdeflate" (bound at run time when present) or "zlib" */
+
 /* ---- measurement hooks ------------------------------------------------------ */
 
 /* Kernel names reported by br_ctx_kernel_ms / rocprof. */
