@@ -123,9 +123,9 @@ def main():
             if r.returncode != 0:
                 print(r.stderr, file=sys.stderr)
                 sys.exit(1)
-            tail = [l for l in r.stdout.splitlines() if "bundles" in l]
+            tail = [l for l in r.stdout.splitlines() if "bundles" in l or "stage busy" in l]
             res["level%d" % level] = {"wall_s": round(wall, 2), "alignments_per_s": len(rlen) / wall, "out_bam_bytes": os.path.getsize(out_bam),
-                                       "report": tail[-1] if tail else ""}
+                                       "report": " | ".join(tail)}
         # CPU beside it: the oracle's reader side + projection + write_to_bam on a sample, one thread, no (de)compression
         m = min(len(rlen), 200_000)
         while m < len(rlen) and batch["name_off"][m + 1] - batch["name_off"][m] == batch["name_off"][m] - batch["name_off"][m - 1] and \

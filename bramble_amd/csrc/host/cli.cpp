@@ -283,6 +283,9 @@ extern "C" int br_cli_main(int argc, char **argv) {
   Slot<Bundle> to_gpu; Slot<OutChunk> to_writer;
   uint64_t total_reads = 0, unmapped_reads = 0;
   std::string reader_err, writer_err;
+  double t_inflate = 0, t_split = 0, t_copy = 0, t_deflate = 0, t_wait_gpu_in = 0;
+  auto now = []() { return std::chrono::steady_clock::now(); };
+  auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
 
   std::thread reader([&]() {
     buf.erase(buf.begin(), buf.begin() + (ptrdiff_t)pos); pos = 0;
@@ -298,6 +301,7 @@ extern "C" int br_cli_main(int argc, char **argv) {
         size_t base = off.size();
         off.resize(base + cap); len.resize(base + cap);
         int64_t n = 0, un = 0; uint64_t used = 0;
+        auto ts0 = now();
         int r = br_bam_split(buf.data() + scanned, buf.size() - scanned, (int64_t)cap, off.data() + base, len.data() + base, &n, &un, &used);
         if (r) { reader_err = "malformed BAM record"; to_gpu.finish(); return; }
         for (int64_t i = 0; i < n; i++) off[base + (size_t)i] += scanned;
@@ -310,13 +314,17 @@ extern "C" int br_cli_main(int argc, char **argv) {
           if (la != lb || memcmp(a, b, la) != 0) { cut = (int64_t)i; break; }
         }
         searched = std::max(searched, off.size());
+        t_split += secs(ts0, now());
         if (cut >= 0 || eof) break;
+        auto ti0 = now();
         int64_t got = rd.read(buf, 256u << 20);
+        t_inflate += secs(ti0, now());
         if (got < 0) { reader_err = rd.error(); to_gpu.finish(); return; }
         if (got == 0) { eof = true; if (scanned != buf.size()) { reader_err = "truncated BAM record at end of file"; to_gpu.finish(); return; } }
       }
       size_t n_take = cut >= 0 ? (size_t)cut : off.size();
       if (n_take) {
+        auto tc0 = now();
         auto b = std::make_unique<Bundle>();
         size_t byte_end = (n_take < off.size()) ? (size_t)off[n_take] - 4 : scanned;
         b->off.assign(off.begin(), off.begin() + (ptrdiff_t)n_take); b->len.assign(len.begin(), len.begin() + (ptrdiff_t)n_take);
@@ -327,6 +335,7 @@ extern "C" int br_cli_main(int argc, char **argv) {
         std::vector<uint64_t> noff(off.begin() + (ptrdiff_t)n_take, off.end()); std::vector<uint32_t> nlen(len.begin() + (ptrdiff_t)n_take, len.end());
         for (auto &x : noff) x -= byte_end;
         off.swap(noff); len.swap(nlen);
+        t_copy += secs(tc0, now());
         to_gpu.put(std::move(b));
       }
       if (cut < 0 && eof) break;
@@ -338,7 +347,9 @@ extern "C" int br_cli_main(int argc, char **argv) {
     for (;;) {
       OutChunk *c = to_writer.hold();
       if (!c) break;
+      auto td0 = now();
       if (writer_err.empty() && c->n && !wr.write(c->data, (size_t)c->n)) writer_err = wr.error();
+      t_deflate += secs(td0, now());
       to_writer.release();
     }
   });
@@ -347,7 +358,9 @@ extern "C" int br_cli_main(int argc, char **argv) {
   double gpu_seconds = 0;
   int fail = 0;
   for (;;) {
+    auto tw0 = now();
     auto b = to_gpu.take();
+    t_wait_gpu_in += secs(tw0, now());
     if (!b) break;
     if (fail) continue;  // drain
     br_bam_bundle bb{b->blob.data(), b->blob.size(), b->off.data(), b->len.data(), (int64_t)b->off.size(), ref_map.data(), (int32_t)ref_map.size()};
@@ -375,6 +388,8 @@ extern "C" int br_cli_main(int argc, char **argv) {
     printf("# unique alignments:  %llu\n\n", (unsigned long long)total_unique);
     printf("[bramble] %llu bundles, %.2fs on the device path (upload + kernels + download), %.2fs wall (setup %.2fs, codec %s)\n",
            (unsigned long long)n_bundles, gpu_seconds, since(), t_setup, brio::codec_name());
+    printf("[bramble] stage busy time: inflate %.2fs, split %.2fs, bundle copy %.2fs, device %.2fs (waited for input %.2fs), deflate+write %.2fs\n",
+           t_inflate, t_split, t_copy, gpu_seconds, t_wait_gpu_in, t_deflate);
   }
   return fail;
 }

@@ -89,7 +89,11 @@ __global__ void __launch_bounds__(256) k_rec_fields(ParseArgs P) {
     ncig = max(ncig, (uint32_t)__shfl_xor((int)ncig, o));
     max_s = max(max_s, (uint32_t)__shfl_xor((int)max_s, o));
   }
-  if ((threadIdx.x & 63) == 0) { if (ncig) atomicMax(P.maxima, ncig); if (max_s) atomicMax(P.maxima + 1, max_s); }
+  // the maxima only grow: a (possibly stale) plain read filters out nearly every same-address atomic
+  if ((threadIdx.x & 63) == 0) {
+    if (ncig > __builtin_nontemporal_load(P.maxima)) atomicMax(P.maxima, ncig);
+    if (max_s > __builtin_nontemporal_load(P.maxima + 1)) atomicMax(P.maxima + 1, max_s);
+  }
 }
 
 // after the exclusive scan of isnew: group g starts at record i when isnew[i]

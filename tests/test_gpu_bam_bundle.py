@@ -179,3 +179,65 @@ def test_bam_bundle_empty():
     assert got.size == 0 and counters["n_rows"] == 0
     ctx.close()
     idx.close()
+
+
+def _rec_full(name, ref, pos0, flag, cigar, mref, mpos0, seq, qual, aux, mapq=37):
+    """One BAM record from explicit parts (seq: ASCII or '', qual: bytes / None for 0xff fill, aux: raw bytes)."""
+    ops = "MIDNSHP=X"
+    cg, num = [], ""
+    for ch in cigar:
+        if ch.isdigit():
+            num += ch
+        else:
+            cg.append((int(num) << 4) | ops.index(ch))
+            num = ""
+    nm = name.encode() + b"\0"
+    code = {c: i for i, c in enumerate("=ACMGRSVTWYHKDBN")}
+    ls = len(seq)
+    packed = bytearray((ls + 1) // 2)
+    for i, ch in enumerate(seq):
+        packed[i >> 1] |= code[ch] << (4 if i % 2 == 0 else 0)
+    q = bytes([0xff] * ls) if qual is None else bytes(qual)
+    body = bytearray()
+    body += int(ref).to_bytes(4, "little", signed=True) + int(pos0).to_bytes(4, "little", signed=True)
+    body += bytes([len(nm), mapq]) + (4680).to_bytes(2, "little") + len(cg).to_bytes(2, "little") + int(flag).to_bytes(2, "little")
+    body += int(ls).to_bytes(4, "little") + int(mref).to_bytes(4, "little", signed=True)
+    body += int(mpos0).to_bytes(4, "little", signed=True) + (0).to_bytes(4, "little")
+    body += nm
+    for w in cg:
+        body += int(w).to_bytes(4, "little")
+    body += bytes(packed) + q + aux
+    return len(body).to_bytes(4, "little") + bytes(body)
+
+
+def test_bam_bundle_unusual_records():
+    """Records real aligners produce that the generator does not: hard clips, =/X ops, odd and empty sequences, absent
+    qualities, IUPAC codes, long and one-character names, every aux value type (incl. Z strings holding tag-like text,
+    H, B arrays, f), repeated NH tags, XS as Z, no aux at all, no CIGAR."""
+    txs = [{"id": "fw", "ref_id": 0, "strand": "+", "exons": [[1000, 1200], [2000, 2200], [3000, 3300]]},
+           {"id": "rv", "ref_id": 0, "strand": "-", "exons": [[900, 1200], [2000, 2200]]},
+           {"id": "rv2", "ref_id": 0, "strand": "-", "exons": [[5000, 5400]]}]
+    ann = {"refnames": ["chr1"], "transcripts": txs}
+    rng = np.random.RandomState(3)
+
+    def rs(n):
+        return "".join("ACGTNRYK"[int(x)] for x in rng.randint(0, 8, size=n))
+    i32 = lambda v: int(v).to_bytes(4, "little", signed=True)
+    recs = []
+    aux_all = (b"NHC\x03" + b"XSA-" + b"ZZZNH:i:1 HI\x00" + b"HHH1AE3\x00" + b"fff" + b"\x00\x00\x80?" + b"BBBs\x03\x00\x00\x00\x01\x00\x02\x00\x03\x00" +
+               b"ASs\xfe\xff" + b"HIi" + i32(7) + b"NHS\x09\x00" + b"tsA+" + b"BIBI\x01\x00\x00\x00\xff\xff\xff\xff" + b"cc" + b"c\x80")
+    recs.append(_rec_full("n1", 0, 1049, 0, "3H5S40=2X53M", -1, -1, rs(100), rng.randint(2, 40, 100).astype(np.uint8).tobytes(), aux_all))
+    recs.append(_rec_full("n2", 0, 5099, 16, "101M", -1, -1, rs(101), rng.randint(2, 40, 101).astype(np.uint8).tobytes(), b"XSZ-foo\x00NMC\x01"))
+    recs.append(_rec_full("n3", 0, 5099, 0, "33M", -1, -1, rs(33), None, b""))                          # odd length, no quals, no aux
+    recs.append(_rec_full("n3", 0, 5149, 256, "33M", -1, -1, "", None, b"NHC\x02"))                     # secondary without SEQ
+    recs.append(_rec_full("q" * 250, 0, 1149, 0, "51M800N50M", -1, -1, rs(101), rng.randint(2, 40, 101).astype(np.uint8).tobytes(), b"XSA+"))
+    recs.append(_rec_full("x", 0, 949, 0x1 | 0x40, "1M", 0, 1999, rs(1), bytes([30]), b"NHi" + i32(1)))
+    recs.append(_rec_full("x", 0, 1999, 0x1 | 0x80 | 0x10, "7M", 0, 949, rs(7), bytes([30] * 7), b""))
+    recs.append(_rec_full("nocigar", 0, 1000, 0, "", -1, -1, rs(10), bytes([1] * 10), b"NHC\x01"))
+    recs.append(_rec_full("clipH", 0, 2049, 0, "10H100M10H", -1, -1, rs(100), rng.randint(2, 40, 100).astype(np.uint8).tobytes(), b"MDZ100\x00"))
+    recs.append(_rec_full("del", 0, 1099, 0, "50M3D2I48M", -1, -1, rs(100), rng.randint(2, 40, 100).astype(np.uint8).tobytes(), b"tsA-"))
+    stream = np.frombuffer(b"".join(recs), dtype=np.uint8)
+    for flags in ({}, {"lr": 1}, {"strict": 1}, {"fr": 1}):
+        got, counters, orc, _ = run_both_bam(ann, stream, np.array([0], dtype=np.int32), **flags)
+        assert orc["n_rows"] >= 6
+        assert_streams_equal(got, orc["bam_stream"])
