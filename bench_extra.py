@@ -110,7 +110,19 @@ def main():
         bamio.write_gtf(gtf, annd)
         refs = [(r, 250_000_000) for r in annd["refnames"]]
         t0 = time.perf_counter()
-        bamio.write_bam(in_bam, "@HD\tVN:1.6\tSO:unsorted\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % r for r in refs), refs, stream_h.tobytes(), level=1)
+        # input preparation (not measured): BAM header + the framed records, BGZF-compressed with the library's writer
+        import ctypes as C
+        import struct
+        text = ("@HD\tVN:1.6\tSO:unsorted\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % r for r in refs)).encode()
+        hb = bytearray(b"BAM\x01" + struct.pack("<i", len(text)) + text + struct.pack("<i", len(refs)))
+        for name, ln in refs:
+            nm = name.encode() + b"\0"
+            hb += struct.pack("<i", len(nm)) + nm + struct.pack("<i", ln)
+        whole = np.concatenate([np.frombuffer(bytes(hb), dtype=np.uint8), stream_h])
+        L = lib.lib()
+        L.br_bgzf_write_file.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int]
+        assert L.br_bgzf_write_file(in_bam.encode(), whole.ctypes.data, whole.size, args.threads, 6) == 0
+        del whole
         prep = time.perf_counter() - t0
         exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bramble_amd", "bin", "bramble")
         res = {}

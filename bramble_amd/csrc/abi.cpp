@@ -388,6 +388,8 @@ struct br_ctx {
   DevBuf seg, meta, head, head2, fast_flag, fast_pre, m_k, n_matches, ranges, mask, match_off, cig_base, tile_sums, totals, counters_d;
   DevBuf m_tid, m_aux, m_a, m_b, m_cigoff, cig_arena, big_list, n_big, m_aln;
   DevBuf bam_aux, bam_len, bam_off, bam_out;
+  DevBuf z_slots, z_sizes, z_off, z_dense, z_tabs;
+  bool z_tabs_ready = false;
   DevBuf p_ncig, p_name_len, p_isnew, p_group_pre, p_small, p_big, p_seq_len, p_ref_map, p_blob, p_rec_off, p_rec_len;
   uint8_t *h_bam[2] = {nullptr, nullptr}; size_t h_bam_cap[2] = {0, 0}; int h_bam_next = 0;  // pinned download buffers of br_project_bam_bundle (alternating)
   int64_t last_n_rows = 0, last_n_aln = 0;
@@ -424,6 +426,8 @@ extern "C" int br_ctx_new(const br_index *ix, br_ctx **out) {
   HIPCHK(hipGetDeviceProperties(&prop, ix->device));
   c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   HIPCHK(hipHostMalloc((void **)&c->h_totals, 32 * sizeof(uint64_t), hipHostMallocDefault));
+  const char *bl = getenv("BRAMBLE_AMD_BAM_LANES");
+  if (bl) { int v = atoi(bl); if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64 || v == 104 || v == 108 || v == 116) c->bam_lanes = v; }
   const char *g = getenv("BRAMBLE_AMD_GROUP_LANES");
   if (g) { int v = atoi(g); if (v == 8 || v == 16 || v == 32 || v == 64) c->group_lanes = v; }
   *out = c;
@@ -436,7 +440,7 @@ extern "C" void br_ctx_free(br_ctx *c) {
   DevBuf *bufs[] = {&c->seg, &c->meta, &c->head, &c->head2, &c->fast_flag, &c->fast_pre, &c->m_k, &c->n_matches, &c->ranges, &c->mask, &c->match_off, &c->cig_base,
                     &c->tile_sums, &c->totals, &c->counters_d, &c->m_tid, &c->m_aux, &c->m_a, &c->m_b,
                     &c->m_cigoff, &c->cig_arena, &c->big_list, &c->n_big, &c->m_aln,
-                    &c->bam_aux, &c->bam_len, &c->bam_off, &c->bam_out, &c->p_ncig, &c->p_name_len, &c->p_isnew, &c->p_group_pre, &c->p_small, &c->p_big, &c->p_seq_len, &c->p_ref_map, &c->p_blob, &c->p_rec_off, &c->p_rec_len, &c->fa_stats, &c->fa_n_prob, &c->fa_seq_bytes, &c->fa_prob_off, &c->fa_seqarena_off, &c->fa_probs, &c->fa_results,
+                    &c->bam_aux, &c->bam_len, &c->bam_off, &c->bam_out, &c->z_slots, &c->z_sizes, &c->z_off, &c->z_dense, &c->z_tabs, &c->p_ncig, &c->p_name_len, &c->p_isnew, &c->p_group_pre, &c->p_small, &c->p_big, &c->p_seq_len, &c->p_ref_map, &c->p_blob, &c->p_rec_off, &c->p_rec_len, &c->fa_stats, &c->fa_n_prob, &c->fa_seq_bytes, &c->fa_prob_off, &c->fa_seqarena_off, &c->fa_probs, &c->fa_results,
                     &c->fa_seq_arena, &c->fa_clip_ops, &c->fa_ideal_cap, &c->fa_scratch, &c->b_seq_off, &c->b_seqs, &c->b_seq_src,
                     &c->n_rows, &c->row_off, &c->aln_group, &c->r_input, &c->r_rec, &c->r_nh, &c->r_hi, &c->r_mapq,
                     &c->r_group, &c->r_mate_tid, &c->r_mate_pos, &c->r_isize, &c->r_tid, &c->r_pos,
@@ -455,7 +459,7 @@ extern "C" int br_ctx_set_profiling(br_ctx *c, int enabled) { if (!c) return BR_
 extern "C" int br_ctx_set_param(br_ctx *c, const char *key, int64_t v) {
   if (!c || !key) return BR_ERR_INVALID_ARG;
   if (!strcmp(key, "group_lanes")) { if (v != 8 && v != 16 && v != 32 && v != 64) return BR_ERR_INVALID_ARG; c->group_lanes = (int)v; return BR_OK; }
-  if (!strcmp(key, "bam_lanes")) { if (v != 4 && v != 8 && v != 16 && v != 32 && v != 64) return BR_ERR_INVALID_ARG; c->bam_lanes = (int)v; return BR_OK; }
+  if (!strcmp(key, "bam_lanes")) { if (v != 4 && v != 8 && v != 16 && v != 32 && v != 64 && v != 104 && v != 108 && v != 116) return BR_ERR_INVALID_ARG; c->bam_lanes = (int)v; return BR_OK; }
   if (!strcmp(key, "blocks_per_cu")) { if (v < 1 || v > 64) return BR_ERR_INVALID_ARG; c->blocks_per_cu = (int)v; return BR_OK; }
   return BR_ERR_INVALID_ARG;
 }
@@ -960,6 +964,62 @@ extern "C" int br_project_bam_device(br_ctx *c, const br_config *cfg, const br_d
   return BR_OK;
 }
 
+// ---------------------------------------------------------------------------
+// BGZF deflate on the device
+// ---------------------------------------------------------------------------
+static int deflate_device_impl(br_ctx *c, const uint8_t *src, uint64_t n, hipStream_t st, const uint8_t **out, uint64_t *out_bytes,
+                               bool keep_events) {
+  *out = nullptr; *out_bytes = 0;
+  Prof pf{c, st};
+  if (!keep_events) c->events_used = 0;
+  if (n == 0) { if (!keep_events) pf.collect(); return BR_OK; }
+  if (!c->z_tabs_ready) {
+    // CRC-32 (reflected 0xEDB88320) byte table and the operator that appends DEFLATE_CRC_CHUNK zero bytes to a
+    // register (zlib's crc32_combine does the same with squared matrices; here the length is fixed)
+    std::vector<uint32_t> t(256 + 1024);
+    for (uint32_t i = 0; i < 256; i++) { uint32_t v = i; for (int k = 0; k < 8; k++) v = (v & 1u) ? 0xEDB88320u ^ (v >> 1) : v >> 1; t[i] = v; }
+    uint32_t col[32];
+    for (int b = 0; b < 32; b++) { uint32_t v = 1u << b; for (uint32_t k = 0; k < DEFLATE_CRC_CHUNK; k++) v = (v >> 8) ^ t[v & 0xffu]; col[b] = v; }
+    for (int byte = 0; byte < 4; byte++)
+      for (uint32_t x = 0; x < 256; x++) { uint32_t v = 0; for (int b = 0; b < 8; b++) if (x & (1u << b)) v ^= col[8 * byte + b]; t[256 + 256 * byte + x] = v; }
+    RC(c->z_tabs.ensure(t.size() * 4));
+    HIPCHK(hipMemcpyAsync(c->z_tabs.p, t.data(), t.size() * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    c->z_tabs_ready = true;
+  }
+  uint64_t nb = (n + DEFLATE_PAYLOAD - 1) / DEFLATE_PAYLOAD;
+  RC(c->z_slots.ensure((size_t)nb * DEFLATE_SLOT)); RC(c->z_sizes.ensure((size_t)nb * 4)); RC(c->z_off.ensure(((size_t)nb + 1) * 8));
+  RC(c->tile_sums.ensure((size_t)std::max<int64_t>(scan_tiles_for((int64_t)nb + 1), 1) * 8 * 3));
+  RC(c->totals.ensure(8 * 8));
+  DeflateArgs A{};
+  A.src = src; A.n_bytes = n; A.n_blocks = nb; A.slots = c->z_slots.as<uint8_t>(); A.sizes = c->z_sizes.as<uint32_t>();
+  A.crc_tab = c->z_tabs.as<uint32_t>(); A.crc_shift = c->z_tabs.as<uint32_t>() + 256;
+  RC(pf.begin(BR_K_CODEC));
+  launch_deflate(st, A);
+  RC(pf.end());
+  ScanArgs S{}; S.n = (int64_t)nb; S.src32 = A.sizes; S.tile_sums = c->tile_sums.as<uint64_t>();
+  RC(pf.begin(BR_K_SCAN));
+  launch_scan(st, S, 2, c->z_off.p, true, c->totals.as<uint64_t>() + 5);
+  RC(pf.end());
+  HIPCHK(hipMemcpyAsync(c->h_totals + 24, c->totals.as<uint64_t>() + 5, 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  uint64_t total = c->h_totals[24];
+  RC(c->z_dense.ensure((size_t)total + 16));
+  RC(pf.begin(BR_K_CODEC));
+  launch_bgzf_compact(st, A, c->z_off.as<uint64_t>(), c->z_dense.as<uint8_t>());
+  RC(pf.end());
+  if (!keep_events) { HIPCHK(hipStreamSynchronize(st)); RC(pf.collect()); }
+  *out = c->z_dense.as<uint8_t>(); *out_bytes = total;
+  return BR_OK;
+}
+
+extern "C" int br_bgzf_deflate_device(br_ctx *c, const uint8_t *src, uint64_t n, void *stream, const uint8_t **out,
+                                      uint64_t *out_bytes) {
+  if (!c || (!src && n) || !out || !out_bytes) return BR_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(c->ix->device));
+  return deflate_device_impl(c, src, n, (hipStream_t)stream, out, out_bytes, false);
+}
+
 extern "C" int br_bam_split(const uint8_t *data, uint64_t n_bytes, int64_t cap, uint64_t *rec_off, uint32_t *rec_len,
                             int64_t *n_records, int64_t *n_unmapped, uint64_t *consumed) {
   if ((!data && n_bytes) || !rec_off || !rec_len || !n_records || !consumed || cap < 0) return BR_ERR_INVALID_ARG;
@@ -1003,6 +1063,11 @@ extern "C" int br_project_bam_bundle(br_ctx *c, const br_config *cfg, const br_b
   br_device_records dr{c->p_blob.as<uint8_t>(), c->p_rec_off.as<uint64_t>(), n, c->p_rec_len.as<uint32_t>()};
   br_device_rows rows; br_device_bam db;
   RC(br_project_bam_device(c, cfg, &dr, bb->ref_map, bb->n_ref_map, st, &rows, &db));
+  if (bb->bgzf_on_device && db.n_bytes) {
+    const uint8_t *z = nullptr; uint64_t zn = 0;
+    RC(deflate_device_impl(c, db.data, db.n_bytes, st, &z, &zn, false));
+    db.data = z; db.n_bytes = zn;
+  }
   int slot = c->h_bam_next; c->h_bam_next ^= 1;
   if (db.n_bytes > c->h_bam_cap[slot]) {
     if (c->h_bam[slot]) { HIPCHK(hipHostFree(c->h_bam[slot])); c->h_bam[slot] = nullptr; c->h_bam_cap[slot] = 0; }

@@ -155,6 +155,21 @@ struct BamArgs {
 };
 void launch_bam_scan(hipStream_t st, const BamArgs &B);
 
+// BGZF on the device (codec_kernels.hip)
+#define DEFLATE_PAYLOAD 57344u   // uncompressed bytes per BGZF block: worst case (all 9-bit literals) still fits 64 KiB
+#define DEFLATE_SLOT 65536u
+#define DEFLATE_CRC_CHUNK 896u   // 64 lane-chunks per full block
+struct DeflateArgs {
+  const uint8_t *src;
+  uint64_t n_bytes, n_blocks;
+  uint8_t *slots;              // n_blocks * DEFLATE_SLOT
+  uint32_t *sizes;             // [n_blocks] BGZF block sizes
+  const uint32_t *crc_tab;     // [256] reflected CRC-32 table
+  const uint32_t *crc_shift;   // [4][256] "append DEFLATE_CRC_CHUNK zero bytes" operator
+};
+void launch_deflate(hipStream_t st, const DeflateArgs &A);
+void launch_bgzf_compact(hipStream_t st, const DeflateArgs &A, const uint64_t *off, uint8_t *dense);
+
 // BAM records -> input tables (parse_kernels.hip)
 struct ParseArgs {
   int64_t n, n_groups;

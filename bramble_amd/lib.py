@@ -12,10 +12,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbramble_amd.so")
 _P = C.POINTER
 
-K_SEGMENT, K_COUNT, K_EMIT, K_PAIR_COUNT, K_PAIR_EMIT, K_GATHER, K_SCAN, K_EMIT_AUX, K_KSW, K_BAM, K_PARSE, K_NUM = range(12)
+K_SEGMENT, K_COUNT, K_EMIT, K_PAIR_COUNT, K_PAIR_EMIT, K_GATHER, K_SCAN, K_EMIT_AUX, K_KSW, K_BAM, K_PARSE, K_CODEC, K_NUM = range(13)
 KERNEL_NAMES = ["k_segment", "k_project<G,false>", "k_emit_dense", "k_group_ids+k_pair<false>", "k_pair<true>",
                 "k_row_fill+k_group_stats+k_gather", "k_scan_*", "k_expand+k_project<64,true>", "k_ksw", "k_bam_scan+k_bam_size+k_bam_encode",
-                "k_rec_fields+k_group_off+k_rec_copy+k_mates+k_seq_*"]
+                "k_rec_fields+k_group_off+k_rec_copy+k_mates+k_seq_*", "k_deflate_fixed+k_bgzf_compact"]
 
 
 class BrambleError(RuntimeError):
@@ -93,7 +93,7 @@ class BrDeviceRecords(C.Structure):
 
 class BrBamBundle(C.Structure):
     _fields_ = [("blob", C.c_void_p), ("n_bytes", C.c_uint64), ("rec_off", C.c_void_p), ("rec_len", C.c_void_p),
-                ("n_records", C.c_int64), ("ref_map", C.c_void_p), ("n_ref_map", C.c_int32)]
+                ("n_records", C.c_int64), ("ref_map", C.c_void_p), ("n_ref_map", C.c_int32), ("bgzf_on_device", C.c_int32)]
 
 
 class BrHostBam(C.Structure):
@@ -110,7 +110,7 @@ EXPORTS = ["br_index_build", "br_index_build_flat", "br_index_free", "br_index_n
            "br_config_long_read", "br_config_resolve", "br_batch_prepare", "br_batch_seq_source", "br_ctx_new", "br_ctx_free",
            "br_project_batch", "br_project_batch_device", "br_project_group", "br_bam_encode_device", "br_project_bam_device", "br_project_bam_bundle", "br_bam_split", "br_annotation_load", "br_annotation_free",
            "br_annotation_num_transcripts", "br_annotation_transcripts", "br_annotation_num_refs", "br_annotation_refnames", "br_cli_main", "br_bgzf_write_file", "br_bgzf_read_file",
-           "br_free_buffer", "br_bgzf_codec", "br_ctx_set_profiling",
+           "br_free_buffer", "br_bgzf_codec", "br_bgzf_deflate_device", "br_ctx_set_profiling",
            "br_ctx_set_param", "br_ctx_kernel_ms", "br_ctx_collect_counters", "br_ctx_last_counters", "br_ctx_rescue_stats", "br_primary_pick", "br_version", "br_strerror"]
 
 _LIB = None
@@ -177,6 +177,7 @@ def lib():
                                    _P(C.c_uint64)]
         L.br_index_num_refs.restype = C.c_size_t
         L.br_index_num_refs.argtypes = [C.c_void_p]
+        L.br_bgzf_deflate_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, _P(C.c_void_p), _P(C.c_uint64)]
         L.br_ctx_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.br_ctx_set_param.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
         L.br_ctx_kernel_ms.argtypes = [C.c_void_p, C.c_int, _P(C.c_double), _P(C.c_int32)]
@@ -439,14 +440,26 @@ class Context:
                                           C.byref(rows), C.byref(out)), "br_project_bam_device")
         return rows, out
 
-    def project_bam_bundle(self, cfg, blob, rec_off, rec_len, ref_map):
+    def bgzf_deflate_device(self, src, stream=0):
+        """src: torch CUDA uint8 tensor -> torch CUDA uint8 tensor view of the concatenated BGZF blocks (valid until the
+        next call on this context)."""
+        import torch
+        from .device import _DevArray
+        out, n = C.c_void_p(), C.c_uint64()
+        check(lib().br_bgzf_deflate_device(self.h, C.c_void_p(src.data_ptr()), src.numel(), C.c_void_p(stream), C.byref(out),
+                                           C.byref(n)), "br_bgzf_deflate_device")
+        if n.value == 0:
+            return torch.zeros(0, dtype=torch.uint8, device=src.device)
+        return torch.as_tensor(_DevArray(out.value, n.value, "|u1"), device=src.device)
+
+    def project_bam_bundle(self, cfg, blob, rec_off, rec_len, ref_map, bgzf_on_device=False):
         """Host form: numpy blob / rec_off (uint64) / rec_len (uint32) in, (stream uint8[], counters dict) out."""
         blob = np.ascontiguousarray(blob, dtype=np.uint8)
         rec_off = np.ascontiguousarray(rec_off, dtype=np.uint64)
         rec_len = np.ascontiguousarray(rec_len, dtype=np.uint32)
         rm = np.ascontiguousarray(ref_map, dtype=np.int32)
         bb = BrBamBundle(blob.ctypes.data, blob.size, rec_off.ctypes.data, rec_len.ctypes.data, len(rec_len),
-                         rm.ctypes.data, len(rm))
+                         rm.ctypes.data, len(rm), 1 if bgzf_on_device else 0)
         out = BrHostBam()
         check(lib().br_project_bam_bundle(self.h, C.byref(cfg), C.byref(bb), C.byref(out)), "br_project_bam_bundle")
         n = int(out.n_bytes)

@@ -317,6 +317,8 @@ typedef struct br_bam_bundle {
   int64_t n_records;
   const int32_t *ref_map;
   int32_t n_ref_map;
+  int32_t bgzf_on_device;   /* 1: deflate the projected stream on the device; br_host_bam.data then holds complete
+                             * BGZF blocks (append them to the output file as they are) */
 } br_bam_bundle;
 
 typedef struct br_host_bam {
@@ -337,6 +339,10 @@ int br_project_bam_bundle(br_ctx *, const br_config *, const br_bam_bundle *, br
  * block_size. */
 int br_bam_split(const uint8_t *data, uint64_t n_bytes, int64_t cap, uint64_t *rec_off, uint32_t *rec_len,
                  int64_t *n_records, int64_t *n_unmapped, uint64_t *consumed);
+
+/* BGZF-compress n bytes that sit in HBM (one wave per 56 KiB block: hash-table LZ77 + fixed-Huffman DEFLATE + CRC32);
+ * *out is a device pointer to the concatenated blocks (no EOF marker), valid until the next call on the context. */
+int br_bgzf_deflate_device(br_ctx *, const uint8_t *src, uint64_t n, void *stream, const uint8_t **out, uint64_t *out_bytes);
 
 /* ---- annotation loading and the command line (scope table rows f-1 / f-3) ----------------- */
 
@@ -381,7 +387,8 @@ const char *br_bgzf_codec(void); /* "libdeflate" (bound at run time when present
 #define BR_K_KSW 8        /* k_ksw (-S clip rescue DP) */
 #define BR_K_BAM 9        /* k_bam_scan + k_bam_size + k_bam_encode */
 #define BR_K_PARSE 10     /* k_rec_fields + k_group_off + k_rec_copy + k_mates* + k_seq_* */
-#define BR_K_NUM 11
+#define BR_K_CODEC 11     /* k_deflate_fixed + k_bgzf_compact */
+#define BR_K_NUM 12
 /* When enabled, every launch is bracketed by hipEvents on the launch stream. */
 int br_ctx_set_profiling(br_ctx *, int enabled);
 /* Launch tuning: "group_lanes" (8|16|32|64 lanes cooperating on one alignment),
