@@ -89,7 +89,20 @@ def main():
                 kms[k] = kms.get(k, 0.0) + ms
         torch.cuda.synchronize()
         el = (time.perf_counter() - t0) / args.steps
-        print(json.dumps({"config": "bundle", "workload": "%d raw paired-end BAM records resident in HBM -> %d projected BAM records (reader side, projection and re-encoding on the device)" % (len(rlen), int(bam.n_rows)),
+        # optional last stage: BGZF deflate of the projected stream on the device
+        z = ctx.bgzf_deflate_device(torch.as_tensor(brdev._DevArray(bam.data, int(bam.n_bytes), "|u1"), device="cuda:0"), st)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        zk = {}
+        for _ in range(args.steps):
+            z = ctx.bgzf_deflate_device(torch.as_tensor(brdev._DevArray(bam.data, int(bam.n_bytes), "|u1"), device="cuda:0"), st)
+            for k, (ms, ln) in ctx.kernel_ms().items():
+                zk[k] = zk.get(k, 0.0) + ms
+        torch.cuda.synchronize()
+        zel = (time.perf_counter() - t0) / args.steps
+        deflate = {"ms_per_step": zel * 1e3, "compressed_bytes": int(z.numel()), "ratio": int(bam.n_bytes) / max(int(z.numel()), 1),
+                   "GBps_in": int(bam.n_bytes) / zel / 1e9, "kernel_ms_per_step": {k: round(v / args.steps, 3) for k, v in zk.items() if v}}
+        print(json.dumps({"config": "bundle", "device_deflate": deflate, "workload": "%d raw paired-end BAM records resident in HBM -> %d projected BAM records (reader side, projection and re-encoding on the device)" % (len(rlen), int(bam.n_rows)),
                           "alignments_per_s": len(rlen) / el, "ms_per_step": el * 1e3, "input_bytes": int(stream_h.size),
                           "output_bytes": int(bam.n_bytes), "kernel_ms_per_step": {k: round(v / args.steps, 3) for k, v in kms.items() if v}}))
         return
@@ -126,17 +139,18 @@ def main():
         prep = time.perf_counter() - t0
         exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bramble_amd", "bin", "bramble")
         res = {}
-        for level in (1, 6):
-            out_bam = os.path.join(tmp, "out%d.bam" % level)
+        for level in (1, 6, "device"):
+            out_bam = os.path.join(tmp, "out%s.bam" % level)
             t0 = time.perf_counter()
-            r = subprocess.run([exe, in_bam, "-G", gtf, "-o", out_bam, "-p", str(args.threads), "--compression-level", str(level)],
+            codec = ["--device-deflate"] if level == "device" else ["--compression-level", str(level)]
+            r = subprocess.run([exe, in_bam, "-G", gtf, "-o", out_bam, "-p", str(args.threads)] + codec,
                                capture_output=True, text=True)
             wall = time.perf_counter() - t0
             if r.returncode != 0:
                 print(r.stderr, file=sys.stderr)
                 sys.exit(1)
             tail = [l for l in r.stdout.splitlines() if "bundles" in l or "stage busy" in l]
-            res["level%d" % level] = {"wall_s": round(wall, 2), "alignments_per_s": len(rlen) / wall, "out_bam_bytes": os.path.getsize(out_bam),
+            res["level%s" % level] = {"wall_s": round(wall, 2), "alignments_per_s": len(rlen) / wall, "out_bam_bytes": os.path.getsize(out_bam),
                                        "report": " | ".join(tail)}
         # CPU beside it: the oracle's reader side + projection + write_to_bam on a sample, one thread, no (de)compression
         m = min(len(rlen), 200_000)

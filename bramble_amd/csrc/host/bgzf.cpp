@@ -4,6 +4,10 @@
 #include <zlib.h>
 
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <stdlib.h>
 
 #include <atomic>
@@ -67,13 +71,19 @@ static const size_t BLOCK_DATA = 0xff00;  // htslib BGZF_BLOCK_SIZE: uncompresse
 static const uint8_t EOF_BLOCK[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0,
                                       0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
-BgzfReader::~BgzfReader() { if (f_) fclose(f_); }
+BgzfReader::~BgzfReader() { if (map_) munmap((void *)map_, map_size_); if (f_) fclose(f_); }
 
 bool BgzfReader::open(const char *path, int threads) {
   f_ = fopen(path, "rb");
   threads_ = threads < 1 ? 1 : threads;
   if (!f_) { err_ = std::string("cannot open ") + path; return false; }
-  if (!fill(18) || cbuf_.size() - cpos_ < 18 || cbuf_[cpos_] != 0x1f || cbuf_[cpos_ + 1] != 0x8b || !(cbuf_[cpos_ + 3] & 4)) {
+  // regular files are mapped: the inflate workers read the page cache directly (no fread copy on the reader thread)
+  struct stat sb;
+  if (fstat(fileno(f_), &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) {
+    void *m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fileno(f_), 0);
+    if (m != MAP_FAILED) { map_ = (const uint8_t *)m; map_size_ = (size_t)sb.st_size; madvise(m, map_size_, MADV_SEQUENTIAL); }
+  }
+  if (!fill(18) || have() < 18 || cur()[0] != 0x1f || cur()[1] != 0x8b || !(cur()[3] & 4)) {
     err_ = std::string(path) + " is not a BGZF (BAM) file";
     return false;
   }
@@ -82,8 +92,9 @@ bool BgzfReader::open(const char *path, int threads) {
 
 // make at least `need` compressed bytes available at cpos_ (fewer at end of file)
 bool BgzfReader::fill(size_t need) {
+  if (map_) return have() >= need;
   if (cbuf_.size() - cpos_ >= need) return true;
-  if (cpos_ > 0) { cbuf_.erase(cbuf_.begin(), cbuf_.begin() + (ptrdiff_t)cpos_); cpos_ = 0; }
+  if (cpos_ > 0) { cbuf_.erase_front(cpos_); cpos_ = 0; }
   size_t chunk = std::max<size_t>(need, 16u << 20);
   size_t old = cbuf_.size();
   cbuf_.resize(old + chunk);
@@ -117,22 +128,22 @@ static void inflate_one(size_t i, void *arg) {
   if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), j.dst, j.ulen) != j.crc) c->bad = 1;
 }
 
-int64_t BgzfReader::read(std::vector<uint8_t> &out, size_t want) {
+int64_t BgzfReader::read(ByteBuf &out, size_t want) {
   if (eof_) return 0;
   std::vector<InflateJob> jobs;
   std::vector<size_t> src_off;  // offsets into cbuf_ (pointers are fixed up after the last fill)
   size_t total = 0, rel = 0;  // rel: offset of the next block relative to cpos_ (fill() may compact cbuf_)
   while (total < want) {
     fill(rel + 18);
-    size_t avail = cbuf_.size() - cpos_;
+    size_t avail = have();
     if (avail == rel) { eof_ = true; break; }
     if (avail - rel < 18) { err_ = "truncated BGZF block header"; return -1; }
-    const uint8_t *h = cbuf_.data() + cpos_ + rel;
+    const uint8_t *h = cur() + rel;
     if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) { err_ = "bad BGZF block magic"; return -1; }
     uint32_t xlen = h[10] | (h[11] << 8);
     fill(rel + 12 + xlen);
-    if (cbuf_.size() - cpos_ - rel < 12 + (size_t)xlen) { err_ = "truncated BGZF extra field"; return -1; }
-    h = cbuf_.data() + cpos_ + rel;
+    if (have() - rel < 12 + (size_t)xlen) { err_ = "truncated BGZF extra field"; return -1; }
+    h = cur() + rel;
     int64_t bsize = -1;
     for (uint32_t p = 0; p + 4 <= xlen;) {
       const uint8_t *x = h + 12 + p;
@@ -142,8 +153,8 @@ int64_t BgzfReader::read(std::vector<uint8_t> &out, size_t want) {
     }
     if (bsize < (int64_t)(12 + xlen + 8)) { err_ = "BGZF block without BC subfield"; return -1; }
     fill(rel + (size_t)bsize);
-    if (cbuf_.size() - cpos_ - rel < (size_t)bsize) { err_ = "truncated BGZF block"; return -1; }
-    h = cbuf_.data() + cpos_ + rel;
+    if (have() - rel < (size_t)bsize) { err_ = "truncated BGZF block"; return -1; }
+    h = cur() + rel;
     InflateJob j;
     j.clen = (uint32_t)(bsize - 12 - xlen - 8);
     const uint8_t *tail = h + bsize - 8;
@@ -160,7 +171,7 @@ int64_t BgzfReader::read(std::vector<uint8_t> &out, size_t want) {
   out.resize(base + total);
   size_t o = base;
   for (size_t i = 0; i < jobs.size(); i++) {
-    jobs[i].src = cbuf_.data() + cpos_ + src_off[i];
+    jobs[i].src = cur() + src_off[i];
     jobs[i].dst = out.data() + o; o += jobs[i].ulen;
   }
   InflateCtx ctx; ctx.jobs = &jobs;
@@ -250,6 +261,13 @@ bool BgzfWriter::write(const uint8_t *p, size_t n) {
   size_t full = n / BLOCK_DATA;
   if (full && !flush_blocks(p, full, BLOCK_DATA)) return false;
   pending_.insert(pending_.end(), p + full * BLOCK_DATA, p + n);
+  return true;
+}
+
+bool BgzfWriter::write_raw(const uint8_t *p, size_t n) {
+  if (!pending_.empty()) { if (!flush_blocks(pending_.data(), 1, pending_.size())) return false; pending_.clear(); }
+  if (n && fwrite(p, 1, n, f_) != n) { err_ = "short write"; return false; }
+  bytes_out_ += n;
   return true;
 }
 

@@ -5,11 +5,38 @@
 #pragma once
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace brio {
+
+// growable byte buffer without value-initialisation (std::vector<uint8_t>::resize zero-fills gigabytes here)
+class ByteBuf {
+ public:
+  ByteBuf() {}
+  ~ByteBuf() { free(p_); }
+  ByteBuf(const ByteBuf &) = delete;
+  ByteBuf &operator=(const ByteBuf &) = delete;
+  uint8_t *data() { return p_; }
+  const uint8_t *data() const { return p_; }
+  size_t size() const { return n_; }
+  uint8_t &operator[](size_t i) { return p_[i]; }
+  const uint8_t &operator[](size_t i) const { return p_[i]; }
+  void resize(size_t n) {
+    if (n > cap_) { size_t c = cap_ + cap_ / 2; if (c < n) c = n; if (c < 4096) c = 4096; p_ = (uint8_t *)realloc(p_, c); if (!p_) abort(); cap_ = c; }
+    n_ = n;
+  }
+  void erase_front(size_t k) { if (k >= n_) { n_ = 0; return; } memmove(p_, p_ + k, n_ - k); n_ -= k; }
+  void swap(ByteBuf &o) { std::swap(p_, o.p_); std::swap(n_, o.n_); std::swap(cap_, o.cap_); }
+  void clear() { n_ = 0; }
+
+ private:
+  uint8_t *p_ = nullptr; size_t n_ = 0, cap_ = 0;
+};
 
 class BgzfReader {
  public:
@@ -18,16 +45,19 @@ class BgzfReader {
   bool open(const char *path, int threads);
   // appends at least `want` uncompressed bytes to `out` unless the stream ends first;
   // returns the number of bytes appended, 0 at end of stream, -1 on a corrupt block
-  int64_t read(std::vector<uint8_t> &out, size_t want);
+  int64_t read(ByteBuf &out, size_t want);
   bool eof() const { return eof_; }
   const std::string &error() const { return err_; }
 
  private:
   bool fill(size_t need);
+  const uint8_t *cur() const { return map_ ? map_ + cpos_ : cbuf_.data() + cpos_; }
+  size_t have() const { return (map_ ? map_size_ : cbuf_.size()) - cpos_; }
+  const uint8_t *map_ = nullptr; size_t map_size_ = 0;
   FILE *f_ = nullptr;
   int threads_ = 1;
   bool eof_ = false;
-  std::vector<uint8_t> cbuf_;  // compressed bytes not yet consumed
+  ByteBuf cbuf_;  // compressed bytes not yet consumed
   size_t cpos_ = 0;
   std::string err_;
 };
@@ -38,6 +68,8 @@ class BgzfWriter {
   bool open(const char *path, int threads, int level);
   // compresses [p, p+n) into 0xff00-byte blocks (a trailing partial block is kept for the next call)
   bool write(const uint8_t *p, size_t n);
+  // closes the pending partial block, then appends bytes that already ARE complete BGZF blocks (device deflate)
+  bool write_raw(const uint8_t *p, size_t n);
   bool close();  // flushes and appends the 28-byte EOF block
   const std::string &error() const { return err_; }
   uint64_t bytes_out() const { return bytes_out_; }

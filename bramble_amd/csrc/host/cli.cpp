@@ -38,6 +38,7 @@ struct Options {
   int threads = 1, level = 6, device = 0;
   int64_t bundle_records = 2000000;
   bool quiet = false;
+  bool device_deflate = false;
 };
 
 void usage(FILE *f) {
@@ -47,7 +48,7 @@ void usage(FILE *f) {
           " [--help] [--version] [--quiet] [--fr] [--rf] [--lr] [--lr-hq] [--strict]\n"
           " [--max-soft-clip N] [--max-junction-insertion N] [--max-junction-deletion N]\n"
           " [--max-error-exon N] [--similarity-threshold X]\n"
-          " [--compression-level 0-9] [--bundle-size N] [--device N]\n\n"
+          " [--compression-level 0-9] [--device-deflate] [--bundle-size N] [--device N]\n\n"
           "Project spliced genomic alignments into transcriptomic space.\n");
 }
 
@@ -82,6 +83,7 @@ int parse_args(int argc, char **argv, Options &o) {
     else if (a == "-p") { const char *v = value(); if (!v) return -1; o.threads = atoi(v); if (o.threads < 1) o.threads = 1; }
     else if (a == "--compression-level") { const char *v = value(); if (!v) return -1; o.level = atoi(v); if (o.level < 0 || o.level > 9) return -1; }
     else if (a == "--bundle-size") { const char *v = value(); if (!v) return -1; o.bundle_records = atoll(v); if (o.bundle_records < 1) return -1; }
+    else if (a == "--device-deflate") o.device_deflate = true;
     else if (a == "--device") { const char *v = value(); if (!v) return -1; o.device = atoi(v); }
     else if (!a.empty() && a[0] == '-' && a != "-") { fprintf(stderr, "unknown option %s\n", a.c_str()); return -1; }
     else if (o.in_bam.empty()) o.in_bam = a;
@@ -120,7 +122,7 @@ bool load_fasta(const char *path, Fasta &fa) {
 struct BamHeader { std::string text; std::vector<std::string> ref_names; std::vector<uint32_t> ref_lens; };
 
 // consumes the header from the front of `buf` (reading more as needed); false on a malformed file
-bool read_header(BgzfReader &rd, std::vector<uint8_t> &buf, size_t &pos, BamHeader &h, std::string &err) {
+bool read_header(BgzfReader &rd, brio::ByteBuf &buf, size_t &pos, BamHeader &h, std::string &err) {
   auto need = [&](size_t n) -> bool {
     while (buf.size() - pos < n) { int64_t got = rd.read(buf, 1 << 20); if (got < 0) { err = rd.error(); return false; } if (got == 0) { err = "truncated BAM header"; return false; } }
     return true;
@@ -213,10 +215,10 @@ struct Slot {
   void release() { std::unique_lock<std::mutex> l(m); item.reset(); cv.notify_all(); }
 };
 
-struct Bundle { std::vector<uint8_t> blob; std::vector<uint64_t> off; std::vector<uint32_t> len; };
+struct Bundle { brio::ByteBuf blob; std::vector<uint64_t> off; std::vector<uint32_t> len; };
 struct OutChunk { const uint8_t *data; uint64_t n; };
 
-const uint8_t *rec_name(const std::vector<uint8_t> &b, uint64_t off, uint32_t &l) { l = b[off + 8]; return b.data() + off + 32; }
+const uint8_t *rec_name(const brio::ByteBuf &b, uint64_t off, uint32_t &l) { l = b[off + 8]; return b.data() + off + 32; }
 
 }  // namespace
 
@@ -260,7 +262,7 @@ extern "C" int br_cli_main(int argc, char **argv) {
 
   BgzfReader rd;
   if (!rd.open(o.in_bam.c_str(), o.threads)) { fprintf(stderr, "error: %s\n", rd.error().c_str()); return 1; }
-  std::vector<uint8_t> buf; size_t pos = 0;
+  brio::ByteBuf buf; size_t pos = 0;
   BamHeader hdr; std::string err;
   if (!read_header(rd, buf, pos, hdr, err)) { fprintf(stderr, "error: %s: %s\n", o.in_bam.c_str(), err.c_str()); return 1; }
   // input refID -> annotation reference index; names the annotation lacks get ids past its table
@@ -281,6 +283,8 @@ extern "C" int br_cli_main(int argc, char **argv) {
   double t_setup = since();
 
   Slot<Bundle> to_gpu; Slot<OutChunk> to_writer;
+  // consumed bundle buffers go back to the reader: their pages are already faulted in
+  std::mutex pool_m; std::vector<std::unique_ptr<brio::ByteBuf>> pool;
   uint64_t total_reads = 0, unmapped_reads = 0;
   std::string reader_err, writer_err;
   double t_inflate = 0, t_split = 0, t_copy = 0, t_deflate = 0, t_wait_gpu_in = 0;
@@ -288,7 +292,7 @@ extern "C" int br_cli_main(int argc, char **argv) {
   auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
 
   std::thread reader([&]() {
-    buf.erase(buf.begin(), buf.begin() + (ptrdiff_t)pos); pos = 0;
+    buf.erase_front(pos); pos = 0;
     std::vector<uint64_t> off; std::vector<uint32_t> len;
     bool eof = false;
     size_t scanned = 0;  // bytes of buf already split into off/len
@@ -317,7 +321,7 @@ extern "C" int br_cli_main(int argc, char **argv) {
         t_split += secs(ts0, now());
         if (cut >= 0 || eof) break;
         auto ti0 = now();
-        int64_t got = rd.read(buf, 256u << 20);
+        int64_t got = rd.read(buf, 64u << 20);
         t_inflate += secs(ti0, now());
         if (got < 0) { reader_err = rd.error(); to_gpu.finish(); return; }
         if (got == 0) { eof = true; if (scanned != buf.size()) { reader_err = "truncated BAM record at end of file"; to_gpu.finish(); return; } }
@@ -328,9 +332,14 @@ extern "C" int br_cli_main(int argc, char **argv) {
         auto b = std::make_unique<Bundle>();
         size_t byte_end = (n_take < off.size()) ? (size_t)off[n_take] - 4 : scanned;
         b->off.assign(off.begin(), off.begin() + (ptrdiff_t)n_take); b->len.assign(len.begin(), len.begin() + (ptrdiff_t)n_take);
-        b->blob.assign(buf.begin(), buf.begin() + (ptrdiff_t)byte_end);
-        // keep the tail for the next bundle
-        buf.erase(buf.begin(), buf.begin() + (ptrdiff_t)byte_end);
+        // the bundle takes the buffer; only the tail (records past the cut, < one read chunk) is copied over
+        brio::ByteBuf tail;
+        { std::lock_guard<std::mutex> l(pool_m); if (!pool.empty()) { tail.swap(*pool.back()); pool.pop_back(); } }
+        tail.resize(buf.size() - byte_end);
+        if (tail.size()) memcpy(tail.data(), buf.data() + byte_end, tail.size());
+        buf.resize(byte_end);
+        b->blob.swap(buf);
+        buf.swap(tail);
         scanned -= byte_end;
         std::vector<uint64_t> noff(off.begin() + (ptrdiff_t)n_take, off.end()); std::vector<uint32_t> nlen(len.begin() + (ptrdiff_t)n_take, len.end());
         for (auto &x : noff) x -= byte_end;
@@ -348,7 +357,7 @@ extern "C" int br_cli_main(int argc, char **argv) {
       OutChunk *c = to_writer.hold();
       if (!c) break;
       auto td0 = now();
-      if (writer_err.empty() && c->n && !wr.write(c->data, (size_t)c->n)) writer_err = wr.error();
+      if (writer_err.empty() && c->n && !(o.device_deflate ? wr.write_raw(c->data, (size_t)c->n) : wr.write(c->data, (size_t)c->n))) writer_err = wr.error();
       t_deflate += secs(td0, now());
       to_writer.release();
     }
@@ -363,11 +372,12 @@ extern "C" int br_cli_main(int argc, char **argv) {
     t_wait_gpu_in += secs(tw0, now());
     if (!b) break;
     if (fail) continue;  // drain
-    br_bam_bundle bb{b->blob.data(), b->blob.size(), b->off.data(), b->len.data(), (int64_t)b->off.size(), ref_map.data(), (int32_t)ref_map.size()};
+    br_bam_bundle bb{b->blob.data(), b->blob.size(), b->off.data(), b->len.data(), (int64_t)b->off.size(), ref_map.data(), (int32_t)ref_map.size(), o.device_deflate ? 1 : 0};
     br_host_bam hb;
     auto t0 = std::chrono::steady_clock::now();
     rc = br_project_bam_bundle(ctx, &o.cfg, &bb, &hb);
     gpu_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    { auto spare = std::make_unique<brio::ByteBuf>(); spare->swap(b->blob); std::lock_guard<std::mutex> l(pool_m); pool.push_back(std::move(spare)); }
     if (rc) { fprintf(stderr, "error: projection failed: %s\n", br_strerror(rc)); fail = 1; continue; }
     total_complete += hb.total_complete; total_unique += hb.total_unique; dropped += hb.dropped_reads; n_bundles++;
     auto c = std::make_unique<OutChunk>(); c->data = hb.data; c->n = hb.n_bytes;
@@ -408,7 +418,7 @@ extern "C" int br_bgzf_read_file(const char *path, int threads, uint8_t **out, u
   *out = nullptr; *n = 0;
   BgzfReader rd;
   if (!rd.open(path, threads)) return BR_ERR_INVALID_ARG;
-  std::vector<uint8_t> buf;
+  brio::ByteBuf buf;
   for (;;) { int64_t got = rd.read(buf, 64u << 20); if (got < 0) return BR_ERR_INVALID_ARG; if (got == 0) break; }
   uint8_t *p = (uint8_t *)malloc(buf.size() ? buf.size() : 1);
   if (!p) return BR_ERR_CAPACITY;

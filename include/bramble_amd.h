@@ -362,7 +362,7 @@ const char *const *br_annotation_refnames(const br_annotation *);
 
 /* The reference's command line (src/bramble.cpp:443-485): in.bam -G -o [-S] [-p] [--fr|--rf]
  * [--lr|--lr-hq] [--strict] [--max-*] [--similarity-threshold] [--quiet], plus --compression-level,
- * --bundle-size and --device.  Returns the process exit code. */
+ * --device-deflate (BGZF blocks made on the GPU), --bundle-size and --device.  Returns the process exit code. */
 int br_cli_main(int argc, char **argv);
 
 /* BGZF container utilities (host only; what the reference gets from htslib's bgzf layer behind

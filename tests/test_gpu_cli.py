@@ -127,16 +127,17 @@ def test_cli_result_does_not_depend_on_bundle_size(tmp_path):
     in_bam = str(tmp_path / "in.bam")
     bamio.write_bam(in_bam, "@HD\tVN:1.6\n", bam_refs, stream.tobytes())
     outs = []
-    for k, bundle in enumerate((1, 777, 10 ** 7)):
+    for k, (bundle, extra) in enumerate(((1, []), (777, []), (10 ** 7, []), (900, ["--device-deflate"]))):
         out_bam = str(tmp_path / ("o%d.bam" % k))
         r = subprocess.run([BIN, in_bam, "-G", gtf, "-o", out_bam, "-p", "2", "--bundle-size", str(bundle), "--quiet",
-                            "--strict", "--max-soft-clip", "3"], capture_output=True, text=True, timeout=600)
+                            "--strict", "--max-soft-clip", "3"] + extra, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr
         outs.append(bamio.read_bam(out_bam)[2])
         sizes = bamio.bgzf_block_sizes(out_bam)
         assert max(sizes) <= 65536 and sizes[-1] == 28
     assert len(outs[0]) > 100000
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    assert np.array_equal(outs[0], outs[3])   # BGZF blocks made on the device hold the same stream
 
 
 def test_cli_errors(tmp_path):
