@@ -2,7 +2,7 @@
 // inflate/deflate is a plausible follow-on": after the device path the host-side deflate is the command
 // line's bottleneck).
 //
-//   k_deflate_fixed   one wave per BGZF block (56 KiB payload): greedy LZ77 with a 4096-entry hash table in
+//   k_deflate_fixed   one wave per BGZF block (56 KiB payload): greedy LZ77 with a 2048-entry hash table in
 //                     LDS, 64 positions per round (one per lane), fixed-Huffman bit stream (RFC 1951 3.2.6),
 //                     CRC32 of the payload by 64 lane-chunks folded with a precomputed zero-append operator.
 //   k_bgzf_compact    slots -> one dense byte stream (after a scan of the block sizes).
@@ -22,7 +22,9 @@ typedef uint32_t u32u __attribute__((aligned(1)));
 typedef uint64_t u64u __attribute__((aligned(1)));
 typedef uint16_t u16u __attribute__((aligned(1)));
 
-#define HASH_BITS 12
+#ifndef HASH_BITS
+#define HASH_BITS 11   // 4 KiB of LDS per wave: occupancy (7 workgroups per CU) matters more than the last 0.3 % of ratio
+#endif
 #define HASH_SIZE (1 << HASH_BITS)
 #define EMPTY16 0xffffu
 #define OBUF_WORDS 72   // one round emits <= 31 carried bits + 64 * 31 bits
@@ -77,35 +79,35 @@ __global__ void __launch_bounds__(256) k_deflate_fixed(DeflateArgs A) {
   uint32_t wbase = 0;                                // payload dwords already written
   uint32_t skip_until = 0;
 
+  // the dword at each lane's position is loaded one round ahead (its latency hides behind the current round)
+  uint32_t w_next = (lane + 4u <= n) ? *(const u32u *)(in + lane) : 0u;
   for (uint32_t p = 0; p < n; p += 64) {
     const uint32_t q = p + lane;
     const bool act = q < n;
     const bool can = q + 4u <= n;
-    uint32_t w = 0, h = 0;
-    if (can) { w = *(const u32u *)(in + q); h = (w * 2654435761u) >> (32 - HASH_BITS); }
+    const uint32_t w = w_next;
+    if (q + 64u + 4u <= n) w_next = *(const u32u *)(in + q + 64u);
+    uint32_t h = (w * 2654435761u) >> (32 - HASH_BITS);
+    if (p + 64u <= skip_until) {                     // the whole round lies inside a match: only feed the table
+      if (can) tab[h] = (uint16_t)q;
+      continue;
+    }
     uint32_t cand = can ? tab[h] : EMPTY16;
     __builtin_amdgcn_wave_barrier();
     if (can) tab[h] = (uint16_t)q;                   // any writer of a clashing slot is fine: all are < next round's p
     const uint64_t active = __ballot(act);
     uint64_t covered = __ballot(act && q < skip_until);
-    uint32_t mlen = 0, dist = 0;
+    // a lane has a match candidate when the table entry is within the window and its first four bytes agree
+    uint32_t dist = 0;
+    bool v4 = false;
     if (can && q >= skip_until && cand != EMPTY16) {
       dist = q - cand;
-      if (dist <= 32768u && *(const u32u *)(in + cand) == w) {
-        uint32_t lim = n - q; if (lim > 258u) lim = 258u;
-        uint32_t l = 4;
-        while (l + 8u <= lim) {
-          uint64_t x = *(const u64u *)(in + cand + l) ^ *(const u64u *)(in + q + l);
-          if (x) { l += (uint32_t)(__builtin_ctzll(x) >> 3); goto done; }
-          l += 8;
-        }
-        while (l < lim && in[cand + l] == in[q + l]) l++;
-      done:
-        mlen = l;
-      }
+      v4 = dist <= 32768u && *(const u32u *)(in + cand) == w;
     }
-    const uint64_t hasm = __ballot(mlen >= 4u);
-    // greedy parse of the 64 positions (wave-uniform scalar loop)
+    const uint64_t hasm = __ballot(v4);
+    // greedy parse of the 64 positions (wave-uniform loop).  Only the matches that are TAKEN get their length
+    // computed, and that by the whole wave: lane L compares bytes [4 + 4L, 8 + 4L), one step covers all 258
+    uint32_t mlen = 0;
     uint64_t lit = 0, mat = 0, undec = active & ~covered;
     while (undec) {
       uint64_t mm = hasm & undec;
@@ -114,7 +116,27 @@ __global__ void __launch_bounds__(256) k_deflate_fixed(DeflateArgs A) {
       uint64_t below = (1ull << f) - 1ull;
       lit |= undec & below;
       mat |= 1ull << f;
-      uint32_t L = (uint32_t)__builtin_amdgcn_readlane((int)mlen, f);
+      const uint32_t qf = p + (uint32_t)f;
+      const uint32_t cf = (uint32_t)__builtin_amdgcn_readlane((int)cand, f);
+      uint32_t lim = n - qf; if (lim > 258u) lim = 258u;
+      const uint32_t off = 4u + 4u * (uint32_t)lane;
+      uint32_t x = 0;
+      if (off < lim) {
+        if (qf + off + 4u <= n) {                    // the dword lies inside the block
+          x = *(const u32u *)(in + cf + off) ^ *(const u32u *)(in + qf + off);
+          if (off + 4u > lim) x &= (1u << (8u * (lim - off))) - 1u;
+        } else {
+          for (uint32_t b2 = 0; b2 < 4u && off + b2 < lim; b2++) x |= (uint32_t)(in[cf + off + b2] ^ in[qf + off + b2]) << (8u * b2);
+        }
+      }
+      uint64_t mis = __ballot(x != 0);
+      uint32_t L = lim;
+      if (mis) {
+        int fl = __builtin_ctzll(mis);
+        uint32_t xf = (uint32_t)__builtin_amdgcn_readlane((int)x, fl);
+        L = 4u + 4u * (uint32_t)fl + ((uint32_t)__builtin_ctz(xf) >> 3);
+      }
+      if (lane == f) mlen = L;
       uint32_t end = (uint32_t)f + L;
       uint64_t cov = end >= 64u ? (~0ull << f) : (((1ull << end) - 1ull) & ~below);
       undec &= ~(below | cov);
@@ -124,7 +146,7 @@ __global__ void __launch_bounds__(256) k_deflate_fixed(DeflateArgs A) {
     const bool is_lit = (lit >> lane) & 1ull, is_mat = (mat >> lane) & 1ull;
     uint64_t val = 0; uint32_t nb = 0;
     if (is_lit) {
-      uint32_t b = in[q];
+      uint32_t b = can ? (w & 0xffu) : (uint32_t)in[q];
       if (b < 144u) { val = bitrev(0x30u + b, 8); nb = 8; } else { val = bitrev(0x190u + (b - 144u), 9); nb = 9; }
     } else if (is_mat) {
       uint32_t lv, dv;
@@ -168,7 +190,15 @@ __global__ void __launch_bounds__(256) k_deflate_fixed(DeflateArgs A) {
     uint32_t s = lane == 0 ? 0u : first + (uint32_t)(lane - 1) * DEFLATE_CRC_CHUNK;
     uint32_t e = lane == 0 ? first : s + DEFLATE_CRC_CHUNK;
     c = 0xffffffffu;
-    for (uint32_t i = s; i < e; i++) c = sh_crc[(c ^ in[i]) & 0xffu] ^ (c >> 8);
+    uint32_t i = s;
+    for (; i + 4u <= e; i += 4u) {
+      uint32_t d = *(const u32u *)(in + i);
+      c = sh_crc[(c ^ d) & 0xffu] ^ (c >> 8);
+      c = sh_crc[(c ^ (d >> 8)) & 0xffu] ^ (c >> 8);
+      c = sh_crc[(c ^ (d >> 16)) & 0xffu] ^ (c >> 8);
+      c = sh_crc[(c ^ (d >> 24)) & 0xffu] ^ (c >> 8);
+    }
+    for (; i < e; i++) c = sh_crc[(c ^ in[i]) & 0xffu] ^ (c >> 8);
     c ^= 0xffffffffu;
   }
   uint32_t acc = (uint32_t)__builtin_amdgcn_readlane((int)c, 0);
