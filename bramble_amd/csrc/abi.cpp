@@ -427,7 +427,7 @@ extern "C" int br_ctx_new(const br_index *ix, br_ctx **out) {
   c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   HIPCHK(hipHostMalloc((void **)&c->h_totals, 32 * sizeof(uint64_t), hipHostMallocDefault));
   const char *bl = getenv("BRAMBLE_AMD_BAM_LANES");
-  if (bl) { int v = atoi(bl); if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64 || v == 104 || v == 108 || v == 116) c->bam_lanes = v; }
+  if (bl) { int v = atoi(bl); if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) c->bam_lanes = v; }
   const char *g = getenv("BRAMBLE_AMD_GROUP_LANES");
   if (g) { int v = atoi(g); if (v == 8 || v == 16 || v == 32 || v == 64) c->group_lanes = v; }
   *out = c;
@@ -459,7 +459,7 @@ extern "C" int br_ctx_set_profiling(br_ctx *c, int enabled) { if (!c) return BR_
 extern "C" int br_ctx_set_param(br_ctx *c, const char *key, int64_t v) {
   if (!c || !key) return BR_ERR_INVALID_ARG;
   if (!strcmp(key, "group_lanes")) { if (v != 8 && v != 16 && v != 32 && v != 64) return BR_ERR_INVALID_ARG; c->group_lanes = (int)v; return BR_OK; }
-  if (!strcmp(key, "bam_lanes")) { if (v != 4 && v != 8 && v != 16 && v != 32 && v != 64 && v != 104 && v != 108 && v != 116) return BR_ERR_INVALID_ARG; c->bam_lanes = (int)v; return BR_OK; }
+  if (!strcmp(key, "bam_lanes")) { if (v != 4 && v != 8 && v != 16 && v != 32 && v != 64) return BR_ERR_INVALID_ARG; c->bam_lanes = (int)v; return BR_OK; }
   if (!strcmp(key, "blocks_per_cu")) { if (v < 1 || v > 64) return BR_ERR_INVALID_ARG; c->blocks_per_cu = (int)v; return BR_OK; }
   return BR_ERR_INVALID_ARG;
 }

@@ -271,173 +271,6 @@ __global__ void __launch_bounds__(256) k_bam_encode(BamArgs B) {
   }
 }
 
-// ---- v2: one unified chunk loop over all byte segments of a row -------------------------------------
-// A row is at most eight byte segments (name; SEQ; QUAL; up to five kept aux pieces -- on '+' rows SEQ,
-// QUAL and the first aux piece are one contiguous copy).  Every lane takes 16-byte chunks from the
-// concatenated chunk list, so the loads of a row's different regions are in flight together instead of
-// one region after the other (the v1 kernel waits for memory ~70 times per row).
-typedef uint64_t u64u __attribute__((aligned(1)));
-enum { SEG_COPY = 0, SEG_REV = 1, SEG_RC = 2 };
-
-struct Seg { uint32_t dst, src, len, mode; };  // offsets relative to the output record / the input record
-
-__device__ __forceinline__ W4 rev16(W4 w) {
-  W4 o; o.a = __builtin_bswap32(w.d); o.b = __builtin_bswap32(w.c); o.c = __builtin_bswap32(w.b); o.d = __builtin_bswap32(w.a);
-  return o;
-}
-__device__ __forceinline__ W4 rc16(W4 w) { W4 o; o.a = revcomp8(w.d); o.b = revcomp8(w.c); o.c = revcomp8(w.b); o.d = revcomp8(w.a); return o; }
-
-// one chunk (index j) of segment g
-__device__ __forceinline__ void seg_chunk(uint8_t *out, const uint8_t *rec, Seg g, uint32_t j) {
-  uint32_t off = 16u * j;
-  uint32_t n = g.len - off;
-  if (n < 16u && g.len >= 16u) { off = g.len - 16u; n = 16u; }  // last chunk of a long segment: overlap, same bytes
-  uint8_t *d = out + g.dst + off;
-  const uint8_t *s = rec + g.src;
-  if (n >= 16u) {
-    if (g.mode == SEG_COPY) *(W4 *)d = *(const W4 *)(s + off);
-    else if (g.mode == SEG_REV) *(W4 *)d = rev16(*(const W4 *)(s + (g.len - 16u - off)));
-    else *(W4 *)d = rc16(*(const W4 *)(s + (g.len - 16u - off)));
-  } else {
-    for (uint32_t i = 0; i < n; i++) {
-      if (g.mode == SEG_COPY) d[i] = s[off + i];
-      else if (g.mode == SEG_REV) d[i] = s[g.len - 1 - (off + i)];
-      else { uint8_t v = s[g.len - 1 - (off + i)]; d[i] = (uint8_t)((comp4(v & 0xf) << 4) | comp4(v >> 4)); }
-    }
-  }
-}
-
-template <int G>
-__global__ void __launch_bounds__(256) k_bam_encode2(BamArgs B) {
-  const int lane = threadIdx.x & (G - 1);
-  int64_t r = (int64_t)blockIdx.x * (256 / G) + (threadIdx.x / G);
-  if (r >= B.n_rows) return;
-  // every scalar of the row first: independent loads, one wait
-  int32_t a = B.r_input[r];
-  uint64_t o0 = B.out_off[r], o1 = B.out_off[r + 1];
-  uint32_t n_cig = B.r_ncig[r];
-  bool minus = B.r_strand[r] == '-';
-  bool paired = B.r_paired[r], same = B.r_same[r], primary = B.r_primary[r];
-  uint32_t tid = B.r_tid[r], pos = B.r_pos[r], mapq = B.r_mapq[r], nh = B.r_nh[r], hi = B.r_hi[r];
-  int32_t mtid_v = B.r_mate_tid[r], mpos_v = B.r_mate_pos[r], isize_v = B.r_isize[r];
-  uint64_t cigoff = B.r_cigoff[r];
-  const uint8_t *rec = B.blob + B.rec_off[a];
-  BamAux x = B.aux[a];
-  uint8_t *out = B.out + o0;
-  uint32_t total = (uint32_t)(o1 - o0);
-  bool lr = B.long_reads != 0;
-
-  W4 c0 = *(const W4 *)(rec + 8);   // l_qname|mapq|bin, n_cigar|flag, l_seq, next_refID
-  uint32_t l_qname = c0.a & 0xffu;
-  uint32_t bin = c0.a >> 16;
-  uint32_t n_cig_in = c0.b & 0xffffu, flag = c0.b >> 16;
-  int32_t l_seq = (int32_t)c0.c;
-  uint32_t ls = l_seq > 0 ? (uint32_t)l_seq : 0, sb = (ls + 1) / 2;
-  if (primary) flag &= ~0x100u; else flag |= 0x100u;
-  if (minus) flag ^= 0x10u;
-  int32_t mtid = -1, mpos = -1, tlen = 0;
-  if (!paired) flag &= ~(0x1u | 0x2u | 0x20u);
-  else {
-    flag |= 0x1u;
-    if (minus) flag |= 0x20u;
-    mtid = mtid_v; mpos = mpos_v;
-    if (same) { flag |= 0x2u; tlen = isize_v; } else flag &= ~0x2u;
-  }
-  uint32_t o_cig = 36u + l_qname, o_seq = o_cig + 4u * n_cig, o_qual = o_seq + sb, o_aux = o_qual + ls;
-  uint32_t s_seq = 32u + l_qname + 4u * n_cig_in, s_qual = s_seq + sb;
-  uint32_t n_tags = lr ? 3u : 2u;
-  uint32_t o_tags = total - 7u * n_tags;
-
-  // fixed part, CIGAR and the appended tags: a handful of dword stores
-  if (lane == 0) {
-    W4 h0; h0.a = total - 4u; h0.b = tid; h0.c = pos; h0.d = l_qname | ((mapq & 0xffu) << 8) | (bin << 16);
-    *(W4 *)out = h0;
-  } else if (lane == 1) {
-    W4 h1; h1.a = (n_cig & 0xffffu) | (flag << 16); h1.b = (uint32_t)l_seq; h1.c = (uint32_t)mtid; h1.d = (uint32_t)mpos;
-    *(W4 *)(out + 16) = h1;
-  } else if (lane == 2) {
-    *(u32u *)(out + 32) = (uint32_t)tlen;
-  } else if (lane >= G - 3 && (uint32_t)(lane - (G - 3)) < n_tags) {
-    // NH:i, (AS:i,) HI:i in that order (bam.cpp:590-634, core.cpp:118-161): two overlapping dword stores per tag
-    uint32_t which = (uint32_t)(lane - (G - 3));
-    uint32_t kind = which == 0 ? 0u : (lr ? (which == 1 ? 1u : 2u) : 2u);
-    uint32_t val = kind == 0 ? nh : kind == 2 ? hi : (uint32_t)(int32_t)(((double)x.as_val + (double)B.r_clip[r]) * B.r_sim[r]);
-    uint32_t head = kind == 0 ? ('N' | 'H' << 8) : kind == 1 ? ('A' | 'S' << 8) : ('H' | 'I' << 8);
-    uint8_t *t = out + o_tags + 7u * which;
-    *(u32u *)t = head | ((uint32_t)'i' << 16) | (val << 24);
-    *(u32u *)(t + 3) = val;
-  }
-  const uint32_t *cg = B.cigar + cigoff;
-  for (uint32_t k = lane; k < n_cig; k += G) *(u32u *)(out + o_cig + 4 * k) = cg[minus ? n_cig - 1 - k : k];
-
-  // segment list
-  bool rev_q = minus && ls > 0 && rec[s_qual] != 0xff;
-  bool rc_dwords = minus && (ls & 1u) == 0;      // even length: byte-aligned reverse complement
-  bool rc_odd = minus && (ls & 1u) != 0;
-  uint32_t first_piece = x.off[0] == 0xffffffffu ? x.aux_len : x.off[0];
-  // eight fixed slots (static indices keep them in registers): 0 name; 1 '+': SEQ+QUAL+first aux piece in one copy,
-  // '-': SEQ; 2 '-': QUAL; 3 '-': first aux piece; 4..7: the aux pieces after each removed tag
-  Seg g0{36u, 32u, l_qname, SEG_COPY};
-  Seg g1 = minus ? Seg{o_seq, s_seq, rc_odd ? 0u : sb, rc_dwords ? (uint32_t)SEG_RC : (uint32_t)SEG_COPY}
-                 : Seg{o_seq, s_seq, sb + ls + first_piece, SEG_COPY};
-  Seg g2{o_qual, s_qual, minus ? ls : 0u, rev_q ? (uint32_t)SEG_REV : (uint32_t)SEG_COPY};
-  Seg g3{o_aux, x.aux_start, minus ? first_piece : 0u, SEG_COPY};
-  Seg g4{0, 0, 0, SEG_COPY}, g5 = g4, g6 = g4, g7 = g4;
-  {
-    // explicit scalars (no indexed access to the aux struct: that would put it in scratch)
-    uint32_t f0 = x.off[0], f1 = x.off[1], f2 = x.off[2], f3 = x.off[3];
-    uint32_t e0 = f0 + x.len[0], e1 = f1 + x.len[1], e2 = f2 + x.len[2], e3 = f3 + x.len[3];
-    const uint32_t NONE = 0xffffffffu;
-    uint32_t dstp = o_aux + first_piece;
-    if (f0 != NONE) { uint32_t nxt = f1 != NONE ? f1 : x.aux_len; g4 = Seg{dstp, x.aux_start + e0, nxt - e0, SEG_COPY}; dstp += nxt - e0; }
-    if (f1 != NONE) { uint32_t nxt = f2 != NONE ? f2 : x.aux_len; g5 = Seg{dstp, x.aux_start + e1, nxt - e1, SEG_COPY}; dstp += nxt - e1; }
-    if (f2 != NONE) { uint32_t nxt = f3 != NONE ? f3 : x.aux_len; g6 = Seg{dstp, x.aux_start + e2, nxt - e2, SEG_COPY}; dstp += nxt - e2; }
-    if (f3 != NONE) { g7 = Seg{dstp, x.aux_start + e3, x.aux_len - e3, SEG_COPY}; }
-  }
-  auto chunks = [](const Seg &g) { return (g.len + 15u) / 16u; };
-  uint32_t p1 = chunks(g0), p2 = p1 + chunks(g1), p3 = p2 + chunks(g2), p4 = p3 + chunks(g3), p5 = p4 + chunks(g4),
-           p6 = p5 + chunks(g5), p7 = p6 + chunks(g6), p8 = p7 + chunks(g7);
-  // the segment table lives in LDS (indexed per chunk; left to the compiler it becomes a scratch array)
-  __shared__ uint4 sh_seg[256 / G][8];
-  uint4 *tab = sh_seg[threadIdx.x / G];
-  if (lane == 0) {
-    tab[0] = make_uint4(g0.dst, g0.src, g0.len, g0.mode | (0u << 8));
-    tab[1] = make_uint4(g1.dst, g1.src, g1.len, g1.mode | (p1 << 8));
-    tab[2] = make_uint4(g2.dst, g2.src, g2.len, g2.mode | (p2 << 8));
-    tab[3] = make_uint4(g3.dst, g3.src, g3.len, g3.mode | (p3 << 8));
-    tab[4] = make_uint4(g4.dst, g4.src, g4.len, g4.mode | (p4 << 8));
-    tab[5] = make_uint4(g5.dst, g5.src, g5.len, g5.mode | (p5 << 8));
-    tab[6] = make_uint4(g6.dst, g6.src, g6.len, g6.mode | (p6 << 8));
-    tab[7] = make_uint4(g7.dst, g7.src, g7.len, g7.mode | (p7 << 8));
-  }
-  __builtin_amdgcn_wave_barrier();  // same wave: LDS operations retire in order
-  for (uint32_t c = lane; c < p8; c += G) {
-    uint32_t k = (c >= p1) + (c >= p2) + (c >= p3) + (c >= p4) + (c >= p5) + (c >= p6) + (c >= p7);
-    uint4 t = tab[k];
-    seg_chunk(out, rec, Seg{t.x, t.y, t.z, t.w & 0xffu}, c - (t.w >> 8));
-  }
-  if (rc_odd) {
-    // odd length on '-': the reversed nibble stream starts one nibble into a byte.  Output dword w holds source
-    // nibbles q0 .. q0+7, q0 = ls - 8 - 8w (odd): five source bytes from b0 = (q0 - 1) / 2
-    const uint8_t *seq = rec + s_seq;
-    uint32_t full = ls / 8u;
-    for (uint32_t w = lane; w < full; w += G) {
-      uint32_t b0 = (ls - 9u) / 2u - 4u * w;
-      uint64_t L = *(const u64u *)(seq + b0);   // 5 bytes needed; the 3 beyond are QUAL bytes of the same record
-      uint32_t v = __builtin_bswap32((uint32_t)((__builtin_bswap64(L) << 4) >> 32));
-      *(u32u *)(out + o_seq + 4u * w) = revcomp8(v);
-    }
-    for (uint32_t i = 4u * full + lane; i < sb; i += G) {
-      uint32_t p0 = 2 * i, p1 = 2 * i + 1;
-      uint32_t s0 = ls - 1 - p0;
-      uint8_t n0 = (seq[s0 >> 1] >> ((~s0 & 1) << 2)) & 0xf;
-      uint8_t v = (uint8_t)(comp4(n0) << 4);
-      if (p1 < ls) { uint32_t s1 = ls - 1 - p1; uint8_t n1 = (seq[s1 >> 1] >> ((~s1 & 1) << 2)) & 0xf; v |= comp4(n1); }
-      out[o_seq + i] = v;
-    }
-  }
-}
-
 void launch_bam_scan(hipStream_t st, const BamArgs &B) {
   if (B.n_aln > 0) hipLaunchKernelGGL(k_bam_scan, dim3((unsigned)((B.n_aln + 255) / 256)), dim3(256), 0, st, B);
 }
@@ -446,13 +279,6 @@ void launch_bam_size(hipStream_t st, const BamArgs &B) {
 }
 void launch_bam_encode(hipStream_t st, const BamArgs &B, int lanes) {
   if (B.n_rows <= 0) return;
-  if (lanes >= 100) {  // v2 kernels: 100 + lanes
-    lanes -= 100;
-    if (lanes == 4) hipLaunchKernelGGL((k_bam_encode2<4>), dim3((unsigned)((B.n_rows + 63) / 64)), dim3(256), 0, st, B);
-    else if (lanes == 16) hipLaunchKernelGGL((k_bam_encode2<16>), dim3((unsigned)((B.n_rows + 15) / 16)), dim3(256), 0, st, B);
-    else hipLaunchKernelGGL((k_bam_encode2<8>), dim3((unsigned)((B.n_rows + 31) / 32)), dim3(256), 0, st, B);
-    return;
-  }
   if (lanes == 4) hipLaunchKernelGGL((k_bam_encode<4>), dim3((unsigned)((B.n_rows + 63) / 64)), dim3(256), 0, st, B);
   else if (lanes == 8) hipLaunchKernelGGL((k_bam_encode<8>), dim3((unsigned)((B.n_rows + 31) / 32)), dim3(256), 0, st, B);
   else if (lanes == 32) hipLaunchKernelGGL((k_bam_encode<32>), dim3((unsigned)((B.n_rows + 7) / 8)), dim3(256), 0, st, B);

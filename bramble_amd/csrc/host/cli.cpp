@@ -12,6 +12,7 @@
 #include <string.h>
 #include <zlib.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <map>
@@ -233,60 +234,17 @@ extern "C" int br_cli_main(int argc, char **argv) {
   auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
   if (!o.quiet) { printf("\n[bramble] starting version: %s (bramble_amd %s)\n", BRAMBLE_REF_VERSION, br_version()); printf("[bramble] loading reference annotation...\n"); }
 
-  br_annotation *ann = nullptr;
-  int rc = br_annotation_load(o.gff.c_str(), &ann);
-  if (rc) { fprintf(stderr, "error: could not load reference annotation %s: %s\n", o.gff.c_str(), br_strerror(rc)); return 1; }
-  size_t n_tx = br_annotation_num_transcripts(ann), n_refs = br_annotation_num_refs(ann);
-  const char *const *refnames = br_annotation_refnames(ann);
-  Fasta fa;
-  std::vector<br_fasta_seq> fseqs;
-  if (o.cfg.use_fasta) {
-    if (!load_fasta(o.fasta.c_str(), fa)) { fprintf(stderr, "error: could not open genome %s\n", o.fasta.c_str()); return 1; }
-    for (size_t i = 0; i < fa.names.size(); i++) fseqs.push_back({fa.names[i].c_str(), fa.seqs[i].data(), fa.seqs[i].size()});
-  }
-  if (!o.quiet) {
-    printf("[bramble] reference annotation loaded! %zu unique transcripts were found (%.1fs)\n", n_tx, since());
-    if (o.cfg.lr) printf("[bramble] using long-read mode (--lr)\n");
-    else if (o.cfg.lr_hq) printf("[bramble] using long-read mode (--lr-hq)\n");
-    else printf("[bramble] using short-read mode (have long reads? try running with --lr or --lr-hq)\n");
-    printf("[bramble] building g2t index\n");
-  }
-  br_index *ix = nullptr;
-  rc = br_index_build(br_annotation_transcripts(ann), n_tx, refnames, n_refs, fseqs.empty() ? nullptr : fseqs.data(), fseqs.size(),
-                      o.device, &ix);
-  if (rc) { fprintf(stderr, "error: index build failed: %s\n", br_strerror(rc)); br_annotation_free(ann); return 1; }
-  fa = Fasta();  // the index holds the exon sequences now
-  br_ctx *ctx = nullptr;
-  rc = br_ctx_new(ix, &ctx);
-  if (rc) { fprintf(stderr, "error: %s\n", br_strerror(rc)); br_index_free(ix); br_annotation_free(ann); return 1; }
-
   BgzfReader rd;
   if (!rd.open(o.in_bam.c_str(), o.threads)) { fprintf(stderr, "error: %s\n", rd.error().c_str()); return 1; }
   brio::ByteBuf buf; size_t pos = 0;
   BamHeader hdr; std::string err;
   if (!read_header(rd, buf, pos, hdr, err)) { fprintf(stderr, "error: %s: %s\n", o.in_bam.c_str(), err.c_str()); return 1; }
-  // input refID -> annotation reference index; names the annotation lacks get ids past its table
-  // (gseqs.addName, src/bramble.cpp:384: a new id with no interval tree behind it)
-  std::unordered_map<std::string, int32_t> ref_of;
-  for (size_t r = 0; r < n_refs; r++) ref_of.emplace(refnames[r], (int32_t)r);
-  std::vector<int32_t> ref_map(hdr.ref_names.size());
-  int32_t extra = (int32_t)n_refs;
-  for (size_t r = 0; r < hdr.ref_names.size(); r++) { auto it = ref_of.find(hdr.ref_names[r]); ref_map[r] = it != ref_of.end() ? it->second : extra++; }
-
-  BgzfWriter wr;
-  if (!wr.open(o.out_bam.c_str(), o.threads, o.level)) { fprintf(stderr, "error: %s\n", wr.error().c_str()); return 1; }
-  {
-    std::vector<uint8_t> h = make_bam_header(make_header_text(hdr.text, ix, cl, o.gff), ix);
-    if (!wr.write(h.data(), h.size()) ) { fprintf(stderr, "error: %s\n", wr.error().c_str()); return 1; }
-  }
-  if (!o.quiet) printf("[bramble] processing alignments :-)\n");
-  double t_setup = since();
-
   Slot<Bundle> to_gpu; Slot<OutChunk> to_writer;
   // consumed bundle buffers go back to the reader: their pages are already faulted in
   std::mutex pool_m; std::vector<std::unique_ptr<brio::ByteBuf>> pool;
   uint64_t total_reads = 0, unmapped_reads = 0;
   std::string reader_err, writer_err;
+  std::atomic<bool> cancel{false};
   double t_inflate = 0, t_split = 0, t_copy = 0, t_deflate = 0, t_wait_gpu_in = 0;
   auto now = []() { return std::chrono::steady_clock::now(); };
   auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
@@ -297,6 +255,7 @@ extern "C" int br_cli_main(int argc, char **argv) {
     bool eof = false;
     size_t scanned = 0;  // bytes of buf already split into off/len
     for (;;) {
+      if (cancel) break;
       // split what is there; read more until a cut point exists
       int64_t cut = -1;
       size_t searched = std::max<size_t>((size_t)o.bundle_records, 1);  // records below this index cannot be a cut
@@ -351,6 +310,52 @@ extern "C" int br_cli_main(int argc, char **argv) {
     }
     to_gpu.finish();
   });
+
+  // the reader is already inflating while the guides are parsed and the index is built
+  auto stop_reader = [&]() -> int { cancel = true; while (to_gpu.take()) {} reader.join(); return 1; };
+  br_annotation *ann = nullptr;
+  int rc = br_annotation_load(o.gff.c_str(), &ann);
+  if (rc) { fprintf(stderr, "error: could not load reference annotation %s: %s\n", o.gff.c_str(), br_strerror(rc)); return stop_reader(); }
+  size_t n_tx = br_annotation_num_transcripts(ann), n_refs = br_annotation_num_refs(ann);
+  const char *const *refnames = br_annotation_refnames(ann);
+  Fasta fa;
+  std::vector<br_fasta_seq> fseqs;
+  if (o.cfg.use_fasta) {
+    if (!load_fasta(o.fasta.c_str(), fa)) { fprintf(stderr, "error: could not open genome %s\n", o.fasta.c_str()); return stop_reader(); }
+    for (size_t i = 0; i < fa.names.size(); i++) fseqs.push_back({fa.names[i].c_str(), fa.seqs[i].data(), fa.seqs[i].size()});
+  }
+  if (!o.quiet) {
+    printf("[bramble] reference annotation loaded! %zu unique transcripts were found (%.1fs)\n", n_tx, since());
+    if (o.cfg.lr) printf("[bramble] using long-read mode (--lr)\n");
+    else if (o.cfg.lr_hq) printf("[bramble] using long-read mode (--lr-hq)\n");
+    else printf("[bramble] using short-read mode (have long reads? try running with --lr or --lr-hq)\n");
+    printf("[bramble] building g2t index\n");
+  }
+  br_index *ix = nullptr;
+  rc = br_index_build(br_annotation_transcripts(ann), n_tx, refnames, n_refs, fseqs.empty() ? nullptr : fseqs.data(), fseqs.size(),
+                      o.device, &ix);
+  if (rc) { fprintf(stderr, "error: index build failed: %s\n", br_strerror(rc)); br_annotation_free(ann); return stop_reader(); }
+  fa = Fasta();  // the index holds the exon sequences now
+  br_ctx *ctx = nullptr;
+  rc = br_ctx_new(ix, &ctx);
+  if (rc) { fprintf(stderr, "error: %s\n", br_strerror(rc)); br_index_free(ix); br_annotation_free(ann); return stop_reader(); }
+
+  // input refID -> annotation reference index; names the annotation lacks get ids past its table
+  // (gseqs.addName, src/bramble.cpp:384: a new id with no interval tree behind it)
+  std::unordered_map<std::string, int32_t> ref_of;
+  for (size_t r = 0; r < n_refs; r++) ref_of.emplace(refnames[r], (int32_t)r);
+  std::vector<int32_t> ref_map(hdr.ref_names.size());
+  int32_t extra = (int32_t)n_refs;
+  for (size_t r = 0; r < hdr.ref_names.size(); r++) { auto it = ref_of.find(hdr.ref_names[r]); ref_map[r] = it != ref_of.end() ? it->second : extra++; }
+
+  BgzfWriter wr;
+  if (!wr.open(o.out_bam.c_str(), o.threads, o.level)) { fprintf(stderr, "error: %s\n", wr.error().c_str()); return stop_reader(); }
+  {
+    std::vector<uint8_t> h = make_bam_header(make_header_text(hdr.text, ix, cl, o.gff), ix);
+    if (!wr.write(h.data(), h.size()) ) { fprintf(stderr, "error: %s\n", wr.error().c_str()); return stop_reader(); }
+  }
+  if (!o.quiet) printf("[bramble] processing alignments :-)\n");
+  double t_setup = since();
 
   std::thread writer([&]() {
     for (;;) {
