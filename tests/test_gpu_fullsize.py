@@ -106,3 +106,86 @@ def test_unpaired_emits_every_match(setup):
     b2["flags"] = (batch["flags"] & ~np.uint16(0x1)).astype(np.uint16)
     rows = ctx.project_batch_device(lib.make_config(), brdev.upload_batch(b2, "cuda:0"), 0)
     assert rows.n_rows == rows.n_matches and rows.n_matches > 5 * PAIRS
+
+
+def test_full_size_bam_bundle_stream_properties():
+    """The records-in / records-out path at full size (20.9 M raw records -> 108.8 M projected records, 24 GB):
+      * the output is a well-formed chain: every record's block_size equals the distance to the next row offset;
+      * the fixed fields written into the stream equal the row table (refID = transcript id, pos, mapq, flag bits);
+      * l_seq of every output record equals its input record's, and the rewritten n_cigar_op equals the row's;
+      * the rows equal those of the flat-batch path on the same alignments (checksums);
+      * BGZF deflate on the device: the first and the last blocks and a sample in between inflate (zlib) to the
+        stream bytes they cover, with correct CRC32 / ISIZE, and all block sizes chain up to the compressed length."""
+    import struct
+    import zlib
+    ann = synth.Annotation("G")
+    idx = lib.Index.from_flat(ann.flat, device=0)
+    ctx = lib.Context(idx)
+    batch = ann.reads(PAIRS, "pe", with_records=1)
+    stream_h, roff, rlen = synth.Annotation.frame_records(batch)
+    cfg = lib.make_config()
+    blob = torch.from_numpy(stream_h).cuda()
+    off_d = torch.from_numpy(roff.view(np.int64)).cuda()
+    len_d = torch.from_numpy(rlen.view(np.int32)).cuda()
+    rows, bam = ctx.project_bam_device(cfg, blob, off_d, len_d, np.arange(ann.flat["n_refs"], dtype=np.int32), 0)
+    t = brdev.rows_as_tensors(rows)
+    n = t["n_rows"]
+    assert n > 5 * PAIRS and int(bam.n_rows) == n
+    out = torch.as_tensor(brdev._DevArray(bam.data, int(bam.n_bytes), "|u1"), device="cuda:0")
+    row_off = torch.as_tensor(brdev._DevArray(bam.row_off, n + 1, "<i8"), device="cuda:0")
+    assert int(row_off[-1].item()) == int(bam.n_bytes) and int(row_off[0].item()) == 0
+
+    def u32_at(base, rel):
+        idx8 = base + rel
+        v = out[idx8].to(torch.int64) | (out[idx8 + 1].to(torch.int64) << 8) | (out[idx8 + 2].to(torch.int64) << 16) | \
+            (out[idx8 + 3].to(torch.int64) << 24)
+        return v
+    starts = row_off[:-1]
+    assert bool((u32_at(starts, 0) == (row_off[1:] - starts - 4)).all())            # block_size chain
+    assert bool((u32_at(starts, 4) == t["transcript_id"].to(torch.int64)).all())    # refID
+    assert bool((u32_at(starts, 8) == t["pos"].to(torch.int64)).all())              # pos
+    w3 = u32_at(starts, 12)
+    assert bool((((w3 >> 8) & 0xff) == (t["mapq"].to(torch.int64) & 0xff)).all())
+    w4 = u32_at(starts, 16)
+    ncig_rows = (t["cigar_off"][1:] - t["cigar_off"][:-1])
+    assert bool(((w4 & 0xffff) == ncig_rows).all())
+    flag = w4 >> 16
+    assert bool((((flag & 0x100) == 0) == (t["is_primary"] != 0)).all())
+    assert bool((((flag & 0x1) != 0) == (t["is_paired"] != 0)).all())
+    lq_in = torch.from_numpy(batch["l_qseq"].astype(np.int64)).cuda()
+    assert bool((u32_at(starts, 20) == lq_in[t["input_index"].to(torch.int64)]).all())
+    cs_bundle = _checksums(t)
+    del w3, w4, flag
+
+    # the flat-batch path on the same alignments gives the same rows
+    db = brdev.upload_batch(batch, "cuda:0")
+    rows2 = ctx.project_batch_device(cfg, db, 0)
+    assert _checksums(brdev.rows_as_tensors(rows2)) == cs_bundle
+    del db
+
+    # device deflate of the whole stream; inflate a sample of blocks on the host
+    rows, bam = ctx.project_bam_device(cfg, blob, off_d, len_d, np.arange(ann.flat["n_refs"], dtype=np.int32), 0)
+    out = torch.as_tensor(brdev._DevArray(bam.data, int(bam.n_bytes), "|u1"), device="cuda:0")
+    z = ctx.bgzf_deflate_device(out, 0)
+    nblk = (int(bam.n_bytes) + 57343) // 57344
+    assert z.numel() < 0.4 * int(bam.n_bytes)
+    zh = z.cpu().numpy()
+    p, b = 0, 0
+    sample = set([0, 1, nblk - 1, nblk - 2] + list(range(7, nblk, max(nblk // 300, 1))))
+    while p < len(zh):
+        bsize = int(zh[p + 16]) | (int(zh[p + 17]) << 8)
+        bsize += 1
+        if b in sample:
+            raw = zh[p:p + bsize].tobytes()
+            assert raw[:4] == b"\x1f\x8b\x08\x04"
+            crc, isize = struct.unpack_from("<II", raw, bsize - 8)
+            data = zlib.decompressobj(-15).decompress(raw[18:bsize - 8])
+            lo = b * 57344
+            assert len(data) == isize == min(57344, int(bam.n_bytes) - lo)
+            assert (zlib.crc32(data) & 0xffffffff) == crc
+            assert data == out[lo:lo + isize].cpu().numpy().tobytes()
+        p += bsize
+        b += 1
+    assert b == nblk and p == len(zh)
+    ctx.close()
+    idx.close()
