@@ -163,16 +163,11 @@ __device__ __forceinline__ uint32_t revcomp8(uint32_t v) {
 
 // G lanes cooperate on one row (records are ~200-300 bytes: a full wave per row would
 // leave most lanes idle in every region loop)
+// one output record: `rec` = the input record (global memory, or its staged copy in LDS), `out` = where the
+// record goes (global memory, or the block's staging span in LDS)
 template <int G>
-__global__ void __launch_bounds__(256) k_bam_encode(BamArgs B) {
-  const int lane = threadIdx.x & (G - 1);
-  int64_t r = (int64_t)blockIdx.x * (256 / G) + (threadIdx.x / G);
-  if (r >= B.n_rows) return;
-  int32_t a = B.r_input[r];
-  const uint8_t *rec = B.blob + B.rec_off[a];
-  BamAux x = B.aux[a];
-  uint8_t *out = B.out + B.out_off[r];
-  uint32_t total = (uint32_t)(B.out_off[r + 1] - B.out_off[r]);
+__device__ __forceinline__ void encode_row(const BamArgs &B, int64_t r, int lane, const uint8_t *rec, const BamAux &x,
+                                           uint8_t *out, uint32_t total) {
 
   W4 c0 = *(const W4 *)(rec + 8);   // l_qname|mapq|bin, n_cigar|flag, l_seq, next_refID
   uint32_t l_qname = c0.a & 0xffu;
@@ -269,6 +264,15 @@ __global__ void __launch_bounds__(256) k_bam_encode(BamArgs B) {
       out[o + 7 * which + k] = byte;
     }
   }
+}
+
+template <int G>
+__global__ void __launch_bounds__(256) k_bam_encode(BamArgs B) {
+  const int lane = threadIdx.x & (G - 1);
+  int64_t r = (int64_t)blockIdx.x * (256 / G) + (threadIdx.x / G);
+  if (r >= B.n_rows) return;
+  int32_t a = B.r_input[r];
+  encode_row<G>(B, r, lane, B.blob + B.rec_off[a], B.aux[a], B.out + B.out_off[r], (uint32_t)(B.out_off[r + 1] - B.out_off[r]));
 }
 
 void launch_bam_scan(hipStream_t st, const BamArgs &B) {
