@@ -365,7 +365,7 @@ Reads *gen_reads(const Annotation &A, const ReadParams &P) {
       if (P.mode == 2) {
         uint32_t tx = rng.below((uint32_t)ntx);
         uint32_t L = tlen[tx];
-        uint32_t len = (uint32_t)std::max(80.0, std::min((double)L, rng.lognormal(P.long_median, P.long_sigma)));
+        uint32_t len = (uint32_t)std::min((double)L, std::max(80.0, rng.lognormal(P.long_median, P.long_sigma)));  // never longer than the transcript
         uint32_t f = rng.below(L - len + 1), pos;
         splice_map(A, tx, f, len, pos, b1);
         // soft clips: an aligner that could not place a short terminal exon piece clips it,
