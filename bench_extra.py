@@ -11,6 +11,7 @@ Same protocol as bench.py: inputs resident in HBM, warmup, hipEvent kernel times
 """
 import argparse
 import json
+import os
 
 import numpy as np
 import sys
@@ -36,7 +37,7 @@ def main():
         cfg = lib.make_config()
         idx = lib.Index.from_flat(ann.flat, device=0)
         ctx = lib.Context(idx)
-        import os
+        pass
         if os.environ.get("BAM_LANES"):
             ctx.set_param("bam_lanes", int(os.environ["BAM_LANES"]))
         db = brdev.upload_batch(batch, "cuda:0")
@@ -90,6 +91,8 @@ def main():
         torch.cuda.synchronize()
         el = (time.perf_counter() - t0) / args.steps
         # optional last stage: BGZF deflate of the projected stream on the device
+        if os.environ.get("DEFLATE_DYNAMIC") is not None:
+            ctx.set_param("deflate_dynamic", int(os.environ["DEFLATE_DYNAMIC"]))
         z = ctx.bgzf_deflate_device(torch.as_tensor(brdev._DevArray(bam.data, int(bam.n_bytes), "|u1"), device="cuda:0"), st)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -107,7 +110,7 @@ def main():
                           "output_bytes": int(bam.n_bytes), "kernel_ms_per_step": {k: round(v / args.steps, 3) for k, v in kms.items() if v}}))
         return
     if args.config == "cli":
-        import os
+        pass
         import subprocess
         import tempfile
         sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

@@ -27,7 +27,7 @@ typedef uint16_t u16u __attribute__((aligned(1)));
 #endif
 #define HASH_SIZE (1 << HASH_BITS)
 #define EMPTY16 0xffffu
-#define OBUF_WORDS 72   // one round emits <= 31 carried bits + 64 * 31 bits
+#define OBUF_WORDS 132  // one round emits <= 31 carried bits + 64 * (31 + 31) bits
 
 __device__ __forceinline__ uint32_t bitrev(uint32_t v, int nbits) { return __builtin_bitreverse32(v) >> (32 - nbits); }
 
@@ -53,136 +53,123 @@ __device__ __forceinline__ int dist_bits(uint32_t dist, uint32_t &v) {
   return 5 + (int)eb;
 }
 
-__global__ void __launch_bounds__(256) k_deflate_fixed(DeflateArgs A) {
-  __shared__ uint16_t sh_tab[4][HASH_SIZE];
-  __shared__ uint32_t sh_obuf[4][OBUF_WORDS];
-  __shared__ uint32_t sh_crc[256];
-  __shared__ uint32_t sh_shift[4][256];
-  for (int i = threadIdx.x; i < 256; i += 256) sh_crc[i] = A.crc_tab[i];
-  for (int i = threadIdx.x; i < 1024; i += 256) sh_shift[i >> 8][i & 255] = A.crc_shift[i];
-  __syncthreads();
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  uint64_t blk = (uint64_t)blockIdx.x * 4 + wave;
-  if (blk >= A.n_blocks) return;                     // wave-uniform; no block barrier below
-  uint16_t *tab = sh_tab[wave];
-  uint32_t *obuf = sh_obuf[wave];
-  const uint8_t *in = A.src + blk * DEFLATE_PAYLOAD;
-  uint64_t left = A.n_bytes - blk * DEFLATE_PAYLOAD;
-  const uint32_t n = left < DEFLATE_PAYLOAD ? (uint32_t)left : DEFLATE_PAYLOAD;
-  uint8_t *out = A.slots + blk * DEFLATE_SLOT;
-  uint8_t *pay = out + 18;
+// ---- shared pieces ----------------------------------------------------------------------------------
+// LSB-first bit stream of one BGZF payload, assembled 64 tokens at a time in an LDS buffer with atomic ORs
+struct BitWriter {
+  uint32_t *obuf;   // LDS, all zero between rounds
+  uint8_t *pay;     // payload start in the slot
+  uint32_t carry, cbits, wbase;
 
-  for (int i = lane; i < HASH_SIZE; i += 64) tab[i] = EMPTY16;
-  for (int i = lane; i < OBUF_WORDS; i += 64) obuf[i] = 0;
-  __builtin_amdgcn_wave_barrier();
-  uint32_t carry = 3u, cbits = 3u;                   // BFINAL = 1, BTYPE = 01 (fixed Huffman)
-  uint32_t wbase = 0;                                // payload dwords already written
-  uint32_t skip_until = 0;
-
-  // the dword at each lane's position is loaded one round ahead (its latency hides behind the current round)
-  uint32_t w_next = (lane + 4u <= n) ? *(const u32u *)(in + lane) : 0u;
-  for (uint32_t p = 0; p < n; p += 64) {
-    const uint32_t q = p + lane;
-    const bool act = q < n;
-    const bool can = q + 4u <= n;
-    const uint32_t w = w_next;
-    if (q + 64u + 4u <= n) w_next = *(const u32u *)(in + q + 64u);
-    uint32_t h = (w * 2654435761u) >> (32 - HASH_BITS);
-    if (p + 64u <= skip_until) {                     // the whole round lies inside a match: only feed the table
-      if (can) tab[h] = (uint16_t)q;
-      continue;
-    }
-    uint32_t cand = can ? tab[h] : EMPTY16;
-    __builtin_amdgcn_wave_barrier();
-    if (can) tab[h] = (uint16_t)q;                   // any writer of a clashing slot is fine: all are < next round's p
-    const uint64_t active = __ballot(act);
-    uint64_t covered = __ballot(act && q < skip_until);
-    // a lane has a match candidate when the table entry is within the window and its first four bytes agree
-    uint32_t dist = 0;
-    bool v4 = false;
-    if (can && q >= skip_until && cand != EMPTY16) {
-      dist = q - cand;
-      v4 = dist <= 32768u && *(const u32u *)(in + cand) == w;
-    }
-    const uint64_t hasm = __ballot(v4);
-    // greedy parse of the 64 positions (wave-uniform loop).  Only the matches that are TAKEN get their length
-    // computed, and that by the whole wave: lane L compares bytes [4 + 4L, 8 + 4L), one step covers all 258
-    uint32_t mlen = 0;
-    uint64_t lit = 0, mat = 0, undec = active & ~covered;
-    while (undec) {
-      uint64_t mm = hasm & undec;
-      if (!mm) { lit |= undec; break; }
-      int f = __builtin_ctzll(mm);
-      uint64_t below = (1ull << f) - 1ull;
-      lit |= undec & below;
-      mat |= 1ull << f;
-      const uint32_t qf = p + (uint32_t)f;
-      const uint32_t cf = (uint32_t)__builtin_amdgcn_readlane((int)cand, f);
-      uint32_t lim = n - qf; if (lim > 258u) lim = 258u;
-      const uint32_t off = 4u + 4u * (uint32_t)lane;
-      uint32_t x = 0;
-      if (off < lim) {
-        if (qf + off + 4u <= n) {                    // the dword lies inside the block
-          x = *(const u32u *)(in + cf + off) ^ *(const u32u *)(in + qf + off);
-          if (off + 4u > lim) x &= (1u << (8u * (lim - off))) - 1u;
-        } else {
-          for (uint32_t b2 = 0; b2 < 4u && off + b2 < lim; b2++) x |= (uint32_t)(in[cf + off + b2] ^ in[qf + off + b2]) << (8u * b2);
-        }
-      }
-      uint64_t mis = __ballot(x != 0);
-      uint32_t L = lim;
-      if (mis) {
-        int fl = __builtin_ctzll(mis);
-        uint32_t xf = (uint32_t)__builtin_amdgcn_readlane((int)x, fl);
-        L = 4u + 4u * (uint32_t)fl + ((uint32_t)__builtin_ctz(xf) >> 3);
-      }
-      if (lane == f) mlen = L;
-      uint32_t end = (uint32_t)f + L;
-      uint64_t cov = end >= 64u ? (~0ull << f) : (((1ull << end) - 1ull) & ~below);
-      undec &= ~(below | cov);
-      if (p + end > skip_until) skip_until = p + end;
-    }
-    // tokens -> bits
-    const bool is_lit = (lit >> lane) & 1ull, is_mat = (mat >> lane) & 1ull;
-    uint64_t val = 0; uint32_t nb = 0;
-    if (is_lit) {
-      uint32_t b = can ? (w & 0xffu) : (uint32_t)in[q];
-      if (b < 144u) { val = bitrev(0x30u + b, 8); nb = 8; } else { val = bitrev(0x190u + (b - 144u), 9); nb = 9; }
-    } else if (is_mat) {
-      uint32_t lv, dv;
-      int ln = len_bits(mlen, lv), dn = dist_bits(dist, dv);
-      val = (uint64_t)lv | ((uint64_t)dv << ln); nb = (uint32_t)(ln + dn);
-    }
-    // exclusive prefix of nb over the lanes
-    uint32_t inc = nb;
+  // every lane contributes up to two pieces (<= 31 bits each), A before B, lane order
+  __device__ __forceinline__ void round(int lane, uint32_t va, uint32_t na, uint32_t vb, uint32_t nb) {
+    uint32_t nbits = na + nb, inc = nbits;
     for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o); if (lane >= o) inc += t; }
     uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63) + cbits;
-    uint32_t pos = cbits + inc - nb;
-    if (lane == 0) obuf[0] = carry;                  // obuf is zero apart from this
+    uint32_t pos = cbits + inc - nbits;
+    if (lane == 0) obuf[0] = carry;
     __builtin_amdgcn_wave_barrier();
+    if (na) {
+      uint64_t lo = (uint64_t)va << (pos & 31u);
+      atomicOr(&obuf[pos >> 5], (uint32_t)lo);
+      if ((uint32_t)(lo >> 32)) atomicOr(&obuf[(pos >> 5) + 1], (uint32_t)(lo >> 32));
+    }
     if (nb) {
-      uint32_t sh = pos & 31u, wi = pos >> 5;
-      uint64_t lo = val << sh;                       // nb <= 31, sh <= 31: fits 64 bits
-      atomicOr(&obuf[wi], (uint32_t)lo);
-      uint32_t hi = (uint32_t)(lo >> 32);
-      if (hi) atomicOr(&obuf[wi + 1], hi);
+      uint32_t p2 = pos + na;
+      uint64_t lo = (uint64_t)vb << (p2 & 31u);
+      atomicOr(&obuf[p2 >> 5], (uint32_t)lo);
+      if ((uint32_t)(lo >> 32)) atomicOr(&obuf[(p2 >> 5) + 1], (uint32_t)(lo >> 32));
     }
     __builtin_amdgcn_wave_barrier();
-    uint32_t full = total >> 5;
-    if ((uint32_t)lane < full) *(u32u *)(pay + 4u * (wbase + lane)) = obuf[lane];
-    uint32_t nxt_carry = obuf[full];
+    uint32_t full = total >> 5;                       // <= (31 + 64 * 62) / 32 = 124
+    for (uint32_t i = lane; i < full; i += 64) *(u32u *)(pay + 4u * (wbase + i)) = obuf[i];
+    uint32_t nxt = obuf[full];
     __builtin_amdgcn_wave_barrier();
-    if ((uint32_t)lane <= full + 1u && lane < OBUF_WORDS) obuf[lane] = 0;
+    for (uint32_t i = lane; i <= full + 1u && i < OBUF_WORDS; i += 64) obuf[i] = 0;
     __builtin_amdgcn_wave_barrier();
     cbits = total & 31u;
-    carry = cbits ? (nxt_carry & ((1u << cbits) - 1u)) : 0u;
+    carry = cbits ? (nxt & ((1u << cbits) - 1u)) : 0u;
     wbase += full;
   }
-  // end-of-block symbol: seven zero bits; then the trailing partial bytes
-  uint32_t total = cbits + 7u;
-  uint32_t nbytes = 4u * wbase + (total + 7u) / 8u;  // total <= 38: at most 5 tail bytes
-  if (lane < 5) { uint32_t b = (lane < 4) ? (carry >> (8 * lane)) & 0xffu : 0u; if (4u * wbase + (uint32_t)lane < nbytes) pay[4u * wbase + lane] = (uint8_t)b; }
-  // CRC32 of the payload: K lane-chunks (the first takes the remainder), then acc = shift(acc) ^ crc_i
+  // flush the remaining bits (plus `extra_zero_bits` zero bits) and return the payload byte count
+  __device__ __forceinline__ uint32_t finish(int lane) {
+    uint32_t nbytes = 4u * wbase + (cbits + 7u) / 8u;
+    if (lane < 4) { if (4u * wbase + (uint32_t)lane < nbytes) pay[4u * wbase + lane] = (uint8_t)(carry >> (8 * lane)); }
+    return nbytes;
+  }
+};
+
+// one greedy parse round over positions p .. p+63: returns this lane's token (0 none, 1 literal, 2 match)
+struct Token { uint32_t kind, byte, len, dist; };
+
+__device__ __forceinline__ Token parse_round(const uint8_t *in, uint32_t n, uint32_t p, int lane, uint16_t *tab, uint32_t w,
+                                             uint32_t &skip_until) {
+  Token tk{0, 0, 0, 0};
+  const uint32_t q = p + lane;
+  const bool act = q < n;
+  const bool can = q + 4u <= n;
+  uint32_t h = (w * 2654435761u) >> (32 - HASH_BITS);
+  if (p + 64u <= skip_until) {                       // the whole round lies inside a match: only feed the table
+    if (can) tab[h] = (uint16_t)q;
+    return tk;
+  }
+  uint32_t cand = can ? tab[h] : EMPTY16;
+  __builtin_amdgcn_wave_barrier();
+  if (can) tab[h] = (uint16_t)q;                     // any writer of a clashing slot is fine: all are < next round's p
+  const uint64_t active = __ballot(act);
+  uint64_t covered = __ballot(act && q < skip_until);
+  uint32_t dist = 0;
+  bool v4 = false;
+  if (can && q >= skip_until && cand != EMPTY16) {
+    dist = q - cand;
+    v4 = dist <= 32768u && *(const u32u *)(in + cand) == w;
+  }
+  const uint64_t hasm = __ballot(v4);
+  // only the matches that are TAKEN get their length computed, by the whole wave: lane L compares bytes
+  // [4 + 4L, 8 + 4L), one step covers all 258
+  uint32_t mlen = 0;
+  uint64_t lit = 0, mat = 0, undec = active & ~covered;
+  while (undec) {
+    uint64_t mm = hasm & undec;
+    if (!mm) { lit |= undec; break; }
+    int f = __builtin_ctzll(mm);
+    uint64_t below = (1ull << f) - 1ull;
+    lit |= undec & below;
+    mat |= 1ull << f;
+    const uint32_t qf = p + (uint32_t)f;
+    const uint32_t cf = (uint32_t)__builtin_amdgcn_readlane((int)cand, f);
+    uint32_t lim = n - qf; if (lim > 258u) lim = 258u;
+    const uint32_t off = 4u + 4u * (uint32_t)lane;
+    uint32_t x = 0;
+    if (off < lim) {
+      if (qf + off + 4u <= n) {
+        x = *(const u32u *)(in + cf + off) ^ *(const u32u *)(in + qf + off);
+        if (off + 4u > lim) x &= (1u << (8u * (lim - off))) - 1u;
+      } else {
+        for (uint32_t b2 = 0; b2 < 4u && off + b2 < lim; b2++) x |= (uint32_t)(in[cf + off + b2] ^ in[qf + off + b2]) << (8u * b2);
+      }
+    }
+    uint64_t mis = __ballot(x != 0);
+    uint32_t L = lim;
+    if (mis) {
+      int fl = __builtin_ctzll(mis);
+      uint32_t xf = (uint32_t)__builtin_amdgcn_readlane((int)x, fl);
+      L = 4u + 4u * (uint32_t)fl + ((uint32_t)__builtin_ctz(xf) >> 3);
+    }
+    if (lane == f) mlen = L;
+    uint32_t end = (uint32_t)f + L;
+    uint64_t cov = end >= 64u ? (~0ull << f) : (((1ull << end) - 1ull) & ~below);
+    undec &= ~(below | cov);
+    if (p + end > skip_until) skip_until = p + end;
+  }
+  if ((lit >> lane) & 1ull) { tk.kind = 1; tk.byte = can ? (w & 0xffu) : (uint32_t)in[q]; }
+  else if ((mat >> lane) & 1ull) { tk.kind = 2; tk.len = mlen; tk.dist = dist; }
+  return tk;
+}
+
+// CRC32 of the payload (K lane-chunks, the first takes the remainder; acc = shift(acc) ^ crc_i), then the
+// BGZF header, trailer and the block size
+__device__ __forceinline__ void finish_block(const DeflateArgs &A, uint64_t blk, const uint8_t *in, uint32_t n, uint8_t *out,
+                                             uint32_t nbytes, int lane, const uint32_t *sh_crc, const uint32_t (*sh_shift)[256]) {
   const uint32_t K = (n + DEFLATE_CRC_CHUNK - 1u) / DEFLATE_CRC_CHUNK;
   uint32_t c = 0;
   if ((uint32_t)lane < K) {
@@ -212,9 +199,253 @@ __global__ void __launch_bounds__(256) k_deflate_fixed(DeflateArgs A) {
     const uint8_t head[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
     for (int k = 0; k < 16; k++) out[k] = head[k];
     out[16] = (uint8_t)bsize; out[17] = (uint8_t)(bsize >> 8);
-    uint8_t *t = pay + nbytes;
+    uint8_t *t = out + 18 + nbytes;
     for (int k = 0; k < 4; k++) { t[k] = (uint8_t)(acc >> (8 * k)); t[4 + k] = (uint8_t)(n >> (8 * k)); }
     A.sizes[blk] = bsize + 1u;
+  }
+}
+
+// length 3..258 -> (symbol, extra bit count, extra value); distance 1..32768 likewise
+__device__ __forceinline__ void len_symbol(uint32_t len, uint32_t &sym, uint32_t &eb, uint32_t &ev) {
+  uint32_t m = len - 3u; eb = 0; ev = 0;
+  if (len == 258u) sym = 285u;
+  else if (m < 8u) sym = 257u + m;
+  else { eb = (31u - (uint32_t)__builtin_clz(m)) - 2u; sym = 261u + 4u * eb + ((m >> eb) - 4u); ev = m & ((1u << eb) - 1u); }
+}
+__device__ __forceinline__ void dist_symbol(uint32_t dist, uint32_t &sym, uint32_t &eb, uint32_t &ev) {
+  uint32_t m = dist - 1u; eb = 0; ev = 0;
+  if (m < 4u) sym = m;
+  else { eb = (31u - (uint32_t)__builtin_clz(m)) - 1u; sym = 2u * (eb + 1u) + ((m >> eb) & 1u); ev = m & ((1u << eb) - 1u); }
+}
+
+__global__ void __launch_bounds__(256) k_deflate_fixed(DeflateArgs A) {
+  __shared__ uint16_t sh_tab[4][HASH_SIZE];
+  __shared__ uint32_t sh_obuf[4][OBUF_WORDS];
+  __shared__ uint32_t sh_crc[256];
+  __shared__ uint32_t sh_shift[4][256];
+  for (int i = threadIdx.x; i < 256; i += 256) sh_crc[i] = A.crc_tab[i];
+  for (int i = threadIdx.x; i < 1024; i += 256) sh_shift[i >> 8][i & 255] = A.crc_shift[i];
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  uint64_t blk = (uint64_t)blockIdx.x * 4 + wave;
+  if (blk >= A.n_blocks) return;                     // wave-uniform; no block barrier below
+  uint16_t *tab = sh_tab[wave];
+  const uint8_t *in = A.src + blk * DEFLATE_PAYLOAD;
+  uint64_t left = A.n_bytes - blk * DEFLATE_PAYLOAD;
+  const uint32_t n = left < DEFLATE_PAYLOAD ? (uint32_t)left : DEFLATE_PAYLOAD;
+  uint8_t *out = A.slots + blk * DEFLATE_SLOT;
+  for (int i = lane; i < HASH_SIZE; i += 64) tab[i] = EMPTY16;
+  for (int i = lane; i < OBUF_WORDS; i += 64) sh_obuf[wave][i] = 0;
+  __builtin_amdgcn_wave_barrier();
+  BitWriter bw{sh_obuf[wave], out + 18, 3u, 3u, 0u};   // BFINAL = 1, BTYPE = 01 (fixed Huffman)
+  uint32_t skip_until = 0;
+  // the dword at each lane's position is loaded one round ahead (its latency hides behind the current round)
+  uint32_t w_next = (lane + 4u <= n) ? *(const u32u *)(in + lane) : 0u;
+  for (uint32_t p = 0; p < n; p += 64) {
+    const uint32_t w = w_next;
+    if (p + lane + 64u + 4u <= n) w_next = *(const u32u *)(in + p + lane + 64u);
+    const bool inside = p + 64u <= skip_until;
+    Token tk = parse_round(in, n, p, lane, tab, w, skip_until);
+    if (inside) continue;
+    uint32_t va = 0, na = 0;
+    if (tk.kind == 1) {
+      if (tk.byte < 144u) { va = bitrev(0x30u + tk.byte, 8); na = 8; } else { va = bitrev(0x190u + (tk.byte - 144u), 9); na = 9; }
+    } else if (tk.kind == 2) {
+      uint32_t lv, dv;
+      int ln = len_bits(tk.len, lv), dn = dist_bits(tk.dist, dv);
+      // <= 13 + 18 = 31 bits: one piece
+      va = lv | (dv << ln); na = (uint32_t)(ln + dn);
+    }
+    bw.round(lane, va, na, 0, 0);
+  }
+  bw.round(lane, 0, lane == 0 ? 7u : 0u, 0, 0);        // end-of-block symbol 256: seven zero bits
+  uint32_t nbytes = bw.finish(lane);
+  finish_block(A, blk, in, n, out, nbytes, lane, sh_crc, sh_shift);
+}
+
+// ---- dynamic Huffman ---------------------------------------------------------------------------------------
+// Same parse; the tokens of a block go to a per-wave scratch list while the literal/length and distance
+// histograms build up in LDS.  Code lengths: Shannon lengths ceil(log2(total / f)) limited to 15 bits, then the
+// Kraft sum is brought to exactly one -- lengthening the rarest symbols while it is above, shortening the most
+// frequent ones that still fit while it is below (a complete prefix code, which inflaters require).  The code
+// lengths travel uncompressed-run-length (every length as a 4-bit symbol of a flat code-length code): 167 bytes
+// of header per 56 KiB block.  Then the token list is replayed through the canonical codes.
+#define DYN_LL 286
+#define DYN_D 30
+
+__device__ __forceinline__ void build_lengths(uint32_t *freq, uint8_t *lens, int nsym, int lane, bool allow_single) {
+  // symbols of this lane: lane, lane + 64, ...
+  uint32_t total = 0, used = 0;
+  for (int i = lane; i < nsym; i += 64) { total += freq[i]; used += freq[i] ? 1u : 0u; }
+  for (int o = 32; o > 0; o >>= 1) { total += __shfl_xor(total, o); used += __shfl_xor(used, o); }
+  if (used == 0) { for (int i = lane; i < nsym; i += 64) lens[i] = 0; return; }
+  if (used == 1) {   // one symbol: one bit (an inflater accepts the incomplete code only for distances; callers make
+                     // sure the literal/length alphabet has at least two symbols: a literal or match plus end-of-block)
+    for (int i = lane; i < nsym; i += 64) lens[i] = freq[i] ? 1 : 0;
+    (void)allow_single;
+    return;
+  }
+  int32_t k15 = 0;   // Kraft sum in units of 2^-15
+  for (int i = lane; i < nsym; i += 64) {
+    uint32_t f = freq[i]; uint8_t l = 0;
+    if (f) {
+      // ceil(log2(total / f)) without floating point: smallest l with f << l >= total
+      uint32_t ll = 1; while (ll < 15u && ((uint64_t)f << ll) < total) ll++;
+      l = (uint8_t)ll; k15 += 1 << (15 - ll);
+    }
+    lens[i] = l;
+  }
+  for (int o = 32; o > 0; o >>= 1) k15 += __shfl_xor(k15, o);
+  __builtin_amdgcn_wave_barrier();
+  // above one (only through the 15-bit limit): lengthen the rarest symbol that is not at the limit yet
+  while (k15 > 32768) {
+    uint32_t best = 0xffffffffu; int bi = -1;
+    for (int i = lane; i < nsym; i += 64) if (lens[i] && lens[i] < 15 && freq[i] < best) { best = freq[i]; bi = i; }
+    uint64_t key = ((uint64_t)best << 32) | (uint32_t)bi;
+    for (int o = 32; o > 0; o >>= 1) { uint64_t t = __shfl_xor(key, o); key = t < key ? t : key; }
+    int pick = (int)(uint32_t)key;
+    if (pick < 0) break;                              // cannot happen: 286 symbols at 15 bits sum to < 1
+    uint8_t l = lens[pick];
+    k15 -= 1 << (15 - l - 1);
+    if (lane == 0) lens[pick] = l + 1;
+    __builtin_amdgcn_wave_barrier();
+  }
+  // below one: shorten the most frequent symbol whose step still fits
+  while (k15 < 32768) {
+    int32_t slack = 32768 - k15;
+    uint64_t key = 0;
+    for (int i = lane; i < nsym; i += 64) {
+      uint8_t l = lens[i];
+      if (l > 1 && (1 << (15 - l)) <= slack) { uint64_t kk = ((uint64_t)freq[i] << 32) | (uint32_t)(0xffff - i); if (kk > key) key = kk; }
+    }
+    for (int o = 32; o > 0; o >>= 1) { uint64_t t = __shfl_xor(key, o); key = t > key ? t : key; }
+    if (!key) break;                                  // cannot happen while slack > 0 (a longest code always fits)
+    int pick = 0xffff - (int)(uint32_t)(key & 0xffffu);
+    uint8_t l = lens[pick];
+    k15 += 1 << (15 - l);
+    if (lane == 0) lens[pick] = l - 1;
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// canonical codes (RFC 1951 3.2.2) -> enc[i] = reversed code | length << 16; nc: 16 words of LDS scratch
+__device__ __forceinline__ void build_codes(const uint8_t *lens, uint32_t *enc, int nsym, int lane, uint32_t *nc) {
+  // bl_count: lane l counts the symbols of length l
+  uint32_t cnt = 0;
+  if (lane >= 1 && lane <= 15) for (int i = 0; i < nsym; i++) cnt += lens[i] == lane;
+  // next_code[l] = (next_code[l-1] + bl_count[l-1]) << 1: a serial chain over the 15 lengths
+  uint32_t code = 0, prev_cnt = 0;
+  for (int l = 1; l <= 15; l++) {
+    code = (code + prev_cnt) << 1;
+    if (lane == l) nc[l] = code;
+    prev_cnt = (uint32_t)__builtin_amdgcn_readlane((int)cnt, l);
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int i = lane; i < nsym; i += 64) {
+    uint32_t l = lens[i], e = 0;
+    if (l) {
+      uint32_t rank = 0;
+      for (int j = 0; j < i; j++) rank += lens[j] == l;
+      e = bitrev(nc[l] + rank, (int)l) | (l << 16);
+    }
+    enc[i] = e;
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+__global__ void __launch_bounds__(256) k_deflate_dynamic(DeflateArgs A) {
+  __shared__ uint16_t sh_tab[4][HASH_SIZE];
+  __shared__ uint32_t sh_obuf[4][OBUF_WORDS];
+  __shared__ uint32_t sh_crc[256];
+  __shared__ uint32_t sh_shift[4][256];
+  __shared__ uint32_t sh_fll[4][DYN_LL + 2], sh_fd[4][DYN_D + 2];   // histograms, then the encode tables
+  __shared__ uint8_t sh_lll[4][DYN_LL + 2], sh_ld[4][DYN_D + 2];
+  __shared__ uint32_t sh_nc[4][16];
+  for (int i = threadIdx.x; i < 256; i += 256) sh_crc[i] = A.crc_tab[i];
+  for (int i = threadIdx.x; i < 1024; i += 256) sh_shift[i >> 8][i & 255] = A.crc_shift[i];
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint64_t wave_id = (uint64_t)blockIdx.x * 4 + wave, n_waves = (uint64_t)gridDim.x * 4;
+  uint16_t *tab = sh_tab[wave];
+  uint32_t *fll = sh_fll[wave], *fd = sh_fd[wave];
+  uint8_t *lll = sh_lll[wave], *ld = sh_ld[wave];
+  uint32_t *tokens = A.tokens + wave_id * DEFLATE_PAYLOAD;
+  for (uint64_t blk = wave_id; blk < A.n_blocks; blk += n_waves) {   // persistent waves: the token scratch is per wave
+    const uint8_t *in = A.src + blk * DEFLATE_PAYLOAD;
+    uint64_t left = A.n_bytes - blk * DEFLATE_PAYLOAD;
+    const uint32_t n = left < DEFLATE_PAYLOAD ? (uint32_t)left : DEFLATE_PAYLOAD;
+    uint8_t *out = A.slots + blk * DEFLATE_SLOT;
+    for (int i = lane; i < HASH_SIZE; i += 64) tab[i] = EMPTY16;
+    for (int i = lane; i < OBUF_WORDS; i += 64) sh_obuf[wave][i] = 0;
+    for (int i = lane; i < DYN_LL + 2; i += 64) fll[i] = 0;
+    for (int i = lane; i < DYN_D + 2; i += 64) fd[i] = 0;
+    __builtin_amdgcn_wave_barrier();
+    // ---- parse: tokens + histograms
+    uint32_t skip_until = 0, n_tok = 0;
+    uint32_t w_next = (lane + 4u <= n) ? *(const u32u *)(in + lane) : 0u;
+    for (uint32_t p = 0; p < n; p += 64) {
+      const uint32_t w = w_next;
+      if (p + lane + 64u + 4u <= n) w_next = *(const u32u *)(in + p + lane + 64u);
+      const bool inside = p + 64u <= skip_until;
+      Token tk = parse_round(in, n, p, lane, tab, w, skip_until);
+      if (inside) continue;
+      uint64_t sel = __ballot(tk.kind != 0);
+      uint32_t rank = (uint32_t)__builtin_popcountll(sel & ((1ull << lane) - 1ull));
+      if (tk.kind == 1) { tokens[n_tok + rank] = tk.byte; atomicAdd(&fll[tk.byte], 1u); }
+      else if (tk.kind == 2) {
+        tokens[n_tok + rank] = 0x80000000u | ((tk.len - 3u) << 16) | (tk.dist - 1u);
+        uint32_t s1, e1, v1, s2, e2, v2;
+        len_symbol(tk.len, s1, e1, v1); dist_symbol(tk.dist, s2, e2, v2);
+        atomicAdd(&fll[s1], 1u); atomicAdd(&fd[s2], 1u);
+      }
+      n_tok += (uint32_t)__builtin_popcountll(sel);
+    }
+    if (lane == 0) fll[256] = 1;                      // end of block
+    __builtin_amdgcn_wave_barrier();
+    // ---- codes
+    build_lengths(fll, lll, DYN_LL, lane, false);
+    build_lengths(fd, ld, DYN_D, lane, true);
+    __builtin_amdgcn_wave_barrier();
+    build_codes(lll, fll, DYN_LL, lane, sh_nc[wave]);  // the histograms become the encode tables
+    build_codes(ld, fd, DYN_D, lane, sh_nc[wave]);
+    __builtin_amdgcn_wave_barrier();
+    // ---- header: BFINAL 1, BTYPE 10, HLIT 29 (286), HDIST 29 (30), HCLEN 15 (19); code-length code: symbols 0..15 get
+    // four bits each (flat, complete), 16/17/18 unused; order 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
+    BitWriter bw{sh_obuf[wave], out + 18, 0u, 0u, 0u};
+    {
+      uint32_t va = 0, na = 0;
+      if (lane == 0) { va = 1u | (2u << 1) | (29u << 3) | (29u << 8) | (15u << 13); na = 17; }
+      else if (lane <= 19) { va = (lane <= 3) ? 0u : 4u; na = 3; }   // lanes 1..3: symbols 16, 17, 18
+      bw.round(lane, va, na, 0, 0);
+    }
+    for (int base = 0; base < DYN_LL + DYN_D; base += 64) {          // 316 code lengths, 4 bits each (code = reversed value)
+      int i = base + lane;
+      uint32_t va = 0, na = 0;
+      if (i < DYN_LL + DYN_D) { uint32_t l = i < DYN_LL ? lll[i] : ld[i - DYN_LL]; va = bitrev(l, 4); na = 4; }
+      bw.round(lane, va, na, 0, 0);
+    }
+    // ---- tokens through the codes
+    for (uint32_t t0 = 0; t0 < n_tok; t0 += 64) {
+      uint32_t t = t0 + lane;
+      uint32_t va = 0, na = 0, vb = 0, nb = 0;
+      if (t < n_tok) {
+        uint32_t tk = tokens[t];
+        if (!(tk & 0x80000000u)) { uint32_t e = fll[tk]; va = e & 0xffffu; na = e >> 16; }
+        else {
+          uint32_t len = ((tk >> 16) & 0xffu) + 3u, dist = (tk & 0x7fffu) + 1u;
+          uint32_t s1, e1, v1, s2, e2, v2;
+          len_symbol(len, s1, e1, v1); dist_symbol(dist, s2, e2, v2);
+          uint32_t c1 = fll[s1], c2 = fd[s2];
+          va = (c1 & 0xffffu) | (v1 << (c1 >> 16)); na = (c1 >> 16) + e1;      // <= 15 + 5
+          vb = (c2 & 0xffffu) | (v2 << (c2 >> 16)); nb = (c2 >> 16) + e2;      // <= 15 + 13
+        }
+      }
+      bw.round(lane, va, na, vb, nb);
+    }
+    { uint32_t e = fll[256]; bw.round(lane, lane == 0 ? (e & 0xffffu) : 0u, lane == 0 ? (e >> 16) : 0u, 0, 0); }
+    uint32_t nbytes = bw.finish(lane);
+    finish_block(A, blk, in, n, out, nbytes, lane, sh_crc, sh_shift);
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -231,8 +462,10 @@ __global__ void __launch_bounds__(256) k_bgzf_compact(DeflateArgs A, const uint6
   for (uint32_t i = n16 + lane; i < n; i += 64) d[i] = s[i];
 }
 
-void launch_deflate(hipStream_t st, const DeflateArgs &A) {
-  if (A.n_blocks) hipLaunchKernelGGL(k_deflate_fixed, dim3((unsigned)((A.n_blocks + 3) / 4)), dim3(256), 0, st, A);
+void launch_deflate(hipStream_t st, const DeflateArgs &A, int dynamic_waves) {
+  if (!A.n_blocks) return;
+  if (dynamic_waves > 0) hipLaunchKernelGGL(k_deflate_dynamic, dim3((unsigned)(dynamic_waves / 4)), dim3(256), 0, st, A);
+  else hipLaunchKernelGGL(k_deflate_fixed, dim3((unsigned)((A.n_blocks + 3) / 4)), dim3(256), 0, st, A);
 }
 void launch_bgzf_compact(hipStream_t st, const DeflateArgs &A, const uint64_t *off, uint8_t *dense) {
   if (A.n_blocks) hipLaunchKernelGGL(k_bgzf_compact, dim3((unsigned)((A.n_blocks + 3) / 4)), dim3(256), 0, st, A, off, dense);

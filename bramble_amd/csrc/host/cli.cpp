@@ -15,6 +15,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <deque>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -39,7 +40,7 @@ struct Options {
   int threads = 1, level = 6, device = 0;
   int64_t bundle_records = 2000000;
   bool quiet = false;
-  bool device_deflate = false;
+  bool device_deflate = true;   // BGZF blocks made on the GPU unless a host level is asked for
 };
 
 void usage(FILE *f) {
@@ -49,8 +50,10 @@ void usage(FILE *f) {
           " [--help] [--version] [--quiet] [--fr] [--rf] [--lr] [--lr-hq] [--strict]\n"
           " [--max-soft-clip N] [--max-junction-insertion N] [--max-junction-deletion N]\n"
           " [--max-error-exon N] [--similarity-threshold X]\n"
-          " [--compression-level 0-9] [--device-deflate] [--bundle-size N] [--device N]\n\n"
-          "Project spliced genomic alignments into transcriptomic space.\n");
+          " [--device-deflate | --host-deflate | --compression-level 0-9] [--bundle-size N] [--device N]\n\n"
+          "Project spliced genomic alignments into transcriptomic space.\n"
+          "The output BGZF blocks are deflated on the GPU by default (per-block Huffman codes); --host-deflate or\n"
+          "--compression-level N use the host codec (libdeflate / zlib, level 6 like the reference unless N is given).\n");
 }
 
 bool parse_u32(const char *s, uint32_t &v) { char *e; unsigned long x = strtoul(s, &e, 10); if (e == s || *e) return false; v = (uint32_t)x; return true; }
@@ -82,7 +85,8 @@ int parse_args(int argc, char **argv, Options &o) {
     else if (a == "-S" || a == "--genome") { const char *v = value(); if (!v) return -1; o.fasta = v; }
     else if (a == "-o" || a == "--out") { const char *v = value(); if (!v) return -1; o.out_bam = v; }
     else if (a == "-p") { const char *v = value(); if (!v) return -1; o.threads = atoi(v); if (o.threads < 1) o.threads = 1; }
-    else if (a == "--compression-level") { const char *v = value(); if (!v) return -1; o.level = atoi(v); if (o.level < 0 || o.level > 9) return -1; }
+    else if (a == "--compression-level") { const char *v = value(); if (!v) return -1; o.level = atoi(v); if (o.level < 0 || o.level > 9) return -1; o.device_deflate = false; }
+    else if (a == "--host-deflate") o.device_deflate = false;
     else if (a == "--bundle-size") { const char *v = value(); if (!v) return -1; o.bundle_records = atoll(v); if (o.bundle_records < 1) return -1; }
     else if (a == "--device-deflate") o.device_deflate = true;
     else if (a == "--device") { const char *v = value(); if (!v) return -1; o.device = atoi(v); }
@@ -206,14 +210,19 @@ std::vector<uint8_t> make_bam_header(const std::string &text, const br_index *ix
 
 // ---- bounded single-slot hand-off between pipeline stages ---------------------------------------
 template <typename T>
-struct Slot {
-  std::mutex m; std::condition_variable cv; std::unique_ptr<T> item; bool done = false;
-  void put(std::unique_ptr<T> v) { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return !item; }); item = std::move(v); cv.notify_all(); }
+struct Slot {  // bounded FIFO between two pipeline stages
+  explicit Slot(size_t depth = 1) : depth_(depth) {}
+  std::mutex m; std::condition_variable cv; std::deque<std::unique_ptr<T>> q; bool done = false; size_t depth_;
+  void put(std::unique_ptr<T> v) { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return q.size() < depth_; }); q.push_back(std::move(v)); cv.notify_all(); }
   void finish() { std::unique_lock<std::mutex> l(m); done = true; cv.notify_all(); }
-  std::unique_ptr<T> take() { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return item || done; }); auto v = std::move(item); cv.notify_all(); return v; }
-  // consumer that keeps the slot occupied while it works on the item: put() of the next one waits for release()
-  T *hold() { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return item || done; }); return item.get(); }
-  void release() { std::unique_lock<std::mutex> l(m); item.reset(); cv.notify_all(); }
+  std::unique_ptr<T> take() {
+    std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return !q.empty() || done; });
+    if (q.empty()) return nullptr;
+    auto v = std::move(q.front()); q.pop_front(); cv.notify_all(); return v;
+  }
+  // consumer that keeps the (depth-1) slot occupied while it works on the item: put() of the next one waits for release()
+  T *hold() { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return !q.empty() || done; }); return q.empty() ? nullptr : q.front().get(); }
+  void release() { std::unique_lock<std::mutex> l(m); q.pop_front(); cv.notify_all(); }
 };
 
 struct Bundle { brio::ByteBuf blob; std::vector<uint64_t> off; std::vector<uint32_t> len; };
@@ -239,7 +248,8 @@ extern "C" int br_cli_main(int argc, char **argv) {
   brio::ByteBuf buf; size_t pos = 0;
   BamHeader hdr; std::string err;
   if (!read_header(rd, buf, pos, hdr, err)) { fprintf(stderr, "error: %s: %s\n", o.in_bam.c_str(), err.c_str()); return 1; }
-  Slot<Bundle> to_gpu; Slot<OutChunk> to_writer;
+  Slot<Bundle> to_gpu(4);      // the reader runs ahead while the guides are parsed and the index is built
+  Slot<OutChunk> to_writer(1); // exactly one: the two pinned download buffers alternate
   // consumed bundle buffers go back to the reader: their pages are already faulted in
   std::mutex pool_m; std::vector<std::unique_ptr<brio::ByteBuf>> pool;
   uint64_t total_reads = 0, unmapped_reads = 0;
@@ -393,7 +403,9 @@ extern "C" int br_cli_main(int argc, char **argv) {
   if (!reader_err.empty()) { fprintf(stderr, "error: %s: %s\n", o.in_bam.c_str(), reader_err.c_str()); fail = 1; }
   if (!writer_err.empty()) { fprintf(stderr, "error: %s: %s\n", o.out_bam.c_str(), writer_err.c_str()); fail = 1; }
   if (!wr.close()) { fprintf(stderr, "error: %s: %s\n", o.out_bam.c_str(), wr.error().c_str()); fail = 1; }
+  double t_done = since();
   br_ctx_free(ctx); br_index_free(ix); br_annotation_free(ann);
+  double t_freed = since();
   if (!o.quiet) {  // src/bramble.cpp:727-736
     printf("\n[bramble] final report:\n");
     printf("# input alignments:   %llu\n", (unsigned long long)total_reads);
@@ -403,6 +415,7 @@ extern "C" int br_cli_main(int argc, char **argv) {
     printf("# unique alignments:  %llu\n\n", (unsigned long long)total_unique);
     printf("[bramble] %llu bundles, %.2fs on the device path (upload + kernels + download), %.2fs wall (setup %.2fs, codec %s)\n",
            (unsigned long long)n_bundles, gpu_seconds, since(), t_setup, brio::codec_name());
+    printf("[bramble] release of device / pinned memory: %.2fs\n", t_freed - t_done);
     printf("[bramble] stage busy time: inflate %.2fs, split %.2fs, bundle copy %.2fs, device %.2fs (waited for input %.2fs), deflate+write %.2fs\n",
            t_inflate, t_split, t_copy, gpu_seconds, t_wait_gpu_in, t_deflate);
   }

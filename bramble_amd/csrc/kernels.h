@@ -166,8 +166,10 @@ struct DeflateArgs {
   uint32_t *sizes;             // [n_blocks] BGZF block sizes
   const uint32_t *crc_tab;     // [256] reflected CRC-32 table
   const uint32_t *crc_shift;   // [4][256] "append DEFLATE_CRC_CHUNK zero bytes" operator
+  uint32_t *tokens;            // dynamic Huffman: DEFLATE_PAYLOAD words per resident wave
 };
-void launch_deflate(hipStream_t st, const DeflateArgs &A);
+// dynamic_waves: 0 = fixed Huffman (one wave per block); > 0 = dynamic Huffman with that many persistent waves
+void launch_deflate(hipStream_t st, const DeflateArgs &A, int dynamic_waves);
 void launch_bgzf_compact(hipStream_t st, const DeflateArgs &A, const uint64_t *off, uint8_t *dense);
 
 // BAM records -> input tables (parse_kernels.hip)

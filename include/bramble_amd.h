@@ -361,8 +361,8 @@ size_t br_annotation_num_refs(const br_annotation *);            /* reference na
 const char *const *br_annotation_refnames(const br_annotation *);
 
 /* The reference's command line (src/bramble.cpp:443-485): in.bam -G -o [-S] [-p] [--fr|--rf]
- * [--lr|--lr-hq] [--strict] [--max-*] [--similarity-threshold] [--quiet], plus --compression-level,
- * --device-deflate (BGZF blocks made on the GPU), --bundle-size and --device.  Returns the process exit code. */
+ * [--lr|--lr-hq] [--strict] [--max-*] [--similarity-threshold] [--quiet], plus --device-deflate (default: BGZF blocks made on the
+ * GPU) / --host-deflate / --compression-level N (host codec), --bundle-size and --device.  Returns the process exit code. */
 int br_cli_main(int argc, char **argv);
 
 /* BGZF container utilities (host only; what the reference gets from htslib's bgzf layer behind

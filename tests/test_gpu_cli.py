@@ -127,7 +127,7 @@ def test_cli_result_does_not_depend_on_bundle_size(tmp_path):
     in_bam = str(tmp_path / "in.bam")
     bamio.write_bam(in_bam, "@HD\tVN:1.6\n", bam_refs, stream.tobytes())
     outs = []
-    for k, (bundle, extra) in enumerate(((1, []), (777, []), (10 ** 7, []), (900, ["--device-deflate"]))):
+    for k, (bundle, extra) in enumerate(((1, ["--host-deflate"]), (777, ["--compression-level", "1"]), (10 ** 7, []), (900, ["--device-deflate"]))):
         out_bam = str(tmp_path / ("o%d.bam" % k))
         r = subprocess.run([BIN, in_bam, "-G", gtf, "-o", out_bam, "-p", "2", "--bundle-size", str(bundle), "--quiet",
                             "--strict", "--max-soft-clip", "3"] + extra, capture_output=True, text=True, timeout=600)

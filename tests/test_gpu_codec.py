@@ -43,6 +43,9 @@ def payloads():
     rng = np.random.RandomState(9)
     text = (b"@read%07d\tACGTACGTTTGACCA\t+\tIIIIHHHGGFF###\n" * 40000)
     yield "one byte", np.frombuffer(b"\x7f", dtype=np.uint8)
+    yield "one symbol only", np.full(5000, 65, dtype=np.uint8)
+    yield "two symbols", np.frombuffer(b"ab" * 3 + b"a" * 50 + b"b", dtype=np.uint8)
+    yield "skewed (long codes for rare bytes)", np.concatenate([np.full(56000, 7, dtype=np.uint8), np.arange(256, dtype=np.uint8)])
     yield "three bytes", np.frombuffer(b"abc", dtype=np.uint8)
     yield "zeros", np.zeros(200_000, dtype=np.uint8)
     yield "random (incompressible, bytes >= 144 take 9 bits)", rng.randint(0, 256, size=300_001).astype(np.uint8)
@@ -55,9 +58,12 @@ def payloads():
                                                        np.repeat(rng.randint(0, 256, size=300).astype(np.uint8), 700)])
 
 
-def test_device_deflate_round_trips():
+@pytest.mark.parametrize("dynamic", [1, 0])
+def test_device_deflate_round_trips(dynamic):
+    """dynamic = 1: k_deflate_dynamic (per-block Huffman codes, the default); 0: k_deflate_fixed."""
     import torch
     idx, ctx = _ctx()
+    ctx.set_param("deflate_dynamic", dynamic)
     for label, data in payloads():
         src = torch.from_numpy(data.copy()).to("cuda:0")
         z = ctx.bgzf_deflate_device(src, 0).cpu().numpy().tobytes()
