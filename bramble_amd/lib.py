@@ -15,7 +15,7 @@ _P = C.POINTER
 K_SEGMENT, K_COUNT, K_EMIT, K_PAIR_COUNT, K_PAIR_EMIT, K_GATHER, K_SCAN, K_EMIT_AUX, K_KSW, K_BAM, K_PARSE, K_CODEC, K_NUM = range(13)
 KERNEL_NAMES = ["k_segment", "k_project<G,false>", "k_emit_dense", "k_group_ids+k_pair<false>", "k_pair<true>",
                 "k_row_fill+k_group_stats+k_gather", "k_scan_*", "k_expand+k_project<64,true>", "k_ksw", "k_bam_scan+k_bam_size+k_bam_encode",
-                "k_rec_fields+k_group_off+k_rec_copy+k_mates+k_seq_*", "k_deflate_fixed+k_bgzf_compact"]
+                "k_rec_fields+k_group_off+k_rec_copy+k_mates+k_seq_*", "k_deflate_*+k_bgzf_compact"]
 
 
 class BrambleError(RuntimeError):

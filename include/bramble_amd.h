@@ -340,7 +340,8 @@ int br_project_bam_bundle(br_ctx *, const br_config *, const br_bam_bundle *, br
 int br_bam_split(const uint8_t *data, uint64_t n_bytes, int64_t cap, uint64_t *rec_off, uint32_t *rec_len,
                  int64_t *n_records, int64_t *n_unmapped, uint64_t *consumed);
 
-/* BGZF-compress n bytes that sit in HBM (one wave per 56 KiB block: hash-table LZ77 + fixed-Huffman DEFLATE + CRC32);
+/* BGZF-compress n bytes that sit in HBM (one wave per 56 KiB block: hash-table LZ77, per-block dynamic Huffman codes --
+ * or the fixed code with br_ctx_set_param("deflate_dynamic", 0) -- and CRC32);
  * *out is a device pointer to the concatenated blocks (no EOF marker), valid until the next call on the context. */
 int br_bgzf_deflate_device(br_ctx *, const uint8_t *src, uint64_t n, void *stream, const uint8_t **out, uint64_t *out_bytes);
 
@@ -387,12 +388,13 @@ const char *br_bgzf_codec(void); /* "libdeflate" (bound at run time when present
 #define BR_K_KSW 8        /* k_ksw (-S clip rescue DP) */
 #define BR_K_BAM 9        /* k_bam_scan + k_bam_size + k_bam_encode */
 #define BR_K_PARSE 10     /* k_rec_fields + k_group_off + k_rec_copy + k_mates* + k_seq_* */
-#define BR_K_CODEC 11     /* k_deflate_fixed + k_bgzf_compact */
+#define BR_K_CODEC 11     /* k_deflate_dynamic | k_deflate_fixed, k_bgzf_compact */
 #define BR_K_NUM 12
 /* When enabled, every launch is bracketed by hipEvents on the launch stream. */
 int br_ctx_set_profiling(br_ctx *, int enabled);
 /* Launch tuning: "group_lanes" (8|16|32|64 lanes cooperating on one alignment),
- * "blocks_per_cu" (grid size of the grid-stride projection kernels). */
+ * "blocks_per_cu" (grid size of the grid-stride projection kernels), "bam_lanes" (4..64 lanes per
+ * re-encoded record), "deflate_dynamic" (1: per-block Huffman codes, 0: the fixed code). */
 int br_ctx_set_param(br_ctx *, const char *key, int64_t value);
 /* Device time (ms) of kernel `which` during the last projection call, summed
  * over its launches; *launches receives the launch count. */
