@@ -71,10 +71,10 @@ static const size_t BLOCK_DATA = 0xff00;  // htslib BGZF_BLOCK_SIZE: uncompresse
 static const uint8_t EOF_BLOCK[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0,
                                       0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
-BgzfReader::~BgzfReader() { if (map_) munmap((void *)map_, map_size_); if (f_) fclose(f_); }
+BgzfReader::~BgzfReader() { if (map_) munmap((void *)map_, map_size_); if (f_ && f_ != stdin) fclose(f_); }
 
 bool BgzfReader::open(const char *path, int threads) {
-  f_ = fopen(path, "rb");
+  f_ = strcmp(path, "-") == 0 ? stdin : fopen(path, "rb");   // "-": standard input, like htslib
   threads_ = threads < 1 ? 1 : threads;
   if (!f_) { err_ = std::string("cannot open ") + path; return false; }
   // regular files are mapped: the inflate workers read the page cache directly (no fread copy on the reader thread)
@@ -181,10 +181,10 @@ int64_t BgzfReader::read(ByteBuf &out, size_t want) {
   return (int64_t)total;
 }
 
-BgzfWriter::~BgzfWriter() { if (f_) fclose(f_); }
+BgzfWriter::~BgzfWriter() { if (f_ && f_ != stdout) fclose(f_); }
 
 bool BgzfWriter::open(const char *path, int threads, int level) {
-  f_ = fopen(path, "wb");
+  f_ = strcmp(path, "-") == 0 ? stdout : fopen(path, "wb");
   threads_ = threads < 1 ? 1 : threads; level_ = level;
   if (!f_) { err_ = std::string("cannot create ") + path; return false; }
   return true;
@@ -277,7 +277,7 @@ bool BgzfWriter::close() {
   if (!pending_.empty()) { ok = flush_blocks(pending_.data(), 1, pending_.size()); pending_.clear(); }
   if (ok && fwrite(EOF_BLOCK, 1, 28, f_) != 28) { err_ = "short write"; ok = false; }
   bytes_out_ += 28;
-  if (fclose(f_) != 0) { err_ = "close failed"; ok = false; }
+  if ((f_ == stdout ? fflush(f_) : fclose(f_)) != 0) { err_ = "close failed"; ok = false; }
   f_ = nullptr;
   return ok;
 }

@@ -241,6 +241,7 @@ extern "C" int br_cli_main(int argc, char **argv) {
   for (int i = 0; i < argc; i++) { if (i) cl += ' '; cl += argv[i]; }
   auto t_start = std::chrono::steady_clock::now();
   auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
+  if (o.out_bam == "-") o.quiet = true;   // the BAM stream owns standard output
   if (!o.quiet) { printf("\n[bramble] starting version: %s (bramble_amd %s)\n", BRAMBLE_REF_VERSION, br_version()); printf("[bramble] loading reference annotation...\n"); }
 
   BgzfReader rd;

@@ -140,6 +140,26 @@ def test_cli_result_does_not_depend_on_bundle_size(tmp_path):
     assert np.array_equal(outs[0], outs[3])   # BGZF blocks made on the device hold the same stream
 
 
+def test_cli_reads_stdin_and_writes_stdout(tmp_path):
+    """"-" as in.bam / out.bam: a pipeline stage like `aligner | samtools view -b | bramble - -G g.gtf -o - | ...`."""
+    ann = synth.Annotation("G", n_genes=300, n_refs=2)
+    annd = ann.as_dict()
+    b = ann.reads(2000, "pe", with_records=1)
+    stream = framed_stream(b)
+    gtf, in_bam, ref_bam = str(tmp_path / "g.gtf"), str(tmp_path / "in.bam"), str(tmp_path / "ref.bam")
+    bamio.write_gtf(gtf, annd)
+    bamio.write_bam(in_bam, "@HD\tVN:1.6\n", [(n, 1000000) for n in annd["refnames"]], stream.tobytes())
+    r = subprocess.run([BIN, in_bam, "-G", gtf, "-o", ref_bam, "--quiet"], capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    piped = subprocess.run([BIN, "-", "-G", gtf, "-o", "-"], input=open(in_bam, "rb").read(), capture_output=True, timeout=600)
+    assert piped.returncode == 0, piped.stderr
+    out_path = tmp_path / "piped.bam"
+    out_path.write_bytes(piped.stdout)
+    t1, refs1, s1 = bamio.read_bam(ref_bam)
+    t2, refs2, s2 = bamio.read_bam(str(out_path))
+    assert refs1 == refs2 and np.array_equal(s1, s2) and len(s1) > 100000
+
+
 def test_cli_errors(tmp_path):
     r = subprocess.run([BIN, "--version"], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.startswith("version: ")
