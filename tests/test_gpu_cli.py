@@ -160,6 +160,24 @@ def test_cli_reads_stdin_and_writes_stdout(tmp_path):
     assert refs1 == refs2 and np.array_equal(s1, s2) and len(s1) > 100000
 
 
+def test_cli_empty_and_all_unmapped_inputs(tmp_path):
+    gtf = str(tmp_path / "g.gtf")
+    open(gtf, "w").write('chr1\tx\texon\t10\t500\t.\t+\t.\tgene_id "g"; transcript_id "t1";\n')
+    refs = [("chr1", 10000)]
+    ann = {"refnames": ["chr1"], "transcripts": [{"id": "t1", "ref_id": 0, "strand": "+", "exons": [[10, 501]]}]}
+    from tests.test_gpu_bam_bundle import _rec_full
+    unmapped = b"".join(_rec_full("u%d" % i, -1, -1, 4, "", -1, -1, "ACGT", bytes([20] * 4), b"") for i in range(10))
+    for label, stream in (("empty", b""), ("unmapped", unmapped)):
+        in_bam, out_bam = str(tmp_path / (label + ".bam")), str(tmp_path / (label + ".out.bam"))
+        bamio.write_bam(in_bam, "@HD\tVN:1.6\n@SQ\tSN:chr1\tLN:10000\n", refs, stream)
+        r = subprocess.run([BIN, in_bam, "-G", gtf, "-o", out_bam], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        text, orefs, recs = bamio.read_bam(out_bam)
+        assert orefs == [("t1", 491)] and recs.size == 0
+        assert "# input alignments:   %d" % (0 if label == "empty" else 10) in r.stdout
+        assert "# unmapped reads:     %d" % (0 if label == "empty" else 10) in r.stdout
+
+
 def test_cli_errors(tmp_path):
     r = subprocess.run([BIN, "--version"], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.startswith("version: ")
