@@ -70,11 +70,13 @@ int parse_args(int argc, char **argv, Options &o) {
     auto value = [&]() -> const char * { if (has_eq) return val.c_str(); return need(i); };
     if (a == "--help" || a == "-h") { usage(stdout); return 1; }
     else if (a == "--version" || a == "-V") { printf("version: %s (bramble_amd %s)\n", BRAMBLE_REF_VERSION, br_version()); return 1; }
-    else if (a == "--quiet") o.quiet = true;
+    else if (a == "--quiet" || a == "-q") o.quiet = true;          // -q: bramble-cli/src/cli.rs:60
     else if (a == "--fr") o.cfg.fr = 1;
     else if (a == "--rf") o.cfg.rf = 1;
     else if (a == "--lr") o.cfg.lr = 1;
-    else if (a == "--lr-hq") o.cfg.lr_hq = 1;
+    else if (a == "--lr-hq" || a == "--lr:hq") o.cfg.lr_hq = 1;    // Rust spelling: bramble-cli/src/cli.rs:32
+    else if (a == "--unordered") {}                                // bramble-cli/src/cli.rs:64: the order here is always the input order
+    else if (a == "--unordered-flush-records") { if (!value()) return -1; }
     else if (a == "--strict") o.cfg.strict = 1;
     else if (a == "--max-soft-clip") { const char *v = value(); if (!v || !parse_u32(v, o.cfg.max_clip)) return -1; o.cfg.has_max_clip = 1; }
     else if (a == "--max-junction-insertion") { const char *v = value(); if (!v || !parse_u32(v, o.cfg.max_junc_ins)) return -1; o.cfg.has_max_junc_ins = 1; }
@@ -84,7 +86,7 @@ int parse_args(int argc, char **argv, Options &o) {
     else if (a == "-G" || a == "--guide") { const char *v = value(); if (!v) return -1; o.gff = v; }
     else if (a == "-S" || a == "--genome") { const char *v = value(); if (!v) return -1; o.fasta = v; }
     else if (a == "-o" || a == "--out") { const char *v = value(); if (!v) return -1; o.out_bam = v; }
-    else if (a == "-p") { const char *v = value(); if (!v) return -1; o.threads = atoi(v); if (o.threads < 1) o.threads = 1; }
+    else if (a == "-p" || a == "--threads") { const char *v = value(); if (!v) return -1; o.threads = atoi(v); if (o.threads < 1) o.threads = 1; }
     else if (a == "--compression-level") { const char *v = value(); if (!v) return -1; o.level = atoi(v); if (o.level < 0 || o.level > 9) return -1; o.device_deflate = false; }
     else if (a == "--host-deflate") o.device_deflate = false;
     else if (a == "--bundle-size") { const char *v = value(); if (!v) return -1; o.bundle_records = atoll(v); if (o.bundle_records < 1) return -1; }
