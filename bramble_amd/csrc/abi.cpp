@@ -390,6 +390,7 @@ struct br_ctx {
   DevBuf bam_aux, bam_len, bam_off, bam_out;
   DevBuf z_slots, z_sizes, z_off, z_dense, z_tabs, z_tokens;
   int deflate_dynamic = 1;
+  int emit_split = 1;
   bool z_tabs_ready = false;
   DevBuf p_ncig, p_name_len, p_isnew, p_group_pre, p_small, p_big, p_seq_len, p_ref_map, p_blob, p_rec_off, p_rec_len;
   uint8_t *h_bam[2] = {nullptr, nullptr}; size_t h_bam_cap[2] = {0, 0}; int h_bam_next = 0;  // pinned download buffers of br_project_bam_bundle (alternating)
@@ -460,6 +461,7 @@ extern "C" int br_ctx_set_profiling(br_ctx *c, int enabled) { if (!c) return BR_
 extern "C" int br_ctx_set_param(br_ctx *c, const char *key, int64_t v) {
   if (!c || !key) return BR_ERR_INVALID_ARG;
   if (!strcmp(key, "group_lanes")) { if (v != 8 && v != 16 && v != 32 && v != 64) return BR_ERR_INVALID_ARG; c->group_lanes = (int)v; return BR_OK; }
+  if (!strcmp(key, "emit_split")) { c->emit_split = v != 0; return BR_OK; }
   if (!strcmp(key, "deflate_dynamic")) { c->deflate_dynamic = v != 0; return BR_OK; }
   if (!strcmp(key, "bam_lanes")) { if (v != 4 && v != 8 && v != 16 && v != 32 && v != 64) return BR_ERR_INVALID_ARG; c->bam_lanes = (int)v; return BR_OK; }
   if (!strcmp(key, "blocks_per_cu")) { if (v < 1 || v > 64) return BR_ERR_INVALID_ARG; c->blocks_per_cu = (int)v; return BR_OK; }
@@ -642,9 +644,10 @@ static int run_device_impl(br_ctx *c, const br_config *cfg, const br_device_batc
     launch_scan3(st, S, c->match_off.as<uint32_t>(), c->cig_base.as<uint64_t>(), c->fast_pre.as<uint32_t>(), d_tot + 0);
     RC(pf.end());
   }
-  HIPCHK(hipMemcpyAsync(c->h_totals, d_tot, 2 * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(c->h_totals, d_tot, 3 * 8, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   uint64_t n_matches = c->h_totals[0], n_cig_arena = c->h_totals[1];
+  const int64_t n_simple = fa_mode ? -1 : (int64_t)c->h_totals[2];  // matches of the single-M class (first in the emit list)
   if (n_matches >= 0xffffffffull) return BR_ERR_CAPACITY;
   out->n_matches = (int64_t)n_matches;
 
@@ -665,9 +668,18 @@ static int run_device_impl(br_ctx *c, const br_config *cfg, const br_device_batc
       launch_expand(st, A);
       launch_project(st, A, true, 64, c->n_cu);  // alignments with > 64 candidate rows only
       RC(pf.end());
-      RC(pf.begin(BR_K_EMIT));
-      launch_emit_dense(st, A, (int64_t)n_matches);
-      RC(pf.end());
+      if (c->emit_split && n_simple >= 0 && !dc.filter_by_similarity) {
+        RC(pf.begin(BR_K_EMIT_SIMPLE));
+        launch_emit_dense(st, A, (int64_t)n_matches, n_simple, 1);
+        RC(pf.end());
+        RC(pf.begin(BR_K_EMIT));
+        launch_emit_dense(st, A, (int64_t)n_matches, n_simple, 2);
+        RC(pf.end());
+      } else {
+        RC(pf.begin(BR_K_EMIT));
+        launch_emit_dense(st, A, (int64_t)n_matches, -1, 0);
+        RC(pf.end());
+      }
     }
   }
 
@@ -721,7 +733,7 @@ static int run_device_impl(br_ctx *c, const br_config *cfg, const br_device_batc
   launch_row_fill(st, P, (int64_t)n_rows);  // + per-group counters
   RC(pf.end());
   if (n_rows && b->names && b->name_off) {
-    RC(pf.begin(BR_K_GATHER));
+    RC(pf.begin(BR_K_PRIMARY));
     launch_primary(st, P, b->name_off, b->names, c->r_primary.as<uint8_t>());
     RC(pf.end());
   }
@@ -742,7 +754,7 @@ static int run_device_impl(br_ctx *c, const br_config *cfg, const br_device_batc
     n_out_words = c->h_totals[3];
     RC(c->cigar_out.ensure((size_t)std::max<uint64_t>(n_out_words, 1) * 4));
     R.cigar_out = c->cigar_out.as<uint32_t>();
-    RC(pf.begin(BR_K_GATHER));
+    RC(pf.begin(BR_K_CIGAR_POOL));
     launch_gather(st, R);
     RC(pf.end());
   } else {

@@ -215,7 +215,9 @@ void launch_ksw(hipStream_t st, const KswArgs &K, int n_blocks);
 size_t ksw_prob_bytes();
 size_t ksw_res_bytes();
 void launch_expand(hipStream_t st, const ProjectArgs &A);
-void launch_emit_dense(hipStream_t st, const ProjectArgs &A, int64_t n_matches);
+// n_simple: length of the work list's simple-class prefix (k_scan3's third total); part 0: one launch over
+// everything, 1: the simple prefix, 2: the rest
+void launch_emit_dense(hipStream_t st, const ProjectArgs &A, int64_t n_matches, int64_t n_simple, int part);
 int64_t scan_tiles_for(int64_t n);
 // mode 0: src32 as is; 1: n_matches * CIGAR slot capacity; 2: src32 as is (alias of 0);
 // 3: n_matches * CIGAR slot capacity with the per-alignment ideal_cap[] of the -S path

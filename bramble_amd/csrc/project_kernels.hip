@@ -882,10 +882,12 @@ __global__ void __launch_bounds__(256) k_expand(ProjectArgs A) {
 // re-derives the candidate from its slab row, ranks it by tid among the read's
 // survivors, builds the ideal CIGAR, merges it with the real CIGAR and writes the
 // match record at match_off[a] + rank.
-template <bool SIMF>
-__global__ void __launch_bounds__(256, SIMF ? 6 : 8) k_emit_dense(ProjectArgs A, int64_t n_matches) {
-  __shared__ uint32_t sh_cig[256 * LDS_SLOT];
-  int64_t mi64 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// CLS: 0 = the whole work list, 1 = its simple prefix only (no walk, no merge loop, no LDS: a much lighter kernel),
+// 2 = the rest; the list is partitioned by class (k_expand), `first` is where this launch starts
+template <bool SIMF, int CLS>
+__global__ void __launch_bounds__(256, SIMF ? 6 : 8) k_emit_dense(ProjectArgs A, int64_t first, int64_t n_matches) {
+  __shared__ uint32_t sh_cig[CLS == 1 ? 1 : 256 * LDS_SLOT];
+  int64_t mi64 = first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (mi64 >= n_matches) return;
   const DevIndex &ix = A.ix;
   const DevCfg &cfg = A.cfg;
@@ -895,7 +897,7 @@ __global__ void __launch_bounds__(256, SIMF ? 6 : 8) k_emit_dense(ProjectArgs A,
   uint4 hd2 = A.head2[a];
   uint4 rg = A.ranges[a];
   uint64_t mask = A.mask[a];
-  const uint32_t is_fast = A.fast_flag[a] >> 31;
+  const uint32_t is_fast = CLS == 1 ? 1u : CLS == 2 ? 0u : (A.fast_flag[a] >> 31);
   uint32_t moff = A.match_off[a];
   uint64_t cbase = A.cig_base[a];
   uint32_t c0 = A.cigar_off[a], c1 = A.cigar_off[a + 1];
@@ -953,6 +955,7 @@ __global__ void __launch_bounds__(256, SIMF ? 6 : 8) k_emit_dense(ProjectArgs A,
     A.m_cigoff[mo] = cref;
     return;
   }
+  if (CLS == 1) return;
   ReadCtx rd;
   rd.n_seg = n_seg; rd.seg = A.seg + (size_t)c0 + (size_t)a; rd.real = A.cigar + c0; rd.n_real = c1 - c0; rd.q12 = hd2;
   const uint4 *E = ix.tx_ex + pay.w;
@@ -1438,10 +1441,13 @@ void launch_expand(hipStream_t st, const ProjectArgs &A) {
   hipLaunchKernelGGL(k_expand, dim3(grid_for(A.n_aln, 256)), dim3(256), 0, st, A);
 }
 
-void launch_emit_dense(hipStream_t st, const ProjectArgs &A, int64_t n_matches) {
+void launch_emit_dense(hipStream_t st, const ProjectArgs &A, int64_t n_matches, int64_t n_simple, int part) {
   if (A.n_aln <= 0 || n_matches <= 0) return;
-  if (A.cfg.filter_by_similarity) hipLaunchKernelGGL((k_emit_dense<true>), dim3(grid_for(n_matches, 256)), dim3(256), 0, st, A, n_matches);
-  else hipLaunchKernelGGL((k_emit_dense<false>), dim3(grid_for(n_matches, 256)), dim3(256), 0, st, A, n_matches);
+  if (A.cfg.filter_by_similarity) { hipLaunchKernelGGL((k_emit_dense<true, 0>), dim3(grid_for(n_matches, 256)), dim3(256), 0, st, A, (int64_t)0, n_matches); return; }
+  if (part == 0 || n_simple < 0) { hipLaunchKernelGGL((k_emit_dense<false, 0>), dim3(grid_for(n_matches, 256)), dim3(256), 0, st, A, (int64_t)0, n_matches); return; }
+  // the simple prefix of the work list and the rest as two launches: the first needs a third of the registers and no LDS
+  if (part == 1) { if (n_simple > 0) hipLaunchKernelGGL((k_emit_dense<false, 1>), dim3(grid_for(n_simple, 256)), dim3(256), 0, st, A, (int64_t)0, n_simple); }
+  else if (n_matches > n_simple) hipLaunchKernelGGL((k_emit_dense<false, 2>), dim3(grid_for(n_matches - n_simple, 256)), dim3(256), 0, st, A, n_simple, n_matches);
 }
 
 int64_t scan_tiles_for(int64_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE; }

@@ -12,10 +12,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbramble_amd.so")
 _P = C.POINTER
 
-K_SEGMENT, K_COUNT, K_EMIT, K_PAIR_COUNT, K_PAIR_EMIT, K_GATHER, K_SCAN, K_EMIT_AUX, K_KSW, K_BAM, K_PARSE, K_CODEC, K_NUM = range(13)
+K_SEGMENT, K_COUNT, K_EMIT, K_PAIR_COUNT, K_PAIR_EMIT, K_GATHER, K_SCAN, K_EMIT_AUX, K_KSW, K_BAM, K_PARSE, K_CODEC, K_EMIT_SIMPLE, K_PRIMARY, K_CIGAR_POOL, K_NUM = range(16)
 KERNEL_NAMES = ["k_segment", "k_project<G,false>", "k_emit_dense", "k_group_ids+k_pair<false>", "k_pair<true>",
-                "k_row_fill+k_group_stats+k_gather", "k_scan_*", "k_expand+k_project<64,true>", "k_ksw", "k_bam_scan+k_bam_size+k_bam_encode",
-                "k_rec_fields+k_group_off+k_rec_copy+k_mates+k_seq_*", "k_deflate_*+k_bgzf_compact"]
+                "k_row_fill+k_group_stats", "k_scan_*", "k_expand+k_project<64,true>", "k_ksw", "k_bam_scan+k_bam_size+k_bam_encode",
+                "k_rec_fields+k_group_off+k_rec_copy+k_mates+k_seq_*", "k_deflate_*+k_bgzf_compact",
+                "k_emit_dense<simple>", "k_primary", "k_gather"]
 
 
 class BrambleError(RuntimeError):

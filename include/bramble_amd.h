@@ -379,17 +379,20 @@ const char *br_bgzf_codec(void); /* "libdeflate" (bound at run time when present
 /* Kernel names reported by br_ctx_kernel_ms / rocprof. */
 #define BR_K_SEGMENT 0    /* k_segment */
 #define BR_K_COUNT 1      /* k_project<G,false> */
-#define BR_K_EMIT 2       /* k_emit_dense */
+#define BR_K_EMIT 2       /* k_emit_dense (general class; the whole list for long-read presets) */
 #define BR_K_PAIR_COUNT 3 /* k_group_ids + k_pair<false> */
 #define BR_K_PAIR_EMIT 4  /* k_pair<true> */
-#define BR_K_GATHER 5     /* k_row_fill + k_group_stats + k_gather */
+#define BR_K_GATHER 5     /* k_row_fill + k_group_stats */
 #define BR_K_SCAN 6       /* k_scan_* */
 #define BR_K_EMIT_AUX 7   /* k_expand + k_project<64,true> (alignments with > 64 candidate rows) */
 #define BR_K_KSW 8        /* k_ksw (-S clip rescue DP) */
 #define BR_K_BAM 9        /* k_bam_scan + k_bam_size + k_bam_encode */
 #define BR_K_PARSE 10     /* k_rec_fields + k_group_off + k_rec_copy + k_mates* + k_seq_* */
 #define BR_K_CODEC 11     /* k_deflate_dynamic | k_deflate_fixed, k_bgzf_compact */
-#define BR_K_NUM 12
+#define BR_K_EMIT_SIMPLE 12 /* k_emit_dense, simple class (one read exon from a single M op) */
+#define BR_K_PRIMARY 13   /* k_primary */
+#define BR_K_CIGAR_POOL 14 /* k_gather */
+#define BR_K_NUM 15
 /* When enabled, every launch is bracketed by hipEvents on the launch stream. */
 int br_ctx_set_profiling(br_ctx *, int enabled);
 /* Launch tuning: "group_lanes" (8|16|32|64 lanes cooperating on one alignment),

@@ -63,6 +63,8 @@ def main():
             # count and emit instantiations of k_project are different kernels
             if key == "k_project":
                 key = "k_project<64,true>" if re.search(r"<\d+, true", k) else "k_project<G,false>"  # bench.py's bucket names
+            elif re.search(r"<(true|false), 1>", k):
+                key = "k_emit_dense<simple>"
             if key not in kern or v["hbm_bytes_corrected"] > kern[key]["hbm_bytes_corrected"]:
                 kern[key] = v
     traffic = {
