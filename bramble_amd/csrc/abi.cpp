@@ -371,6 +371,24 @@ struct DevBuf {
   template <typename T> T *as() { return (T *)p; }
 };
 
+// growable pinned host array (contents are not preserved across growth: every call rewrites it)
+template <typename T>
+struct PinnedVec {
+  T *p = nullptr; size_t n = 0, cap = 0;
+  int resize(size_t m) {
+    if (m > cap) {
+      if (p) { HIPCHK(hipHostFree(p)); p = nullptr; cap = 0; }
+      size_t want = m + m / 4 + 64;
+      HIPCHK(hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault));
+      cap = want;
+    }
+    n = m;
+    return BR_OK;
+  }
+  T *data() { return p; }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; n = cap = 0; }
+};
+
 struct KEvent { int which; hipEvent_t a, b; };
 
 struct br_ctx {
@@ -405,12 +423,13 @@ struct br_ctx {
   DevBuf b_ref_id, b_ref_start, b_flags, b_xs, b_ts, b_cigar_off, b_cigar, b_mate_idx, b_group_off, b_lqseq;
   uint64_t *h_totals = nullptr;  // pinned, 8 words
   // host result storage (br_project_batch / br_project_group)
-  std::vector<int32_t> h_input, h_clip, h_junc, h_refc, h_mate_tid, h_mate_pos, h_isize;
-  std::vector<uint32_t> h_tid, h_pos, h_nh, h_hi, h_mapq, h_group, h_cigar;
-  std::vector<int8_t> h_strand;
-  std::vector<uint64_t> h_cigoff;
-  std::vector<double> h_sim;
-  std::vector<uint8_t> h_primary, h_paired, h_same, h_first;
+  // pinned: the row download runs at PCIe speed instead of through the pageable bounce path
+  PinnedVec<int32_t> h_input, h_clip, h_junc, h_refc, h_mate_tid, h_mate_pos, h_isize;
+  PinnedVec<uint32_t> h_tid, h_pos, h_nh, h_hi, h_mapq, h_group, h_cigar;
+  PinnedVec<int8_t> h_strand;
+  PinnedVec<uint64_t> h_cigoff;
+  PinnedVec<double> h_sim;
+  PinnedVec<uint8_t> h_primary, h_paired, h_same, h_first;
   std::vector<br_projected> h_proj;
   DevBuf *all() { return &seg; }
 };
@@ -454,6 +473,10 @@ extern "C" void br_ctx_free(br_ctx *c) {
   for (auto &e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if (c->h_totals) (void)hipHostFree(c->h_totals);
   for (int k = 0; k < 2; k++) if (c->h_bam[k]) (void)hipHostFree(c->h_bam[k]);
+  c->h_input.release(); c->h_clip.release(); c->h_junc.release(); c->h_refc.release(); c->h_mate_tid.release(); c->h_mate_pos.release();
+  c->h_isize.release(); c->h_tid.release(); c->h_pos.release(); c->h_nh.release(); c->h_hi.release(); c->h_mapq.release(); c->h_group.release();
+  c->h_cigar.release(); c->h_strand.release(); c->h_cigoff.release(); c->h_sim.release(); c->h_primary.release(); c->h_paired.release();
+  c->h_same.release(); c->h_first.release();
   delete c;
 }
 
@@ -1121,8 +1144,8 @@ static int h2d(DevBuf &buf, const T *src, size_t n, hipStream_t st) {
   return BR_OK;
 }
 template <typename T>
-static int d2h(std::vector<T> &dst, const void *src, size_t n, hipStream_t st) {
-  dst.resize(n);
+static int d2h(PinnedVec<T> &dst, const void *src, size_t n, hipStream_t st) {
+  RC(dst.resize(n));
   if (n) HIPCHK(hipMemcpyAsync(dst.data(), src, n * sizeof(T), hipMemcpyDeviceToHost, st));
   return BR_OK;
 }
@@ -1205,7 +1228,7 @@ extern "C" int br_project_batch(br_ctx *c, const br_config *cfg, const br_batch 
   RC(d2h(c->h_mate_pos, dr.mate_pos, nr, st)); RC(d2h(c->h_isize, dr.insert_size, nr, st));
   RC(d2h(c->h_group, dr.group, nr, st));
   HIPCHK(hipStreamSynchronize(st));
-  if (nr == 0) c->h_cigoff.assign(1, 0);
+  if (nr == 0) { RC(c->h_cigoff.resize(1)); c->h_cigoff.p[0] = 0; }
 
   RC(d2h(c->h_primary, dr.is_primary, nr, st));
   HIPCHK(hipStreamSynchronize(st));
