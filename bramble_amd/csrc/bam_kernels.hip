@@ -10,9 +10,11 @@
 //
 //   k_bam_scan    one lane per alignment: walks the aux area once (htslib
 //                 bam_aux_get semantics: first occurrence wins) and notes where NH, HI,
-//                 XS|ts and (long reads) AS live, plus the AS value (bam_aux2i).
+//                 XS|ts and (long reads) AS live, plus the AS value (bam_aux2i) and the
+//                 tag_char1 value of XS / ts for the reader side (parse_kernels.hip).
 //   k_bam_size    one lane per row: output length -> scanned into offsets.
-//   k_bam_encode  one wave per row: lanes stream the bytes.
+//   k_bam_encode  G lanes (default 8) per row: 16-byte unaligned copies of name / SEQ / QUAL / kept aux pieces,
+//                 bit-reverse reverse complement, the fixed fields and the appended tags.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

@@ -2,9 +2,11 @@
 // inflate/deflate is a plausible follow-on": after the device path the host-side deflate is the command
 // line's bottleneck).
 //
-//   k_deflate_fixed   one wave per BGZF block (56 KiB payload): greedy LZ77 with a 2048-entry hash table in
-//                     LDS, 64 positions per round (one per lane), fixed-Huffman bit stream (RFC 1951 3.2.6),
-//                     CRC32 of the payload by 64 lane-chunks folded with a precomputed zero-append operator.
+//   k_deflate_dynamic one wave per BGZF block (56 KiB payload, persistent waves): greedy LZ77 with a 2048-entry
+//                     hash table in LDS, 64 positions per round (one per lane); per-block Huffman codes
+//                     (RFC 1951 3.2.7) from the token histograms; CRC32 of the payload by 64 lane-chunks folded
+//                     with a precomputed zero-append operator.  The default.
+//   k_deflate_fixed   the same parse with the fixed code (RFC 1951 3.2.6): faster, ~16 % larger output.
 //   k_bgzf_compact    slots -> one dense byte stream (after a scan of the block sizes).
 //
 // The compressed bytes are not part of the parity contract (the reference writes through htslib/zlib);
@@ -273,7 +275,7 @@ __global__ void __launch_bounds__(256) k_deflate_fixed(DeflateArgs A) {
 #define DYN_LL 286
 #define DYN_D 30
 
-__device__ __forceinline__ void build_lengths(uint32_t *freq, uint8_t *lens, int nsym, int lane, bool allow_single) {
+__device__ __forceinline__ void build_lengths(uint32_t *freq, uint8_t *lens, int nsym, int lane) {
   // symbols of this lane: lane, lane + 64, ...
   uint32_t total = 0, used = 0;
   for (int i = lane; i < nsym; i += 64) { total += freq[i]; used += freq[i] ? 1u : 0u; }
@@ -282,7 +284,6 @@ __device__ __forceinline__ void build_lengths(uint32_t *freq, uint8_t *lens, int
   if (used == 1) {   // one symbol: one bit (an inflater accepts the incomplete code only for distances; callers make
                      // sure the literal/length alphabet has at least two symbols: a literal or match plus end-of-block)
     for (int i = lane; i < nsym; i += 64) lens[i] = freq[i] ? 1 : 0;
-    (void)allow_single;
     return;
   }
   int32_t k15 = 0;   // Kraft sum in units of 2^-15
@@ -403,8 +404,8 @@ __global__ void __launch_bounds__(256) k_deflate_dynamic(DeflateArgs A) {
     if (lane == 0) fll[256] = 1;                      // end of block
     __builtin_amdgcn_wave_barrier();
     // ---- codes
-    build_lengths(fll, lll, DYN_LL, lane, false);
-    build_lengths(fd, ld, DYN_D, lane, true);
+    build_lengths(fll, lll, DYN_LL, lane);
+    build_lengths(fd, ld, DYN_D, lane);
     __builtin_amdgcn_wave_barrier();
     build_codes(lll, fll, DYN_LL, lane, sh_nc[wave]);  // the histograms become the encode tables
     build_codes(ld, fd, DYN_D, lane, sh_nc[wave]);
