@@ -30,6 +30,7 @@ class ByteBuf {
     if (n > cap_) { size_t c = cap_ + cap_ / 2; if (c < n) c = n; if (c < 4096) c = 4096; p_ = (uint8_t *)realloc(p_, c); if (!p_) abort(); cap_ = c; }
     n_ = n;
   }
+  void reserve(size_t c) { if (c > cap_) { p_ = (uint8_t *)realloc(p_, c); if (!p_) abort(); cap_ = c; } }
   void erase_front(size_t k) { if (k >= n_) { n_ = 0; return; } memmove(p_, p_ + k, n_ - k); n_ -= k; }
   void swap(ByteBuf &o) { std::swap(p_, o.p_); std::swap(n_, o.n_); std::swap(cap_, o.cap_); }
   void clear() { n_ = 0; }

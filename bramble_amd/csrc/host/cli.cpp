@@ -16,6 +16,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <deque>
+#include <future>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -267,19 +268,35 @@ extern "C" int br_cli_main(int argc, char **argv) {
     std::vector<uint64_t> off; std::vector<uint32_t> len;
     bool eof = false;
     size_t scanned = 0;  // bytes of buf already split into off/len
+    // the next chunk inflates (threaded, into the reserved tail of buf) while this thread walks the records of the
+    // previous one; `valid` is how far the walker may look
+    size_t valid = buf.size();
+    const size_t CHUNK = 64u << 20;
+    std::future<int64_t> fut; bool inflight = false;
+    auto launch = [&]() { buf.reserve(buf.size() + CHUNK + (1u << 20)); fut = std::async(std::launch::async, [&]() { return rd.read(buf, CHUNK); }); inflight = true; };
+    auto land = [&]() -> bool {
+      auto ti0 = now();
+      int64_t got = fut.get(); inflight = false;
+      t_inflate += secs(ti0, now());
+      if (got < 0) { reader_err = rd.error(); return false; }
+      if (got == 0) eof = true;
+      valid = buf.size();
+      return true;
+    };
     for (;;) {
       if (cancel) break;
       // split what is there; read more until a cut point exists
       int64_t cut = -1;
       size_t searched = std::max<size_t>((size_t)o.bundle_records, 1);  // records below this index cannot be a cut
       for (;;) {
-        size_t cap = (size_t)(buf.size() - scanned) / 36 + 1;
+        if (!eof && !inflight) launch();
+        size_t cap = (size_t)(valid - scanned) / 36 + 1;
         size_t base = off.size();
         off.resize(base + cap); len.resize(base + cap);
         int64_t n = 0, un = 0; uint64_t used = 0;
         auto ts0 = now();
-        int r = br_bam_split(buf.data() + scanned, buf.size() - scanned, (int64_t)cap, off.data() + base, len.data() + base, &n, &un, &used);
-        if (r) { reader_err = "malformed BAM record"; to_gpu.finish(); return; }
+        int r = br_bam_split(buf.data() + scanned, valid - scanned, (int64_t)cap, off.data() + base, len.data() + base, &n, &un, &used);
+        if (r) { if (inflight) (void)fut.get(); reader_err = "malformed BAM record"; to_gpu.finish(); return; }
         for (int64_t i = 0; i < n; i++) off[base + (size_t)i] += scanned;
         off.resize(base + (size_t)n); len.resize(base + (size_t)n);
         total_reads += (uint64_t)(n + un); unmapped_reads += (uint64_t)un;
@@ -291,13 +308,13 @@ extern "C" int br_cli_main(int argc, char **argv) {
         }
         searched = std::max(searched, off.size());
         t_split += secs(ts0, now());
-        if (cut >= 0 || eof) break;
-        auto ti0 = now();
-        int64_t got = rd.read(buf, 64u << 20);
-        t_inflate += secs(ti0, now());
-        if (got < 0) { reader_err = rd.error(); to_gpu.finish(); return; }
-        if (got == 0) { eof = true; if (scanned != buf.size()) { reader_err = "truncated BAM record at end of file"; to_gpu.finish(); return; } }
+        if (cut >= 0) break;
+        if (inflight) { if (!land()) { to_gpu.finish(); return; } continue; }
+        // end of stream, nothing in flight
+        if (scanned != valid) { reader_err = "truncated BAM record at end of file"; to_gpu.finish(); return; }
+        break;
       }
+      if (inflight && !land()) { to_gpu.finish(); return; }   // the buffer must be still before its tail moves
       size_t n_take = cut >= 0 ? (size_t)cut : off.size();
       if (n_take) {
         auto tc0 = now();
@@ -312,6 +329,7 @@ extern "C" int br_cli_main(int argc, char **argv) {
         buf.resize(byte_end);
         b->blob.swap(buf);
         buf.swap(tail);
+        valid = buf.size();
         scanned -= byte_end;
         std::vector<uint64_t> noff(off.begin() + (ptrdiff_t)n_take, off.end()); std::vector<uint32_t> nlen(len.begin() + (ptrdiff_t)n_take, len.end());
         for (auto &x : noff) x -= byte_end;
