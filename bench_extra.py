@@ -115,7 +115,6 @@ def main():
         import tempfile
         sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
         from tests import bamio
-        from oracle import oracle_binding as ob
         n = args.reads or 2_000_000
         ann = synth.Annotation("G")
         annd = ann.as_dict()
@@ -155,19 +154,9 @@ def main():
             tail = [l for l in r.stdout.splitlines() if "bundles" in l or "stage busy" in l]
             res["level%s" % level] = {"wall_s": round(wall, 2), "alignments_per_s": len(rlen) / wall, "out_bam_bytes": os.path.getsize(out_bam),
                                        "report": " | ".join(tail)}
-        # CPU beside it: the oracle's reader side + projection + write_to_bam on a sample, one thread, no (de)compression
-        m = min(len(rlen), 200_000)
-        while m < len(rlen) and batch["name_off"][m + 1] - batch["name_off"][m] == batch["name_off"][m] - batch["name_off"][m - 1] and \
-                bytes(batch["names"][int(batch["name_off"][m]):int(batch["name_off"][m + 1])]) == bytes(batch["names"][int(batch["name_off"][m - 1]):int(batch["name_off"][m])]):
-            m += 1
-        oi = ob.OracleIndex(annd)
-        order = bamio.guide_order(annd)
-        t0 = time.perf_counter()
-        ob.run_bam(oi, ob.make_flags(), stream_h, roff[:m], rlen[:m], np.arange(len(refs), dtype=np.int32))
-        cpu = time.perf_counter() - t0
-        print(json.dumps({"config": "cli", "workload": "%d paired-end alignments, BAM file -> BAM file, -p %d, GENCODE-shaped GTF (%d transcripts)" % (len(rlen), args.threads, len(order)),
+        print(json.dumps({"config": "cli", "workload": "%d paired-end alignments, BAM file -> BAM file, -p %d, GENCODE-shaped GTF (%d transcripts)" % (len(rlen), args.threads, len(annd["transcripts"])),
                           "in_bam_bytes": os.path.getsize(in_bam), "uncompressed_in_bytes": int(stream_h.size), "results": res,
-                          "cpu_oracle_1_thread_alignments_per_s_no_codec": m / cpu, "input_prep_s": round(prep, 1)}))
+                          "input_prep_s": round(prep, 1)}))
         return
     if args.config == "c5":
         n = args.reads or 1_000_000
