@@ -1,0 +1,72 @@
+"""Error behaviour of the C ABI on a box without a GPU: every entry point returns a BR_ERR_* code (none aborts,
+INTEGRATION.md section 4) -- the Python binding turns them into BrambleError with the br_strerror text."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from bramble_amd import lib
+
+ANN = {"refnames": ["chr1"], "transcripts": [{"id": "t1", "ref_id": 0, "strand": "+", "exons": [[100, 200], [300, 400]]}]}
+
+
+def test_unknown_seqname_and_overlapping_exons_are_annotation_errors():
+    L = lib.lib()
+    ex = (lib.BrExon * 2)(lib.BrExon(100, 200), lib.BrExon(300, 400))
+    tx = (lib.BrTranscript * 1)(lib.BrTranscript(b"t1", b"chrMissing", b"+", ex, 2))
+    refs = (C.c_char_p * 1)(b"chr1")
+    h = C.c_void_p()
+    rc = L.br_index_build(tx, 1, refs, 1, None, 0, -1, C.byref(h))     # bramble-rs/src/g2t.rs:442-444
+    assert rc == -4 and L.br_strerror(rc)
+    bad = {"refnames": ["chr1"], "transcripts": [{"id": "t", "ref_id": 0, "strand": "+", "exons": [[100, 250], [200, 300]]}]}
+    with pytest.raises(lib.BrambleError, match="annotation|exon"):
+        lib.Index(bad, device=-1)
+
+
+def test_host_only_index_has_accessors_but_no_context():
+    idx = lib.Index(ANN, device=-1)
+    assert idx.num_transcripts() == 1 and idx.transcript_len(0) == 200 and idx.transcript_name(0) == "t1"
+    assert idx.transcript_len(7) is None and idx.transcript_name(7) is None   # out of range (g2t.rs:320-342 return None)
+    with pytest.raises(lib.BrambleError, match="device"):
+        lib.Context(idx)                                                  # there is no CPU fallback
+    idx.close()
+
+
+def test_config_resolution_rejects_the_rust_only_discount():
+    cfg = lib.make_config()
+    cfg.junc_miss_discount = 0.5                                          # bramble-rs/src/api.rs:197-205: no C++ counterpart
+    with pytest.raises(lib.BrambleError):
+        lib.resolve_config(cfg)
+
+
+def test_null_arguments_are_invalid_arg_not_crashes():
+    L = lib.lib()
+    assert L.br_index_build(None, 1, None, 0, None, 0, -1, None) == -1
+    assert L.br_ctx_new(None, None) == -1
+    assert L.br_project_batch(None, None, None, None) == -1
+    assert L.br_project_bam_bundle(None, None, None, None) == -1
+    assert L.br_batch_prepare(None, None, None, None) == -1
+    for code in (0, -1, -2, -3, -4, -5, -6, -99):
+        assert L.br_strerror(code)
+
+
+def test_bam_split_partial_and_malformed_records():
+    def rec(name, body_extra=b""):
+        nm = name + b"\0"
+        body = (0).to_bytes(4, "little") + (10).to_bytes(4, "little") + bytes([len(nm), 30]) + (4680).to_bytes(2, "little") + \
+            (1).to_bytes(2, "little") + (0).to_bytes(2, "little") + (4).to_bytes(4, "little") + (0xffffffff).to_bytes(4, "little") * 2 + \
+            (0).to_bytes(4, "little") + nm + ((4 << 4) | 0).to_bytes(4, "little") + bytes([0x12, 0x48]) + bytes([30] * 4) + body_extra
+        return len(body).to_bytes(4, "little") + body
+    good = np.frombuffer(rec(b"a") + rec(b"bb", b"NHC\x01") + rec(b"ccc"), dtype=np.uint8)
+    off, ln, un, used = lib.bam_split(good)
+    assert len(off) == 3 and used == good.size and un == 0
+    off2, ln2, _, used2 = lib.bam_split(good[:-3])                         # the last record is incomplete: left for the next call
+    assert len(off2) == 2 and used2 == int(off[2]) - 4
+    bad = good.copy()
+    bad[int(off[1]) + 8] = 200                                             # l_read_name runs past the record
+    with pytest.raises(lib.BrambleError):
+        lib.bam_split(bad)
+    tiny = good.copy()
+    tiny[0:4] = np.frombuffer((5).to_bytes(4, "little"), dtype=np.uint8)   # block_size < 32
+    with pytest.raises(lib.BrambleError):
+        lib.bam_split(tiny)
