@@ -409,6 +409,7 @@ struct br_ctx {
   DevBuf z_slots, z_sizes, z_off, z_dense, z_tabs, z_tokens;
   int deflate_dynamic = 1;
   int emit_split = 1;
+  void *zero_cols_sim = nullptr, *zero_cols_clip = nullptr; size_t zero_cols_rows = 0;  // row columns known to be all zero
   bool z_tabs_ready = false;
   DevBuf p_ncig, p_name_len, p_isnew, p_group_pre, p_small, p_big, p_seq_len, p_ref_map, p_blob, p_rec_off, p_rec_len;
   uint8_t *h_bam[2] = {nullptr, nullptr}; size_t h_bam_cap[2] = {0, 0}; int h_bam_next = 0;  // pinned download buffers of br_project_bam_bundle (alternating)
@@ -734,7 +735,15 @@ static int run_device_impl(br_ctx *c, const br_config *cfg, const br_device_batc
   RC(c->r_mapq.ensure(nr * 4)); RC(c->r_group.ensure(nr * 4));
   RC(c->r_mate_tid.ensure(nr * 4)); RC(c->r_mate_pos.ensure(nr * 4)); RC(c->r_isize.ensure(nr * 4));
   RC(c->r_tid.ensure(nr * 4)); RC(c->r_pos.ensure(nr * 4)); RC(c->r_ncig.ensure(nr * 4)); RC(c->r_strand.ensure(nr));
-  RC(c->r_sim.ensure(nr * 8)); RC(c->r_clip.ensure(nr * 4)); RC(c->r_junc.ensure(nr * 4)); RC(c->r_refc.ensure(nr * 4));
+  RC(c->r_sim.ensure(nr * 8)); RC(c->r_clip.ensure(nr * 4));
+  // clip score / similarity score columns: all zero unless the preset filters by similarity (long reads); zero-filled
+  // once per buffer, then left alone
+  const bool aux_cols = dc.filter_by_similarity != 0;
+  if (aux_cols) c->zero_cols_rows = 0;
+  else if (c->zero_cols_sim != c->r_sim.p || c->zero_cols_clip != c->r_clip.p || c->zero_cols_rows < nr) {
+    HIPCHK(hipMemsetAsync(c->r_sim.p, 0, c->r_sim.cap, st)); HIPCHK(hipMemsetAsync(c->r_clip.p, 0, c->r_clip.cap, st));
+    c->zero_cols_sim = c->r_sim.p; c->zero_cols_clip = c->r_clip.p; c->zero_cols_rows = std::min(c->r_sim.cap / 8, c->r_clip.cap / 4);
+  } RC(c->r_junc.ensure(nr * 4)); RC(c->r_refc.ensure(nr * 4));
   RC(c->r_cigoff.ensure((nr + 1) * 8));
   RC(c->r_paired.ensure(nr)); RC(c->r_same.ensure(nr)); RC(c->r_first.ensure(nr)); RC(c->r_primary.ensure(nr));
   HIPCHK(hipMemsetAsync(c->r_primary.p, 0, nr, st));
@@ -753,11 +762,11 @@ static int run_device_impl(br_ctx *c, const br_config *cfg, const br_device_batc
     RC(pf.end());
   }
   RC(pf.begin(BR_K_GATHER));
-  launch_row_fill(st, P, (int64_t)n_rows);  // + per-group counters
+  launch_row_fill(st, P, (int64_t)n_rows, aux_cols);  // + per-group counters
   RC(pf.end());
   if (n_rows && b->names && b->name_off) {
     RC(pf.begin(BR_K_PRIMARY));
-    launch_primary(st, P, b->name_off, b->names, c->r_primary.as<uint8_t>());
+    launch_primary(st, P, b->name_off, b->names, c->r_primary.as<uint8_t>(), dc.filter_by_similarity != 0);
     RC(pf.end());
   }
   HIPCHK(hipMemcpyAsync(c->h_totals + 4, c->counters_d.p, 4 * 8, hipMemcpyDeviceToHost, st));

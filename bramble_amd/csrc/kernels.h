@@ -226,8 +226,10 @@ void launch_group_ids(hipStream_t st, int64_t n_groups, const uint32_t *group_of
 void launch_scan3(hipStream_t st, ScanArgs S, uint32_t *match_off, uint64_t *cig_base, uint32_t *fast_pre,
                   uint64_t *total_out3);
 void launch_pair(hipStream_t st, const PairArgs &P, bool emit);
-void launch_row_fill(hipStream_t st, const PairArgs &P, int64_t n_rows);
-void launch_primary(hipStream_t st, const PairArgs &P, const uint32_t *name_off, const uint8_t *names, uint8_t *r_primary);
+// aux: the batch has clip / similarity scores (else the two row columns must already be zero)
+void launch_row_fill(hipStream_t st, const PairArgs &P, int64_t n_rows, bool aux);
+void launch_primary(hipStream_t st, const PairArgs &P, const uint32_t *name_off, const uint8_t *names, uint8_t *r_primary,
+                    bool has_scores);
 void launch_gather(hipStream_t st, const RowArgs &R);
 
 }  // namespace br

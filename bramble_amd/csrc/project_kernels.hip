@@ -846,8 +846,10 @@ __global__ void __launch_bounds__(256, EMIT ? 4 : 8) k_project(ProjectArgs A) {
           A.m_tid[mi] = pay.x;
           A.m_a[mi] = make_uint4((s == 0) ? p1.fwpos : p1.rcpos, n_out | ((uint32_t)s << 31), (uint32_t)acc.junc_hits,
                                  (uint32_t)acc.ref_consumed);
-          unsigned long long sb64 = (unsigned long long)__double_as_longlong(score);
-          A.m_b[mi] = make_uint4((uint32_t)acc.clip_score, 0u, (uint32_t)sb64, (uint32_t)(sb64 >> 32));
+          if (SIMF) {
+            unsigned long long sb64 = (unsigned long long)__double_as_longlong(score);
+            A.m_b[mi] = make_uint4((uint32_t)acc.clip_score, 0u, (uint32_t)sb64, (uint32_t)(sb64 >> 32));
+          }
           A.m_cigoff[mi] = cig_ref;
         }
       }
@@ -951,7 +953,7 @@ __global__ void __launch_bounds__(256, SIMF ? 6 : 8) k_emit_dense(ProjectArgs A,
     uint32_t mo = moff + rank;
     A.m_tid[mo] = pay.x;
     A.m_a[mo] = make_uint4(h0.pos, n_out | ((uint32_t)s << 31), junc, ml);
-    A.m_b[mo] = make_uint4(0u, 0u, 0u, 0u);
+    if (SIMF) A.m_b[mo] = make_uint4(0u, 0u, 0u, 0u);
     A.m_cigoff[mo] = cref;
     return;
   }
@@ -987,8 +989,12 @@ __global__ void __launch_bounds__(256, SIMF ? 6 : 8) k_emit_dense(ProjectArgs A,
   A.m_tid[mo] = pay.x;
   A.m_a[mo] = make_uint4((s == 0) ? p1.fwpos : p1.rcpos, n_out | ((uint32_t)s << 31), (uint32_t)acc.junc_hits,
                          (uint32_t)acc.ref_consumed);
-  unsigned long long sb64 = (unsigned long long)__double_as_longlong(score);
-  A.m_b[mo] = make_uint4((uint32_t)acc.clip_score, 0u, (uint32_t)sb64, (uint32_t)(sb64 >> 32));
+  // without the similarity filter the score is 0.0 and (no -S rescue in this kernel) the clip score is 0: the row
+  // kernel then neither reads m_b nor rewrites the two all-zero row columns
+  if (SIMF) {
+    unsigned long long sb64 = (unsigned long long)__double_as_longlong(score);
+    A.m_b[mo] = make_uint4((uint32_t)acc.clip_score, 0u, (uint32_t)sb64, (uint32_t)(sb64 >> 32));
+  }
   A.m_cigoff[mo] = cig_ref;
 }
 
@@ -1212,6 +1218,9 @@ __global__ void __launch_bounds__(256) k_pair(PairArgs P) {
 // k_row_fill: one lane per emitted record.  NH / HI / MAPQ of flush
 // (src/core.cpp:237-258,309-325), the match's fields, and the mate fields of
 // set_mate_info (src/bam.cpp:531-588).
+// AUX = false (presets without the similarity filter, hence without -S rescue): every clip score and similarity score
+// is 0; the two row columns were zero-filled once by the host side and m_b is neither written nor read.
+template <bool AUX>
 __global__ void __launch_bounds__(256) k_row_fill(PairArgs P, int64_t n_rows) {
   int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n_rows) return;
@@ -1223,7 +1232,7 @@ __global__ void __launch_bounds__(256) k_row_fill(PairArgs P, int64_t n_rows) {
   uint32_t g = P.aln_group[input];
   uint64_t rs = P.row_off[P.group_off[g]], re = P.row_off[P.group_off[g + 1]];
   uint32_t nh = (uint32_t)(re - rs);
-  uint4 ma = P.m_a[x], mb = P.m_b[x];
+  uint4 ma = P.m_a[x];
   uint32_t tid = P.m_tid[x];
   int32_t mate_tid = -1, mate_pos = -1, isize = 0;
   if (flags & RF_PAIRED) {
@@ -1241,8 +1250,11 @@ __global__ void __launch_bounds__(256) k_row_fill(PairArgs P, int64_t n_rows) {
   P.r_mate_tid[r] = mate_tid; P.r_mate_pos[r] = mate_pos; P.r_isize[r] = isize; P.r_group[r] = g;
   P.r_tid[r] = tid; P.r_pos[r] = ma.x; P.r_strand[r] = (ma.y >> 31) ? (int8_t)'-' : (int8_t)'+';
   P.r_ncig[r] = ma.y & 0x7fffffffu; P.r_junc[r] = (int32_t)ma.z; P.r_refc[r] = (int32_t)ma.w;
-  P.r_clip[r] = (int32_t)mb.x;
-  P.r_sim[r] = __longlong_as_double((long long)(((unsigned long long)mb.w << 32) | mb.z));
+  if (AUX) {
+    uint4 mb = P.m_b[x];
+    P.r_clip[r] = (int32_t)mb.x;
+    P.r_sim[r] = __longlong_as_double((long long)(((unsigned long long)mb.w << 32) | mb.z));
+  }
   P.r_paired[r] = (flags & RF_PAIRED) ? 1 : 0; P.r_same[r] = (flags & RF_SAME_TX) ? 1 : 0;
   P.r_first[r] = (flags & RF_FIRST) ? 1 : 0;
 }
@@ -1269,6 +1281,9 @@ __global__ void __launch_bounds__(256) k_group_stats(PairArgs P) {
 // k_primary: one lane per read name.  Primary = the emitted record (pair) with the
 // best similarity score; ties are broken by get_rand(n_tied, std::hash(name))
 // (src/core.cpp:243-307), restated in primary_pick.h.
+// SCORES = false: presets without the similarity filter leave every score at 0.0 (src/evaluate.cpp:843-865), so
+// every emitted unit ties and r_sim need not be read at all.
+template <bool SCORES>
 __global__ void __launch_bounds__(256) k_primary(PairArgs P, const uint32_t *__restrict__ name_off,
                                                  const uint8_t *__restrict__ names, uint8_t *__restrict__ r_primary) {
   int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1276,12 +1291,14 @@ __global__ void __launch_bounds__(256) k_primary(PairArgs P, const uint32_t *__r
   uint32_t a0 = P.group_off[g], a1 = P.group_off[g + 1];
   uint64_t rs = P.row_off[a0], re = P.row_off[a1];
   if (rs == re) return;
-  double best = -__builtin_inf(); uint64_t best_r = rs; uint32_t at_best = 0;
+  double best = SCORES ? -__builtin_inf() : 0.0; uint64_t best_r = rs; uint32_t at_best = 0;
   for (uint64_t r = rs; r < re;) {
     bool paired = P.r_paired[r];
-    double sc = P.r_sim[r];
-    if (paired) { double s2 = P.r_sim[r + 1]; sc = sc > s2 ? sc : s2; }   // std::max(pair_score, m_align score)
-    if (sc > best) { best = sc; best_r = r; at_best = 1; } else if (sc == best) at_best++;
+    if (SCORES) {
+      double sc = P.r_sim[r];
+      if (paired) { double s2 = P.r_sim[r + 1]; sc = sc > s2 ? sc : s2; }   // std::max(pair_score, m_align score)
+      if (sc > best) { best = sc; best_r = r; at_best = 1; } else if (sc == best) at_best++;
+    } else at_best++;
     r += paired ? 2 : 1;
   }
   uint64_t pick = best_r;
@@ -1290,9 +1307,13 @@ __global__ void __launch_bounds__(256) k_primary(PairArgs P, const uint32_t *__r
     uint32_t seen = 0;
     for (uint64_t r = rs; r < re;) {
       bool paired = P.r_paired[r];
-      double sc = P.r_sim[r];
-      if (paired) { double s2 = P.r_sim[r + 1]; sc = sc > s2 ? sc : s2; }
-      if (sc == best) { if (seen == idx) { pick = r; break; } seen++; }
+      bool tied = true;
+      if (SCORES) {
+        double sc = P.r_sim[r];
+        if (paired) { double s2 = P.r_sim[r + 1]; sc = sc > s2 ? sc : s2; }
+        tied = sc == best;
+      }
+      if (tied) { if (seen == idx) { pick = r; break; } seen++; }
       r += paired ? 2 : 1;
     }
   }
@@ -1501,14 +1522,19 @@ void launch_pair(hipStream_t st, const PairArgs &P, bool emit) {
   else hipLaunchKernelGGL((k_pair<false>), dim3(grid_for(P.n_aln, 256)), dim3(256), 0, st, P);
 }
 
-void launch_row_fill(hipStream_t st, const PairArgs &P, int64_t n_rows) {
-  if (n_rows > 0) hipLaunchKernelGGL(k_row_fill, dim3(grid_for(n_rows, 256)), dim3(256), 0, st, P, n_rows);
+void launch_row_fill(hipStream_t st, const PairArgs &P, int64_t n_rows, bool aux) {
+  if (n_rows > 0) {
+    if (aux) hipLaunchKernelGGL((k_row_fill<true>), dim3(grid_for(n_rows, 256)), dim3(256), 0, st, P, n_rows);
+    else hipLaunchKernelGGL((k_row_fill<false>), dim3(grid_for(n_rows, 256)), dim3(256), 0, st, P, n_rows);
+  }
   if (P.n_groups > 0) hipLaunchKernelGGL(k_group_stats, dim3(std::min(grid_for(P.n_groups, 256), 1024)), dim3(256), 0, st, P);
 }
 
-void launch_primary(hipStream_t st, const PairArgs &P, const uint32_t *name_off, const uint8_t *names, uint8_t *r_primary) {
+void launch_primary(hipStream_t st, const PairArgs &P, const uint32_t *name_off, const uint8_t *names, uint8_t *r_primary,
+                    bool has_scores) {
   if (P.n_groups <= 0) return;
-  hipLaunchKernelGGL(k_primary, dim3(grid_for(P.n_groups, 256)), dim3(256), 0, st, P, name_off, names, r_primary);
+  if (has_scores) hipLaunchKernelGGL((k_primary<true>), dim3(grid_for(P.n_groups, 256)), dim3(256), 0, st, P, name_off, names, r_primary);
+  else hipLaunchKernelGGL((k_primary<false>), dim3(grid_for(P.n_groups, 256)), dim3(256), 0, st, P, name_off, names, r_primary);
 }
 
 void launch_gather(hipStream_t st, const RowArgs &R) {

@@ -216,3 +216,24 @@ def test_empty_and_degenerate_inputs():
     assert_rows_equal(prod, orc)
     ctx.close()
     idx.close()
+
+
+def test_one_context_across_presets_and_batch_sizes():
+    """A context is reused for batches of different presets and sizes: the clip / similarity score columns are written by
+    long-read runs and must read as zero again in the short-read runs that follow (they are zero-filled lazily)."""
+    ann = synth.Annotation("G", n_genes=800, n_refs=3)
+    annd = ann.as_dict()
+    idx = lib.Index(annd, device=0)
+    ctx = lib.Context(idx)
+    oi = ob.OracleIndex(annd)
+    plan = [("pe", {}, 1500), ("hifi", {"lr_hq": 1}, 2500), ("pe", {}, 6000), ("ont", {"lr": 1}, 1200), ("se", {"strict": 1}, 9000),
+            ("pe", {"lr": 1}, 2000), ("pe", {}, 500)]
+    for mode, flags, n in plan:
+        b = ann.reads(n, mode, seed=n)
+        prod = ctx.project_batch(lib.make_config(**flags), b)
+        orc, _, _ = ob.run(oi, ob.make_flags(**flags), b, want_matches=False)
+        assert_rows_equal(prod, orc)
+        if not flags.get("lr") and not flags.get("lr_hq"):
+            assert not prod["similarity_score"].any() and not prod["clip_score"].any()
+    ctx.close()
+    idx.close()
