@@ -787,7 +787,7 @@ static int run_device_impl(br_ctx *c, const br_config *cfg, const br_device_batc
     RC(c->cigar_out.ensure((size_t)std::max<uint64_t>(n_out_words, 1) * 4));
     R.cigar_out = c->cigar_out.as<uint32_t>();
     RC(pf.begin(BR_K_CIGAR_POOL));
-    launch_gather(st, R);
+    launch_gather(st, R, (int64_t)n_out_words);
     RC(pf.end());
   } else {
     HIPCHK(hipMemsetAsync(c->r_cigoff.p, 0, 8, st));

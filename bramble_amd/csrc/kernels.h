@@ -230,6 +230,6 @@ void launch_pair(hipStream_t st, const PairArgs &P, bool emit);
 void launch_row_fill(hipStream_t st, const PairArgs &P, int64_t n_rows, bool aux);
 void launch_primary(hipStream_t st, const PairArgs &P, const uint32_t *name_off, const uint8_t *names, uint8_t *r_primary,
                     bool has_scores);
-void launch_gather(hipStream_t st, const RowArgs &R);
+void launch_gather(hipStream_t st, const RowArgs &R, int64_t n_words);  // n_words: total rewritten-CIGAR words of the rows
 
 }  // namespace br

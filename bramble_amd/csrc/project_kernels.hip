@@ -1322,20 +1322,25 @@ __global__ void __launch_bounds__(256) k_primary(PairArgs P, const uint32_t *__r
 }
 
 // k_gather: one lane per row copies its rewritten CIGAR to the dense pool
+// G lanes per row: 1 for short reads (one or two words per row), 16 for long reads (hundreds of words per row)
+template <int G>
 __global__ void __launch_bounds__(256) k_gather(RowArgs R) {
-  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & (G - 1);
+  int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
   if (r >= R.n_rows) return;
   uint32_t x = R.r_rec[r].x;
   uint64_t ref = R.m_cigoff[x];
   uint64_t d0 = R.r_cigoff[r];
   uint32_t n = R.r_ncig[r];
   if (n <= 2) {  // inline words
-    if (n > 0) R.cigar_out[d0] = (uint32_t)ref;
-    if (n > 1) R.cigar_out[d0 + 1] = (uint32_t)(ref >> 32);
+    if (lane == 0) {
+      if (n > 0) R.cigar_out[d0] = (uint32_t)ref;
+      if (n > 1) R.cigar_out[d0 + 1] = (uint32_t)(ref >> 32);
+    }
     return;
   }
   const uint32_t *src = R.cig_arena + ref;
-  for (uint32_t k = 0; k < n; k++) R.cigar_out[d0 + k] = src[k];
+  for (uint32_t k = lane; k < n; k += G) R.cigar_out[d0 + k] = src[k];
 }
 
 // ---------------------------------------------------------------------------
@@ -1537,9 +1542,10 @@ void launch_primary(hipStream_t st, const PairArgs &P, const uint32_t *name_off,
   else hipLaunchKernelGGL((k_primary<false>), dim3(grid_for(P.n_groups, 256)), dim3(256), 0, st, P, name_off, names, r_primary);
 }
 
-void launch_gather(hipStream_t st, const RowArgs &R) {
+void launch_gather(hipStream_t st, const RowArgs &R, int64_t n_words) {
   if (R.n_rows <= 0) return;
-  hipLaunchKernelGGL(k_gather, dim3(grid_for(R.n_rows, 256)), dim3(256), 0, st, R);
+  if (n_words > 8 * R.n_rows) hipLaunchKernelGGL((k_gather<16>), dim3(grid_for(R.n_rows * 16, 256)), dim3(256), 0, st, R);
+  else hipLaunchKernelGGL((k_gather<1>), dim3(grid_for(R.n_rows, 256)), dim3(256), 0, st, R);
 }
 
 }  // namespace br
