@@ -16,9 +16,8 @@ from oracle import oracle_binding as ob  # noqa: E402
 from tests.parity import assert_rows_equal  # noqa: E402
 
 
-def main():
-    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+def run(rounds, seed, verbose=True, read_counts=(500, 3000, 9000), gene_counts=(30, 300, 1500)):
+    """Returns None when every round agrees, else the description of the first diverging configuration."""
     rng = np.random.RandomState(seed)
     for it in range(rounds):
         mode = ["pe", "se", "hifi", "ont"][rng.randint(0, 4)]
@@ -40,7 +39,7 @@ def main():
         with_genome = long_mode and rng.rand() < 0.5
         if with_genome:
             flags["use_fasta"] = 1
-        n_genes = int(rng.choice([30, 300, 1500]))
+        n_genes = int(rng.choice(list(gene_counts)))
         n_refs = int(rng.randint(1, 5))
         kw = {}
         if not long_mode:
@@ -52,7 +51,7 @@ def main():
             kw = {"p_wobble": float(rng.uniform(0, 0.4)), "p_skip_small": float(rng.uniform(0, 0.3)),
                   "p_novel_small": float(rng.uniform(0, 0.1)), "p_clip": float(rng.uniform(0, 0.8))}
         xs = (not long_mode) and locals().get("xs", False)
-        n_reads = int(rng.choice([500, 3000, 9000]))
+        n_reads = int(rng.choice(list(read_counts)))
         desc = dict(it=it, mode=mode, flags=flags, n_genes=n_genes, n_refs=n_refs, n_reads=n_reads, kw=kw, seed=seed)
         ann = synth.Annotation("G", n_genes=n_genes, n_refs=n_refs, with_genome=with_genome, seed=int(rng.randint(1, 1 << 30)))
         annd = ann.as_dict()
@@ -73,12 +72,22 @@ def main():
             if not np.array_equal(got, orc2["bam_stream"]):
                 raise AssertionError("BAM streams differ (%d vs %d bytes)" % (len(got), len(orc2["bam_stream"])))
         except Exception as e:  # noqa: BLE001
-            print("DIVERGENCE", desc, repr(e)[:500])
-            sys.exit(1)
+            return "%s %s" % (desc, repr(e)[:500])
         finally:
             ctx.close()
             idx.close()
-        print("ok", it, mode, flags, "rows", orc["n_rows"], flush=True)
+        if verbose:
+            print("ok", it, mode, flags, "rows", orc["n_rows"], flush=True)
+    return None
+
+
+def main():
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    bad = run(rounds, seed)
+    if bad:
+        print("DIVERGENCE", bad)
+        sys.exit(1)
     print("fuzz ok: %d rounds" % rounds)
 
 
