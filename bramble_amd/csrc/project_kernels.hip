@@ -1397,6 +1397,9 @@ __global__ void __launch_bounds__(256) k_sum_ncig(const uint4 *m_a, int64_t n, u
   if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long *)out, acc);
 }
 
+#ifndef FA_GROUP_LANES
+#define FA_GROUP_LANES 8   // lanes per alignment in the -S kernels
+#endif
 #include "rescue_kernels.inc"
 
 // ---------------------------------------------------------------------------
@@ -1407,15 +1410,16 @@ size_t ksw_res_bytes() { return sizeof(KswRes); }
 
 void launch_project_fa(hipStream_t st, const ProjectArgs &A, const FaArgs &F, int mode, int n_blocks) {
   if (A.n_aln <= 0) return;
-  int64_t need = (A.n_aln + 3) / 4;
+  constexpr int FG = FA_GROUP_LANES;
+  int64_t need = (A.n_aln + (256 / FG) - 1) / (256 / FG);
   if (need < n_blocks) n_blocks = (int)need;
   if (n_blocks < 1) n_blocks = 1;
   dim3 g(n_blocks), b(256);
   switch (mode) {
-    case 0: hipLaunchKernelGGL((k_project_fa<0>), g, b, 0, st, A, F); break;
-    case 1: hipLaunchKernelGGL((k_project_fa<1>), g, b, 0, st, A, F); break;
-    case 2: hipLaunchKernelGGL((k_project_fa<2>), g, b, 0, st, A, F); break;
-    default: hipLaunchKernelGGL((k_project_fa<3>), g, b, 0, st, A, F); break;
+    case 0: hipLaunchKernelGGL((k_project_fa<0, FG>), g, b, 0, st, A, F); break;
+    case 1: hipLaunchKernelGGL((k_project_fa<1, FG>), g, b, 0, st, A, F); break;
+    case 2: hipLaunchKernelGGL((k_project_fa<2, FG>), g, b, 0, st, A, F); break;
+    default: hipLaunchKernelGGL((k_project_fa<3, FG>), g, b, 0, st, A, F); break;
   }
 }
 
