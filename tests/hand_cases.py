@@ -13,8 +13,11 @@ def load():
 
 
 def annotation(case):
-    return {"refnames": ["chr1"], "transcripts": [{"id": t["id"], "ref_id": 0, "strand": t["strand"], "exons": t["exons"]}
-                                                   for t in case["transcripts"]]}
+    ann = {"refnames": ["chr1"], "transcripts": [{"id": t["id"], "ref_id": 0, "strand": t["strand"], "exons": t["exons"]}
+                                                  for t in case["transcripts"]]}
+    if case.get("genome"):          # -S cases: chr1's sequence (1-based position p is genome[p - 1])
+        ann["ref_seqs"] = {0: case["genome"]}
+    return ann
 
 
 def batch(case):
@@ -36,6 +39,8 @@ def check(case, rows, key_tid, key_refc=None):
         assert format_cigar(rows["cigar"][c0:c1]) == e["cigar"], tag
         for f in ("nh", "hi", "mapq", "junc_hits", "is_paired"):
             assert rows[f][k] == e[f], tag + (f,)
+        if "clip_score" in e:
+            assert rows["clip_score"][k] == e["clip_score"], tag + ("clip_score",)
         if e.get("is_paired"):
             same = rows.get("same_transcript_as_mate", rows.get("same_transcript"))
             mtid = rows.get("mate_transcript_id", rows.get("mate_tid"))
