@@ -38,7 +38,10 @@ def build_input():
     # read a: on the '+' transcript, secondary in the input; read b: on the '-' transcript, reverse strand in the input
     a = record(0, 1009, "ra", 17, 4681, 0x100, [M(11)], SEQ1, QUAL1, AUX_IN)
     b = record(0, 5019, "rb", 60, 4681, 0x10, [(2 << 4) | 4, M(9)], SEQ1, QUAL1, b"NHi\x01\x00\x00\x00")
-    return np.frombuffer(a + b, dtype=np.uint8)
+    # a proper pair on the '+' transcript: read1 forward at 1011 (1-based), read2 reverse at 1041, 50 bases each: transcript positions 11 and 41
+    p1 = record(0, 1010, "pp", 60, 4681, 0x1 | 0x40 | 0x20, [M(50)], "ACGTA" * 10, [30] * 50, b"", mtid=0, mpos=1040, tlen=80)
+    p2 = record(0, 1040, "pp", 60, 4681, 0x1 | 0x80 | 0x10, [M(50)], "TTGCA" * 10, [31] * 50, b"", mtid=0, mpos=1010, tlen=-80)
+    return np.frombuffer(a + b + p1 + p2, dtype=np.uint8)
 
 
 def expected_stream():
@@ -53,7 +56,14 @@ def expected_stream():
     # complemented: CIGAR op order reversed, SEQ complemented and reversed (N stays N), QUAL reversed, reverse flag toggled
     rc = "".join(CODES[COMP.get(CODES.index(c), 15)] for c in reversed(SEQ1))
     out_b = record(1, 71, "rb", 255, 4681, 0x00, [M(9), (2 << 4) | 4], rc, list(reversed(QUAL1)), tag_i(b"NH", 1) + tag_i(b"HI", 1))
-    return np.frombuffer(out_a + out_b, dtype=np.uint8)
+    # the pair: both mates on 'plus' (same transcript): paired + proper-pair bits set, mate fields = the mate's transcript
+    # coordinates, tlen = +-(distance between the outer ends) (src/bam.cpp:531-588); hit_index runs over records, the
+    # mate included (src/core.cpp:250-258): HI 1 and 2, NH 2 -> MAPQ 3 (src/core.cpp:46-58)
+    out_p1 = record(0, 11, "pp", 3, 4681, 0x1 | 0x2 | 0x40 | 0x20, [M(50)], "ACGTA" * 10, [30] * 50, tag_i(b"NH", 2) + tag_i(b"HI", 1),
+                    mtid=0, mpos=41, tlen=80)
+    out_p2 = record(0, 41, "pp", 3, 4681, 0x1 | 0x2 | 0x80 | 0x10, [M(50)], "TTGCA" * 10, [31] * 50, tag_i(b"NH", 2) + tag_i(b"HI", 2),
+                    mtid=0, mpos=11, tlen=-80)
+    return np.frombuffer(out_a + out_b + out_p1 + out_p2, dtype=np.uint8)
 
 
 def test_oracle_record_bytes_follow_the_rules():
@@ -61,7 +71,7 @@ def test_oracle_record_bytes_follow_the_rules():
     roff, rlen, _, _ = lib.bam_split(stream)
     orc, _, _, _ = ob.run_bam(ob.OracleIndex(ANN), ob.make_flags(), stream, roff, rlen, np.array([0], dtype=np.int32))
     exp = expected_stream()
-    assert orc["n_rows"] == 2
+    assert orc["n_rows"] == 4
     assert orc["bam_stream"].tobytes() == exp.tobytes()
 
 
