@@ -406,12 +406,15 @@ struct br_ctx {
   DevBuf seg, meta, head, head2, fast_flag, fast_pre, m_k, n_matches, ranges, mask, match_off, cig_base, tile_sums, totals, counters_d;
   DevBuf m_tid, m_aux, m_a, m_b, m_cigoff, cig_arena, big_list, n_big, m_aln;
   DevBuf bam_aux, bam_len, bam_off, bam_out;
+  struct StageSlot { DevBuf blob, off, len; hipEvent_t ready = nullptr; std::vector<uint64_t> h_off; int64_t n = 0; };
+  StageSlot stage[3];              // br_bam_bundle_stage: uploads of the next bundles overlap the current projection
+  hipStream_t copy_stream = nullptr;
   DevBuf z_slots, z_sizes, z_off, z_dense, z_tabs, z_tokens;
   int deflate_dynamic = 1;
   int emit_split = 1;
   void *zero_cols_sim = nullptr, *zero_cols_clip = nullptr; size_t zero_cols_rows = 0;  // row columns known to be all zero
   bool z_tabs_ready = false;
-  DevBuf p_ncig, p_name_len, p_isnew, p_group_pre, p_small, p_big, p_seq_len, p_ref_map, p_blob, p_rec_off, p_rec_len;
+  DevBuf p_ncig, p_name_len, p_isnew, p_group_pre, p_small, p_big, p_seq_len, p_ref_map;
   uint8_t *h_bam[2] = {nullptr, nullptr}; size_t h_bam_cap[2] = {0, 0}; int h_bam_next = 0;  // pinned download buffers of br_project_bam_bundle (alternating)
   int64_t last_n_rows = 0, last_n_aln = 0;
   DevBuf fa_stats, fa_n_prob, fa_seq_bytes, fa_prob_off, fa_seqarena_off, fa_probs, fa_results, fa_seq_arena, fa_clip_ops,
@@ -462,7 +465,7 @@ extern "C" void br_ctx_free(br_ctx *c) {
   DevBuf *bufs[] = {&c->seg, &c->meta, &c->head, &c->head2, &c->fast_flag, &c->fast_pre, &c->m_k, &c->n_matches, &c->ranges, &c->mask, &c->match_off, &c->cig_base,
                     &c->tile_sums, &c->totals, &c->counters_d, &c->m_tid, &c->m_aux, &c->m_a, &c->m_b,
                     &c->m_cigoff, &c->cig_arena, &c->big_list, &c->n_big, &c->m_aln,
-                    &c->bam_aux, &c->bam_len, &c->bam_off, &c->bam_out, &c->z_slots, &c->z_sizes, &c->z_off, &c->z_dense, &c->z_tabs, &c->z_tokens, &c->p_ncig, &c->p_name_len, &c->p_isnew, &c->p_group_pre, &c->p_small, &c->p_big, &c->p_seq_len, &c->p_ref_map, &c->p_blob, &c->p_rec_off, &c->p_rec_len, &c->fa_stats, &c->fa_n_prob, &c->fa_seq_bytes, &c->fa_prob_off, &c->fa_seqarena_off, &c->fa_probs, &c->fa_results,
+                    &c->bam_aux, &c->bam_len, &c->bam_off, &c->bam_out, &c->z_slots, &c->z_sizes, &c->z_off, &c->z_dense, &c->z_tabs, &c->z_tokens, &c->p_ncig, &c->p_name_len, &c->p_isnew, &c->p_group_pre, &c->p_small, &c->p_big, &c->p_seq_len, &c->p_ref_map, &c->fa_stats, &c->fa_n_prob, &c->fa_seq_bytes, &c->fa_prob_off, &c->fa_seqarena_off, &c->fa_probs, &c->fa_results,
                     &c->fa_seq_arena, &c->fa_clip_ops, &c->fa_ideal_cap, &c->fa_scratch, &c->b_seq_off, &c->b_seqs, &c->b_seq_src,
                     &c->n_rows, &c->row_off, &c->aln_group, &c->r_input, &c->r_rec, &c->r_nh, &c->r_hi, &c->r_mapq,
                     &c->r_group, &c->r_mate_tid, &c->r_mate_pos, &c->r_isize, &c->r_tid, &c->r_pos,
@@ -474,6 +477,8 @@ extern "C" void br_ctx_free(br_ctx *c) {
   for (auto &e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if (c->h_totals) (void)hipHostFree(c->h_totals);
   for (int k = 0; k < 2; k++) if (c->h_bam[k]) (void)hipHostFree(c->h_bam[k]);
+  for (auto &S : c->stage) { S.blob.release(); S.off.release(); S.len.release(); if (S.ready) (void)hipEventDestroy(S.ready); }
+  if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   c->h_input.release(); c->h_clip.release(); c->h_junc.release(); c->h_refc.release(); c->h_mate_tid.release(); c->h_mate_pos.release();
   c->h_isize.release(); c->h_tid.release(); c->h_pos.release(); c->h_nh.release(); c->h_hi.release(); c->h_mapq.release(); c->h_group.release();
   c->h_cigar.release(); c->h_strand.release(); c->h_cigoff.release(); c->h_sim.release(); c->h_primary.release(); c->h_paired.release();
@@ -1095,26 +1100,42 @@ extern "C" int br_bam_split(const uint8_t *data, uint64_t n_bytes, int64_t cap, 
   return BR_OK;
 }
 
-extern "C" int br_project_bam_bundle(br_ctx *c, const br_config *cfg, const br_bam_bundle *bb, br_host_bam *out) {
-  if (!c || !cfg || !bb || !out) return BR_ERR_INVALID_ARG;
-  memset(out, 0, sizeof(*out));
+extern "C" int br_bam_bundle_stage(br_ctx *c, const br_bam_bundle *bb, int slot) {
+  if (!c || !bb || slot < 0 || slot > 2) return BR_ERR_INVALID_ARG;
   int64_t n = bb->n_records;
   if (n < 0 || (n && (!bb->blob || !bb->rec_off || !bb->rec_len))) return BR_ERR_INVALID_ARG;
   HIPCHK(hipSetDevice(c->ix->device));
+  br_ctx::StageSlot &S = c->stage[slot];
+  if (!c->copy_stream) HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  if (!S.ready) HIPCHK(hipEventCreateWithFlags(&S.ready, hipEventDisableTiming));
+  S.n = n;
+  if (n) {
+    // upload only the span the records cover
+    uint64_t lo = bb->rec_off[0], hi = bb->rec_off[n - 1] + bb->rec_len[n - 1];
+    if (hi > bb->n_bytes || lo > hi) return BR_ERR_INVALID_ARG;
+    RC(S.blob.ensure((size_t)(hi - lo) + 16)); RC(S.off.ensure((size_t)n * 8)); RC(S.len.ensure((size_t)n * 4));
+    S.h_off.resize((size_t)n);
+    for (int64_t i = 0; i < n; i++) S.h_off[(size_t)i] = bb->rec_off[i] - lo;
+    HIPCHK(hipMemcpyAsync(S.blob.p, bb->blob + lo, (size_t)(hi - lo), hipMemcpyHostToDevice, c->copy_stream));
+    HIPCHK(hipMemcpyAsync(S.off.p, S.h_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, c->copy_stream));
+    HIPCHK(hipMemcpyAsync(S.len.p, bb->rec_len, (size_t)n * 4, hipMemcpyHostToDevice, c->copy_stream));
+  }
+  HIPCHK(hipEventRecord(S.ready, c->copy_stream));
+  return BR_OK;
+}
+
+extern "C" int br_project_bam_staged(br_ctx *c, const br_config *cfg, const br_bam_bundle *bb, int slot, br_host_bam *out) {
+  if (!c || !cfg || !bb || !out || slot < 0 || slot > 2) return BR_ERR_INVALID_ARG;
+  memset(out, 0, sizeof(*out));
+  br_ctx::StageSlot &S = c->stage[slot];
+  if (!S.ready || S.n != bb->n_records) return BR_ERR_INVALID_ARG;   // not staged (or another bundle was)
+  HIPCHK(hipSetDevice(c->ix->device));
   hipStream_t st = nullptr;
+  int64_t n = S.n;
   out->total_processed = (uint64_t)n;
+  HIPCHK(hipEventSynchronize(S.ready));
   if (n == 0) return BR_OK;
-  // upload only the span the records cover
-  uint64_t lo = bb->rec_off[0], hi = bb->rec_off[n - 1] + bb->rec_len[n - 1];
-  if (hi > bb->n_bytes || lo > hi) return BR_ERR_INVALID_ARG;
-  RC(c->p_blob.ensure((size_t)(hi - lo) + 16)); RC(c->p_rec_off.ensure((size_t)n * 8)); RC(c->p_rec_len.ensure((size_t)n * 4));
-  HIPCHK(hipMemcpyAsync(c->p_blob.p, bb->blob + lo, (size_t)(hi - lo), hipMemcpyHostToDevice, st));
-  std::vector<uint64_t> off((size_t)n);
-  for (int64_t i = 0; i < n; i++) off[(size_t)i] = bb->rec_off[i] - lo;
-  HIPCHK(hipMemcpyAsync(c->p_rec_off.p, off.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemcpyAsync(c->p_rec_len.p, bb->rec_len, (size_t)n * 4, hipMemcpyHostToDevice, st));
-  HIPCHK(hipStreamSynchronize(st));
-  br_device_records dr{c->p_blob.as<uint8_t>(), c->p_rec_off.as<uint64_t>(), n, c->p_rec_len.as<uint32_t>()};
+  br_device_records dr{S.blob.as<uint8_t>(), S.off.as<uint64_t>(), n, S.len.as<uint32_t>()};
   br_device_rows rows; br_device_bam db;
   RC(br_project_bam_device(c, cfg, &dr, bb->ref_map, bb->n_ref_map, st, &rows, &db));
   if (bb->bgzf_on_device && db.n_bytes) {
@@ -1122,19 +1143,26 @@ extern "C" int br_project_bam_bundle(br_ctx *c, const br_config *cfg, const br_b
     RC(deflate_device_impl(c, db.data, db.n_bytes, st, &z, &zn, false));
     db.data = z; db.n_bytes = zn;
   }
-  int slot = c->h_bam_next; c->h_bam_next ^= 1;
-  if (db.n_bytes > c->h_bam_cap[slot]) {
-    if (c->h_bam[slot]) { HIPCHK(hipHostFree(c->h_bam[slot])); c->h_bam[slot] = nullptr; c->h_bam_cap[slot] = 0; }
+  int hs = c->h_bam_next; c->h_bam_next ^= 1;
+  if (db.n_bytes > c->h_bam_cap[hs]) {
+    if (c->h_bam[hs]) { HIPCHK(hipHostFree(c->h_bam[hs])); c->h_bam[hs] = nullptr; c->h_bam_cap[hs] = 0; }
     size_t want = (size_t)db.n_bytes + (size_t)db.n_bytes / 4 + 4096;
-    HIPCHK(hipHostMalloc((void **)&c->h_bam[slot], want, hipHostMallocDefault));
-    c->h_bam_cap[slot] = want;
+    HIPCHK(hipHostMalloc((void **)&c->h_bam[hs], want, hipHostMallocDefault));
+    c->h_bam_cap[hs] = want;
   }
-  if (db.n_bytes) HIPCHK(hipMemcpyAsync(c->h_bam[slot], db.data, (size_t)db.n_bytes, hipMemcpyDeviceToHost, st));
+  if (db.n_bytes) HIPCHK(hipMemcpyAsync(c->h_bam[hs], db.data, (size_t)db.n_bytes, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
-  out->data = c->h_bam[slot]; out->n_bytes = db.n_bytes; out->n_rows = db.n_rows;
+  out->data = c->h_bam[hs]; out->n_bytes = db.n_bytes; out->n_rows = db.n_rows;
   out->total_complete = rows.total_complete; out->total_unique = rows.total_unique;
   out->dropped_reads = rows.dropped_reads; out->total_processed = rows.total_processed;
   return BR_OK;
+}
+
+extern "C" int br_project_bam_bundle(br_ctx *c, const br_config *cfg, const br_bam_bundle *bb, br_host_bam *out) {
+  if (!c || !cfg || !bb || !out) return BR_ERR_INVALID_ARG;
+  memset(out, 0, sizeof(*out));
+  RC(br_bam_bundle_stage(c, bb, 0));
+  return br_project_bam_staged(c, cfg, bb, 0, out);
 }
 
 extern "C" int br_project_batch_device(br_ctx *c, const br_config *cfg, const br_device_batch *b, void *stream,

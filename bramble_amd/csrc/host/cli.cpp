@@ -5,7 +5,8 @@
 //   reader thread : BGZF inflate (threaded) -> record boundaries -> bundles cut at a read-name change
 //                   (process_reads, src/bramble.cpp:330-441; a bundle here is millions of records, the
 //                   result does not depend on where a name-collated stream is cut)
-//   main thread   : br_project_bam_bundle (everything between the raw records on the device)
+//   uploader      : br_bam_bundle_stage (records to one of three device slots, own copy stream)
+//   main thread   : br_project_bam_staged (everything between the raw records on the device)
 //   writer thread : BGZF deflate (threaded) -> output file
 #include <stdio.h>
 #include <stdlib.h>
@@ -400,25 +401,55 @@ extern "C" int br_cli_main(int argc, char **argv) {
   });
 
   uint64_t total_complete = 0, total_unique = 0, dropped = 0, n_bundles = 0;
-  double gpu_seconds = 0;
+  double gpu_seconds = 0, t_upload = 0;
   int fail = 0;
+  // uploader thread: stages bundle k into device slot k % 3 on the context's copy stream while the main thread
+  // projects an earlier one; three permits = three slots, a permit returns when a slot's projection is done
+  struct Staged { std::unique_ptr<Bundle> b; int slot; int rc; };
+  Slot<Staged> to_main(2);
+  std::mutex permit_m; std::condition_variable permit_cv; int permits = 3;
+  std::thread uploader([&]() {
+    int64_t seq = 0;
+    for (;;) {
+      auto b = to_gpu.take();
+      if (!b) break;
+      { std::unique_lock<std::mutex> l(permit_m); permit_cv.wait(l, [&] { return permits > 0; }); permits--; }
+      auto st = std::make_unique<Staged>();
+      st->slot = (int)(seq++ % 3);
+      br_bam_bundle bb{b->blob.data(), b->blob.size(), b->off.data(), b->len.data(), (int64_t)b->off.size(), ref_map.data(), (int32_t)ref_map.size(), o.device_deflate ? 1 : 0};
+      auto t0 = now();
+      st->rc = br_bam_bundle_stage(ctx, &bb, st->slot);
+      t_upload += secs(t0, now());
+      st->b = std::move(b);
+      to_main.put(std::move(st));
+    }
+    to_main.finish();
+  });
   for (;;) {
     auto tw0 = now();
-    auto b = to_gpu.take();
+    auto st = to_main.take();
     t_wait_gpu_in += secs(tw0, now());
-    if (!b) break;
-    if (fail) continue;  // drain
-    br_bam_bundle bb{b->blob.data(), b->blob.size(), b->off.data(), b->len.data(), (int64_t)b->off.size(), ref_map.data(), (int32_t)ref_map.size(), o.device_deflate ? 1 : 0};
+    if (!st) break;
+    auto &b = st->b;
+    if (!fail && st->rc) { fprintf(stderr, "error: upload failed: %s\n", br_strerror(st->rc)); fail = 1; }
     br_host_bam hb;
-    auto t0 = std::chrono::steady_clock::now();
-    rc = br_project_bam_bundle(ctx, &o.cfg, &bb, &hb);
-    gpu_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    memset(&hb, 0, sizeof(hb));
+    if (!fail) {
+      br_bam_bundle bb{b->blob.data(), b->blob.size(), b->off.data(), b->len.data(), (int64_t)b->off.size(), ref_map.data(), (int32_t)ref_map.size(), o.device_deflate ? 1 : 0};
+      auto t0 = now();
+      rc = br_project_bam_staged(ctx, &o.cfg, &bb, st->slot, &hb);
+      gpu_seconds += secs(t0, now());
+      if (rc) { fprintf(stderr, "error: projection failed: %s\n", br_strerror(rc)); fail = 1; }
+    }
     { auto spare = std::make_unique<brio::ByteBuf>(); spare->swap(b->blob); std::lock_guard<std::mutex> l(pool_m); pool.push_back(std::move(spare)); }
-    if (rc) { fprintf(stderr, "error: projection failed: %s\n", br_strerror(rc)); fail = 1; continue; }
+    { std::lock_guard<std::mutex> l(permit_m); permits++; }
+    permit_cv.notify_all();
+    if (fail) continue;  // drain
     total_complete += hb.total_complete; total_unique += hb.total_unique; dropped += hb.dropped_reads; n_bundles++;
     auto c = std::make_unique<OutChunk>(); c->data = hb.data; c->n = hb.n_bytes;
     to_writer.put(std::move(c));  // returns once the writer has FINISHED the previous chunk: the two pinned buffers alternate
   }
+  uploader.join();
   to_writer.finish();
   reader.join(); writer.join();
   if (!reader_err.empty()) { fprintf(stderr, "error: %s: %s\n", o.in_bam.c_str(), reader_err.c_str()); fail = 1; }
@@ -437,8 +468,8 @@ extern "C" int br_cli_main(int argc, char **argv) {
     printf("[bramble] %llu bundles, %.2fs on the device path (upload + kernels + download), %.2fs wall (setup %.2fs, codec %s)\n",
            (unsigned long long)n_bundles, gpu_seconds, since(), t_setup, brio::codec_name());
     printf("[bramble] release of device / pinned memory: %.2fs\n", t_freed - t_done);
-    printf("[bramble] stage busy time: inflate %.2fs, split %.2fs, bundle copy %.2fs, device %.2fs (waited for input %.2fs), deflate+write %.2fs\n",
-           t_inflate, t_split, t_copy, gpu_seconds, t_wait_gpu_in, t_deflate);
+    printf("[bramble] stage busy time: inflate %.2fs, split %.2fs, bundle copy %.2fs, upload %.2fs, device %.2fs (waited for input %.2fs), deflate+write %.2fs\n",
+           t_inflate, t_split, t_copy, t_upload, gpu_seconds, t_wait_gpu_in, t_deflate);
   }
   return fail;
 }

@@ -332,6 +332,13 @@ typedef struct br_host_bam {
 
 int br_project_bam_bundle(br_ctx *, const br_config *, const br_bam_bundle *, br_host_bam *out);
 
+/* The same call in two steps, so that the upload of the next bundles (own copy stream; may be issued from another
+ * host thread) overlaps the projection of the current one: stage bundle k into slot k % 3, later project it from that
+ * slot.  A slot may be staged again once its br_project_bam_staged call has returned; the bundle's host memory must
+ * stay valid until then. */
+int br_bam_bundle_stage(br_ctx *, const br_bam_bundle *, int slot /* 0..2 */);
+int br_project_bam_staged(br_ctx *, const br_config *, const br_bam_bundle *, int slot, br_host_bam *out);
+
 /* Walks the block_size chain of an uncompressed BAM alignment section (host): fills rec_off /
  * rec_len for up to `cap` MAPPED records (unmapped ones are counted and skipped like
  * bramble.cpp:376-379) and reports how many bytes were consumed (a trailing partial record is
