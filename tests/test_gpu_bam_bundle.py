@@ -241,3 +241,35 @@ def test_bam_bundle_unusual_records():
         got, counters, orc, _ = run_both_bam(ann, stream, np.array([0], dtype=np.int32), **flags)
         assert orc["n_rows"] >= 6
         assert_streams_equal(got, orc["bam_stream"])
+
+
+def test_staged_bundles_equal_one_shot_calls():
+    """br_bam_bundle_stage / br_project_bam_staged: three bundles staged ahead into the three device slots give the
+    streams of three one-shot br_project_bam_bundle calls; projecting a slot that holds another bundle is refused."""
+    import ctypes as C
+    ann = synth.Annotation("G", n_genes=600, n_refs=3)
+    idx = lib.Index(ann.as_dict(), device=0)
+    ctx = lib.Context(idx)
+    cfg = lib.make_config()
+    L = lib.lib()
+    L.br_bam_bundle_stage.argtypes = [C.c_void_p, C.POINTER(lib.BrBamBundle), C.c_int]
+    L.br_project_bam_staged.argtypes = [C.c_void_p, C.POINTER(lib.BrConfig), C.POINTER(lib.BrBamBundle), C.c_int, C.POINTER(lib.BrHostBam)]
+    ref_map = np.arange(3, dtype=np.int32)
+    bundles, expect, keep = [], [], []
+    for k, n in enumerate((1500, 400, 2600)):
+        b = ann.reads(n, "pe", with_records=1, seed=77 + k)
+        stream, roff, rlen = synth.Annotation.frame_records(b)
+        exp, _ = ctx.project_bam_bundle(cfg, stream, roff, rlen, ref_map)
+        expect.append(exp)
+        keep.append((stream, roff, rlen))
+        bundles.append(lib.BrBamBundle(stream.ctypes.data, stream.size, roff.ctypes.data, rlen.ctypes.data, len(rlen), ref_map.ctypes.data, 3, 0))
+    for k, bb in enumerate(bundles):
+        assert L.br_bam_bundle_stage(ctx.h, C.byref(bb), k) == 0
+    out = lib.BrHostBam()
+    assert L.br_project_bam_staged(ctx.h, C.byref(cfg), C.byref(bundles[0]), 1, C.byref(out)) == -1     # slot 1 holds bundle 1
+    for k in (2, 0, 1):
+        assert L.br_project_bam_staged(ctx.h, C.byref(cfg), C.byref(bundles[k]), k, C.byref(out)) == 0
+        got = np.ctypeslib.as_array(C.cast(out.data, C.POINTER(C.c_uint8)), shape=(int(out.n_bytes),)).copy()
+        assert_streams_equal(got, expect[k])
+    ctx.close()
+    idx.close()
