@@ -1046,8 +1046,8 @@ static int deflate_device_impl(br_ctx *c, const uint8_t *src, uint64_t n, hipStr
   A.src = src; A.n_bytes = n; A.n_blocks = nb; A.slots = c->z_slots.as<uint8_t>(); A.sizes = c->z_sizes.as<uint32_t>();
   A.crc_tab = c->z_tabs.as<uint32_t>(); A.crc_shift = c->z_tabs.as<uint32_t>() + 256;
   int dyn_waves = 0;
-  if (c->deflate_dynamic) {  // persistent waves: as many as the chip holds (LDS: ~7.5 KiB per wave -> 5 workgroups per CU), a token list each
-    uint64_t want = (uint64_t)c->n_cu * 20;
+  if (c->deflate_dynamic) {  // persistent waves: as many as the chip holds (up to 8 workgroups of 4 waves per CU), a token list each
+    uint64_t want = (uint64_t)c->n_cu * 32;
     dyn_waves = (int)std::min<uint64_t>((nb + 3) / 4 * 4, want / 4 * 4);
     if (dyn_waves < 4) dyn_waves = 4;
     RC(c->z_tokens.ensure((size_t)dyn_waves * DEFLATE_PAYLOAD * 4));

@@ -171,7 +171,8 @@ __device__ __forceinline__ Token parse_round(const uint8_t *in, uint32_t n, uint
 // CRC32 of the payload (K lane-chunks, the first takes the remainder; acc = shift(acc) ^ crc_i), then the
 // BGZF header, trailer and the block size
 __device__ __forceinline__ void finish_block(const DeflateArgs &A, uint64_t blk, const uint8_t *in, uint32_t n, uint8_t *out,
-                                             uint32_t nbytes, int lane, const uint32_t *sh_crc, const uint32_t (*sh_shift)[256]) {
+                                             uint32_t nbytes, int lane, const uint32_t *sh_crc) {
+  const uint32_t *shift = A.crc_shift;   // [4][256], 256 look-ups per block: read from global memory, not worth 4 KiB of LDS
   const uint32_t K = (n + DEFLATE_CRC_CHUNK - 1u) / DEFLATE_CRC_CHUNK;
   uint32_t c = 0;
   if ((uint32_t)lane < K) {
@@ -193,7 +194,7 @@ __device__ __forceinline__ void finish_block(const DeflateArgs &A, uint64_t blk,
   uint32_t acc = (uint32_t)__builtin_amdgcn_readlane((int)c, 0);
   for (uint32_t i = 1; i < K; i++) {
     uint32_t ci = (uint32_t)__builtin_amdgcn_readlane((int)c, i);
-    acc = sh_shift[0][acc & 0xffu] ^ sh_shift[1][(acc >> 8) & 0xffu] ^ sh_shift[2][(acc >> 16) & 0xffu] ^ sh_shift[3][acc >> 24];
+    acc = shift[acc & 0xffu] ^ shift[256 + ((acc >> 8) & 0xffu)] ^ shift[512 + ((acc >> 16) & 0xffu)] ^ shift[768 + (acc >> 24)];
     acc ^= ci;
   }
   if (lane == 0) {
@@ -224,9 +225,7 @@ __global__ void __launch_bounds__(256) k_deflate_fixed(DeflateArgs A) {
   __shared__ uint16_t sh_tab[4][HASH_SIZE];
   __shared__ uint32_t sh_obuf[4][OBUF_WORDS];
   __shared__ uint32_t sh_crc[256];
-  __shared__ uint32_t sh_shift[4][256];
   for (int i = threadIdx.x; i < 256; i += 256) sh_crc[i] = A.crc_tab[i];
-  for (int i = threadIdx.x; i < 1024; i += 256) sh_shift[i >> 8][i & 255] = A.crc_shift[i];
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   uint64_t blk = (uint64_t)blockIdx.x * 4 + wave;
@@ -262,7 +261,7 @@ __global__ void __launch_bounds__(256) k_deflate_fixed(DeflateArgs A) {
   }
   bw.round(lane, 0, lane == 0 ? 7u : 0u, 0, 0);        // end-of-block symbol 256: seven zero bits
   uint32_t nbytes = bw.finish(lane);
-  finish_block(A, blk, in, n, out, nbytes, lane, sh_crc, sh_shift);
+  finish_block(A, blk, in, n, out, nbytes, lane, sh_crc);
 }
 
 // ---- dynamic Huffman ---------------------------------------------------------------------------------------
@@ -311,21 +310,30 @@ __device__ __forceinline__ void build_lengths(uint32_t *freq, uint8_t *lens, int
     if (lane == 0) lens[pick] = l + 1;
     __builtin_amdgcn_wave_barrier();
   }
-  // below one: shorten the most frequent symbol whose step still fits
-  while (k15 < 32768) {
-    int32_t slack = 32768 - k15;
-    uint64_t key = 0;
-    for (int i = lane; i < nsym; i += 64) {
-      uint8_t l = lens[i];
-      if (l > 1 && (1 << (15 - l)) <= slack) { uint64_t kk = ((uint64_t)freq[i] << 32) | (uint32_t)(0xffff - i); if (kk > key) key = kk; }
+  // below one: hand the slack out from the big steps to the small ones -- at length l a symbol may move to l - 1 for
+  // 2^(15-l) units; floor(slack / step) of the length-l symbols (in index order: symbols of one Shannon length have
+  // frequencies within a factor two of each other) take it.  A sweep always makes progress (the slack is a multiple
+  // of the longest code's step), a few sweeps reach exactly one.
+  int32_t slack = 32768 - k15;
+  const uint64_t lt = (1ull << lane) - 1ull;
+  while (slack > 0) {
+    for (int l = 2; l <= 15 && slack > 0; l++) {
+      const int32_t step = 1 << (15 - l);
+      if (step > slack) continue;
+      const int32_t can = slack / step;
+      int32_t taken = 0;
+      for (int base = 0; base < nsym && taken < can; base += 64) {
+        int i = base + lane;
+        bool has = i < nsym && lens[i] == l;
+        uint64_t m = __ballot(has);
+        int32_t before = (int32_t)__builtin_popcountll(m & lt);
+        if (has && taken + before < can) lens[i] = (uint8_t)(l - 1);
+        int32_t c = (int32_t)__builtin_popcountll(m);
+        taken += c < can - taken ? c : can - taken;
+      }
+      slack -= taken * step;
+      __builtin_amdgcn_wave_barrier();
     }
-    for (int o = 32; o > 0; o >>= 1) { uint64_t t = __shfl_xor(key, o); key = t > key ? t : key; }
-    if (!key) break;                                  // cannot happen while slack > 0 (a longest code always fits)
-    int pick = 0xffff - (int)(uint32_t)(key & 0xffffu);
-    uint8_t l = lens[pick];
-    k15 += 1 << (15 - l);
-    if (lane == 0) lens[pick] = l - 1;
-    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -358,12 +366,10 @@ __global__ void __launch_bounds__(256) k_deflate_dynamic(DeflateArgs A) {
   __shared__ uint16_t sh_tab[4][HASH_SIZE];
   __shared__ uint32_t sh_obuf[4][OBUF_WORDS];
   __shared__ uint32_t sh_crc[256];
-  __shared__ uint32_t sh_shift[4][256];
   __shared__ uint32_t sh_fll[4][DYN_LL + 2], sh_fd[4][DYN_D + 2];   // histograms, then the encode tables
   __shared__ uint8_t sh_lll[4][DYN_LL + 2], sh_ld[4][DYN_D + 2];
   __shared__ uint32_t sh_nc[4][16];
   for (int i = threadIdx.x; i < 256; i += 256) sh_crc[i] = A.crc_tab[i];
-  for (int i = threadIdx.x; i < 1024; i += 256) sh_shift[i >> 8][i & 255] = A.crc_shift[i];
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint64_t wave_id = (uint64_t)blockIdx.x * 4 + wave, n_waves = (uint64_t)gridDim.x * 4;
@@ -445,7 +451,7 @@ __global__ void __launch_bounds__(256) k_deflate_dynamic(DeflateArgs A) {
     }
     { uint32_t e = fll[256]; bw.round(lane, lane == 0 ? (e & 0xffffu) : 0u, lane == 0 ? (e >> 16) : 0u, 0, 0); }
     uint32_t nbytes = bw.finish(lane);
-    finish_block(A, blk, in, n, out, nbytes, lane, sh_crc, sh_shift);
+    finish_block(A, blk, in, n, out, nbytes, lane, sh_crc);
     __builtin_amdgcn_wave_barrier();
   }
 }
