@@ -10,6 +10,12 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a checkout without build artefacts (they are git-ignored): build once, the way __graft_entry__.build() does
+    need = [os.path.join(ROOT, "bramble_amd", "libbramble_amd.so"), os.path.join(ROOT, "bramble_amd", "libbramble_synth.so"),
+            os.path.join(ROOT, "bramble_amd", "bin", "bramble"), os.path.join(ROOT, "oracle", "liboracle.so")]
+    if not all(os.path.exists(p) for p in need):
+        import __graft_entry__
+        __graft_entry__.build()
 
 
 @pytest.fixture(scope="session")
