@@ -100,32 +100,23 @@ struct BitWriter {
   }
 };
 
-// one greedy parse round over positions p .. p+63: returns this lane's token (0 none, 1 literal, 2 match)
+// Greedy parse, 128 positions per step (two half-rounds of 64, one position per lane each).  The table look-ups and the
+// four-byte candidate checks of both halves are issued together -- the step is bound by dependent memory latency, and
+// this halves the number of latency chains per byte.  The second half does not see the first half's table entries
+// (distances below 128 are rare in a record stream and cost little).  Token kinds: 0 none, 1 literal, 2 match.
 struct Token { uint32_t kind, byte, len, dist; };
 
-__device__ __forceinline__ Token parse_round(const uint8_t *in, uint32_t n, uint32_t p, int lane, uint16_t *tab, uint32_t w,
-                                             uint32_t &skip_until) {
+// the greedy walk over one half-round: which of the 64 positions start a token, given each lane's checked candidate
+__device__ __forceinline__ Token parse_half(const uint8_t *in, uint32_t n, uint32_t p, int lane, uint32_t w, uint32_t cand,
+                                            uint32_t dist, bool v4, uint32_t &skip_until) {
   Token tk{0, 0, 0, 0};
   const uint32_t q = p + lane;
   const bool act = q < n;
   const bool can = q + 4u <= n;
-  uint32_t h = (w * 2654435761u) >> (32 - HASH_BITS);
-  if (p + 64u <= skip_until) {                       // the whole round lies inside a match: only feed the table
-    if (can) tab[h] = (uint16_t)q;
-    return tk;
-  }
-  uint32_t cand = can ? tab[h] : EMPTY16;
-  __builtin_amdgcn_wave_barrier();
-  if (can) tab[h] = (uint16_t)q;                     // any writer of a clashing slot is fine: all are < next round's p
+  if (p + 64u <= skip_until) return tk;              // the whole half lies inside a match
   const uint64_t active = __ballot(act);
-  uint64_t covered = __ballot(act && q < skip_until);
-  uint32_t dist = 0;
-  bool v4 = false;
-  if (can && q >= skip_until && cand != EMPTY16) {
-    dist = q - cand;
-    v4 = dist <= 32768u && *(const u32u *)(in + cand) == w;
-  }
-  const uint64_t hasm = __ballot(v4);
+  const uint64_t covered = __ballot(act && q < skip_until);
+  const uint64_t hasm = __ballot(v4 && q >= skip_until);
   // only the matches that are TAKEN get their length computed, by the whole wave: lane L compares bytes
   // [4 + 4L, 8 + 4L), one step covers all 258
   uint32_t mlen = 0;
@@ -166,6 +157,32 @@ __device__ __forceinline__ Token parse_round(const uint8_t *in, uint32_t n, uint
   if ((lit >> lane) & 1ull) { tk.kind = 1; tk.byte = can ? (w & 0xffu) : (uint32_t)in[q]; }
   else if ((mat >> lane) & 1ull) { tk.kind = 2; tk.len = mlen; tk.dist = dist; }
   return tk;
+}
+
+__device__ __forceinline__ void parse_step(const uint8_t *in, uint32_t n, uint32_t p, int lane, uint16_t *tab, uint32_t w0, uint32_t w1,
+                                           uint32_t &skip_until, Token &ta, Token &tb) {
+  const uint32_t q0 = p + lane, q1 = p + 64u + lane;
+  const bool can0 = q0 + 4u <= n, can1 = q1 + 4u <= n;
+  const uint32_t h0 = (w0 * 2654435761u) >> (32 - HASH_BITS), h1 = (w1 * 2654435761u) >> (32 - HASH_BITS);
+  ta = Token{0, 0, 0, 0}; tb = Token{0, 0, 0, 0};
+  if (p + 128u <= skip_until) {                      // everything lies inside a match: only feed the table
+    if (can0) tab[h0] = (uint16_t)q0;
+    __builtin_amdgcn_wave_barrier();
+    if (can1) tab[h1] = (uint16_t)q1;
+    return;
+  }
+  uint32_t c0 = can0 ? tab[h0] : EMPTY16, c1 = can1 ? tab[h1] : EMPTY16;
+  __builtin_amdgcn_wave_barrier();
+  if (can0) tab[h0] = (uint16_t)q0;                  // any writer of a clashing slot is fine: all are < the next step's p
+  __builtin_amdgcn_wave_barrier();
+  if (can1) tab[h1] = (uint16_t)q1;                  // the later half wins a clash within the lane
+  uint32_t d0 = q0 - c0, d1 = q1 - c1;
+  bool try0 = can0 && q0 >= skip_until && c0 != EMPTY16 && d0 <= 32768u;
+  bool try1 = can1 && q1 >= skip_until && c1 != EMPTY16 && d1 <= 32768u;
+  uint32_t f0 = try0 ? *(const u32u *)(in + c0) : 0u, f1 = try1 ? *(const u32u *)(in + c1) : 0u;   // both in flight together
+  bool v0 = try0 && f0 == w0, v1 = try1 && f1 == w1;
+  ta = parse_half(in, n, p, lane, w0, c0, d0, v0, skip_until);
+  if (p + 64u < n) tb = parse_half(in, n, p + 64u, lane, w1, c1, d1, v1, skip_until);
 }
 
 // CRC32 of the payload (K lane-chunks, the first takes the remainder; acc = shift(acc) ^ crc_i), then the
@@ -240,24 +257,27 @@ __global__ void __launch_bounds__(256) k_deflate_fixed(DeflateArgs A) {
   __builtin_amdgcn_wave_barrier();
   BitWriter bw{sh_obuf[wave], out + 18, 3u, 3u, 0u};   // BFINAL = 1, BTYPE = 01 (fixed Huffman)
   uint32_t skip_until = 0;
-  // the dword at each lane's position is loaded one round ahead (its latency hides behind the current round)
-  uint32_t w_next = (lane + 4u <= n) ? *(const u32u *)(in + lane) : 0u;
-  for (uint32_t p = 0; p < n; p += 64) {
-    const uint32_t w = w_next;
-    if (p + lane + 64u + 4u <= n) w_next = *(const u32u *)(in + p + lane + 64u);
-    const bool inside = p + 64u <= skip_until;
-    Token tk = parse_round(in, n, p, lane, tab, w, skip_until);
-    if (inside) continue;
-    uint32_t va = 0, na = 0;
-    if (tk.kind == 1) {
-      if (tk.byte < 144u) { va = bitrev(0x30u + tk.byte, 8); na = 8; } else { va = bitrev(0x190u + (tk.byte - 144u), 9); na = 9; }
-    } else if (tk.kind == 2) {
-      uint32_t lv, dv;
-      int ln = len_bits(tk.len, lv), dn = dist_bits(tk.dist, dv);
-      // <= 13 + 18 = 31 bits: one piece
-      va = lv | (dv << ln); na = (uint32_t)(ln + dn);
+  // the dwords at each lane's two positions are loaded one step ahead (their latency hides behind the current step)
+  uint32_t wn0 = (lane + 4u <= n) ? *(const u32u *)(in + lane) : 0u, wn1 = (lane + 68u <= n) ? *(const u32u *)(in + lane + 64u) : 0u;
+  for (uint32_t p = 0; p < n; p += 128) {
+    const uint32_t w0 = wn0, w1 = wn1;
+    if (p + lane + 128u + 4u <= n) wn0 = *(const u32u *)(in + p + lane + 128u);
+    if (p + lane + 192u + 4u <= n) wn1 = *(const u32u *)(in + p + lane + 192u);
+    Token tk[2];
+    parse_step(in, n, p, lane, tab, w0, w1, skip_until, tk[0], tk[1]);
+#pragma unroll
+    for (int hh = 0; hh < 2; hh++) {
+      if (!__ballot(tk[hh].kind != 0)) continue;     // nothing starts in this half
+      uint32_t va = 0, na = 0;
+      if (tk[hh].kind == 1) {
+        if (tk[hh].byte < 144u) { va = bitrev(0x30u + tk[hh].byte, 8); na = 8; } else { va = bitrev(0x190u + (tk[hh].byte - 144u), 9); na = 9; }
+      } else if (tk[hh].kind == 2) {
+        uint32_t lv, dv;
+        int ln = len_bits(tk[hh].len, lv), dn = dist_bits(tk[hh].dist, dv);
+        va = lv | (dv << ln); na = (uint32_t)(ln + dn);   // <= 13 + 18 = 31 bits: one piece
+      }
+      bw.round(lane, va, na, 0, 0);
     }
-    bw.round(lane, va, na, 0, 0);
   }
   bw.round(lane, 0, lane == 0 ? 7u : 0u, 0, 0);        // end-of-block symbol 256: seven zero bits
   uint32_t nbytes = bw.finish(lane);
@@ -389,23 +409,28 @@ __global__ void __launch_bounds__(256) k_deflate_dynamic(DeflateArgs A) {
     __builtin_amdgcn_wave_barrier();
     // ---- parse: tokens + histograms
     uint32_t skip_until = 0, n_tok = 0;
-    uint32_t w_next = (lane + 4u <= n) ? *(const u32u *)(in + lane) : 0u;
-    for (uint32_t p = 0; p < n; p += 64) {
-      const uint32_t w = w_next;
-      if (p + lane + 64u + 4u <= n) w_next = *(const u32u *)(in + p + lane + 64u);
-      const bool inside = p + 64u <= skip_until;
-      Token tk = parse_round(in, n, p, lane, tab, w, skip_until);
-      if (inside) continue;
-      uint64_t sel = __ballot(tk.kind != 0);
-      uint32_t rank = (uint32_t)__builtin_popcountll(sel & ((1ull << lane) - 1ull));
-      if (tk.kind == 1) { tokens[n_tok + rank] = tk.byte; atomicAdd(&fll[tk.byte], 1u); }
-      else if (tk.kind == 2) {
-        tokens[n_tok + rank] = 0x80000000u | ((tk.len - 3u) << 16) | (tk.dist - 1u);
-        uint32_t s1, e1, v1, s2, e2, v2;
-        len_symbol(tk.len, s1, e1, v1); dist_symbol(tk.dist, s2, e2, v2);
-        atomicAdd(&fll[s1], 1u); atomicAdd(&fd[s2], 1u);
+    uint32_t wn0 = (lane + 4u <= n) ? *(const u32u *)(in + lane) : 0u, wn1 = (lane + 68u <= n) ? *(const u32u *)(in + lane + 64u) : 0u;
+    for (uint32_t p = 0; p < n; p += 128) {
+      const uint32_t w0 = wn0, w1 = wn1;
+      if (p + lane + 128u + 4u <= n) wn0 = *(const u32u *)(in + p + lane + 128u);
+      if (p + lane + 192u + 4u <= n) wn1 = *(const u32u *)(in + p + lane + 192u);
+      Token tk2[2];
+      parse_step(in, n, p, lane, tab, w0, w1, skip_until, tk2[0], tk2[1]);
+#pragma unroll
+      for (int hh = 0; hh < 2; hh++) {
+        const Token tk = tk2[hh];
+        uint64_t sel = __ballot(tk.kind != 0);
+        if (!sel) continue;
+        uint32_t rank = (uint32_t)__builtin_popcountll(sel & ((1ull << lane) - 1ull));
+        if (tk.kind == 1) { tokens[n_tok + rank] = tk.byte; atomicAdd(&fll[tk.byte], 1u); }
+        else if (tk.kind == 2) {
+          tokens[n_tok + rank] = 0x80000000u | ((tk.len - 3u) << 16) | (tk.dist - 1u);
+          uint32_t s1, e1, v1, s2, e2, v2;
+          len_symbol(tk.len, s1, e1, v1); dist_symbol(tk.dist, s2, e2, v2);
+          atomicAdd(&fll[s1], 1u); atomicAdd(&fd[s2], 1u);
+        }
+        n_tok += (uint32_t)__builtin_popcountll(sel);
       }
-      n_tok += (uint32_t)__builtin_popcountll(sel);
     }
     if (lane == 0) fll[256] = 1;                      // end of block
     __builtin_amdgcn_wave_barrier();
