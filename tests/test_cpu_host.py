@@ -109,3 +109,17 @@ def test_primary_tie_break_matches_libstdcxx():
         name = bytes(rng.randint(33, 126, size=ln).astype(np.uint8))
         n = int(rng.randint(1, 9)) if it % 2 else int(rng.randint(1, 10 ** 6))
         assert L.br_primary_pick(name, len(name), n) == ob.primary_pick(name, n), (name, n)
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/bramble_amd.h is the drop-in boundary: it must compile as C99 (and C++11) on its own, no torch / HIP types."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "bramble_amd.h"\nint main(void) { br_config c; br_config_short_read(&c); return (int)br_index_num_refs(0); }\n')
+    inc = os.path.join(root, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-c", str(src), "-o", str(tmp_path / "a.o")])
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-x", "c++", "-I", inc, "-c", str(src), "-o", str(tmp_path / "b.o")])
+    code = "\n".join(l for l in open(os.path.join(inc, "bramble_amd.h")) if l.lstrip().startswith("#include"))
+    assert code.split() == ["#include", "<stddef.h>", "#include", "<stdint.h>"]      # nothing but the two C headers
