@@ -40,12 +40,12 @@ struct br_index {
   uint32_t n_refs = 0;
   bool has_seq = false;
   // host copies of the flattened tables
-  std::vector<uint32_t> slab_off, s_start, s_end, s_pmax, s_next, s_tid, tx_first, bin_off, t_hi, t_lo;
-  std::vector<uint4> s_pay, tx_ex;
+  std::vector<uint32_t> slab_off, s_start, s_pmax, s_tid, tx_first, bin_off, t_hi, t_lo;
+  std::vector<uint4> s_row, tx_ex;
   std::vector<uint8_t> seq_pool;
   // device copies
-  void *d_slab_off = nullptr, *d_s_start = nullptr, *d_s_end = nullptr, *d_s_pmax = nullptr, *d_s_next = nullptr, *d_bin_off = nullptr, *d_t_hi = nullptr, *d_t_lo = nullptr, *d_s_tid = nullptr,
-       *d_s_pay = nullptr, *d_tx_ex = nullptr, *d_tx_first = nullptr, *d_seq_pool = nullptr;
+  void *d_slab_off = nullptr, *d_s_start = nullptr, *d_s_pmax = nullptr, *d_bin_off = nullptr, *d_t_hi = nullptr, *d_t_lo = nullptr, *d_s_tid = nullptr,
+       *d_s_row = nullptr, *d_tx_ex = nullptr, *d_tx_first = nullptr, *d_seq_pool = nullptr;
   size_t device_bytes = 0;
   DevIndex dev{};
 };
@@ -131,9 +131,10 @@ static int build_index_flat(size_t n_tx, const int32_t *tx_ref, const int8_t *tx
     uint32_t m = 0;
     for (auto &r : rows) {
       m = std::max(m, r.end);
-      ix->s_start.push_back(r.start); ix->s_end.push_back(r.end); ix->s_pmax.push_back(m);
-      ix->s_pay.push_back(make_uint4(r.tid, r.gidx, r.pos_start, ix->tx_first[r.tid]));
-      ix->s_next.push_back(ix->tx_ex[ix->tx_first[r.tid] + r.gidx + 1].x);  // sentinel start = ~0u
+      ix->s_start.push_back(r.start); ix->s_pmax.push_back(m);
+      // one 32-byte row = everything a candidate lane needs, in one 64-byte sector
+      ix->s_row.push_back(make_uint4(r.start, r.end, ix->tx_ex[ix->tx_first[r.tid] + r.gidx + 1].x /* sentinel start = ~0u */, r.pos_start));
+      ix->s_row.push_back(make_uint4(r.tid, r.gidx, ix->tx_first[r.tid], 0));
       ix->s_tid.push_back(r.tid);
     }
     ix->slab_off.push_back((uint32_t)ix->s_start.size());
@@ -164,11 +165,10 @@ static int build_index_flat(size_t n_tx, const int32_t *tx_ref, const int8_t *tx
     HIPCHK(hipSetDevice(device));
     size_t acc = 0;
     if ((rc = upload(&ix->d_slab_off, ix->slab_off, acc)) || (rc = upload(&ix->d_s_start, ix->s_start, acc)) ||
-        (rc = upload(&ix->d_s_end, ix->s_end, acc)) || (rc = upload(&ix->d_s_pmax, ix->s_pmax, acc)) ||
-        (rc = upload(&ix->d_s_next, ix->s_next, acc)) || (rc = upload(&ix->d_bin_off, ix->bin_off, acc)) ||
+        (rc = upload(&ix->d_s_pmax, ix->s_pmax, acc)) || (rc = upload(&ix->d_bin_off, ix->bin_off, acc)) ||
         (rc = upload(&ix->d_t_hi, ix->t_hi, acc)) || (rc = upload(&ix->d_t_lo, ix->t_lo, acc)) ||
         (rc = upload(&ix->d_s_tid, ix->s_tid, acc)) ||
-        (rc = upload(&ix->d_s_pay, ix->s_pay, acc)) || (rc = upload(&ix->d_tx_ex, ix->tx_ex, acc)) ||
+        (rc = upload(&ix->d_s_row, ix->s_row, acc)) || (rc = upload(&ix->d_tx_ex, ix->tx_ex, acc)) ||
         (rc = upload(&ix->d_tx_first, ix->tx_first, acc)) || (rc = upload(&ix->d_seq_pool, ix->seq_pool, acc))) {
       br_index_free(ix); return rc;
     }
@@ -176,12 +176,11 @@ static int build_index_flat(size_t n_tx, const int32_t *tx_ref, const int8_t *tx
     DevIndex &d = ix->dev;
     d.n_refs = ix->n_refs; d.n_tx = (uint32_t)n_tx; d.n_rows = (uint32_t)ix->s_start.size();
     d.slab_off = (const uint32_t *)ix->d_slab_off; d.s_start = (const uint32_t *)ix->d_s_start;
-    d.s_end = (const uint32_t *)ix->d_s_end; d.s_pmax = (const uint32_t *)ix->d_s_pmax;
-    d.s_next = (const uint32_t *)ix->d_s_next;
+    d.s_pmax = (const uint32_t *)ix->d_s_pmax;
     d.bin_shift = SHIFT; d.bin_off = (const uint32_t *)ix->d_bin_off;
     d.t_hi = (const uint32_t *)ix->d_t_hi; d.t_lo = (const uint32_t *)ix->d_t_lo;
     d.s_tid = (const uint32_t *)ix->d_s_tid;
-    d.s_pay = (const uint4 *)ix->d_s_pay; d.tx_ex = (const uint4 *)ix->d_tx_ex;
+    d.s_row = (const uint4 *)ix->d_s_row; d.tx_ex = (const uint4 *)ix->d_tx_ex;
     d.tx_first = (const uint32_t *)ix->d_tx_first; d.seq_pool = (const uint8_t *)ix->d_seq_pool;
   }
   *out = ix;
@@ -234,7 +233,7 @@ extern "C" void br_index_free(br_index *ix) {
   if (!ix) return;
   if (ix->device >= 0) {
     (void)hipSetDevice(ix->device);
-    void *ptrs[] = {ix->d_slab_off, ix->d_s_start, ix->d_s_end, ix->d_s_pmax, ix->d_s_next, ix->d_bin_off, ix->d_t_hi, ix->d_t_lo, ix->d_s_tid, ix->d_s_pay, ix->d_tx_ex,
+    void *ptrs[] = {ix->d_slab_off, ix->d_s_start, ix->d_s_pmax, ix->d_bin_off, ix->d_t_hi, ix->d_t_lo, ix->d_s_tid, ix->d_s_row, ix->d_tx_ex,
                     ix->d_tx_first, ix->d_seq_pool};
     for (void *p : ptrs) if (p) (void)hipFree(p);
   }
@@ -580,7 +579,7 @@ static int run_device_impl(br_ctx *c, const br_config *cfg, const br_device_batc
   RC(c->n_matches.ensure((size_t)n * 4)); RC(c->ranges.ensure((size_t)n * sizeof(uint4)));
   RC(c->mask.ensure((size_t)n * 8)); RC(c->match_off.ensure((size_t)(n + 1) * 4));
   RC(c->cig_base.ensure((size_t)(n + 1) * 8)); RC(c->tile_sums.ensure((size_t)tiles * 8 * 3));
-  RC(c->totals.ensure(8 * 8)); RC(c->counters_d.ensure(4 * 8));
+  RC(c->totals.ensure(16 * 8)); RC(c->counters_d.ensure(4 * 8));
   uint64_t *d_tot = c->totals.as<uint64_t>();
 
   // a1/a2/a6: CIGAR -> read exons
@@ -827,7 +826,7 @@ extern "C" int br_ctx_collect_counters(br_ctx *c, const br_device_batch *b, void
   if (!c || !b) return BR_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;
   HIPCHK(hipSetDevice(c->ix->device));
-  RC(c->totals.ensure(8 * 8));
+  RC(c->totals.ensure(16 * 8));
   DevBuf stats; RC(stats.ensure(8 * 8));
   HIPCHK(hipMemsetAsync(stats.p, 0, 8 * 8, st));
   StatsArgs T{};
@@ -872,7 +871,7 @@ static int bam_encode_impl(br_ctx *c, const br_config *cfg, const br_device_reco
   B.r_clip = c->r_clip.as<int32_t>(); B.r_sim = c->r_sim.as<double>(); B.r_cigoff = c->r_cigoff.as<uint64_t>();
   B.cigar = c->cigar_out.as<uint32_t>(); B.out_len = c->bam_len.as<uint32_t>(); B.out_off = c->bam_off.as<uint64_t>();
   RC(c->tile_sums.ensure((size_t)std::max<int64_t>(scan_tiles_for(nr + 1), 1) * 8 * 3));
-  RC(c->totals.ensure(8 * 8));
+  RC(c->totals.ensure(16 * 8));
   B.too_long = c->totals.as<uint64_t>() + 6;
   HIPCHK(hipMemsetAsync(B.too_long, 0, 8, st));
   RC(pf.begin(BR_K_BAM));
@@ -938,7 +937,7 @@ extern "C" int br_project_bam_device(br_ctx *c, const br_config *cfg, const br_d
   RC(c->p_ref_map.ensure(std::max<size_t>((size_t)n_ref_map, 1) * 4));
   RC(c->bam_aux.ensure(nn * sizeof(BamAux)));
   RC(c->tile_sums.ensure((size_t)std::max<int64_t>(scan_tiles_for(n + 1), 1) * 8 * 3));
-  RC(c->totals.ensure(8 * 8));
+  RC(c->totals.ensure(16 * 8));
   if (n_ref_map) HIPCHK(hipMemcpyAsync(c->p_ref_map.p, ref_map, (size_t)n_ref_map * 4, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemsetAsync(c->p_small.p, 0, 64, st));  // [0] max n_cigar, [1] max soft clip, [2] big-group count
 
@@ -1041,7 +1040,7 @@ static int deflate_device_impl(br_ctx *c, const uint8_t *src, uint64_t n, hipStr
   uint64_t nb = (n + DEFLATE_PAYLOAD - 1) / DEFLATE_PAYLOAD;
   RC(c->z_slots.ensure((size_t)nb * DEFLATE_SLOT)); RC(c->z_sizes.ensure((size_t)nb * 4)); RC(c->z_off.ensure(((size_t)nb + 1) * 8));
   RC(c->tile_sums.ensure((size_t)std::max<int64_t>(scan_tiles_for((int64_t)nb + 1), 1) * 8 * 3));
-  RC(c->totals.ensure(8 * 8));
+  RC(c->totals.ensure(16 * 8));
   DeflateArgs A{};
   A.src = src; A.n_bytes = n; A.n_blocks = nb; A.slots = c->z_slots.as<uint8_t>(); A.sizes = c->z_sizes.as<uint32_t>();
   A.crc_tab = c->z_tabs.as<uint32_t>(); A.crc_shift = c->z_tabs.as<uint32_t>() + 256;

@@ -413,7 +413,7 @@ __device__ bool any_pass_global(const DevIndex &ix, uint32_t sb, uint32_t se, bo
   a = sb; b = hi;           // lo: first row whose running max end exceeds qs
   while (a < b) { uint32_t m = (a + b) >> 1; if (ix.s_pmax[m] <= qs) a = m + 1; else b = m; }
   for (uint32_t r = a; r < hi; r++) {
-    uint32_t e = ix.s_end[r];
+    uint32_t e = ix.s_row[2 * (size_t)r].y;
     if (e <= qs) continue;
     Hit h;
     if (classify(minus, status, qs, qe, ix.s_start[r], e, 0, cfg, h)) return true;
@@ -758,15 +758,16 @@ __global__ void __launch_bounds__(256, EMIT ? 4 : 8) k_project(ProjectArgs A) {
         if (valid) {
           s = item < n0 ? 0 : 1;
           row = s == 0 ? lo[0] + item : lo[1] + (item - n0);
-          // one round trip: all four row fields are independent of each other
-          gs = ix.s_start[row]; gend = ix.s_end[row]; nxt = ix.s_next[row]; pay = ix.s_pay[row];
+          // one round trip, one sector: the 32-byte row
+          const uint4 r_a = ix.s_row[2 * (size_t)row], r_b = ix.s_row[2 * (size_t)row + 1];
+          gs = r_a.x; gend = r_a.y; nxt = r_a.z; pay = make_uint4(r_b.x, r_b.y, r_a.w, r_b.z);
           bool want = true;
           if (EMIT && have_mask) want = (mask_in >> item) & 1ull;
           if (want && gend > q0.x && classify(s == 1, st0, q0.x, q0.y, gs, gend, pay.z, cfg, h0)) {
             E = ix.tx_ex + pay.w; i0 = pay.y;
             // first-exon duplicate tid: the LAST passing row of the tid wins
             // (src/evaluate.cpp:218-224); later rows of the same tid are the
-            // following exons of its table.  s_next = start of the next one.
+            // following exons of its table.  r_a.z = start of the next one.
             bool superseded = false;
             if (nxt < q0.y) {
               for (uint32_t i = i0 + 1;; i++) {
@@ -809,7 +810,7 @@ __global__ void __launch_bounds__(256, EMIT ? 4 : 8) k_project(ProjectArgs A) {
             if ((uint32_t)b >= base && (uint32_t)b < base + G) t2 = __shfl(pay.x, b - (int)base, G);
             else {
               uint32_t r2 = (uint32_t)b < n0 ? lo[0] + (uint32_t)b : lo[1] + ((uint32_t)b - n0);
-              t2 = ix.s_pay[r2].x;
+              t2 = ix.s_tid[r2];
             }
             rank += (t2 < pay.x) ? 1u : 0u;
           }
@@ -914,8 +915,9 @@ __global__ void __launch_bounds__(256, SIMF ? 6 : 8) k_emit_dense(ProjectArgs A,
   uint32_t item = (uint32_t)(__ffsll((long long)mm) - 1);
   int s = item < n0 ? 0 : 1;
   uint32_t row = s == 0 ? rg.x + item : rg.z + (item - n0);
-  uint32_t gs = ix.s_start[row], gend = ix.s_end[row];
-  uint4 pay = ix.s_pay[row];
+  const uint4 r_a = ix.s_row[2 * (size_t)row], r_b = ix.s_row[2 * (size_t)row + 1];
+  uint32_t gs = r_a.x, gend = r_a.y;
+  uint4 pay = make_uint4(r_b.x, r_b.y, r_a.w, r_b.z);
   // rank by tid among the survivors
   uint32_t rank = 0;
   for (uint64_t m2 = mask; m2;) {  // four independent loads in flight per step
@@ -1372,7 +1374,7 @@ __global__ void __launch_bounds__(256) k_stats(StatsArgs T) {
           uint32_t hi = x; x = sb; y = hi;
           while (x < y) { uint32_t m = (x + y) >> 1; if (T.ix.s_pmax[m] <= q.x) x = m + 1; else y = m; }
           uint32_t h = 0;
-          for (uint32_t r = x; r < hi; r++) h += T.ix.s_end[r] > q.x ? 1u : 0u;
+          for (uint32_t r = x; r < hi; r++) h += T.ix.s_row[2 * (size_t)r].y > q.x ? 1u : 0u;
           hits += h; b_idx += 8ull * lg + 40ull * h;
         }
       }
