@@ -666,8 +666,11 @@ __global__ void __launch_bounds__(256, EMIT ? 4 : 8) k_project(ProjectArgs A) {
     uint4 hd = A.head[a];
     uint4 hd2 = A.head2[a];
     uint32_t n_seg = hd.z;
-    if (n_seg == 0) { if (!EMIT && gl == 0) { A.n_matches[a] = 0; A.ranges[a] = make_uint4(0, 0, 0, 0); A.mask[a] = 0; } continue; }
+    if (EMIT && n_seg == 0) continue;
     uint2 q0 = make_uint2(hd.x, hd.y);
+    // count pass: an alignment without read exons (head = {0, 0, 0, 0}) runs through with no strand to try instead
+    // of leaving early, so that the head is ONE 16-byte load (an early exit on hd.z makes the compiler fetch that
+    // word first and the rest a round trip later)
     uint32_t smode = hd.w & 3u, rid = hd.w >> 2;
     int st0 = (n_seg == 1) ? ST_ONLY : ST_FIRST;
     uint32_t sb[2], se[2];
@@ -685,32 +688,43 @@ __global__ void __launch_bounds__(256, EMIT ? 4 : 8) k_project(ProjectArgs A) {
       // start >= qend and lo = first row whose running max end exceeds qstart.  The
       // bucket tables bound both to one coordinate bin; a G-wide count finishes.
       uint32_t ra[4], rb[4];  // 0/1: hi/lo on '+', 2/3: hi/lo on '-'
+      // Memory-level parallelism first: the waves spend their time in dependent round trips, not in issue
+      // (profiles/r01/pmc_count_pass.txt), so every load of a stage is unconditional (clamped to a valid
+      // entry; every slab owns >= 3 table entries) and all of a stage's loads are in flight together.
+      uint32_t tw[8];
 #pragma unroll
       for (int s = 0; s < 2; s++) {
-        ra[2 * s] = rb[2 * s] = ra[2 * s + 1] = rb[2 * s + 1] = sb[s];
-        if (!((smode >> s) & 1u) || sb[s] == se[s]) continue;
         uint32_t bo = slab_in_lds ? sh_bin[2 * rid + s] : ix.bin_off[2 * rid + s];
         uint32_t nb = (slab_in_lds ? sh_bin[2 * rid + s + 1] : ix.bin_off[2 * rid + s + 1]) - bo - 1;
         uint32_t bh = q0.y >> ix.bin_shift, bl = q0.x >> ix.bin_shift;
         bh = bh < nb - 1 ? bh : nb - 1; bl = bl < nb - 1 ? bl : nb - 1;
-        ra[2 * s] = ix.t_hi[bo + bh]; rb[2 * s] = ix.t_hi[bo + bh + 1];
-        ra[2 * s + 1] = ix.t_lo[bo + bl]; rb[2 * s + 1] = ix.t_lo[bo + bl + 1];
+        tw[4 * s + 0] = ix.t_hi[bo + bh]; tw[4 * s + 1] = ix.t_hi[bo + bh + 1];
+        tw[4 * s + 2] = ix.t_lo[bo + bl]; tw[4 * s + 3] = ix.t_lo[bo + bl + 1];
+      }
+#pragma unroll
+      for (int s = 0; s < 2; s++) {
+        const bool use = ((smode >> s) & 1u) && sb[s] != se[s];
+        ra[2 * s] = use ? tw[4 * s + 0] : sb[s]; rb[2 * s] = use ? tw[4 * s + 1] : sb[s];
+        ra[2 * s + 1] = use ? tw[4 * s + 2] : sb[s]; rb[2 * s + 1] = use ? tw[4 * s + 3] : sb[s];
       }
       // all four counts advance together: one round trip per G rows instead of four
       uint32_t res[4] = {ra[0], ra[1], ra[2], ra[3]};
+      const uint32_t last_row = ix.n_rows - 1;  // only read when some range is non-empty, i.e. n_rows >= 1
       for (uint32_t it = 0;; it += G) {
-        uint32_t vv[4]; bool in[4]; bool any = false;
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < 4; k++) any |= (ra[k] + it) < rb[k];
+        if (!any) break;
+        uint32_t vv[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           uint32_t r = ra[k] + it + (uint32_t)gl;
-          in[k] = r < rb[k];
-          any |= (ra[k] + it) < rb[k];
-          vv[k] = in[k] ? ((k & 1) ? ix.s_pmax[r] : ix.s_start[r]) : 0u;
+          r = r < last_row ? r : last_row;
+          vv[k] = (k & 1) ? ix.s_pmax[r] : ix.s_start[r];
         }
-        if (!any) break;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-          bool t = in[k] && ((k & 1) ? (vv[k] <= q0.x) : (vv[k] < q0.y));
+          bool t = (ra[k] + it + (uint32_t)gl < rb[k]) && ((k & 1) ? (vv[k] <= q0.x) : (vv[k] < q0.y));
           res[k] += (uint32_t)__popcll((__ballot(t) >> gbase) & gmask);
         }
       }
@@ -1454,6 +1468,12 @@ static void launch_project_g(hipStream_t st, const ProjectArgs &A, bool emit, in
 }
 
 void launch_project(hipStream_t st, const ProjectArgs &A, bool emit, int group_lanes, int n_blocks) {
+  if (!emit && A.ix.n_rows == 0) {  // empty annotation: nothing can match (and the kernel's clamped loads need one row)
+    (void)hipMemsetAsync(A.n_matches, 0, (size_t)A.n_aln * 4, st);
+    (void)hipMemsetAsync(A.mask, 0, (size_t)A.n_aln * 8, st);
+    (void)hipMemsetAsync(A.ranges, 0, (size_t)A.n_aln * sizeof(uint4), st);
+    return;
+  }
   if (A.n_aln <= 0) return;
   int64_t groups = A.n_aln;
   int per_block = 256 / group_lanes;
