@@ -280,7 +280,22 @@ __device__ __forceinline__ uint32_t merge_ops(uint32_t r, uint32_t i) {
 // get_new_cigar + merge_cigars (src/bam.cpp:443-472, :113-315).  `real` is the
 // alignment's packed CIGAR, `ideal` the lane's ideal CIGAR; the rewritten CIGAR
 // goes to `out` (room for n_real + n_ideal words).  Returns its length.
-__device__ uint32_t merge_cigars(const uint32_t *__restrict__ real, uint32_t n_real,
+// The alignment's packed CIGAR with its first four words in registers: merge_cigars' loop depends on the word it
+// just read, so every word left in memory is a (cache-hit) round trip on the critical path; fetch() is issued as
+// soon as the CIGAR's offset is known, together with the other loads of that stage.
+struct RealCig {
+  const uint32_t *p; uint32_t w0, w1, w2, w3;
+  __device__ __forceinline__ void fetch(const uint32_t *q, uint32_t n) {  // n >= 1
+    const uint32_t l = n - 1;
+    p = q; w0 = q[0]; w1 = q[l < 1u ? l : 1u]; w2 = q[l < 2u ? l : 2u]; w3 = q[l < 3u ? l : 3u];
+  }
+  __device__ __forceinline__ uint32_t operator[](uint32_t i) const {
+    if (i >= 4u) return p[i];
+    return i == 0 ? w0 : i == 1 ? w1 : i == 2 ? w2 : w3;
+  }
+};
+
+__device__ uint32_t merge_cigars(const RealCig &real, uint32_t n_real,
                                  const uint32_t *ideal, uint32_t n_ideal, uint32_t *out) {
   uint32_t front_h = 0, front_s = 0, ci = 0;
   if (n_real > 0 && CIG_OP(real[0]) == OP_H) { front_h = CIG_LEN(real[0]); ci++; }
@@ -853,7 +868,8 @@ __global__ void __launch_bounds__(256, EMIT ? 4 : 8) k_project(ProjectArgs A) {
           similarity(cfg, acc, score);
           bool out_lds = ideal_lds && (rd.n_real + n_ideal <= LDS_SLOT - LDS_IDEAL);
           uint32_t *outp = out_lds ? lds + LDS_IDEAL : slot;
-          uint32_t n_out = merge_cigars(rd.real, rd.n_real, ideal, n_ideal, outp);
+          RealCig rc; rc.fetch(rd.real, rd.n_real);
+          uint32_t n_out = merge_cigars(rc, rd.n_real, ideal, n_ideal, outp);
           uint64_t cig_ref = cbase + (uint64_t)rank * cap;
           if (n_out <= 2) cig_ref = (uint64_t)(n_out > 0 ? outp[0] : 0u) | ((uint64_t)(n_out > 1 ? outp[1] : 0u) << 32);
           else if (out_lds) for (uint32_t k = 0; k < n_out; k++) slot[k] = outp[k];
@@ -922,6 +938,8 @@ __global__ void __launch_bounds__(256, SIMF ? 6 : 8) k_emit_dense(ProjectArgs A,
   uint2 q0 = make_uint2(hd.x, hd.y);
   int st0 = (n_seg == 1) ? ST_ONLY : ST_FIRST;
   uint32_t n0 = rg.y - rg.x;
+  RealCig rc;
+  if (CLS != 1) rc.fetch(A.cigar + c0, c1 - c0);  // in flight with the row and rank loads below
   // k-th survivor in candidate-row order
   uint32_t k = A.m_k[mi64];
   uint64_t mm = mask;
@@ -934,19 +952,17 @@ __global__ void __launch_bounds__(256, SIMF ? 6 : 8) k_emit_dense(ProjectArgs A,
   uint4 pay = make_uint4(r_b.x, r_b.y, r_a.w, r_b.z);
   // rank by tid among the survivors
   uint32_t rank = 0;
-  for (uint64_t m2 = mask; m2;) {  // four independent loads in flight per step
-    uint32_t t4[4];
+  for (uint64_t m2 = mask; m2;) {  // eight loads in flight per step: unconditional (spent slots re-read the lane's own row)
+    uint32_t t8[8]; bool ok[8];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      t4[u] = 0xffffffffu;
-      if (m2) {
-        uint32_t b = (uint32_t)(__ffsll((long long)m2) - 1);
-        m2 &= m2 - 1;
-        t4[u] = ix.s_tid[b < n0 ? rg.x + b : rg.z + (b - n0)];
-      }
+    for (int u = 0; u < 8; u++) {
+      ok[u] = m2 != 0;
+      uint32_t b = ok[u] ? (uint32_t)(__ffsll((long long)m2) - 1) : item;
+      m2 &= m2 - 1;
+      t8[u] = ix.s_tid[b < n0 ? rg.x + b : rg.z + (b - n0)];
     }
 #pragma unroll
-    for (int u = 0; u < 4; u++) rank += (t4[u] < pay.x) ? 1u : 0u;
+    for (int u = 0; u < 8; u++) rank += (ok[u] && t8[u] < pay.x) ? 1u : 0u;
   }
   Hit h0;
   classify(s == 1, st0, q0.x, q0.y, gs, gend, pay.z, cfg, h0);
@@ -995,7 +1011,7 @@ __global__ void __launch_bounds__(256, SIMF ? 6 : 8) k_emit_dense(ProjectArgs A,
   if (SIMF) similarity(cfg, acc, score);
   bool out_lds = ideal_lds && (rd.n_real + n_ideal <= LDS_SLOT - LDS_IDEAL);
   uint32_t *outp = out_lds ? lds + LDS_IDEAL : slot;
-  uint32_t n_out = merge_cigars(rd.real, rd.n_real, ideal, n_ideal, outp);
+  uint32_t n_out = merge_cigars(rc, rd.n_real, ideal, n_ideal, outp);
   // rewritten CIGARs of <= 2 ops travel inside the match record (m_cigoff holds the
   // words themselves); longer ones stay in the arena slot
   uint64_t cig_ref = cbase + (uint64_t)rank * cap;
