@@ -445,27 +445,38 @@ struct Walker {
   bool minus;
 };
 
+// The exon after a candidate's slab row, from the row itself: e0 = {start, end, pos_start, -}, nx = {next start,
+// next end} (nx.x == 0: not known, ~0u: none).  pos_start runs in transcript order (src/bramble.cpp:161-175): on '+'
+// the next exon starts where this one ends, on '-' it lies before this one by its own length.
+__device__ __forceinline__ uint4 next_row(uint4 e0, uint2 nx, bool minus) {
+  return make_uint4(nx.x, nx.y, minus ? e0.z - (nx.y - nx.x) : e0.z + (e0.y - e0.x), 0u);
+}
+
 // One read exon against the candidate's transcript: the passing hits of this
 // tid (src/evaluate.cpp:205-237), correct_for_gaps (:111-182) and the
 // injectivity rules (:1023-1047) folded together.  i_last = table index of the
 // last guide segment; on STEP_HIT i_hit/h/gap2 are set (gap2: a GAP_EXON segment
 // for exon i_hit-1 precedes the match segment).
 __device__ __forceinline__ int step_exon(const DevIndex &ix, const DevCfg &cfg, const uint4 *E, bool minus,
-                                         uint32_t sb, uint32_t se, uint32_t i_last, uint4 e_last, int status,
-                                         uint32_t qs, uint32_t qe, uint32_t &i_hit, Hit &h, uint4 &ge, bool &gap2) {
+                                         uint32_t sb, uint32_t se, uint32_t i_last, uint4 e_last, bool have_e1, uint4 e1k,
+                                         int status, uint32_t qs, uint32_t qe, uint32_t &i_hit, Hit &h, uint4 &ge, bool &gap2) {
   uint32_t cnt = 0;
   Hit hh; uint4 ee;
-  // the row of the last guide segment is already in registers; the following rows are
-  // fetched two ahead so one round trip covers the usual "next exon, then stop" walk
-  // (tx_ex is padded, reading past a sentinel is harmless)
-  uint4 e = e_last, e1 = E[i_last + 1], e2 = E[i_last + 2];
+  // The row of the last guide segment is in registers, and so is the one after it when the walk still stands on
+  // the candidate's slab row (have_e1: the 32-byte row carries the next exon's start and end).  A later row is
+  // fetched only if the current one does not end the scan: exons of a transcript are disjoint and sorted, so
+  // once one reaches qend every later one starts at or beyond it (sentinel start = ~0u).
+  uint4 e = e_last, e1 = e1k;
+  if (!have_e1) e1 = E[i_last + 1];
   for (uint32_t i = i_last;; i++) {
-    if (e.x >= qe) break;             // start >= qend (sentinel start = ~0u)
+    if (e.x >= qe) break;             // start >= qend
     if (e.y > qs && classify(minus, status, qs, qe, e.x, e.y, e.z, cfg, hh)) {
       if (cnt == 0) { i_hit = i; h = hh; ee = e; }
       cnt++;
     }
-    e = e1; e1 = e2; e2 = E[i + 3];
+    if (e.y >= qe) break;
+    e = e1;
+    if (e.x < qe && e.y < qe) e1 = E[i + 2];
   }
   gap2 = false;
   if (cnt == 0) {
@@ -524,7 +535,7 @@ __device__ __forceinline__ ClipSide no_clip() { ClipSide c; c.ok = false; c.ops 
 // Pass 1 (src/evaluate.cpp:1004-1065): survival, segment counts, fwpos/rcpos.
 __device__ __forceinline__ CandOut walk_pass1(const DevIndex &ix, const DevCfg &cfg, const ReadCtx &rd,
                                               const uint4 *E, bool minus, uint32_t sb, uint32_t se,
-                                              uint32_t i0, uint4 e0, uint2 q0, const Hit &h0) {
+                                              uint32_t i0, uint4 e0, uint2 nx, uint2 q0, const Hit &h0) {
   CandOut o; o.alive = true; o.fwpos = h0.pos; o.rcpos = h0.pos; o.n_seg = 1; o.n_gex = 1;
   o.i_lastm = i0; o.last_right_ins = h0.right_ins; o.last_right_gap = h0.right_gap;
   uint32_t i_last = i0;
@@ -534,7 +545,7 @@ __device__ __forceinline__ CandOut walk_pass1(const DevIndex &ix, const DevCfg &
     uint2 q = rd.exon(j);
     int status = (j < rd.n_seg - 1) ? ST_MIDDLE : ST_LAST;
     uint32_t i_hit = 0; Hit h; uint4 ge; bool gap2;
-    int r = step_exon(ix, cfg, E, minus, sb, se, i_last, e_last, status, q.x, q.y, i_hit, h, ge, gap2);
+    int r = step_exon(ix, cfg, E, minus, sb, se, i_last, e_last, nx.x != 0 && i_last == i0, next_row(e0, nx, minus), status, q.x, q.y, i_hit, h, ge, gap2);
     if (r == STEP_DEAD || (q.x == pq.x && q.y == pq.y)) { o.alive = false; break; }
     pq = q;
     if (r == STEP_INS) { o.n_seg++; continue; }
@@ -580,7 +591,7 @@ __device__ __forceinline__ void build_clip(Acc &m, IdealSink &sk, const ClipSide
 // td.has_left_clip / has_right_clip for build_cigar_match.
 __device__ __forceinline__ void walk_pass2(const DevIndex &ix, const DevCfg &cfg, const ReadCtx &rd,
                                            const uint4 *E, bool minus, uint32_t sb, uint32_t se, uint32_t i0,
-                                           uint2 q0, uint4 e0, const Hit &h0_in,
+                                           uint2 q0, uint4 e0, uint2 nx, const Hit &h0_in,
                                            const CandOut &p1, Acc &acc, IdealSink &sk, const ClipSide &L,
                                            const ClipSide &R) {
   acc.init();
@@ -598,7 +609,7 @@ __device__ __forceinline__ void walk_pass2(const DevIndex &ix, const DevCfg &cfg
     uint2 q = rd.exon(j);
     int status = (j < rd.n_seg - 1) ? ST_MIDDLE : ST_LAST;
     uint32_t i_hit = 0; Hit h; uint4 ge; bool gap2;
-    int r = step_exon(ix, cfg, E, minus, sb, se, i_last, e_last, status, q.x, q.y, i_hit, h, ge, gap2);
+    int r = step_exon(ix, cfg, E, minus, sb, se, i_last, e_last, nx.x != 0 && i_last == i0, next_row(e0, nx, minus), status, q.x, q.y, i_hit, h, ge, gap2);
     if (r == STEP_INS) {  // build_cigar_ins (:788-806) + junc_hits (:1089-1091)
       uint32_t len = q.y - q.x;
       bool edge = (k == 0 || k == p1.n_seg - 1);
@@ -779,7 +790,7 @@ __global__ void __launch_bounds__(256, EMIT ? 4 : 8) k_project(ProjectArgs A) {
         uint32_t item = base + (uint32_t)gl;
         bool valid = item < n_items;
         bool alive = false;
-        int s = 0; uint32_t row = 0, gs = 0, gend = 0, nxt = 0;
+        int s = 0; uint32_t row = 0, gs = 0, gend = 0, nxt = 0, nxe = 0;
         uint4 pay = make_uint4(0xffffffffu, 0, 0, 0);
         Hit h0; CandOut p1; const uint4 *E = nullptr; uint32_t i0 = 0;
         p1.alive = false; p1.fwpos = 0; p1.rcpos = 0; p1.n_seg = 0; p1.n_gex = 0;
@@ -789,7 +800,7 @@ __global__ void __launch_bounds__(256, EMIT ? 4 : 8) k_project(ProjectArgs A) {
           row = s == 0 ? lo[0] + item : lo[1] + (item - n0);
           // one round trip, one sector: the 32-byte row
           const uint4 r_a = ix.s_row[2 * (size_t)row], r_b = ix.s_row[2 * (size_t)row + 1];
-          gs = r_a.x; gend = r_a.y; nxt = r_a.z; pay = make_uint4(r_b.x, r_b.y, r_a.w, r_b.z);
+          gs = r_a.x; gend = r_a.y; nxt = r_a.z; nxe = r_b.w; pay = make_uint4(r_b.x, r_b.y, r_a.w, r_b.z);
           bool want = true;
           if (EMIT && have_mask) want = (mask_in >> item) & 1ull;
           if (want && gend > q0.x && classify(s == 1, st0, q0.x, q0.y, gs, gend, pay.z, cfg, h0)) {
@@ -808,7 +819,7 @@ __global__ void __launch_bounds__(256, EMIT ? 4 : 8) k_project(ProjectArgs A) {
             }
             if (!superseded) {
               if (n_seg == 1) { p1.alive = true; p1.fwpos = h0.pos; p1.rcpos = h0.pos; p1.n_seg = 1; p1.n_gex = 1; p1.i_lastm = i0; p1.last_right_ins = h0.right_ins; p1.last_right_gap = h0.right_gap; }
-              else p1 = walk_pass1(ix, cfg, rd, E, s == 1, sb[s], se[s], i0, make_uint4(gs, gend, pay.z, 0), q0, h0);
+              else p1 = walk_pass1(ix, cfg, rd, E, s == 1, sb[s], se[s], i0, make_uint4(gs, gend, pay.z, 0), make_uint2(nxt, nxe), q0, h0);
               alive = p1.alive;
             }
           }
@@ -819,7 +830,7 @@ __global__ void __launch_bounds__(256, EMIT ? 4 : 8) k_project(ProjectArgs A) {
           // cfg.filter_by_similarity lifted to compile time so the short-read kernel drops this code)
           if (SIMF && alive) {
             sk.init(nullptr);
-            walk_pass2(ix, cfg, rd, E, s == 1, sb[s], se[s], i0, q0, make_uint4(gs, gend, pay.z, 0), h0, p1, acc, sk, no_clip(), no_clip());
+            walk_pass2(ix, cfg, rd, E, s == 1, sb[s], se[s], i0, q0, make_uint4(gs, gend, pay.z, 0), make_uint2(nxt, nxe), h0, p1, acc, sk, no_clip(), no_clip());
             alive = similarity(cfg, acc, score);
           }
         }
@@ -863,7 +874,7 @@ __global__ void __launch_bounds__(256, EMIT ? 4 : 8) k_project(ProjectArgs A) {
           bool ideal_lds = ideal_cap <= LDS_IDEAL;
           uint32_t *ideal = ideal_lds ? lds : slot + rd.n_real + ideal_cap;
           sk.init(ideal);
-          walk_pass2(ix, cfg, rd, E, s == 1, sb[s], se[s], i0, q0, make_uint4(gs, gend, pay.z, 0), h0, p1, acc, sk, no_clip(), no_clip());
+          walk_pass2(ix, cfg, rd, E, s == 1, sb[s], se[s], i0, q0, make_uint4(gs, gend, pay.z, 0), make_uint2(nxt, nxe), h0, p1, acc, sk, no_clip(), no_clip());
           uint32_t n_ideal = sk.finish();
           similarity(cfg, acc, score);
           bool out_lds = ideal_lds && (rd.n_real + n_ideal <= LDS_SLOT - LDS_IDEAL);
@@ -997,7 +1008,7 @@ __global__ void __launch_bounds__(256, SIMF ? 6 : 8) k_emit_dense(ProjectArgs A,
   CandOut p1;
   uint32_t sb = ix.slab_off[2 * rid + s], se = ix.slab_off[2 * rid + s + 1];
   if (n_seg == 1) { p1.alive = true; p1.fwpos = h0.pos; p1.rcpos = h0.pos; p1.n_seg = 1; p1.n_gex = 1; p1.i_lastm = i0; p1.last_right_ins = h0.right_ins; p1.last_right_gap = h0.right_gap; }
-  else p1 = walk_pass1(ix, cfg, rd, E, s == 1, sb, se, i0, make_uint4(gs, gend, pay.z, 0), q0, h0);
+  else p1 = walk_pass1(ix, cfg, rd, E, s == 1, sb, se, i0, make_uint4(gs, gend, pay.z, 0), make_uint2(r_a.z, r_b.w), q0, h0);
   uint32_t ideal_cap = 4u * n_seg + 2u;
   uint32_t cap = rd.n_real + 2u * ideal_cap;
   uint32_t *slot = A.cig_arena + cbase + (uint64_t)rank * cap;
@@ -1006,7 +1017,7 @@ __global__ void __launch_bounds__(256, SIMF ? 6 : 8) k_emit_dense(ProjectArgs A,
   uint32_t *ideal = ideal_lds ? lds : slot + rd.n_real + ideal_cap;
   Acc acc; IdealSink sk; double score = 0.0;
   sk.init(ideal);
-  walk_pass2(ix, cfg, rd, E, s == 1, sb, se, i0, q0, make_uint4(gs, gend, pay.z, 0), h0, p1, acc, sk, no_clip(), no_clip());
+  walk_pass2(ix, cfg, rd, E, s == 1, sb, se, i0, q0, make_uint4(gs, gend, pay.z, 0), make_uint2(r_a.z, r_b.w), h0, p1, acc, sk, no_clip(), no_clip());
   uint32_t n_ideal = sk.finish();
   if (SIMF) similarity(cfg, acc, score);
   bool out_lds = ideal_lds && (rd.n_real + n_ideal <= LDS_SLOT - LDS_IDEAL);
