@@ -1078,13 +1078,50 @@ __device__ __forceinline__ uint64_t scan_value(const ScanArgs &S, int64_t i) {
   return (uint64_t)nm * (uint64_t)(n_real + 2u * ideal_cap);
 }
 
+// A thread's SCAN_ITEMS consecutive 32-bit inputs as two 16-byte loads (base is a multiple of 8 items = 32 bytes; the
+// arrays are allocations or 16-byte aligned offsets into one).  One 4-byte load per item made a wave touch every
+// eighth word of a 2 KB span eight times over.
+__device__ __forceinline__ void load8(const uint32_t *p, int64_t base, int64_t n, uint32_t v[SCAN_ITEMS]) {
+  if (base + SCAN_ITEMS <= n && ((uintptr_t)(p + base) & 15u) == 0) {
+    const uint4 a = *(const uint4 *)(p + base), b = *(const uint4 *)(p + base + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  } else {
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) v[k] = (base + k < n) ? p[base + k] : 0u;
+  }
+}
+__device__ __forceinline__ void store8(uint32_t *p, int64_t base, int64_t n, const uint32_t v[SCAN_ITEMS]) {
+  if (base + SCAN_ITEMS <= n && ((uintptr_t)(p + base) & 15u) == 0) {
+    *(uint4 *)(p + base) = make_uint4(v[0], v[1], v[2], v[3]); *(uint4 *)(p + base + 4) = make_uint4(v[4], v[5], v[6], v[7]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) if (base + k < n) p[base + k] = v[k];
+  }
+}
+__device__ __forceinline__ void store8(uint64_t *p, int64_t base, int64_t n, const uint64_t v[SCAN_ITEMS]) {
+  if (base + SCAN_ITEMS <= n && ((uintptr_t)(p + base) & 15u) == 0) {
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k += 2) *(ulonglong2 *)(p + base + k) = make_ulonglong2(v[k], v[k + 1]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) if (base + k < n) p[base + k] = v[k];
+  }
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(256) k_scan_tiles(ScanArgs S) {
   __shared__ uint64_t sh[4];
   int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
   uint64_t sum = 0;
+  if (MODE == 0 || MODE == 2) {
+    uint32_t v[SCAN_ITEMS];
+    load8(S.src32, base, S.n, v);
 #pragma unroll
-  for (int k = 0; k < SCAN_ITEMS; k++) { int64_t i = base + k; if (i < S.n) sum += scan_value<MODE>(S, i); }
+    for (int k = 0; k < SCAN_ITEMS; k++) sum += v[k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) { int64_t i = base + k; if (i < S.n) sum += scan_value<MODE>(S, i); }
+  }
   uint64_t tot;
   block_excl_scan_256(sum, sh, tot);
   if (threadIdx.x == 0) S.tile_sums[blockIdx.x] = tot;
@@ -1111,12 +1148,21 @@ __global__ void __launch_bounds__(256) k_scan_apply(ScanArgs S, OutT *out) {
   int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
   uint64_t v[SCAN_ITEMS];
   uint64_t sum = 0;
+  if (MODE == 0 || MODE == 2) {
+    uint32_t w[SCAN_ITEMS];
+    load8(S.src32, base, S.n, w);
 #pragma unroll
-  for (int k = 0; k < SCAN_ITEMS; k++) { int64_t i = base + k; v[k] = i < S.n ? scan_value<MODE>(S, i) : 0; sum += v[k]; }
+    for (int k = 0; k < SCAN_ITEMS; k++) { v[k] = w[k]; sum += v[k]; }
+  } else {
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) { int64_t i = base + k; v[k] = i < S.n ? scan_value<MODE>(S, i) : 0; sum += v[k]; }
+  }
   uint64_t tot;
   uint64_t ex = block_excl_scan_256(sum, sh, tot) + S.tile_sums[blockIdx.x];
+  OutT o[SCAN_ITEMS];
 #pragma unroll
-  for (int k = 0; k < SCAN_ITEMS; k++) { int64_t i = base + k; if (i < S.n) out[i] = (OutT)ex; ex += v[k]; }
+  for (int k = 0; k < SCAN_ITEMS; k++) { o[k] = (OutT)ex; ex += v[k]; }
+  store8(out, base, S.n, o);
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) out[S.n] = (OutT)ex;
 }
 
@@ -1135,12 +1181,31 @@ __device__ __forceinline__ Scan3 scan3_value(const ScanArgs &S, int64_t i) {
   }
   return r;
 }
+// a thread's SCAN_ITEMS values: vector loads of n_matches and the class word unless the -S capacities are in play
+__device__ __forceinline__ void scan3_load(const ScanArgs &S, int64_t base, Scan3 v[SCAN_ITEMS]) {
+  if (!S.ideal_cap) {
+    uint32_t nm[SCAN_ITEMS], cf[SCAN_ITEMS];
+    load8(S.src32, base, S.n, nm); load8(S.fast_flag, base, S.n, cf);
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+      v[k].v[0] = nm[k]; v[k].v[1] = (uint64_t)nm[k] * (uint64_t)(cf[k] & 0x7fffffffu); v[k].v[2] = (cf[k] >> 31) ? nm[k] : 0;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+      int64_t i = base + k;
+      if (i < S.n) v[k] = scan3_value(S, i); else { v[k].v[0] = v[k].v[1] = v[k].v[2] = 0; }
+    }
+  }
+}
 __global__ void __launch_bounds__(256) k_scan3_tiles(ScanArgs S) {
   __shared__ uint64_t sh[4];
   int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
   uint64_t sum[3] = {0, 0, 0};
+  Scan3 v[SCAN_ITEMS];
+  scan3_load(S, base, v);
 #pragma unroll
-  for (int k = 0; k < SCAN_ITEMS; k++) { int64_t i = base + k; if (i < S.n) { Scan3 x = scan3_value(S, i); sum[0] += x.v[0]; sum[1] += x.v[1]; sum[2] += x.v[2]; } }
+  for (int k = 0; k < SCAN_ITEMS; k++) { sum[0] += v[k].v[0]; sum[1] += v[k].v[1]; sum[2] += v[k].v[2]; }
 #pragma unroll
   for (int c = 0; c < 3; c++) { uint64_t tot; block_excl_scan_256(sum[c], sh, tot); if (threadIdx.x == 0) S.tile_sums[(int64_t)c * S.n_tiles + blockIdx.x] = tot; }
 }
@@ -1165,21 +1230,19 @@ __global__ void __launch_bounds__(256) k_scan3_apply(ScanArgs S, uint32_t *match
   int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
   Scan3 v[SCAN_ITEMS];
   uint64_t sum[3] = {0, 0, 0};
+  scan3_load(S, base, v);
 #pragma unroll
-  for (int k = 0; k < SCAN_ITEMS; k++) {
-    int64_t i = base + k;
-    if (i < S.n) v[k] = scan3_value(S, i); else { v[k].v[0] = v[k].v[1] = v[k].v[2] = 0; }
-    sum[0] += v[k].v[0]; sum[1] += v[k].v[1]; sum[2] += v[k].v[2];
-  }
+  for (int k = 0; k < SCAN_ITEMS; k++) { sum[0] += v[k].v[0]; sum[1] += v[k].v[1]; sum[2] += v[k].v[2]; }
   uint64_t ex[3];
 #pragma unroll
   for (int c = 0; c < 3; c++) { uint64_t tot; ex[c] = block_excl_scan_256(sum[c], sh, tot) + S.tile_sums[(int64_t)c * S.n_tiles + blockIdx.x]; }
+  uint32_t o0[SCAN_ITEMS], o2[SCAN_ITEMS]; uint64_t o1[SCAN_ITEMS];
 #pragma unroll
   for (int k = 0; k < SCAN_ITEMS; k++) {
-    int64_t i = base + k;
-    if (i < S.n) { match_off[i] = (uint32_t)ex[0]; cig_base[i] = ex[1]; fast_pre[i] = (uint32_t)ex[2]; }
+    o0[k] = (uint32_t)ex[0]; o1[k] = ex[1]; o2[k] = (uint32_t)ex[2];
     ex[0] += v[k].v[0]; ex[1] += v[k].v[1]; ex[2] += v[k].v[2];
   }
+  store8(match_off, base, S.n, o0); store8(cig_base, base, S.n, o1); store8(fast_pre, base, S.n, o2);
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) { match_off[S.n] = (uint32_t)ex[0]; cig_base[S.n] = ex[1]; fast_pre[S.n] = (uint32_t)ex[2]; }
 }
 
