@@ -710,52 +710,59 @@ __global__ void __launch_bounds__(256, EMIT ? 4 : 8) k_project(ProjectArgs A) {
       uint4 rg = A.ranges[a];
       lo[0] = rg.x; hi[0] = rg.y; lo[1] = rg.z; hi[1] = rg.w;
     } else {
-      // Candidate rows of read exon 0 on strand s: [lo, hi) with hi = first row with
-      // start >= qend and lo = first row whose running max end exceeds qstart.  The
-      // bucket tables bound both to one coordinate bin; a G-wide count finishes.
-      uint32_t ra[4], rb[4];  // 0/1: hi/lo on '+', 2/3: hi/lo on '-'
-      // Memory-level parallelism first: the waves spend their time in dependent round trips, not in issue
-      // (profiles/r01/pmc_count_pass.txt), so every load of a stage is unconditional (clamped to a valid
-      // entry; every slab owns >= 3 table entries) and all of a stage's loads are in flight together.
-      uint32_t tw[8];
+      // Candidate rows of read exon 0 on strand s, bounded by the bucket tables alone: from the first row whose
+      // running max end exceeds the bin edge at or below qstart to the first row that starts at or beyond the bin
+      // edge above qend.  A superset (x1.5 rows on GENCODE-shaped data) of the exact [lo, hi) a search inside the bins
+      // would give -- every row is tested for overlap anyway -- that costs one dependent round trip less.
+      uint32_t tw[4];
 #pragma unroll
-      for (int s = 0; s < 2; s++) {
+      for (int s = 0; s < 2; s++) {  // every slab owns >= 3 table entries: unconditional loads
         uint32_t bo = slab_in_lds ? sh_bin[2 * rid + s] : ix.bin_off[2 * rid + s];
         uint32_t nb = (slab_in_lds ? sh_bin[2 * rid + s + 1] : ix.bin_off[2 * rid + s + 1]) - bo - 1;
         uint32_t bh = q0.y >> ix.bin_shift, bl = q0.x >> ix.bin_shift;
         bh = bh < nb - 1 ? bh : nb - 1; bl = bl < nb - 1 ? bl : nb - 1;
-        tw[4 * s + 0] = ix.t_hi[bo + bh]; tw[4 * s + 1] = ix.t_hi[bo + bh + 1];
-        tw[4 * s + 2] = ix.t_lo[bo + bl]; tw[4 * s + 3] = ix.t_lo[bo + bl + 1];
+        tw[2 * s] = ix.t_lo[bo + bl]; tw[2 * s + 1] = ix.t_hi[bo + bh + 1];
       }
 #pragma unroll
       for (int s = 0; s < 2; s++) {
         const bool use = ((smode >> s) & 1u) && sb[s] != se[s];
-        ra[2 * s] = use ? tw[4 * s + 0] : sb[s]; rb[2 * s] = use ? tw[4 * s + 1] : sb[s];
-        ra[2 * s + 1] = use ? tw[4 * s + 2] : sb[s]; rb[2 * s + 1] = use ? tw[4 * s + 3] : sb[s];
+        hi[s] = use ? tw[2 * s + 1] : sb[s];
+        lo[s] = use ? (tw[2 * s] < hi[s] ? tw[2 * s] : hi[s]) : sb[s];
       }
-      // all four counts advance together: one round trip per G rows instead of four
-      uint32_t res[4] = {ra[0], ra[1], ra[2], ra[3]};
-      const uint32_t last_row = ix.n_rows - 1;  // only read when some range is non-empty, i.e. n_rows >= 1
-      for (uint32_t it = 0;; it += G) {
-        bool any = false;
+      if ((hi[0] - lo[0]) + (hi[1] - lo[1]) > 64u) {
+        // Dense locus: more rows than the survivor mask has bits.  Tighten to the exact range (hi = first row with
+        // start >= qend, lo = first row whose running max end exceeds qstart) with a G-wide count inside the two bins,
+        // so that only alignments with > 64 overlapping-range rows go to the wave-per-alignment emit kernel.
+        uint32_t ra[4], rb[4];  // 0/1: hi/lo on '+', 2/3: hi/lo on '-'
 #pragma unroll
-        for (int k = 0; k < 4; k++) any |= (ra[k] + it) < rb[k];
-        if (!any) break;
-        uint32_t vv[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          uint32_t r = ra[k] + it + (uint32_t)gl;
-          r = r < last_row ? r : last_row;
-          vv[k] = (k & 1) ? ix.s_pmax[r] : ix.s_start[r];
+        for (int s = 0; s < 2; s++) {
+          ra[2 * s] = rb[2 * s] = ra[2 * s + 1] = rb[2 * s + 1] = sb[s];
+          if (!((smode >> s) & 1u) || sb[s] == se[s]) continue;
+          uint32_t bo = slab_in_lds ? sh_bin[2 * rid + s] : ix.bin_off[2 * rid + s];
+          uint32_t nb = (slab_in_lds ? sh_bin[2 * rid + s + 1] : ix.bin_off[2 * rid + s + 1]) - bo - 1;
+          uint32_t bh = q0.y >> ix.bin_shift, bl = q0.x >> ix.bin_shift;
+          bh = bh < nb - 1 ? bh : nb - 1; bl = bl < nb - 1 ? bl : nb - 1;
+          ra[2 * s] = ix.t_hi[bo + bh]; rb[2 * s] = hi[s];
+          ra[2 * s + 1] = tw[2 * s]; rb[2 * s + 1] = ix.t_lo[bo + bl + 1];
         }
+        uint32_t res[4] = {ra[0], ra[1], ra[2], ra[3]};
+        for (uint32_t it = 0;; it += G) {
+          bool any = false;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          bool t = (ra[k] + it + (uint32_t)gl < rb[k]) && ((k & 1) ? (vv[k] <= q0.x) : (vv[k] < q0.y));
-          res[k] += (uint32_t)__popcll((__ballot(t) >> gbase) & gmask);
+          for (int k = 0; k < 4; k++) any |= (ra[k] + it) < rb[k];
+          if (!any) break;
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            uint32_t r = ra[k] + it + (uint32_t)gl;
+            bool in = r < rb[k];
+            uint32_t v = in ? ((k & 1) ? ix.s_pmax[r] : ix.s_start[r]) : 0u;
+            bool t = in && ((k & 1) ? (v <= q0.x) : (v < q0.y));
+            res[k] += (uint32_t)__popcll((__ballot(t) >> gbase) & gmask);
+          }
         }
+        hi[0] = res[0]; lo[0] = res[1] < res[0] ? res[1] : res[0];
+        hi[1] = res[2]; lo[1] = res[3] < res[2] ? res[3] : res[2];
       }
-      hi[0] = res[0]; lo[0] = res[1] < res[0] ? res[1] : res[0];
-      hi[1] = res[2]; lo[1] = res[3] < res[2] ? res[3] : res[2];
       if (gl == 0) A.ranges[a] = make_uint4(lo[0], hi[0], lo[1], hi[1]);
     }
     uint32_t n0 = hi[0] - lo[0], n1 = hi[1] - lo[1];
@@ -803,7 +810,7 @@ __global__ void __launch_bounds__(256, EMIT ? 4 : 8) k_project(ProjectArgs A) {
           gs = r_a.x; gend = r_a.y; nxt = r_a.z; nxe = r_b.w; pay = make_uint4(r_b.x, r_b.y, r_a.w, r_b.z);
           bool want = true;
           if (EMIT && have_mask) want = (mask_in >> item) & 1ull;
-          if (want && gend > q0.x && classify(s == 1, st0, q0.x, q0.y, gs, gend, pay.z, cfg, h0)) {
+          if (want && gend > q0.x && gs < q0.y && classify(s == 1, st0, q0.x, q0.y, gs, gend, pay.z, cfg, h0)) {
             E = ix.tx_ex + pay.w; i0 = pay.y;
             // first-exon duplicate tid: the LAST passing row of the tid wins
             // (src/evaluate.cpp:218-224); later rows of the same tid are the
