@@ -140,7 +140,7 @@ static int build_index_flat(size_t n_tx, const int32_t *tx_ref, const int8_t *tx
     ix->slab_off.push_back((uint32_t)ix->s_start.size());
   }
   // bucket tables (replace the per-read binary search of the slab)
-  const uint32_t SHIFT = 11;
+  const uint32_t SHIFT = 10;
   ix->bin_off.push_back(0);
   for (size_t sl = 0; sl + 1 < ix->slab_off.size(); sl++) {
     uint32_t sb = ix->slab_off[sl], se = ix->slab_off[sl + 1];
