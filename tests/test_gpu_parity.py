@@ -237,3 +237,51 @@ def test_one_context_across_presets_and_batch_sizes():
             assert not prod["similarity_score"].any() and not prod["clip_score"].any()
     ctx.close()
     idx.close()
+
+
+def test_bucket_table_ranges_at_bin_edges():
+    """The count pass takes its candidate rows straight from the 1 kb bucket tables ([t_lo[bin(qstart)],
+    t_hi[bin(qend) + 1]), exact search only above 64 rows).  Crafted loci against the oracle: exons that span many bins
+    (the range must reach back to a row that starts far to the left), nested and abutting exons around multiples of
+    1024, a locus with > 64 transcripts in one bin, reads in the last bin of a reference, beyond every exon, and on a
+    reference without transcripts."""
+    txs = []
+    # a 60 kb exon with short exons nested inside its span (other transcripts), on both strands
+    txs.append({"id": "long+", "ref_id": 0, "strand": "+", "exons": [[1000, 61000], [70000, 70200]]})
+    txs.append({"id": "long-", "ref_id": 0, "strand": "-", "exons": [[500, 62000]]})
+    for k in range(40):
+        s = 1024 * (k + 2) - 3 * (k % 5)            # starts hugging bin edges
+        txs.append({"id": "in%d" % k, "ref_id": 0, "strand": "+-"[k & 1], "exons": [[s, s + 90 + k], [s + 400, s + 520]]})
+    # 90 isoforms sharing a first exon inside one bin (more candidates than the mask has bits), second exons differ
+    for k in range(90):
+        txs.append({"id": "iso%d" % k, "ref_id": 1, "strand": "+", "exons": [[5000, 5150], [5300 + 2 * k, 5400 + 2 * k]]})
+    # last bin of reference 1 and an abutting pair across a bin edge
+    txs.append({"id": "tail", "ref_id": 1, "strand": "-", "exons": [[204700, 204801]]})
+    txs.append({"id": "abutA", "ref_id": 1, "strand": "+", "exons": [[8000, 8192]]})
+    txs.append({"id": "abutB", "ref_id": 1, "strand": "+", "exons": [[8192, 8300]]})
+    ann = {"refnames": ["r0", "r1", "empty"], "transcripts": txs}   # exons are 1-based half-open here
+    reads = []
+
+    def rd(ref, start, cigar, **kw):
+        reads.append(dict(name="q%d" % len(reads), ref_id=ref, ref_start=start, cigar=cigar, read_len=100, **kw))
+    for p in (1000, 1023, 1024, 1025, 2040, 30000, 30719, 30720, 60900, 60999, 61000, 61500, 69999, 70100):
+        rd(0, p, "100M")
+    for k in range(0, 40, 3):
+        s = 1024 * (k + 2) - 3 * (k % 5)
+        rd(0, s, "90M%dN10M" % (400 - 90))          # spliced onto the nested transcripts
+        rd(0, s + 5, "50M")
+    for p in (4990, 5000, 5049, 5100):
+        rd(1, p, "100M")
+    rd(1, 5050, "100M%dN50M" % 170)                 # junction into iso10's second exon
+    for p in (204690, 204700, 204750, 204800, 300000):
+        rd(1, p, "50M")
+    for p in (8100, 8150, 8191, 8192, 8200):
+        rd(1, p, "60M")
+    rd(2, 100, "100M")
+    rd(-1, 0, "100M")
+    batch = make_batch(reads)
+    for flags in ({}, {"strict": 1}, {"lr": 1}):
+        for gl in (8, 64):
+            prod, orc = run_both(ann, batch, group_lanes=gl, **flags)
+            assert orc["n_rows"] > 100
+            assert_rows_equal(prod, orc)
