@@ -55,13 +55,15 @@ __global__ void __launch_bounds__(256) k_bam_scan(BamArgs B) {
   int8_t xs_c = 0, ts_c = 0;
   bool have_xs = false, have_ts = false;
   for (int k = 0; k < 4; k++) { x.off[k] = 0xffffffffu; x.len[k] = 0; }
-  x.as_val = 0; x.aux_start = 0; x.aux_len = 0;
+  x.as_val = 0; x.aux_start = 0; x.aux_len = 0; x.c_a = x.c_b = x.c_c = 0; x.qual_present = 0;
   if (rlen >= 32) {
     uint32_t l_qname = rec[8], n_cig = ld_u16(rec + 12);
     int32_t l_seq = (int32_t)ld_u32(rec + 16);
     uint64_t ls = l_seq > 0 ? (uint64_t)l_seq : 0;
     uint64_t start = 32 + (uint64_t)l_qname + 4ull * n_cig + (ls + 1) / 2 + ls;
+    x.c_a = ld_u32(rec + 8); x.c_b = ld_u32(rec + 12); x.c_c = (uint32_t)l_seq;
     if (start <= rlen) {
+      if (ls > 0) x.qual_present = rec[32 + (uint64_t)l_qname + 4ull * n_cig + (ls + 1) / 2] != 0xff;
       x.aux_start = (uint32_t)start; x.aux_len = (uint32_t)(rlen - start);
       const uint8_t *s = rec + start, *end = rec + rlen;
       // slots: 0 NH, 1 XS (short) / ts (long), 2 HI, 3 AS (long reads only)
@@ -110,8 +112,8 @@ __global__ void __launch_bounds__(256) k_bam_scan(BamArgs B) {
 }
 
 __device__ __forceinline__ uint32_t row_out_len(const BamArgs &B, int64_t r, const uint8_t *rec, const BamAux &x) {
-  uint32_t l_qname = rec[8];
-  int32_t l_seq = (int32_t)ld_u32(rec + 16);
+  uint32_t l_qname = x.c_a & 0xffu;
+  int32_t l_seq = (int32_t)x.c_c;
   uint32_t ls = l_seq > 0 ? (uint32_t)l_seq : 0;
   uint32_t removed = x.len[0] + x.len[1] + x.len[2] + x.len[3];
   uint32_t added = 7u + 7u + (B.long_reads ? 7u : 0u);  // NH:i, HI:i, AS:i
@@ -137,20 +139,25 @@ typedef uint32_t u32u __attribute__((aligned(1)));
 
 template <int G>
 __device__ __forceinline__ void copy_fwd(uint8_t *dst, const uint8_t *src, uint32_t n, int lane) {
-  uint32_t n16 = n & ~15u;
-  for (uint32_t i = 16u * lane; i < n16; i += 16u * G) *(W4 *)(dst + i) = *(const W4 *)(src + i);
-  for (uint32_t i = n16 + lane; i < n; i += G) dst[i] = src[i];
+  if (n >= 16u) {  // ceil(n / 16) chunks, the last one ending at n: it overlaps its predecessor (same bytes) and saves the byte tail
+    for (uint32_t i = 16u * lane; i < n; i += 16u * G) { uint32_t o = i + 16u <= n ? i : n - 16u; *(W4 *)(dst + o) = *(const W4 *)(src + o); }
+  } else {
+    for (uint32_t i = lane; i < n; i += G) dst[i] = src[i];
+  }
 }
 // dst[i] = src[n-1-i]
 template <int G>
 __device__ __forceinline__ void copy_rev(uint8_t *dst, const uint8_t *src, uint32_t n, int lane) {
-  uint32_t n16 = n & ~15u;
-  for (uint32_t i = 16u * lane; i < n16; i += 16u * G) {
-    W4 w = *(const W4 *)(src + (n - 16u - i));
-    W4 o; o.a = __builtin_bswap32(w.d); o.b = __builtin_bswap32(w.c); o.c = __builtin_bswap32(w.b); o.d = __builtin_bswap32(w.a);
-    *(W4 *)(dst + i) = o;
+  if (n >= 16u) {
+    for (uint32_t i0 = 16u * lane; i0 < n; i0 += 16u * G) {
+      uint32_t i = i0 + 16u <= n ? i0 : n - 16u;
+      W4 w = *(const W4 *)(src + (n - 16u - i));
+      W4 o; o.a = __builtin_bswap32(w.d); o.b = __builtin_bswap32(w.c); o.c = __builtin_bswap32(w.b); o.d = __builtin_bswap32(w.a);
+      *(W4 *)(dst + i) = o;
+    }
+  } else {
+    for (uint32_t i = lane; i < n; i += G) dst[i] = src[n - 1 - i];
   }
-  for (uint32_t i = n16 + lane; i < n; i += G) dst[i] = src[n - 1 - i];
 }
 // reverse-complement of 8 packed 4-bit bases (one dword of BAM SEQ): reversing all 32 bits
 // reverses the base order AND maps A(1)<->T(8), C(2)<->G(4); every other code becomes N(15)
@@ -171,11 +178,11 @@ template <int G>
 __device__ __forceinline__ void encode_row(const BamArgs &B, int64_t r, int lane, const uint8_t *rec, const BamAux &x,
                                            uint8_t *out, uint32_t total) {
 
-  W4 c0 = *(const W4 *)(rec + 8);   // l_qname|mapq|bin, n_cigar|flag, l_seq, next_refID
-  uint32_t l_qname = c0.a & 0xffu;
-  uint32_t bin = c0.a >> 16;
-  uint32_t n_cig_in = c0.b & 0xffffu, flag = c0.b >> 16;
-  int32_t l_seq = (int32_t)c0.c;
+  // l_qname|mapq|bin, n_cigar|flag, l_seq as k_bam_scan read them: no dependent read of the record before its regions
+  uint32_t l_qname = x.c_a & 0xffu;
+  uint32_t bin = x.c_a >> 16;
+  uint32_t n_cig_in = x.c_b & 0xffffu, flag = x.c_b >> 16;
+  int32_t l_seq = (int32_t)x.c_c;
   uint32_t ls = l_seq > 0 ? (uint32_t)l_seq : 0;
   uint32_t n_cig = B.r_ncig[r];
   bool minus = B.r_strand[r] == '-';
@@ -233,7 +240,7 @@ __device__ __forceinline__ void encode_row(const BamArgs &B, int64_t r, int lane
   o += sb;
   // qualities: reversed on '-' unless absent (0xff) (bam.cpp:680-686)
   const uint8_t *qual = seq + sb;
-  bool rev_q = minus && ls > 0 && qual[0] != 0xff;
+  bool rev_q = minus && ls > 0 && x.qual_present;
   if (rev_q) copy_rev<G>(out + o, qual, ls, lane); else copy_fwd<G>(out + o, qual, ls, lane);
   o += ls;
   // aux: original minus the first NH, XS|ts, HI (and AS for long reads): up to five kept pieces ...
@@ -249,21 +256,19 @@ __device__ __forceinline__ void encode_row(const BamArgs &B, int64_t r, int lane
   copy_fwd<G>(out + o, aux + src, x.aux_len - src, lane);
   o += x.aux_len - src;
   // ... plus NH:i, (AS:i,) HI:i appended in that order (bam.cpp:590-634, core.cpp:118-161)
-  for (int tb = lane; tb < 21; tb += G) {
-    int which = tb / 7, k = tb % 7;
-    bool lr = B.long_reads != 0;
-    if (which < (lr ? 3 : 2)) {
-      int kind = which == 0 ? 0 : (lr ? (which == 1 ? 1 : 2) : 2);  // 0 NH, 1 AS, 2 HI
-      uint32_t val;
-      if (kind == 0) val = B.r_nh[r];
-      else if (kind == 2) val = B.r_hi[r];
-      else val = (uint32_t)(int32_t)(((double)x.as_val + (double)B.r_clip[r]) * B.r_sim[r]);  // set_as_tag
-      uint8_t byte;
-      const char *tags = "NHASHI";
-      if (k < 2) byte = (uint8_t)tags[2 * kind + k];
-      else if (k == 2) byte = 'i';
-      else byte = (uint8_t)(val >> (8 * (k - 3)));
-      out[o + 7 * which + k] = byte;
+  // one lane per tag: seven bytes [t0 t1 'i' v0 v1 v2 v3] as two overlapping unaligned dwords
+  {
+    const bool lr = B.long_reads != 0;
+    const int n_tags = lr ? 3 : 2;
+    if (lane < n_tags) {
+      const int kind = lane == 0 ? 0 : (lr ? (lane == 1 ? 1 : 2) : 2);  // 0 NH, 1 AS, 2 HI
+      uint32_t val, t01;
+      if (kind == 0) { val = B.r_nh[r]; t01 = (uint32_t)'N' | ((uint32_t)'H' << 8); }
+      else if (kind == 2) { val = B.r_hi[r]; t01 = (uint32_t)'H' | ((uint32_t)'I' << 8); }
+      else { val = (uint32_t)(int32_t)(((double)x.as_val + (double)B.r_clip[r]) * B.r_sim[r]); t01 = (uint32_t)'A' | ((uint32_t)'S' << 8); }  // set_as_tag
+      uint8_t *t = out + o + 7 * lane;
+      *(u32u *)t = t01 | ((uint32_t)'i' << 16) | (val << 24);
+      *(u32u *)(t + 3) = val;
     }
   }
 }

@@ -131,6 +131,10 @@ struct BamAux {
   uint32_t off[4], len[4];  // removal intervals inside the aux area, sorted by offset (~0u: none)
   int32_t as_val;           // input AS value (long reads)
   uint32_t aux_start, aux_len;
+  // what the encoder needs of the fixed fields, so that it starts from this one record instead of a dependent read of
+  // the input: l_read_name | mapq << 8 | bin << 16, n_cigar_op | flag << 16, l_seq (record bytes 8..19); and whether
+  // qualities are present (first QUAL byte != 0xff, src/bam.cpp:680)
+  uint32_t c_a, c_b, c_c, qual_present;
 };
 struct BamArgs {
   int64_t n_aln, n_rows;
