@@ -651,12 +651,14 @@ __device__ __forceinline__ bool similarity(const DevCfg &cfg, const Acc &acc, do
 // ---------------------------------------------------------------------------
 // k_project<G, EMIT>: one G-lane group per alignment, grid-stride.
 //
-// Per alignment the group (1) finds the candidate row range of read exon 0 on each
-// strand to try with FOUR interleaved G-ary searches over the start-sorted slab
-// (first row with start >= qend; first row whose running max end exceeds
-// qstart), (2) gives every candidate row to one lane, which classifies it and
-// walks its own transcript, (3) counts (EMIT=false) or writes (EMIT=true) the
-// survivors.  Small ideal / rewritten CIGARs are staged in LDS.
+// Per alignment the group (1) takes the candidate row range of read exon 0 on each
+// strand to try from the bucket tables (a superset of the overlapping rows; an exact
+// G-wide count only when it exceeds the 64-bit survivor mask), (2) gives every
+// candidate row to one lane, which tests it for overlap, classifies it and walks its
+// own transcript, (3) counts (EMIT=false) or writes (EMIT=true) the survivors.  Small
+// ideal / rewritten CIGARs are staged in LDS.  The count pass is a chain of three
+// dependent stages (head -> table words -> rows); each stage's loads are unconditional
+// and issued together.
 // ---------------------------------------------------------------------------
 #define SLAB_LDS 1025   // slab_off entries cached in LDS (<= 512 references)
 #define LDS_SLOT 25     // words of CIGAR scratch per lane (odd: conflict-free)
