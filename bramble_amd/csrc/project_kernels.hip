@@ -828,6 +828,22 @@ __global__ void __launch_bounds__(256, EMIT ? 4 : 8) k_project(ProjectArgs A) {
             }
             if (!superseded) {
               if (n_seg == 1) { p1.alive = true; p1.fwpos = h0.pos; p1.rcpos = h0.pos; p1.n_seg = 1; p1.n_gex = 1; p1.i_lastm = i0; p1.last_right_ins = h0.right_ins; p1.last_right_gap = h0.right_gap; }
+              else if (!EMIT && !SIMF && n_seg == 2 && (nxt >= hd2.y || nxe >= hd2.y)) {
+                // Count pass, two read exons, and the scan of the second one ends at the exon after the candidate's
+                // (the usual spliced short read): survival without the walk -- step_exon + walk_pass1 for j = 1 with
+                // status LAST, written out.  The second read exon must pass against exactly one guide exon, and that
+                // one must be the next exon (a hit on the candidate's own exon is "same guide exon twice").
+                const uint32_t qs1 = hd2.x, qe1 = hd2.y;
+                Hit hh;
+                bool alive2 = false;
+                if (gend < qe1 && !(qs1 == q0.x && qe1 == q0.y)) {
+                  const bool c0 = gend > qs1 && classify(s == 1, ST_LAST, qs1, qe1, gs, gend, pay.z, cfg, hh);
+                  const uint4 e1 = next_row(make_uint4(gs, gend, pay.z, 0), make_uint2(nxt, nxe), s == 1);
+                  const bool c1 = nxt < qe1 && nxe > qs1 && classify(s == 1, ST_LAST, qs1, qe1, e1.x, e1.y, e1.z, cfg, hh);
+                  alive2 = c1 && !c0;
+                }
+                p1.alive = alive2;
+              }
               else p1 = walk_pass1(ix, cfg, rd, E, s == 1, sb[s], se[s], i0, make_uint4(gs, gend, pay.z, 0), make_uint2(nxt, nxe), q0, h0);
               alive = p1.alive;
             }
