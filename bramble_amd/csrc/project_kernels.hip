@@ -143,41 +143,20 @@ struct Hit { uint32_t pos, left_ins, right_ins, left_gap, right_gap; };
 // including the '-' strand right-overhang quirk at :204.
 __device__ __forceinline__ bool classify(bool minus, int status, uint32_t qs, uint32_t qe, uint32_t s,
                                          uint32_t e, uint32_t pos_start, const DevCfg &c, Hit &h) {
-  h.pos = 0; h.left_ins = 0; h.right_ins = 0; h.left_gap = 0; h.right_gap = 0;
-  bool junc_left = (status == ST_MIDDLE || status == ST_LAST);
-  bool junc_right = (status == ST_FIRST || status == ST_MIDDLE);
-  if (!minus) {
-    if (s <= qs) {
-      h.left_gap = qs - s; h.pos = h.left_gap + pos_start;
-      if (junc_left && h.left_gap > c.max_junc_gap) return false;
-    } else {
-      h.pos = pos_start; h.left_ins = s - qs;
-      if (h.left_ins > (junc_left ? c.max_junc_ins : c.max_clip)) return false;
-    }
-    if (e < qe) {
-      h.right_ins = qe - e;
-      if (h.right_ins > (junc_right ? c.max_junc_ins : c.max_clip)) return false;
-    } else if (qe < e) {
-      h.right_gap = e - qe;
-      if (junc_right && h.right_gap > c.max_junc_gap) return false;
-    }
-  } else {
-    if (qe <= e) {
-      h.right_gap = e - qe; h.pos = h.right_gap + pos_start;
-      if (junc_right && h.right_gap > c.max_junc_gap) return false;
-    } else {
-      h.pos = pos_start; h.right_ins = qe - e;
-      if (h.right_ins > c.max_junc_ins) return false;  // always max_junc_ins (g2t.cpp:204)
-    }
-    if (qs < s) {
-      h.left_ins = s - qs;
-      if (h.left_ins > (junc_left ? c.max_junc_ins : c.max_clip)) return false;
-    } else if (s < qs) {
-      h.left_gap = qs - s;
-      if (junc_left && h.left_gap > c.max_junc_gap) return false;
-    }
-  }
-  return true;
+  // Branch-free restatement: the kernels that call this are bound by instruction issue, the scalar unit above all
+  // (divergent control flow), and the table's eight-way branching cost more than its arithmetic.  Both strands share
+  // the left side; on the right '-' tests an overhang against max_junc_ins whatever the status (:204).  pos: '+'
+  // counts from the exon start, '-' from its end.
+  const bool junc_left = (status == ST_MIDDLE || status == ST_LAST);
+  const bool junc_right = (status == ST_FIRST || status == ST_MIDDLE);
+  const uint32_t lg = qs > s ? qs - s : 0u, li = s > qs ? s - qs : 0u;
+  const uint32_t rg = e > qe ? e - qe : 0u, ri = qe > e ? qe - e : 0u;
+  const uint32_t lim_li = junc_left ? c.max_junc_ins : c.max_clip;
+  const uint32_t lim_ri = (junc_right || minus) ? c.max_junc_ins : c.max_clip;
+  const uint32_t lim_lg = junc_left ? c.max_junc_gap : 0xffffffffu;
+  const uint32_t lim_rg = junc_right ? c.max_junc_gap : 0xffffffffu;
+  h.pos = pos_start + (minus ? rg : lg); h.left_ins = li; h.right_ins = ri; h.left_gap = lg; h.right_gap = rg;
+  return (li <= lim_li) & (ri <= lim_ri) & (lg <= lim_lg) & (rg <= lim_rg);
 }
 
 // Ideal-CIGAR accumulator: Cigar::add_operation (include/evaluate.h:108-126).
