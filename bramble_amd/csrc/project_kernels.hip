@@ -274,8 +274,11 @@ struct RealCig {
   }
 };
 
+// mops: merge_ops as a 16 x 16 byte table in LDS (k_emit_dense fills it once per block: the 22-way chain costs more
+// scalar-unit time than anything else in the merge loop), or null = evaluate the chain
 __device__ uint32_t merge_cigars(const RealCig &real, uint32_t n_real,
-                                 const uint32_t *ideal, uint32_t n_ideal, uint32_t *out) {
+                                 const uint32_t *ideal, uint32_t n_ideal, uint32_t *out, const uint8_t *mops = nullptr) {
+#define MERGE_OPS(R, I) ((mops && (I) < 16u) ? (uint32_t)mops[((R) << 4) | (I)] : merge_ops((R), (I)))
   uint32_t front_h = 0, front_s = 0, ci = 0;
   if (n_real > 0 && CIG_OP(real[0]) == OP_H) { front_h = CIG_LEN(real[0]); ci++; }
   if (ci < n_real && CIG_OP(real[ci]) == OP_S) front_s = CIG_LEN(real[ci]);
@@ -315,14 +318,14 @@ __device__ uint32_t merge_cigars(const RealCig &real, uint32_t n_real,
     if (is_ovr) {
       if (ideal_op == OP_DEL_OVR) {
         uint32_t chunk = ideal_rem;
-        ADD_OP(merge_ops(real_op, ideal_op), chunk);
+        ADD_OP(MERGE_OPS(real_op, ideal_op), chunk);
         ideal_pos += chunk;
         if (ideal_pos >= CIG_LEN(iw)) { ii++; ideal_pos = 0; }
       } else {
         uint32_t chunk = clips;
         if (chunk > real_rem) chunk = real_rem;
         if (chunk > ideal_rem) chunk = ideal_rem;
-        ADD_OP(merge_ops(real_op, ideal_op), chunk);
+        ADD_OP(MERGE_OPS(real_op, ideal_op), chunk);
         clips -= chunk; real_pos += chunk; ideal_pos += chunk;
         if (real_pos >= CIG_LEN(rw)) { ri++; real_pos = 0; }
         if (ideal_pos >= CIG_LEN(iw)) { ii++; ideal_pos = 0; }
@@ -330,7 +333,7 @@ __device__ uint32_t merge_cigars(const RealCig &real, uint32_t n_real,
     } else {
       uint32_t chunk = clips;
       if (chunk > real_rem) chunk = real_rem;
-      ADD_OP(merge_ops(real_op, ideal_op), chunk);
+      ADD_OP(MERGE_OPS(real_op, ideal_op), chunk);
       clips -= chunk; real_pos += chunk;
       if (real_pos >= CIG_LEN(rw)) { ri++; real_pos = 0; }
     }
@@ -367,13 +370,14 @@ __device__ uint32_t merge_cigars(const RealCig &real, uint32_t n_real,
       ii++; ideal_pos = 0;
     } else {
       uint32_t chunk = real_rem < ideal_rem ? real_rem : ideal_rem;
-      ADD_OP(merge_ops(real_op, ideal_op), chunk);
+      ADD_OP(MERGE_OPS(real_op, ideal_op), chunk);
       real_pos += chunk; ideal_pos += chunk;
       if (real_pos >= CIG_LEN(rw)) { ri++; real_pos = 0; }
       if (ideal_pos >= CIG_LEN(iw)) { ii++; ideal_pos = 0; }
     }
   }
 #undef ADD_OP
+#undef MERGE_OPS
   // "I between clips -> clip" fix-up (bam.cpp:292-300), then re-coalesce (:302-311)
   // Without an I op the fix-up is a no-op, and ADD_OP never leaves equal
   // neighbours, so re-coalescing only matters after a fix-up rewrote an op.
@@ -935,6 +939,8 @@ __global__ void __launch_bounds__(256) k_expand(ProjectArgs A) {
 template <bool SIMF, int CLS>
 __global__ void __launch_bounds__(256, SIMF ? 6 : 8) k_emit_dense(ProjectArgs A, int64_t first, int64_t n_matches) {
   __shared__ uint32_t sh_cig[CLS == 1 ? 1 : 256 * LDS_SLOT];
+  __shared__ uint8_t sh_mops[CLS == 1 ? 1 : 256];
+  if (CLS != 1) { sh_mops[threadIdx.x] = (uint8_t)merge_ops(threadIdx.x >> 4, threadIdx.x & 15u); __syncthreads(); }
   int64_t mi64 = first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (mi64 >= n_matches) return;
   const DevIndex &ix = A.ix;
@@ -1026,7 +1032,7 @@ __global__ void __launch_bounds__(256, SIMF ? 6 : 8) k_emit_dense(ProjectArgs A,
   if (SIMF) similarity(cfg, acc, score);
   bool out_lds = ideal_lds && (rd.n_real + n_ideal <= LDS_SLOT - LDS_IDEAL);
   uint32_t *outp = out_lds ? lds + LDS_IDEAL : slot;
-  uint32_t n_out = merge_cigars(rc, rd.n_real, ideal, n_ideal, outp);
+  uint32_t n_out = merge_cigars(rc, rd.n_real, ideal, n_ideal, outp, sh_mops);
   // rewritten CIGARs of <= 2 ops travel inside the match record (m_cigoff holds the
   // words themselves); longer ones stay in the arena slot
   uint64_t cig_ref = cbase + (uint64_t)rank * cap;
