@@ -274,11 +274,22 @@ struct RealCig {
   }
 };
 
-// mops: merge_ops as a 16 x 16 byte table in LDS (k_emit_dense fills it once per block: the 22-way chain costs more
-// scalar-unit time than anything else in the merge loop), or null = evaluate the chain
+// What one step of the main merge loop does for (real op, ideal op), src/bam.cpp:236-288: 0 skip the real N op,
+// 1 real D under an ideal S / I (or override): both advance, nothing is written, 2 real I: written whole,
+// 3 ideal D (or override): written whole, 4 the ops are merged over their common length.
+__device__ __forceinline__ uint32_t merge_action(uint32_t r, uint32_t i) {
+  if (r == OP_N) return 0;
+  if (r == OP_D && (i == OP_S || i == OP_CLIP_OVR || i == OP_I || i == OP_INS_OVR)) return 1;
+  if (r == OP_I) return 2;
+  if (i == OP_D || i == OP_DEL_OVR) return 3;
+  return 4;
+}
+// mops: (merge_action << 8 | merge_ops) as a 16 x 16 table in LDS (k_emit_dense fills it once per block: the kernel is
+// bound by the scalar unit, and the 22-way chain of merge_ops and the case ladder of the loop are most of the merge's
+// control flow), or null = evaluate the chains
 __device__ uint32_t merge_cigars(const RealCig &real, uint32_t n_real,
-                                 const uint32_t *ideal, uint32_t n_ideal, uint32_t *out, const uint8_t *mops = nullptr) {
-#define MERGE_OPS(R, I) ((mops && (I) < 16u) ? (uint32_t)mops[((R) << 4) | (I)] : merge_ops((R), (I)))
+                                 const uint32_t *ideal, uint32_t n_ideal, uint32_t *out, const uint16_t *mops = nullptr) {
+#define MERGE_OPS(R, I) ((mops && (I) < 16u) ? (uint32_t)(mops[((R) << 4) | (I)] & 0xffu) : merge_ops((R), (I)))
   uint32_t front_h = 0, front_s = 0, ci = 0;
   if (n_real > 0 && CIG_OP(real[0]) == OP_H) { front_h = CIG_LEN(real[0]); ci++; }
   if (ci < n_real && CIG_OP(real[ci]) == OP_S) front_s = CIG_LEN(real[ci]);
@@ -354,27 +365,19 @@ __device__ uint32_t merge_cigars(const RealCig &real, uint32_t n_real,
     uint32_t iw = ideal[ii];
     uint32_t real_op = CIG_OP(rw), ideal_op = CIG_OP(iw);
     uint32_t real_rem = CIG_LEN(rw) - real_pos, ideal_rem = CIG_LEN(iw) - ideal_pos;
-    if (real_op == OP_N) {
-      ri++; real_pos = 0;
-    } else if (real_op == OP_D && (ideal_op == OP_S || ideal_op == OP_CLIP_OVR || ideal_op == OP_I ||
-                                   ideal_op == OP_INS_OVR)) {
-      uint32_t chunk = real_rem < ideal_rem ? real_rem : ideal_rem;
-      real_pos += chunk; ideal_pos += chunk;
-      if (real_pos >= CIG_LEN(rw)) { ri++; real_pos = 0; }
-      if (ideal_pos >= CIG_LEN(iw)) { ii++; ideal_pos = 0; }
-    } else if (real_op == OP_I) {
-      ADD_OP(OP_I, real_rem);
-      ri++; real_pos = 0;
-    } else if (ideal_op == OP_D || ideal_op == OP_DEL_OVR) {
-      ADD_OP(OP_D, ideal_rem);
-      ii++; ideal_pos = 0;
-    } else {
-      uint32_t chunk = real_rem < ideal_rem ? real_rem : ideal_rem;
-      ADD_OP(MERGE_OPS(real_op, ideal_op), chunk);
-      real_pos += chunk; ideal_pos += chunk;
-      if (real_pos >= CIG_LEN(rw)) { ri++; real_pos = 0; }
-      if (ideal_pos >= CIG_LEN(iw)) { ii++; ideal_pos = 0; }
-    }
+    // one body for the five cases: what is written and how far either side advances follow from the action code
+    const uint32_t t = mops ? (uint32_t)mops[(real_op << 4) | ideal_op] : ((merge_action(real_op, ideal_op) << 8) | merge_ops(real_op, ideal_op));
+    const uint32_t act = t >> 8;
+    const uint32_t chunk = real_rem < ideal_rem ? real_rem : ideal_rem;
+    const bool both = act == 1u || act == 4u;
+    const uint32_t adv_r = (act == 0u || act == 2u) ? real_rem : both ? chunk : 0u;
+    const uint32_t adv_i = act == 3u ? ideal_rem : both ? chunk : 0u;
+    const uint32_t w_len = act == 2u ? real_rem : act == 3u ? ideal_rem : act == 4u ? chunk : 0u;
+    const uint32_t w_op = act == 2u ? (uint32_t)OP_I : act == 3u ? (uint32_t)OP_D : (t & 0xffu);
+    ADD_OP(w_op, w_len);
+    real_pos += adv_r; ideal_pos += adv_i;
+    if (real_pos >= CIG_LEN(rw)) { ri++; real_pos = 0; }
+    if (ideal_pos >= CIG_LEN(iw)) { ii++; ideal_pos = 0; }
   }
 #undef ADD_OP
 #undef MERGE_OPS
@@ -939,8 +942,11 @@ __global__ void __launch_bounds__(256) k_expand(ProjectArgs A) {
 template <bool SIMF, int CLS>
 __global__ void __launch_bounds__(256, SIMF ? 6 : 8) k_emit_dense(ProjectArgs A, int64_t first, int64_t n_matches) {
   __shared__ uint32_t sh_cig[CLS == 1 ? 1 : 256 * LDS_SLOT];
-  __shared__ uint8_t sh_mops[CLS == 1 ? 1 : 256];
-  if (CLS != 1) { sh_mops[threadIdx.x] = (uint8_t)merge_ops(threadIdx.x >> 4, threadIdx.x & 15u); __syncthreads(); }
+  __shared__ uint16_t sh_mops[CLS == 1 ? 1 : 256];
+  if (CLS != 1) {
+    sh_mops[threadIdx.x] = (uint16_t)((merge_action(threadIdx.x >> 4, threadIdx.x & 15u) << 8) | merge_ops(threadIdx.x >> 4, threadIdx.x & 15u));
+    __syncthreads();
+  }
   int64_t mi64 = first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (mi64 >= n_matches) return;
   const DevIndex &ix = A.ix;
