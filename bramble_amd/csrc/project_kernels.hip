@@ -940,7 +940,7 @@ __global__ void __launch_bounds__(256) k_expand(ProjectArgs A) {
 // CLS: 0 = the whole work list, 1 = its simple prefix only (no walk, no merge loop, no LDS: a much lighter kernel),
 // 2 = the rest; the list is partitioned by class (k_expand), `first` is where this launch starts
 template <bool SIMF, int CLS>
-__global__ void __launch_bounds__(256, SIMF ? 6 : 8) k_emit_dense(ProjectArgs A, int64_t first, int64_t n_matches) {
+__global__ void __launch_bounds__(256, CLS == 1 ? 8 : 6) k_emit_dense(ProjectArgs A, int64_t first, int64_t n_matches) {
   __shared__ uint32_t sh_cig[CLS == 1 ? 1 : 256 * LDS_SLOT];
   __shared__ uint16_t sh_mops[CLS == 1 ? 1 : 256];
   if (CLS != 1) {
