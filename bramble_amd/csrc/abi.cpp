@@ -411,6 +411,8 @@ struct br_ctx {
   DevBuf z_slots, z_sizes, z_off, z_dense, z_tabs, z_tokens;
   int deflate_dynamic = 1;
   int emit_split = 1;
+  int count_split = 1;   // count pass as two kernels: the main one without the exon walk, a second one for the alignments that need it
+  DevBuf walk_list;
   void *zero_cols_sim = nullptr, *zero_cols_clip = nullptr; size_t zero_cols_rows = 0;  // row columns known to be all zero
   bool z_tabs_ready = false;
   DevBuf p_ncig, p_name_len, p_isnew, p_group_pre, p_small, p_big, p_seq_len, p_ref_map;
@@ -471,7 +473,7 @@ extern "C" void br_ctx_free(br_ctx *c) {
                     &c->r_ncig, &c->r_strand, &c->r_sim, &c->r_clip, &c->r_junc, &c->r_refc, &c->r_cigoff,
                     &c->cigar_out, &c->r_paired, &c->r_same, &c->r_first, &c->r_primary, &c->b_name_off, &c->b_names, &c->b_ref_id, &c->b_ref_start,
                     &c->b_flags, &c->b_xs, &c->b_ts, &c->b_cigar_off, &c->b_cigar, &c->b_mate_idx,
-                    &c->b_group_off, &c->b_lqseq};
+                    &c->b_group_off, &c->b_lqseq, &c->walk_list};
   for (DevBuf *b : bufs) b->release();
   for (auto &e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if (c->h_totals) (void)hipHostFree(c->h_totals);
@@ -490,6 +492,7 @@ extern "C" int br_ctx_set_param(br_ctx *c, const char *key, int64_t v) {
   if (!c || !key) return BR_ERR_INVALID_ARG;
   if (!strcmp(key, "group_lanes")) { if (v != 8 && v != 16 && v != 32 && v != 64) return BR_ERR_INVALID_ARG; c->group_lanes = (int)v; return BR_OK; }
   if (!strcmp(key, "emit_split")) { c->emit_split = v != 0; return BR_OK; }
+  if (!strcmp(key, "count_split")) { c->count_split = v != 0; return BR_OK; }
   if (!strcmp(key, "deflate_dynamic")) { c->deflate_dynamic = v != 0; return BR_OK; }
   if (!strcmp(key, "bam_lanes")) { if (v != 4 && v != 8 && v != 16 && v != 32 && v != 64) return BR_ERR_INVALID_ARG; c->bam_lanes = (int)v; return BR_OK; }
   if (!strcmp(key, "blocks_per_cu")) { if (v < 1 || v > 64) return BR_ERR_INVALID_ARG; c->blocks_per_cu = (int)v; return BR_OK; }
@@ -596,8 +599,9 @@ static int run_device_impl(br_ctx *c, const br_config *cfg, const br_device_batc
   A.ranges = c->ranges.as<uint4>(); A.mask = c->mask.as<uint64_t>();
   A.match_off = c->match_off.as<uint32_t>(); A.cig_base = c->cig_base.as<uint64_t>();
   RC(c->big_list.ensure((size_t)n * 4)); RC(c->n_big.ensure(16));
-  HIPCHK(hipMemsetAsync(c->n_big.p, 0, 4, st));
+  HIPCHK(hipMemsetAsync(c->n_big.p, 0, 8, st));
   A.big_list = c->big_list.as<uint32_t>(); A.n_big = c->n_big.as<uint32_t>();
+  if (c->count_split) { RC(c->walk_list.ensure((size_t)n * 4)); A.walk_list = c->walk_list.as<uint32_t>(); A.n_walk = c->n_big.as<uint32_t>() + 1; }
   int n_blocks = c->n_cu * c->blocks_per_cu;
   ScanArgs S{};
   S.n = n; S.src32 = c->n_matches.as<uint32_t>(); S.cigar_off = b->cigar_off; S.head = c->head.as<uint4>();

@@ -27,6 +27,8 @@ struct ProjectArgs {
   uint64_t *mask;        // [n_aln] survivor bit per candidate row (<= 64 rows)
   uint32_t *big_list;    // alignments with > 64 candidate rows and >= 1 match
   uint32_t *n_big;       // their count (device counter, zeroed per batch)
+  uint32_t *walk_list;   // count pass, MODE 1 -> 2: alignments left to the kernel that carries the exon walk (null: one kernel)
+  uint32_t *n_walk;      // their count (device counter, zeroed per batch)
   uint32_t *m_aln;       // [n_matches] alignment of each match slot (k_expand)
   const uint32_t *match_off;  // [n_aln + 1]
   const uint64_t *cig_base;   // [n_aln + 1]

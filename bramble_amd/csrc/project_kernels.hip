@@ -647,14 +647,24 @@ __device__ __forceinline__ bool similarity(const DevCfg &cfg, const Acc &acc, do
 // and issued together.
 // ---------------------------------------------------------------------------
 #define SLAB_LDS 1025   // slab_off entries cached in LDS (<= 512 references)
+#define WALK_LDS 2048   // deferred alignments a block of the main count pass collects before it appends them
 #define LDS_SLOT 25     // words of CIGAR scratch per lane (odd: conflict-free)
 #define LDS_IDEAL 10    // ideal CIGAR words kept in LDS (n_seg <= 2)
 
-template <int G, bool EMIT, bool SIMF>
+// MODE (count pass of the presets without the similarity filter): 1 = main pass: an alignment with a candidate that
+// needs the full exon walk (three or more read exons, or a two-exon read outside the shortcut) is put on walk_list
+// instead, so that the walk's code and registers stay out of this kernel (it sits at the 64-VGPR ceiling and is
+// bound by instruction issue); 2 = the listed alignments, with the walk.  0 = everything in one kernel.
+template <int G, bool EMIT, bool SIMF, int MODE = 0>
 __global__ void __launch_bounds__(256, EMIT ? 4 : 8) k_project(ProjectArgs A) {
   __shared__ uint32_t sh_slab[SLAB_LDS];
   __shared__ uint32_t sh_bin[EMIT ? 1 : SLAB_LDS];
   __shared__ uint32_t sh_cig[EMIT ? 256 * LDS_SLOT : 1];
+  // MODE 1: the block's deferred alignments are collected in LDS and appended to walk_list with ONE global atomic at the
+  // end (a same-address atomic per deferred alignment serialises: 13 ms for ~1.5 M of them)
+  __shared__ uint32_t sh_wl[MODE == 1 ? WALK_LDS : 1];
+  __shared__ uint32_t sh_wn, sh_wbase;
+  if (MODE == 1) { if (threadIdx.x == 0) sh_wn = 0; __syncthreads(); }
   const int gl = threadIdx.x & (G - 1);
   const int gbase = (threadIdx.x & 63) & ~(G - 1);
   const uint64_t gmask = (G == 64) ? ~0ull : ((1ull << G) - 1);
@@ -674,9 +684,9 @@ __global__ void __launch_bounds__(256, EMIT ? 4 : 8) k_project(ProjectArgs A) {
 
   // EMIT: only the alignments with more than 64 candidate rows come here (the
   // rest is written by k_emit_dense); the count pass listed them in big_list.
-  const int64_t n_work = EMIT ? (int64_t)*A.n_big : A.n_aln;
+  const int64_t n_work = EMIT ? (int64_t)*A.n_big : MODE == 2 ? (int64_t)*A.n_walk : A.n_aln;
   for (int64_t w = gid; w < n_work; w += groups_total) {
-    const int64_t a = EMIT ? (int64_t)A.big_list[w] : w;
+    const int64_t a = EMIT ? (int64_t)A.big_list[w] : MODE == 2 ? (int64_t)A.walk_list[w] : w;
     uint4 hd = A.head[a];
     uint4 hd2 = A.head2[a];
     uint32_t n_seg = hd.z;
@@ -775,6 +785,7 @@ __global__ void __launch_bounds__(256, EMIT ? 4 : 8) k_project(ProjectArgs A) {
     }
     uint32_t total = 0;
     uint64_t mask_all = 0;
+    bool defer = false;  // MODE 1: some candidate needs the walk
 
     // EMIT without a stored mask (> 64 candidate rows): sweep 0 records every
     // survivor's tid in m_aux[], sweep 1 ranks against that list.
@@ -830,6 +841,7 @@ __global__ void __launch_bounds__(256, EMIT ? 4 : 8) k_project(ProjectArgs A) {
                 }
                 p1.alive = alive2;
               }
+              else if (MODE == 1) { defer = true; p1.alive = false; }
               else p1 = walk_pass1(ix, cfg, rd, E, s == 1, sb[s], se[s], i0, make_uint4(gs, gend, pay.z, 0), make_uint2(nxt, nxe), q0, h0);
               alive = p1.alive;
             }
@@ -908,10 +920,25 @@ __global__ void __launch_bounds__(256, EMIT ? 4 : 8) k_project(ProjectArgs A) {
       }
       if (EMIT && !have_mask && sweep == 0) __threadfence_block();  // m_aux[] written above is read below
     }
+    if (MODE == 1 && ((__ballot(defer) >> gbase) & gmask) != 0) {  // group-uniform: the second pass redoes this alignment
+      if (gl == 0) {
+        uint32_t k = atomicAdd(&sh_wn, 1u);
+        if (k < WALK_LDS) sh_wl[MODE == 1 ? k : 0] = (uint32_t)a;
+        else { uint32_t k2 = atomicAdd(A.n_walk, 1u); A.walk_list[k2] = (uint32_t)a; }   // LDS list full: rare, slow, correct
+      }
+      continue;
+    }
     if (!EMIT && gl == 0) {
       A.n_matches[a] = total; A.mask[a] = mask_all;
       if (n_items > 64 && total) { uint32_t k = atomicAdd(A.n_big, 1u); A.big_list[k] = (uint32_t)a; }
     }
+  }
+  if (MODE == 1) {
+    __syncthreads();
+    const uint32_t n_loc = sh_wn < WALK_LDS ? sh_wn : WALK_LDS;
+    if (threadIdx.x == 0) sh_wbase = n_loc ? atomicAdd(A.n_walk, n_loc) : 0u;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_loc; i += blockDim.x) A.walk_list[sh_wbase + i] = sh_wl[MODE == 1 ? i : 0];
   }
 }
 
@@ -1569,7 +1596,10 @@ static void launch_project_g(hipStream_t st, const ProjectArgs &A, bool emit, in
     else hipLaunchKernelGGL((k_project<G, true, false>), dim3(n_blocks), dim3(256), 0, st, A);
   } else {
     if (simf) hipLaunchKernelGGL((k_project<G, false, true>), dim3(n_blocks), dim3(256), 0, st, A);
-    else hipLaunchKernelGGL((k_project<G, false, false>), dim3(n_blocks), dim3(256), 0, st, A);
+    else if (A.walk_list) {
+      hipLaunchKernelGGL((k_project<G, false, false, 1>), dim3(n_blocks), dim3(256), 0, st, A);
+      hipLaunchKernelGGL((k_project<G, false, false, 2>), dim3(n_blocks), dim3(256), 0, st, A);
+    } else hipLaunchKernelGGL((k_project<G, false, false>), dim3(n_blocks), dim3(256), 0, st, A);
   }
 }
 
