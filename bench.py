@@ -178,6 +178,13 @@ def main():
                 "kernel_ms_per_launch": dom_ms,
                 "kernel_launches_per_step": launches_per_step,
                 "counters": counters,
+                # the same bytes against the whole step (all kernels of the path), and a caution for readers of `frac`
+                "whole_path": {"achieved": alg_bytes / (elapsed / args.steps) / 1e9,
+                               "frac": alg_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
+                "note": "achieved = the WHOLE path's algorithmic bytes (SURVEY 8d formula: it prices a binary search per "
+                        "read exon and 40 B per overlap hit) over the dominant kernel's time; the path reads less than the "
+                        "formula charges (bucket tables instead of searches: see `traffic`), so frac can exceed 1 -- "
+                        "`whole_path` divides the same bytes by the full step",
             },
         }
         if not args.no_cpu_baseline:

@@ -65,7 +65,15 @@ def main():
                 key = "k_project<64,true>" if re.search(r"<\d+, true", k) else "k_project<G,false>"  # bench.py's bucket names
             elif re.search(r"<(true|false), 1>", k):
                 key = "k_emit_dense<simple>"
-            if key not in kern or v["hbm_bytes_corrected"] > kern[key]["hbm_bytes_corrected"]:
+            if key == "k_project<G,false>" and key in kern:
+                # the count pass of the short-read presets is two kernels (main + the alignments that need the exon
+                # walk): one launch of the path runs both, so their per-launch figures add up
+                t = dict(kern[key])
+                for f in ("FETCH_SIZE_KB_per_launch", "WRITE_SIZE_KB_per_launch", "hbm_bytes_corrected"):
+                    t[f] = t[f] + v[f]
+                t["kernels_summed"] = t.get("kernels_summed", 1) + 1
+                kern[key] = t
+            elif key not in kern or v["hbm_bytes_corrected"] > kern[key]["hbm_bytes_corrected"]:
                 kern[key] = v
     traffic = {
         "pairs": pairs,
