@@ -179,7 +179,8 @@ struct Acc {
   double cov, ops;
   int32_t ref_consumed, junc_hits, clip_score;
   uint32_t prev_op;
-  __device__ __forceinline__ void init() { cov = 0; ops = 0; ref_consumed = 0; junc_hits = 0; clip_score = 0; prev_op = OP_M; }
+  uint32_t last_pos;  // transcript position of the last guide segment's hit (rcpos on '-')
+  __device__ __forceinline__ void init() { cov = 0; ops = 0; ref_consumed = 0; junc_hits = 0; clip_score = 0; prev_op = OP_M; last_pos = 0; }
 };
 
 // build_cigar_match (src/evaluate.cpp:675-786)
@@ -615,7 +616,7 @@ __device__ __forceinline__ void walk_pass2(const DevIndex &ix, const DevCfg &cfg
     if (R.ok && j == rd.n_seg - 1) h.right_ins = 0;
     build_match(acc, sk, h, status, q.x, q.y, ge.x, ge.y, k == 0, k == p1.n_gex - 1, L.ok, R.ok);
     k++;
-    i_last = i_hit; e_last = ge;
+    i_last = i_hit; e_last = ge; acc.last_pos = h.pos;
   }
   if (R.ok) { build_clip(acc, sk, R); k++; }
   if (acc.junc_hits < 0) acc.junc_hits = 0;
@@ -1049,8 +1050,17 @@ __global__ void __launch_bounds__(256, CLS == 1 ? 8 : 6) k_emit_dense(ProjectArg
   const uint4 *E = ix.tx_ex + pay.w;
   uint32_t i0 = pay.y;
   CandOut p1;
+  bool plain = false;
   uint32_t sb = ix.slab_off[2 * rid + s], se = ix.slab_off[2 * rid + s + 1];
   if (n_seg == 1) { p1.alive = true; p1.fwpos = h0.pos; p1.rcpos = h0.pos; p1.n_seg = 1; p1.n_gex = 1; p1.i_lastm = i0; p1.last_right_ins = h0.right_ins; p1.last_right_gap = h0.right_gap; }
+  else if (!cfg.long_reads && !cfg.ignore_small_exons) {
+    // short-read presets without --max-error-exon: a survivor's every read exon is one plain hit on the next guide exon
+    // (no skipped-exon or inserted-exon segments), so pass 1's counts are the read's exon count and its walk is not
+    // needed; rcpos comes out of pass 2 (the last hit's position)
+    plain = true;
+    p1.alive = true; p1.fwpos = h0.pos; p1.rcpos = h0.pos; p1.n_seg = n_seg; p1.n_gex = n_seg; p1.i_lastm = i0;
+    p1.last_right_ins = 0; p1.last_right_gap = 0;
+  }
   else p1 = walk_pass1(ix, cfg, rd, E, s == 1, sb, se, i0, make_uint4(gs, gend, pay.z, 0), make_uint2(r_a.z, r_b.w), q0, h0);
   uint32_t ideal_cap = 4u * n_seg + 2u;
   uint32_t cap = rd.n_real + 2u * ideal_cap;
@@ -1073,7 +1083,7 @@ __global__ void __launch_bounds__(256, CLS == 1 ? 8 : 6) k_emit_dense(ProjectArg
   else if (out_lds) for (uint32_t q = 0; q < n_out; q++) slot[q] = outp[q];
   uint32_t mo = moff + rank;
   A.m_tid[mo] = pay.x;
-  A.m_a[mo] = make_uint4((s == 0) ? p1.fwpos : p1.rcpos, n_out | ((uint32_t)s << 31), (uint32_t)acc.junc_hits,
+  A.m_a[mo] = make_uint4((s == 0) ? p1.fwpos : (plain ? acc.last_pos : p1.rcpos), n_out | ((uint32_t)s << 31), (uint32_t)acc.junc_hits,
                          (uint32_t)acc.ref_consumed);
   // without the similarity filter the score is 0.0 and (no -S rescue in this kernel) the clip score is 0: the row
   // kernel then neither reads m_b nor rewrites the two all-zero row columns
