@@ -166,10 +166,13 @@ struct IdealSink {
   uint32_t *buf; uint32_t n; uint32_t cur; bool has;
   __device__ __forceinline__ void init(uint32_t *b) { buf = b; n = 0; cur = 0; has = false; }
   __device__ __forceinline__ void add(uint32_t len, uint32_t op) {
-    if (!has) { cur = CIG_GEN(len, op); has = true; return; }
-    if (CIG_OP(cur) == op) { cur = CIG_GEN(CIG_LEN(cur) + len, op); return; }
-    if (buf) buf[n] = cur;
-    n++; cur = CIG_GEN(len, op);
+    // one predicated store instead of three exits (the emit kernels are bound by instruction issue)
+    const bool same = has && CIG_OP(cur) == op;
+    const bool flush = has && !same;
+    if (flush && buf) buf[n] = cur;
+    n += flush ? 1u : 0u;
+    cur = same ? cur + (len << 4) : CIG_GEN(len, op);
+    has = true;
   }
   __device__ __forceinline__ uint32_t finish() { if (has) { if (buf) buf[n] = cur; n++; has = false; } return n; }
 };
