@@ -385,7 +385,7 @@ const char *br_bgzf_codec(void); /* "libdeflate" (bound at run time when present
 
 /* Kernel names reported by br_ctx_kernel_ms / rocprof. */
 #define BR_K_SEGMENT 0    /* k_segment */
-#define BR_K_COUNT 1      /* k_project<G,false> */
+#define BR_K_COUNT 1      /* k_project<G,false> (both kernels of the split count pass) */
 #define BR_K_EMIT 2       /* k_emit_dense (general class; the whole list for long-read presets) */
 #define BR_K_PAIR_COUNT 3 /* k_group_ids + k_pair<false> */
 #define BR_K_PAIR_EMIT 4  /* k_pair<true> */
@@ -404,7 +404,9 @@ const char *br_bgzf_codec(void); /* "libdeflate" (bound at run time when present
 int br_ctx_set_profiling(br_ctx *, int enabled);
 /* Launch tuning: "group_lanes" (8|16|32|64 lanes cooperating on one alignment),
  * "blocks_per_cu" (grid size of the grid-stride projection kernels), "bam_lanes" (4..64 lanes per
- * re-encoded record), "deflate_dynamic" (1: per-block Huffman codes, 0: the fixed code). */
+ * re-encoded record), "deflate_dynamic" (1: per-block Huffman codes, 0: the fixed code), "emit_split" (1: the emit
+ * work list is launched per class, 0: one launch), "count_split" (1: short-read presets run the count pass as a main
+ * kernel without the exon walk plus a second one for the alignments that need it, 0: one kernel). */
 int br_ctx_set_param(br_ctx *, const char *key, int64_t value);
 /* Device time (ms) of kernel `which` during the last projection call, summed
  * over its launches; *launches receives the launch count. */
