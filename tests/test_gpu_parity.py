@@ -285,3 +285,23 @@ def test_bucket_table_ranges_at_bin_edges():
             prod, orc = run_both(ann, batch, group_lanes=gl, **flags)
             assert orc["n_rows"] > 100
             assert_rows_equal(prod, orc)
+
+
+@pytest.mark.parametrize("key", ["count_split", "emit_split"])
+def test_single_kernel_forms_of_the_split_passes(key):
+    """count_split = 0 / emit_split = 0: the count pass as one kernel (exon walk inline), the emit work list in one
+    launch -- the forms the long-read presets use; same rows as the oracle on short reads, and on long reads under a
+    short-read preset (every alignment takes the second count kernel when the split is on)."""
+    ann = synth.Annotation("G", n_genes=3000, n_refs=3)
+    for mode, n in (("pe", 30000), ("hifi", 4000)):
+        b = ann.reads(n, mode)
+        idx = lib.Index(ann.as_dict(), device=0)
+        oi = ob.OracleIndex(ann.as_dict())
+        orc, _, _ = ob.run(oi, ob.make_flags(), b, want_matches=False)
+        for v in (0, 1):
+            ctx = lib.Context(idx)
+            ctx.set_param(key, v)
+            prod = ctx.project_batch(lib.make_config(), b)
+            assert_rows_equal(prod, orc)
+            ctx.close()
+        idx.close()
