@@ -402,7 +402,7 @@ struct br_ctx {
   uint64_t counters[8] = {0};
   uint64_t rescue_stats[4] = {0};  // problems, DP cells, accepted rescues, coded sequence bytes
   // device scratch
-  DevBuf seg, meta, head, head2, fast_flag, fast_pre, m_k, n_matches, ranges, mask, match_off, cig_base, tile_sums, totals, counters_d;
+  DevBuf seg, meta, head, head2, fast_flag, fast_pre, n_matches, ranges, mask, match_off, cig_base, tile_sums, totals, counters_d;
   DevBuf m_tid, m_aux, m_a, m_b, m_cigoff, cig_arena, big_list, n_big, m_aln;
   DevBuf bam_aux, bam_len, bam_off, bam_out;
   struct StageSlot { DevBuf blob, off, len; hipEvent_t ready = nullptr; std::vector<uint64_t> h_off; int64_t n = 0; };
@@ -463,7 +463,7 @@ extern "C" int br_ctx_new(const br_index *ix, br_ctx **out) {
 extern "C" void br_ctx_free(br_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->ix->device);
-  DevBuf *bufs[] = {&c->seg, &c->meta, &c->head, &c->head2, &c->fast_flag, &c->fast_pre, &c->m_k, &c->n_matches, &c->ranges, &c->mask, &c->match_off, &c->cig_base,
+  DevBuf *bufs[] = {&c->seg, &c->meta, &c->head, &c->head2, &c->fast_flag, &c->fast_pre, &c->n_matches, &c->ranges, &c->mask, &c->match_off, &c->cig_base,
                     &c->tile_sums, &c->totals, &c->counters_d, &c->m_tid, &c->m_aux, &c->m_a, &c->m_b,
                     &c->m_cigoff, &c->cig_arena, &c->big_list, &c->n_big, &c->m_aln,
                     &c->bam_aux, &c->bam_len, &c->bam_off, &c->bam_out, &c->z_slots, &c->z_sizes, &c->z_off, &c->z_dense, &c->z_tabs, &c->z_tokens, &c->p_ncig, &c->p_name_len, &c->p_isnew, &c->p_group_pre, &c->p_small, &c->p_big, &c->p_seq_len, &c->p_ref_map, &c->fa_stats, &c->fa_n_prob, &c->fa_seq_bytes, &c->fa_prob_off, &c->fa_seqarena_off, &c->fa_probs, &c->fa_results,
@@ -685,8 +685,8 @@ static int run_device_impl(br_ctx *c, const br_config *cfg, const br_device_batc
 
   size_t nm = (size_t)std::max<uint64_t>(n_matches, 1);
   RC(c->m_tid.ensure(nm * 4)); RC(c->m_aux.ensure(nm * 4)); RC(c->m_a.ensure(nm * sizeof(uint4)));
-  RC(c->m_b.ensure(nm * sizeof(uint4))); RC(c->m_cigoff.ensure(nm * 8)); RC(c->m_aln.ensure(nm * 4)); RC(c->m_k.ensure(nm));
-  A.m_aln = c->m_aln.as<uint32_t>(); A.m_k = c->m_k.as<uint8_t>();
+  RC(c->m_b.ensure(nm * sizeof(uint4))); RC(c->m_cigoff.ensure(nm * 8)); RC(c->m_aln.ensure(nm * 4));
+  A.m_aln = c->m_aln.as<uint32_t>();
   RC(c->cig_arena.ensure((size_t)std::max<uint64_t>(n_cig_arena, 1) * 4));
   A.m_tid = c->m_tid.as<uint32_t>(); A.m_aux = c->m_aux.as<uint32_t>(); A.m_a = c->m_a.as<uint4>();
   A.m_b = c->m_b.as<uint4>(); A.m_cigoff = c->m_cigoff.as<uint64_t>(); A.cig_arena = c->cig_arena.as<uint32_t>();

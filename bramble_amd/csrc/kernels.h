@@ -20,7 +20,6 @@ struct ProjectArgs {
   const uint4 *head2;    // [n_aln] read exons 1 and 2
   const uint32_t *fast_flag;  // [n_aln] 1: one read exon from a single M op (short-read presets)
   const uint32_t *fast_pre;   // [n_aln + 1] exclusive prefix of the simple alignments' matches
-  uint8_t *m_k;               // [n_matches] emit work list: which survivor of m_aln[w]
   // count pass outputs / emit pass inputs
   uint32_t *n_matches;   // [n_aln]
   uint4 *ranges;         // [n_aln] candidate row ranges (lo+,hi+,lo-,hi-)

@@ -960,7 +960,7 @@ __global__ void __launch_bounds__(256) k_expand(ProjectArgs A) {
   uint4 rg = A.ranges[a];
   uint32_t n_items = (rg.y - rg.x) + (rg.w - rg.z);
   uint32_t v = n_items <= 64 ? (uint32_t)a : 0xffffffffu;
-  for (uint32_t k = 0; k < nm; k++) { A.m_aln[pos + k] = v; A.m_k[pos + k] = (uint8_t)k; }
+  for (uint32_t k = 0; k < nm; k++) A.m_aln[pos + k] = v;
 }
 
 // k_emit_dense: one lane per match.  Match mi of alignment a is the k-th set bit
@@ -999,7 +999,9 @@ __global__ void __launch_bounds__(256, CLS == 1 ? 8 : 6) k_emit_dense(ProjectArg
   RealCig rc;
   if (CLS != 1) rc.fetch(A.cigar + c0, c1 - c0);  // in flight with the row and rank loads below
   // k-th survivor in candidate-row order
-  uint32_t k = A.m_k[mi64];
+  // which survivor: the entry's distance from the alignment's first entry in the class-partitioned list (k_expand)
+  const uint32_t fpre = A.fast_pre[a];
+  uint32_t k = (uint32_t)mi64 - (is_fast ? fpre : A.fast_pre[A.n_aln] + (moff - fpre));
   uint64_t mm = mask;
   for (uint32_t j = 0; j < k; j++) mm &= mm - 1;
   uint32_t item = (uint32_t)(__ffsll((long long)mm) - 1);
