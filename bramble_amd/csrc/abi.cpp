@@ -134,7 +134,8 @@ static int build_index_flat(size_t n_tx, const int32_t *tx_ref, const int8_t *tx
       ix->s_start.push_back(r.start); ix->s_pmax.push_back(m);
       // one 32-byte row = everything a candidate lane needs, in one 64-byte sector
       ix->s_row.push_back(make_uint4(r.start, r.end, ix->tx_ex[ix->tx_first[r.tid] + r.gidx + 1].x /* sentinel start = ~0u */, r.pos_start));
-      ix->s_row.push_back(make_uint4(r.tid, r.gidx, ix->tx_first[r.tid], ix->tx_ex[ix->tx_first[r.tid] + r.gidx + 1].y /* next exon's end */));
+      const uint32_t n_ex = ix->tx_first[r.tid + 1] - ix->tx_first[r.tid] - 1;  // rows of the transcript minus its sentinel
+      ix->s_row.push_back(make_uint4(r.tid, r.gidx | (n_ex > 256u ? 0x80000000u : 0u), ix->tx_first[r.tid], ix->tx_ex[ix->tx_first[r.tid] + r.gidx + 1].y /* next exon's end */));
       ix->s_tid.push_back(r.tid);
     }
     ix->slab_off.push_back((uint32_t)ix->s_start.size());

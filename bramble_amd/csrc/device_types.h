@@ -16,7 +16,7 @@ struct DevIndex {
   const uint32_t *s_pmax;      // [n_rows] running max of s_end inside the slab
   const uint32_t *s_tid;       // [n_rows] tid alone (rank lookups)
   const uint4 *s_row;          // [2*n_rows] 32-byte row: {start, end (exclusive), start of the transcript's next exon
-                               // (genomic order; ~0u if none), pos_start}, {tid, genomic exon idx, first row of tid in tx_ex, end of that next exon}
+                               // (genomic order; ~0u if none), pos_start}, {tid, genomic exon idx (bit 31: the transcript has > 256 exons), first row of tid in tx_ex, end of that next exon}
   const uint4 *tx_ex;          // per transcript: exons in genomic order {start, end, pos_start, seq_off},
                                // closed by a sentinel {~0u, ~0u, 0, 0}
   const uint32_t *tx_first;    // [n_tx + 1] first tx_ex row of each transcript (incl. sentinels)

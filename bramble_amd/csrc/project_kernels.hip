@@ -814,7 +814,7 @@ __global__ void __launch_bounds__(256, EMIT ? 4 : 8) k_project(ProjectArgs A) {
           bool want = true;
           if (EMIT && have_mask) want = (mask_in >> item) & 1ull;
           if (want && gend > q0.x && gs < q0.y && classify(s == 1, st0, q0.x, q0.y, gs, gend, pay.z, cfg, h0)) {
-            E = ix.tx_ex + pay.w; i0 = pay.y;
+            E = ix.tx_ex + pay.w; i0 = pay.y & 0x7fffffffu;  // bit 31: the transcript has more than 256 exons
             // first-exon duplicate tid: the LAST passing row of the tid wins
             // (src/evaluate.cpp:218-224); later rows of the same tid are the
             // following exons of its table.  r_a.z = start of the next one.
@@ -844,6 +844,23 @@ __global__ void __launch_bounds__(256, EMIT ? 4 : 8) k_project(ProjectArgs A) {
                   alive2 = c1 && !c0;
                 }
                 p1.alive = alive2;
+              }
+              else if (MODE == 1 && !cfg.long_reads && !cfg.ignore_small_exons && !(pay.y >> 31)) {
+                // Defer only what can still survive.  In these presets every read exon must hit exactly the next guide
+                // exon (gap 1, no skipped or inserted exon), so a candidate whose second read exon does not pass against
+                // the exon after its own -- or passes against its own -- is dead whatever the rest of the walk finds.
+                // Not for transcripts with more than 256 exons: the reference's uint8 exon-id arithmetic also accepts a hit
+                // 257 exons on (evaluate.cpp:131), which only the walk sees.
+                const uint32_t qs1 = hd2.x, qe1 = hd2.y;
+                const int st1 = n_seg == 2 ? ST_LAST : ST_MIDDLE;
+                Hit hh;
+                if (gend < qe1 && !(qs1 == q0.x && qe1 == q0.y)) {
+                  const bool c0 = gend > qs1 && classify(s == 1, st1, qs1, qe1, gs, gend, pay.z, cfg, hh);
+                  const uint4 e1 = next_row(make_uint4(gs, gend, pay.z, 0), make_uint2(nxt, nxe), s == 1);
+                  const bool c1 = nxt < qe1 && nxe > qs1 && classify(s == 1, st1, qs1, qe1, e1.x, e1.y, e1.z, cfg, hh);
+                  if (c1 && !c0) defer = true;
+                }
+                p1.alive = false;
               }
               else if (MODE == 1) { defer = true; p1.alive = false; }
               else p1 = walk_pass1(ix, cfg, rd, E, s == 1, sb[s], se[s], i0, make_uint4(gs, gend, pay.z, 0), make_uint2(nxt, nxe), q0, h0);
@@ -1053,7 +1070,7 @@ __global__ void __launch_bounds__(256, CLS == 1 ? 8 : 6) k_emit_dense(ProjectArg
   ReadCtx rd;
   rd.n_seg = n_seg; rd.seg = A.seg + (size_t)c0 + (size_t)a; rd.real = A.cigar + c0; rd.n_real = c1 - c0; rd.q12 = hd2;
   const uint4 *E = ix.tx_ex + pay.w;
-  uint32_t i0 = pay.y;
+  uint32_t i0 = pay.y & 0x7fffffffu;
   CandOut p1;
   bool plain = false;
   uint32_t sb = ix.slab_off[2 * rid + s], se = ix.slab_off[2 * rid + s + 1];
