@@ -413,7 +413,7 @@ struct br_ctx {
   int deflate_dynamic = 1;
   int emit_split = 1;
   int count_split = 1;   // count pass as two kernels: the main one without the exon walk, a second one for the alignments that need it
-  DevBuf walk_list;
+  DevBuf walk_list, pmask;
   void *zero_cols_sim = nullptr, *zero_cols_clip = nullptr; size_t zero_cols_rows = 0;  // row columns known to be all zero
   bool z_tabs_ready = false;
   DevBuf p_ncig, p_name_len, p_isnew, p_group_pre, p_small, p_big, p_seq_len, p_ref_map;
@@ -474,7 +474,7 @@ extern "C" void br_ctx_free(br_ctx *c) {
                     &c->r_ncig, &c->r_strand, &c->r_sim, &c->r_clip, &c->r_junc, &c->r_refc, &c->r_cigoff,
                     &c->cigar_out, &c->r_paired, &c->r_same, &c->r_first, &c->r_primary, &c->b_name_off, &c->b_names, &c->b_ref_id, &c->b_ref_start,
                     &c->b_flags, &c->b_xs, &c->b_ts, &c->b_cigar_off, &c->b_cigar, &c->b_mate_idx,
-                    &c->b_group_off, &c->b_lqseq, &c->walk_list};
+                    &c->b_group_off, &c->b_lqseq, &c->walk_list, &c->pmask};
   for (DevBuf *b : bufs) b->release();
   for (auto &e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if (c->h_totals) (void)hipHostFree(c->h_totals);
@@ -725,6 +725,7 @@ static int run_device_impl(br_ctx *c, const br_config *cfg, const br_device_batc
   P.aln_group = c->aln_group.as<uint32_t>();
   P.match_off = c->match_off.as<uint32_t>(); P.n_matches = c->n_matches.as<uint32_t>(); P.m_tid = A.m_tid; P.m_a = A.m_a; P.m_b = A.m_b; P.l_qseq = b->l_qseq;
   P.n_rows = c->n_rows.as<uint32_t>(); P.row_off = c->row_off.as<uint64_t>(); P.counters = c->counters_d.as<uint64_t>();
+  RC(c->pmask.ensure((size_t)n * 8)); P.pmask = c->pmask.as<uint64_t>();
   RC(pf.begin(BR_K_PAIR_COUNT));
   launch_pair(st, P, false);
   RC(pf.end());

@@ -93,6 +93,7 @@ struct PairArgs {
   const uint4 *m_a, *m_b;
   const int32_t *l_qseq;
   uint32_t *n_rows;         // count pass: records per leader alignment
+  uint64_t *pmask;          // [n_aln] count pass -> emit pass: list positions of a pair's common transcripts (lists <= 64)
   const uint64_t *row_off;  // [n_aln + 1] emit pass
   int32_t *r_input;
   uint4 *r_rec;             // per record {match, mate match or ~0u, input alignment, RF_* flags}

@@ -1368,8 +1368,24 @@ __global__ void __launch_bounds__(256) k_pair(PairArgs P) {
         }
       rows = ni;
     } else {
-      // both mates matched: sorted-set intersection (mates.cpp:204-231)
+      // both mates matched: sorted-set intersection (mates.cpp:204-231).  The count pass does the merge and leaves, per
+      // mate, the bit set of its list positions that are common (both lists ascend, so the k-th common position of one
+      // pairs with the k-th of the other); the emit pass only walks those bits -- no second merge over m_tid[].
       uint32_t x = 0, y = 0, common = 0;
+      const bool masked = ni <= 64u && nm <= 64u;
+      if (EMIT && masked) {
+        uint64_t ma = P.pmask[i], mb = P.pmask[m];
+        while (ma) {
+          uint32_t xx = (uint32_t)__builtin_ctzll(ma), yy = (uint32_t)__builtin_ctzll(mb);
+          ma &= ma - 1; mb &= mb - 1;
+          uint64_t r = r0 + 2ull * common;
+          P.r_rec[r] = make_uint4(mi0 + xx, mm0 + yy, i, RF_FIRST | RF_PAIRED | RF_SAME_TX);
+          P.r_rec[r + 1] = make_uint4(mm0 + yy, mi0 + xx, (uint32_t)m, RF_PAIRED | RF_SAME_TX);
+          common++;
+        }
+        x = ni;  // skip the merge
+      }
+      uint64_t bits_a = 0, bits_b = 0;
       while (x < ni && y < nm) {
         uint32_t tx = P.m_tid[mi0 + x], ty = P.m_tid[mm0 + y];
         if (tx < ty) x++;
@@ -1379,10 +1395,11 @@ __global__ void __launch_bounds__(256) k_pair(PairArgs P) {
             uint64_t r = r0 + 2ull * common;
             P.r_rec[r] = make_uint4(mi0 + x, mm0 + y, i, RF_FIRST | RF_PAIRED | RF_SAME_TX);
             P.r_rec[r + 1] = make_uint4(mm0 + y, mi0 + x, (uint32_t)m, RF_PAIRED | RF_SAME_TX);
-          }
+          } else if (masked) { bits_a |= 1ull << x; bits_b |= 1ull << y; }
           common++; x++; y++;
         }
       }
+      if (!EMIT && masked) { P.pmask[i] = bits_a; P.pmask[m] = bits_b; }
       if (common) rows = 2 * common;
       else if (ni == 1 && nm == 1) {  // one transcript each, different ones
         if (EMIT) {
