@@ -409,21 +409,44 @@ struct br_ctx {
   struct StageSlot { DevBuf blob, off, len; hipEvent_t ready = nullptr; std::vector<uint64_t> h_off; int64_t n = 0; };
   StageSlot stage[3];              // br_bam_bundle_stage: uploads of the next bundles overlap the current projection
   hipStream_t copy_stream = nullptr;
+  // flat (br_batch) staging: two input slots, uploads on copy_stream; packed rows go back on d2h_stream into the
+  // slot's pinned arrays while the next batch is being projected on run_stream
+  struct InSlot {
+    DevBuf ref_id, ref_start, flags, xs, ts, cigar_off64, cigar, mate_ref, mate_start, name_off64, names, lqseq, seq_off64, seqs;
+    DevBuf cigar_off, name_off, seq_off, mate_idx, group_off, seq_src, isnew, group_pre;
+    hipEvent_t ready = nullptr, rows_home = nullptr;
+    int64_t n = -1; uint64_t n_words = 0, n_name = 0, n_seq = 0; bool has_seq = false, staged = false, rows_pending = false;
+    PinnedVec<uint4> h_a; PinnedVec<uint64_t> h_c, h_row_off; PinnedVec<uint32_t> h_pool; PinnedVec<uint4> h_x;
+    PinnedVec<int32_t> h_mate, h_clip; PinnedVec<double> h_sim;
+  };
+  InSlot in_slot[2];
+  hipStream_t run_stream = nullptr, d2h_stream = nullptr;
+  hipEvent_t rows_busy = nullptr;   // recorded after the last packed download was queued: k_rows of the next call waits for it
+  bool rows_busy_set = false;
+  int host_detail = 0;              // br_host_rows carries the x (detail) array
   DevBuf z_slots, z_sizes, z_off, z_dense, z_tabs, z_tokens;
   int deflate_dynamic = 1;
   int emit_split = 1;
   int count_split = 1;   // count pass as two kernels: the main one without the exon walk, a second one for the alignments that need it
   DevBuf walk_list, pmask;
-  void *zero_cols_sim = nullptr, *zero_cols_clip = nullptr; size_t zero_cols_rows = 0;  // row columns known to be all zero
+  // packed row table (the product of the row stage) and what its kernels need
+  DevBuf pk_a, pk_c, pk_x, pk_sim, pk_clip, pk_src, pool, pool_cnt, n_pool, pool_off;
+  bool last_aux_cols = false;           // the last call's rows carry similarity / clip scores
+  bool wide_valid = false;              // the wide view below matches the last call's rows
+  const int32_t *last_l_qseq = nullptr; // the last batch's l_qseq (device; insert sizes of the wide view / the encoder)
+  int32_t last_long_reads = 0;
+  int64_t last_n_pool = 0;
   bool z_tabs_ready = false;
   DevBuf p_ncig, p_name_len, p_isnew, p_group_pre, p_small, p_big, p_seq_len, p_ref_map;
   uint8_t *h_bam[2] = {nullptr, nullptr}; size_t h_bam_cap[2] = {0, 0}; int h_bam_next = 0;  // pinned download buffers of br_project_bam_bundle (alternating)
   int64_t last_n_rows = 0, last_n_aln = 0;
   DevBuf fa_stats, fa_n_prob, fa_seq_bytes, fa_prob_off, fa_seqarena_off, fa_probs, fa_results, fa_seq_arena, fa_clip_ops,
       fa_ideal_cap, fa_scratch, b_seq_off, b_seqs, b_seq_src;
-  DevBuf n_rows, row_off, aln_group, r_input, r_rec, r_nh, r_hi, r_mapq, r_group, r_mate_tid, r_mate_pos,
+  DevBuf n_rows, row_off, aln_group;
+  // wide view of the rows (br_device_rows_expand): one array per field
+  DevBuf r_input, r_nh, r_hi, r_mapq, r_group, r_mate_tid, r_mate_pos,
       r_isize, r_tid, r_pos, r_ncig, r_strand, r_sim, r_clip, r_junc, r_refc, r_cigoff, cigar_out;
-  DevBuf r_paired, r_same, r_first, r_primary;  // unpacked flag bytes for the public row view
+  DevBuf r_paired, r_same, r_first, r_primary;
   DevBuf b_name_off, b_names;
   // device staging of host batches (br_project_batch)
   DevBuf b_ref_id, b_ref_start, b_flags, b_xs, b_ts, b_cigar_off, b_cigar, b_mate_idx, b_group_off, b_lqseq;
@@ -469,7 +492,8 @@ extern "C" void br_ctx_free(br_ctx *c) {
                     &c->m_cigoff, &c->cig_arena, &c->big_list, &c->n_big, &c->m_aln,
                     &c->bam_aux, &c->bam_len, &c->bam_off, &c->bam_out, &c->z_slots, &c->z_sizes, &c->z_off, &c->z_dense, &c->z_tabs, &c->z_tokens, &c->p_ncig, &c->p_name_len, &c->p_isnew, &c->p_group_pre, &c->p_small, &c->p_big, &c->p_seq_len, &c->p_ref_map, &c->fa_stats, &c->fa_n_prob, &c->fa_seq_bytes, &c->fa_prob_off, &c->fa_seqarena_off, &c->fa_probs, &c->fa_results,
                     &c->fa_seq_arena, &c->fa_clip_ops, &c->fa_ideal_cap, &c->fa_scratch, &c->b_seq_off, &c->b_seqs, &c->b_seq_src,
-                    &c->n_rows, &c->row_off, &c->aln_group, &c->r_input, &c->r_rec, &c->r_nh, &c->r_hi, &c->r_mapq,
+                    &c->pk_a, &c->pk_c, &c->pk_x, &c->pk_sim, &c->pk_clip, &c->pk_src, &c->pool, &c->pool_cnt, &c->n_pool, &c->pool_off,
+                    &c->n_rows, &c->row_off, &c->aln_group, &c->r_input, &c->r_nh, &c->r_hi, &c->r_mapq,
                     &c->r_group, &c->r_mate_tid, &c->r_mate_pos, &c->r_isize, &c->r_tid, &c->r_pos,
                     &c->r_ncig, &c->r_strand, &c->r_sim, &c->r_clip, &c->r_junc, &c->r_refc, &c->r_cigoff,
                     &c->cigar_out, &c->r_paired, &c->r_same, &c->r_first, &c->r_primary, &c->b_name_off, &c->b_names, &c->b_ref_id, &c->b_ref_start,
@@ -480,6 +504,19 @@ extern "C" void br_ctx_free(br_ctx *c) {
   if (c->h_totals) (void)hipHostFree(c->h_totals);
   for (int k = 0; k < 2; k++) if (c->h_bam[k]) (void)hipHostFree(c->h_bam[k]);
   for (auto &S : c->stage) { S.blob.release(); S.off.release(); S.len.release(); if (S.ready) (void)hipEventDestroy(S.ready); }
+  for (auto &S : c->in_slot) {
+    DevBuf *ib[] = {&S.ref_id, &S.ref_start, &S.flags, &S.xs, &S.ts, &S.cigar_off64, &S.cigar, &S.mate_ref, &S.mate_start, &S.name_off64,
+                    &S.names, &S.lqseq, &S.seq_off64, &S.seqs, &S.cigar_off, &S.name_off, &S.seq_off, &S.mate_idx, &S.group_off,
+                    &S.seq_src, &S.isnew, &S.group_pre};
+    for (DevBuf *b : ib) b->release();
+    if (S.ready) (void)hipEventDestroy(S.ready);
+    if (S.rows_home) (void)hipEventDestroy(S.rows_home);
+    S.h_a.release(); S.h_c.release(); S.h_row_off.release(); S.h_pool.release(); S.h_x.release(); S.h_mate.release();
+    S.h_clip.release(); S.h_sim.release();
+  }
+  if (c->rows_busy) (void)hipEventDestroy(c->rows_busy);
+  if (c->run_stream) (void)hipStreamDestroy(c->run_stream);
+  if (c->d2h_stream) (void)hipStreamDestroy(c->d2h_stream);
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   c->h_input.release(); c->h_clip.release(); c->h_junc.release(); c->h_refc.release(); c->h_mate_tid.release(); c->h_mate_pos.release();
   c->h_isize.release(); c->h_tid.release(); c->h_pos.release(); c->h_nh.release(); c->h_hi.release(); c->h_mapq.release(); c->h_group.release();
@@ -496,6 +533,7 @@ extern "C" int br_ctx_set_param(br_ctx *c, const char *key, int64_t v) {
   if (!strcmp(key, "count_split")) { c->count_split = v != 0; return BR_OK; }
   if (!strcmp(key, "deflate_dynamic")) { c->deflate_dynamic = v != 0; return BR_OK; }
   if (!strcmp(key, "bam_lanes")) { if (v != 4 && v != 8 && v != 16 && v != 32 && v != 64) return BR_ERR_INVALID_ARG; c->bam_lanes = (int)v; return BR_OK; }
+  if (!strcmp(key, "host_detail")) { c->host_detail = v != 0; return BR_OK; }
   if (!strcmp(key, "blocks_per_cu")) { if (v < 1 || v > 64) return BR_ERR_INVALID_ARG; c->blocks_per_cu = (int)v; return BR_OK; }
   return BR_ERR_INVALID_ARG;
 }
@@ -574,6 +612,8 @@ static int run_device_impl(br_ctx *c, const br_config *cfg, const br_device_batc
   Prof pf{c, st};
   if (!keep_events) c->events_used = 0;
   out->total_processed = (uint64_t)n;
+  c->last_n_rows = 0; c->last_n_aln = n; c->last_n_pool = 0; c->wide_valid = false; c->last_aux_cols = false;
+  c->last_l_qseq = b->l_qseq; c->last_long_reads = dc.long_reads;
   if (n == 0) { pf.collect(); return BR_OK; }
 
   int64_t tiles = std::max<int64_t>(scan_tiles_for(std::max<int64_t>(n, ng) + 1), 1);
@@ -601,6 +641,9 @@ static int run_device_impl(br_ctx *c, const br_config *cfg, const br_device_batc
   A.match_off = c->match_off.as<uint32_t>(); A.cig_base = c->cig_base.as<uint64_t>();
   RC(c->big_list.ensure((size_t)n * 4)); RC(c->n_big.ensure(16));
   HIPCHK(hipMemsetAsync(c->n_big.p, 0, 8, st));
+  RC(c->pool_cnt.ensure((size_t)n * 4));
+  HIPCHK(hipMemsetAsync(c->pool_cnt.p, 0, (size_t)n * 4, st));
+  A.pool_cnt = c->pool_cnt.as<uint32_t>();
   A.big_list = c->big_list.as<uint32_t>(); A.n_big = c->n_big.as<uint32_t>();
   if (c->count_split) { RC(c->walk_list.ensure((size_t)n * 4)); A.walk_list = c->walk_list.as<uint32_t>(); A.n_walk = c->n_big.as<uint32_t>() + 1; }
   int n_blocks = c->n_cu * c->blocks_per_cu;
@@ -609,9 +652,15 @@ static int run_device_impl(br_ctx *c, const br_config *cfg, const br_device_batc
   S.tile_sums = c->tile_sums.as<uint64_t>(); S.fast_flag = c->fast_flag.as<uint32_t>();
   FaArgs F{};
   if (!fa_mode) {
+    const bool split = A.walk_list && !dc.filter_by_similarity;
     RC(pf.begin(BR_K_COUNT));
-    launch_project(st, A, false, c->group_lanes, n_blocks);
+    launch_project(st, A, false, c->group_lanes, n_blocks, split ? 1 : 0);
     RC(pf.end());
+    if (split) {
+      RC(pf.begin(BR_K_COUNT_WALK));
+      launch_project(st, A, false, c->group_lanes, n_blocks, 2);
+      RC(pf.end());
+    }
     RC(pf.begin(BR_K_SCAN));
     launch_scan3(st, S, c->match_off.as<uint32_t>(), c->cig_base.as<uint64_t>(), c->fast_pre.as<uint32_t>(), d_tot + 0);
     RC(pf.end());
@@ -697,8 +746,10 @@ static int run_device_impl(br_ctx *c, const br_config *cfg, const br_device_batc
       launch_project_fa(st, A, F, 3, n_blocks);
       RC(pf.end());
     } else {
-      RC(pf.begin(BR_K_EMIT_AUX));
+      RC(pf.begin(BR_K_EXPAND));
       launch_expand(st, A);
+      RC(pf.end());
+      RC(pf.begin(BR_K_EMIT_AUX));
       launch_project(st, A, true, 64, c->n_cu);  // alignments with > 64 candidate rows only
       RC(pf.end());
       if (c->emit_split && n_simple >= 0 && !dc.filter_by_similarity) {
@@ -716,98 +767,133 @@ static int run_device_impl(br_ctx *c, const br_config *cfg, const br_device_batc
     }
   }
 
-  // a16/a17: pairing + NH
+  // a16/a17: pairing + NH -> the packed row table
+  // (a buffer that a queued packed download still reads must not be reallocated under it)
+  if (c->rows_busy_set && c->row_off.cap < (size_t)(n + 1) * 8) HIPCHK(hipEventSynchronize(c->rows_busy));
   RC(c->n_rows.ensure((size_t)n * 4)); RC(c->row_off.ensure((size_t)(n + 1) * 8)); RC(c->aln_group.ensure((size_t)n * 4));
+  RC(c->n_pool.ensure((size_t)n * 4)); RC(c->pool_off.ensure((size_t)(n + 1) * 8));
+  RC(pf.begin(BR_K_GROUP_IDS));
   launch_group_ids(st, ng, b->group_off, c->aln_group.as<uint32_t>());
+  RC(pf.end());
   HIPCHK(hipMemsetAsync(c->counters_d.p, 0, 4 * 8, st));
   PairArgs P{};
   P.n_groups = ng; P.n_aln = n; P.long_reads = dc.long_reads; P.group_off = b->group_off; P.mate_idx = b->mate_idx;
   P.aln_group = c->aln_group.as<uint32_t>();
-  P.match_off = c->match_off.as<uint32_t>(); P.n_matches = c->n_matches.as<uint32_t>(); P.m_tid = A.m_tid; P.m_a = A.m_a; P.m_b = A.m_b; P.l_qseq = b->l_qseq;
-  P.n_rows = c->n_rows.as<uint32_t>(); P.row_off = c->row_off.as<uint64_t>(); P.counters = c->counters_d.as<uint64_t>();
+  P.match_off = c->match_off.as<uint32_t>(); P.n_matches = c->n_matches.as<uint32_t>(); P.m_tid = A.m_tid; P.m_a = A.m_a; P.m_b = A.m_b;
+  P.m_cigoff = A.m_cigoff; P.cig_arena = A.cig_arena; P.pool_cnt = A.pool_cnt;
+  P.n_rows = c->n_rows.as<uint32_t>(); P.n_pool = c->n_pool.as<uint32_t>();
+  P.row_off = c->row_off.as<uint64_t>(); P.pool_off = c->pool_off.as<uint64_t>(); P.counters = c->counters_d.as<uint64_t>();
   RC(c->pmask.ensure((size_t)n * 8)); P.pmask = c->pmask.as<uint64_t>();
   RC(pf.begin(BR_K_PAIR_COUNT));
-  launch_pair(st, P, false);
+  launch_pair(st, P);
   RC(pf.end());
   ScanArgs S2{};
   S2.n = n; S2.src32 = c->n_rows.as<uint32_t>(); S2.tile_sums = c->tile_sums.as<uint64_t>();
+  // a packed download of the previous call may still be reading row_off / the row tables (br_project_staged)
+  if (c->rows_busy_set) { HIPCHK(hipStreamWaitEvent(st, c->rows_busy, 0)); }
   RC(pf.begin(BR_K_SCAN));
   launch_scan(st, S2, 2, c->row_off.p, true, d_tot + 2);
+  S2.src32 = c->n_pool.as<uint32_t>();
+  launch_scan(st, S2, 2, c->pool_off.p, true, d_tot + 3);
   RC(pf.end());
-  HIPCHK(hipMemcpyAsync(c->h_totals + 2, d_tot + 2, 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(c->h_totals + 2, d_tot + 2, 16, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
-  uint64_t n_rows = c->h_totals[2];
-  out->n_rows = (int64_t)n_rows;
+  const uint64_t n_rows = c->h_totals[2], n_pool = c->h_totals[3];
+  out->n_rows = (int64_t)n_rows; out->n_pool_words = (int64_t)n_pool;
 
-  size_t nr = (size_t)std::max<uint64_t>(n_rows, 1);
-  RC(c->r_input.ensure(nr * 4)); RC(c->r_rec.ensure(nr * sizeof(uint4)));
-  RC(c->r_nh.ensure(nr * 4)); RC(c->r_hi.ensure(nr * 4));
+  const size_t nr = (size_t)std::max<uint64_t>(n_rows, 1);
+  // clip score / similarity score columns exist only when the preset filters by similarity (long reads): else all zero
+  const bool aux_cols = dc.filter_by_similarity != 0;
+  if (c->rows_busy_set && (c->pk_a.cap < nr * sizeof(uint4) || c->pk_x.cap < nr * sizeof(uint4) || c->pk_c.cap < nr * sizeof(uint2) ||
+                           c->pool.cap < (size_t)std::max<uint64_t>(n_pool, 1) * 4 ||
+                           (aux_cols && (c->pk_sim.cap < nr * 8 || c->pk_clip.cap < nr * 4))))
+    HIPCHK(hipEventSynchronize(c->rows_busy));
+  RC(c->pk_a.ensure(nr * sizeof(uint4))); RC(c->pk_c.ensure(nr * sizeof(uint2))); RC(c->pk_x.ensure(nr * sizeof(uint4)));
+  RC(c->pool.ensure((size_t)std::max<uint64_t>(n_pool, 1) * 4));
+  if (aux_cols) { RC(c->pk_sim.ensure(nr * 8)); RC(c->pk_clip.ensure(nr * 4)); }
+  // records with hundreds of ops (long reads): the ops move to the pool 16 lanes per record instead of lane-serially
+  const bool long_cigars = n_pool > 8 * n_rows;
+  if (long_cigars) RC(c->pk_src.ensure(nr * 8));
+  P.r_a = c->pk_a.as<uint4>(); P.r_c = c->pk_c.as<uint2>(); P.r_x = c->pk_x.as<uint4>();
+  P.r_sim = aux_cols ? c->pk_sim.as<double>() : nullptr; P.r_clip = aux_cols ? c->pk_clip.as<int32_t>() : nullptr;
+  P.pool = c->pool.as<uint32_t>(); P.r_src = long_cigars ? c->pk_src.as<uint64_t>() : nullptr;
+  if (n_rows) {
+    RC(pf.begin(BR_K_PAIR_EMIT));
+    launch_rows(st, P, aux_cols, long_cigars);
+    RC(pf.end());
+    if (long_cigars) {
+      RC(pf.begin(BR_K_CIGAR_POOL));
+      launch_pool_copy(st, P, (int64_t)n_rows);
+      RC(pf.end());
+    }
+  }
+  RC(pf.begin(BR_K_PRIMARY));
+  launch_primary(st, P, b->name_off, (b->names && b->name_off) ? b->names : nullptr, aux_cols);  // + per-group counters
+  RC(pf.end());
+  HIPCHK(hipMemcpyAsync(c->h_totals + 4, c->counters_d.p, 4 * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (!keep_events) RC(pf.collect());
+  if (c->h_totals[7]) return BR_ERR_UNSUPPORTED;  // a rewritten CIGAR with more than 2^24 - 1 ops
+  out->total_complete = n_rows; out->total_unique = c->h_totals[5]; out->dropped_reads = c->h_totals[6];
+  if (fa_mode && c->rescue_stats[0]) { c->rescue_stats[1] = c->h_totals[8]; c->rescue_stats[2] = c->h_totals[9]; }
+
+  out->a = (const br_row_a *)c->pk_a.p; out->cigar = (const uint64_t *)c->pk_c.p; out->x = (const br_row_x *)c->pk_x.p;
+  out->similarity_score = aux_cols ? c->pk_sim.as<double>() : nullptr;
+  out->clip_score = aux_cols ? c->pk_clip.as<int32_t>() : nullptr;
+  out->pool = c->pool.as<uint32_t>(); out->row_off = c->row_off.as<uint64_t>();
+  c->counters[6] = n_matches;
+  c->last_n_rows = (int64_t)n_rows; c->last_n_aln = n; c->last_n_pool = (int64_t)n_pool;
+  c->last_aux_cols = aux_cols; c->wide_valid = false; c->last_l_qseq = b->l_qseq; c->last_long_reads = dc.long_reads;
+  return BR_OK;
+}
+
+// The wide view of the last call's rows: one device array per field (what tests, debuggers and the host-row entry
+// points read).  Everything is derived from the packed table; nothing here is on the projection's own path.
+static int expand_rows(br_ctx *c, hipStream_t st, br_device_wide_rows *out) {
+  memset(out, 0, sizeof(*out));
+  HIPCHK(hipSetDevice(c->ix->device));
+  const uint64_t n_rows = (uint64_t)c->last_n_rows;
+  const size_t nr = (size_t)std::max<uint64_t>(n_rows, 1);
+  RC(c->r_input.ensure(nr * 4)); RC(c->r_nh.ensure(nr * 4)); RC(c->r_hi.ensure(nr * 4));
   RC(c->r_mapq.ensure(nr * 4)); RC(c->r_group.ensure(nr * 4));
   RC(c->r_mate_tid.ensure(nr * 4)); RC(c->r_mate_pos.ensure(nr * 4)); RC(c->r_isize.ensure(nr * 4));
   RC(c->r_tid.ensure(nr * 4)); RC(c->r_pos.ensure(nr * 4)); RC(c->r_ncig.ensure(nr * 4)); RC(c->r_strand.ensure(nr));
-  RC(c->r_sim.ensure(nr * 8)); RC(c->r_clip.ensure(nr * 4));
-  // clip score / similarity score columns: all zero unless the preset filters by similarity (long reads); zero-filled
-  // once per buffer, then left alone
-  const bool aux_cols = dc.filter_by_similarity != 0;
-  if (aux_cols) c->zero_cols_rows = 0;
-  else if (c->zero_cols_sim != c->r_sim.p || c->zero_cols_clip != c->r_clip.p || c->zero_cols_rows < nr) {
-    HIPCHK(hipMemsetAsync(c->r_sim.p, 0, c->r_sim.cap, st)); HIPCHK(hipMemsetAsync(c->r_clip.p, 0, c->r_clip.cap, st));
-    c->zero_cols_sim = c->r_sim.p; c->zero_cols_clip = c->r_clip.p; c->zero_cols_rows = std::min(c->r_sim.cap / 8, c->r_clip.cap / 4);
-  } RC(c->r_junc.ensure(nr * 4)); RC(c->r_refc.ensure(nr * 4));
+  RC(c->r_sim.ensure(nr * 8)); RC(c->r_clip.ensure(nr * 4)); RC(c->r_junc.ensure(nr * 4)); RC(c->r_refc.ensure(nr * 4));
   RC(c->r_cigoff.ensure((nr + 1) * 8));
   RC(c->r_paired.ensure(nr)); RC(c->r_same.ensure(nr)); RC(c->r_first.ensure(nr)); RC(c->r_primary.ensure(nr));
-  HIPCHK(hipMemsetAsync(c->r_primary.p, 0, nr, st));
-  P.r_input = c->r_input.as<int32_t>(); P.r_rec = c->r_rec.as<uint4>(); P.r_nh = c->r_nh.as<uint32_t>();
-  P.r_hi = c->r_hi.as<uint32_t>(); P.r_mapq = c->r_mapq.as<uint32_t>(); P.r_group = c->r_group.as<uint32_t>();
-  P.r_mate_tid = c->r_mate_tid.as<int32_t>();
-  P.r_mate_pos = c->r_mate_pos.as<int32_t>(); P.r_isize = c->r_isize.as<int32_t>();
-  P.r_tid = c->r_tid.as<uint32_t>(); P.r_pos = c->r_pos.as<uint32_t>(); P.r_ncig = c->r_ncig.as<uint32_t>();
-  P.r_strand = c->r_strand.as<int8_t>(); P.r_sim = c->r_sim.as<double>(); P.r_clip = c->r_clip.as<int32_t>();
-  P.r_junc = c->r_junc.as<int32_t>(); P.r_refc = c->r_refc.as<int32_t>(); P.r_paired = c->r_paired.as<uint8_t>();
-  P.r_same = c->r_same.as<uint8_t>(); P.r_first = c->r_first.as<uint8_t>();
   uint64_t n_out_words = 0;
   if (n_rows) {
-    RC(pf.begin(BR_K_PAIR_EMIT));
-    launch_pair(st, P, true);
-    RC(pf.end());
-  }
-  RC(pf.begin(BR_K_GATHER));
-  launch_row_fill(st, P, (int64_t)n_rows, aux_cols);  // + per-group counters
-  RC(pf.end());
-  if (n_rows && b->names && b->name_off) {
-    RC(pf.begin(BR_K_PRIMARY));
-    launch_primary(st, P, b->name_off, b->names, c->r_primary.as<uint8_t>(), dc.filter_by_similarity != 0);
-    RC(pf.end());
-  }
-  HIPCHK(hipMemcpyAsync(c->h_totals + 4, c->counters_d.p, 4 * 8, hipMemcpyDeviceToHost, st));
-  if (n_rows) {
-    RowArgs R{};
-    R.n_rows = (int64_t)n_rows; R.r_rec = P.r_rec; R.r_ncig = P.r_ncig; R.m_cigoff = A.m_cigoff;
-    R.cig_arena = A.cig_arena; R.r_cigoff = c->r_cigoff.as<uint64_t>();
+    WideArgs W{};
+    W.n_rows = (int64_t)n_rows; W.n_aln = c->last_n_aln; W.long_reads = c->last_long_reads;
+    W.r_a = c->pk_a.as<uint4>(); W.r_c = c->pk_c.as<uint2>(); W.r_x = c->pk_x.as<uint4>();
+    W.r_sim = c->last_aux_cols ? c->pk_sim.as<double>() : nullptr; W.r_clip = c->last_aux_cols ? c->pk_clip.as<int32_t>() : nullptr;
+    W.pool = c->pool.as<uint32_t>(); W.aln_group = c->aln_group.as<uint32_t>(); W.l_qseq = c->last_l_qseq;
+    W.w_input = c->r_input.as<int32_t>(); W.w_nh = c->r_nh.as<uint32_t>(); W.w_hi = c->r_hi.as<uint32_t>();
+    W.w_mapq = c->r_mapq.as<uint32_t>(); W.w_group = c->r_group.as<uint32_t>(); W.w_mate_tid = c->r_mate_tid.as<int32_t>();
+    W.w_mate_pos = c->r_mate_pos.as<int32_t>(); W.w_isize = c->r_isize.as<int32_t>(); W.w_tid = c->r_tid.as<uint32_t>();
+    W.w_pos = c->r_pos.as<uint32_t>(); W.w_ncig = c->r_ncig.as<uint32_t>(); W.w_strand = c->r_strand.as<int8_t>();
+    W.w_sim = c->r_sim.as<double>(); W.w_clip = c->r_clip.as<int32_t>(); W.w_junc = c->r_junc.as<int32_t>();
+    W.w_refc = c->r_refc.as<int32_t>(); W.w_paired = c->r_paired.as<uint8_t>(); W.w_same = c->r_same.as<uint8_t>();
+    W.w_first = c->r_first.as<uint8_t>(); W.w_primary = c->r_primary.as<uint8_t>();
+    launch_wide_fields(st, W);
     ScanArgs S3{};
+    RC(c->tile_sums.ensure((size_t)std::max<int64_t>(scan_tiles_for((int64_t)n_rows + 1), 1) * 8 * 3));
+    RC(c->totals.ensure(16 * 8));
     S3.n = (int64_t)n_rows; S3.src32 = c->r_ncig.as<uint32_t>(); S3.tile_sums = c->tile_sums.as<uint64_t>();
-    RC(c->tile_sums.ensure((size_t)std::max<int64_t>(scan_tiles_for((int64_t)n_rows + 1), 1) * 8));
-    S3.tile_sums = c->tile_sums.as<uint64_t>();
-    RC(pf.begin(BR_K_SCAN));
-    launch_scan(st, S3, 2, c->r_cigoff.p, true, d_tot + 3);
-    RC(pf.end());
-    HIPCHK(hipMemcpyAsync(c->h_totals + 3, d_tot + 3, 8, hipMemcpyDeviceToHost, st));
+    uint64_t *d_tot = c->totals.as<uint64_t>();
+    launch_scan(st, S3, 2, c->r_cigoff.p, true, d_tot + 8);
+    HIPCHK(hipMemcpyAsync(c->h_totals + 12, d_tot + 8, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    n_out_words = c->h_totals[3];
+    n_out_words = c->h_totals[12];
     RC(c->cigar_out.ensure((size_t)std::max<uint64_t>(n_out_words, 1) * 4));
-    R.cigar_out = c->cigar_out.as<uint32_t>();
-    RC(pf.begin(BR_K_CIGAR_POOL));
-    launch_gather(st, R, (int64_t)n_out_words);
-    RC(pf.end());
+    W.w_cigoff = c->r_cigoff.as<uint64_t>(); W.w_cigar = c->cigar_out.as<uint32_t>();
+    launch_wide_cigars(st, W, (int64_t)n_out_words);
   } else {
     HIPCHK(hipMemsetAsync(c->r_cigoff.p, 0, 8, st));
   }
   HIPCHK(hipStreamSynchronize(st));
-  if (!keep_events) RC(pf.collect());
-  out->total_complete = n_rows; out->total_unique = c->h_totals[5]; out->dropped_reads = c->h_totals[6];
-  if (fa_mode && c->rescue_stats[0]) { c->rescue_stats[1] = c->h_totals[8]; c->rescue_stats[2] = c->h_totals[9]; }
-
-  out->n_cigar_words = (int64_t)n_out_words;
+  c->wide_valid = true;
+  out->n_rows = (int64_t)n_rows; out->n_cigar_words = (int64_t)n_out_words;
   out->input_index = c->r_input.as<int32_t>(); out->transcript_id = c->r_tid.as<uint32_t>();
   out->pos = c->r_pos.as<uint32_t>(); out->strand = c->r_strand.as<int8_t>();
   out->cigar_off = c->r_cigoff.as<uint64_t>(); out->cigar = c->cigar_out.as<uint32_t>();
@@ -819,8 +905,6 @@ static int run_device_impl(br_ctx *c, const br_config *cfg, const br_device_batc
   out->mate_transcript_id = c->r_mate_tid.as<int32_t>(); out->mate_pos = c->r_mate_pos.as<int32_t>();
   out->insert_size = c->r_isize.as<int32_t>(); out->group = c->r_group.as<uint32_t>();
   out->is_primary = c->r_primary.as<uint8_t>();
-  c->counters[6] = n_matches;
-  c->last_n_rows = (int64_t)n_rows; c->last_n_aln = n;
   return BR_OK;
 }
 
@@ -869,13 +953,10 @@ static int bam_encode_impl(br_ctx *c, const br_config *cfg, const br_device_reco
   RC(c->bam_aux.ensure(std::max<size_t>((size_t)n, 1) * sizeof(BamAux)));
   RC(c->bam_len.ensure(std::max<size_t>((size_t)nr, 1) * 4)); RC(c->bam_off.ensure(((size_t)nr + 1) * 8));
   B.aux = (BamAux *)c->bam_aux.p;
-  B.r_input = c->r_input.as<int32_t>(); B.r_tid = c->r_tid.as<uint32_t>(); B.r_pos = c->r_pos.as<uint32_t>();
-  B.r_ncig = c->r_ncig.as<uint32_t>(); B.r_nh = c->r_nh.as<uint32_t>(); B.r_hi = c->r_hi.as<uint32_t>();
-  B.r_mapq = c->r_mapq.as<uint32_t>(); B.r_strand = c->r_strand.as<int8_t>(); B.r_paired = c->r_paired.as<uint8_t>();
-  B.r_same = c->r_same.as<uint8_t>(); B.r_primary = c->r_primary.as<uint8_t>();
-  B.r_mate_tid = c->r_mate_tid.as<int32_t>(); B.r_mate_pos = c->r_mate_pos.as<int32_t>(); B.r_isize = c->r_isize.as<int32_t>();
-  B.r_clip = c->r_clip.as<int32_t>(); B.r_sim = c->r_sim.as<double>(); B.r_cigoff = c->r_cigoff.as<uint64_t>();
-  B.cigar = c->cigar_out.as<uint32_t>(); B.out_len = c->bam_len.as<uint32_t>(); B.out_off = c->bam_off.as<uint64_t>();
+  B.r_a = c->pk_a.as<uint4>(); B.r_c = c->pk_c.as<uint2>(); B.r_x = c->pk_x.as<uint4>();
+  B.r_sim = c->last_aux_cols ? c->pk_sim.as<double>() : nullptr; B.r_clip = c->last_aux_cols ? c->pk_clip.as<int32_t>() : nullptr;
+  B.pool = c->pool.as<uint32_t>(); B.l_qseq = c->last_l_qseq;
+  B.out_len = c->bam_len.as<uint32_t>(); B.out_off = c->bam_off.as<uint64_t>();
   RC(c->tile_sums.ensure((size_t)std::max<int64_t>(scan_tiles_for(nr + 1), 1) * 8 * 3));
   RC(c->totals.ensure(16 * 8));
   B.too_long = c->totals.as<uint64_t>() + 6;
@@ -1176,6 +1257,11 @@ extern "C" int br_project_batch_device(br_ctx *c, const br_config *cfg, const br
   return run_device(c, cfg, b, (hipStream_t)stream, out);
 }
 
+extern "C" int br_device_rows_expand(br_ctx *c, void *stream, br_device_wide_rows *out) {
+  if (!c || !out) return BR_ERR_INVALID_ARG;
+  return expand_rows(c, (hipStream_t)stream, out);
+}
+
 // ---------------------------------------------------------------------------
 // host-batch entry: upload, run, download, finalise primary flags
 // ---------------------------------------------------------------------------
@@ -1192,71 +1278,188 @@ static int d2h(PinnedVec<T> &dst, const void *src, size_t n, hipStream_t st) {
   return BR_OK;
 }
 
+// ---- flat batches: staging, the input contract on the device, packed rows home ----
+static int ensure_streams(br_ctx *c) {
+  if (!c->copy_stream) HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  if (!c->run_stream) HIPCHK(hipStreamCreateWithFlags(&c->run_stream, hipStreamNonBlocking));
+  if (!c->d2h_stream) HIPCHK(hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
+  if (!c->rows_busy) HIPCHK(hipEventCreateWithFlags(&c->rows_busy, hipEventDisableTiming));
+  return BR_OK;
+}
+
+extern "C" int br_batch_stage(br_ctx *c, const br_batch *b, int slot) {
+  if (!c || !b || slot < 0 || slot > 1) return BR_ERR_INVALID_ARG;
+  const int64_t n = b->n_aln;
+  if (n < 0 || n >= 0x7fffffffll) return BR_ERR_CAPACITY;
+  if (n && (!b->ref_id || !b->ref_start || !b->flags || !b->xs || !b->ts || !b->cigar_off || !b->name_off || !b->mate_ref_id ||
+            !b->mate_start)) return BR_ERR_INVALID_ARG;
+  const uint64_t n_words = n ? b->cigar_off[n] : 0, n_name = n ? b->name_off[n] : 0;
+  const bool has_seq = b->seq_off && b->seqs;
+  const uint64_t n_seq = (n && has_seq) ? b->seq_off[n] : 0;
+  if (n_words >= 0xfffffff0ull - (uint64_t)n || n_name >= 0xfffffff0ull || n_seq >= 0xfffffff0ull) return BR_ERR_CAPACITY;
+  if ((n_words && !b->cigar) || (n_name && !b->names)) return BR_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(c->ix->device));
+  RC(ensure_streams(c));
+  br_ctx::InSlot &S = c->in_slot[slot];
+  if (!S.ready) HIPCHK(hipEventCreateWithFlags(&S.ready, hipEventDisableTiming));
+  if (!S.rows_home) HIPCHK(hipEventCreateWithFlags(&S.rows_home, hipEventDisableTiming));
+  hipStream_t cs = c->copy_stream;
+  S.n = n; S.n_words = n_words; S.n_name = n_name; S.n_seq = n_seq; S.has_seq = has_seq; S.staged = true;
+  const size_t nn = (size_t)n;
+  RC(h2d(S.ref_id, b->ref_id, nn, cs)); RC(h2d(S.ref_start, b->ref_start, nn, cs)); RC(h2d(S.flags, b->flags, nn, cs));
+  RC(h2d(S.xs, b->xs, nn, cs)); RC(h2d(S.ts, b->ts, nn, cs));
+  RC(h2d(S.mate_ref, b->mate_ref_id, nn, cs)); RC(h2d(S.mate_start, b->mate_start, nn, cs));
+  RC(S.cigar_off64.ensure((nn + 1) * 8)); RC(S.name_off64.ensure((nn + 1) * 8));
+  if (n) {
+    HIPCHK(hipMemcpyAsync(S.cigar_off64.p, b->cigar_off, (nn + 1) * 8, hipMemcpyHostToDevice, cs));
+    HIPCHK(hipMemcpyAsync(S.name_off64.p, b->name_off, (nn + 1) * 8, hipMemcpyHostToDevice, cs));
+  } else {
+    HIPCHK(hipMemsetAsync(S.cigar_off64.p, 0, 8, cs)); HIPCHK(hipMemsetAsync(S.name_off64.p, 0, 8, cs));
+  }
+  RC(h2d(S.cigar, b->cigar, (size_t)n_words, cs)); RC(h2d(S.names, (const uint8_t *)b->names, (size_t)n_name, cs));
+  RC(S.lqseq.ensure(std::max<size_t>(nn, 1) * 4));
+  if (b->l_qseq) { if (n) HIPCHK(hipMemcpyAsync(S.lqseq.p, b->l_qseq, nn * 4, hipMemcpyHostToDevice, cs)); }
+  else HIPCHK(hipMemsetAsync(S.lqseq.p, 0, std::max<size_t>(nn, 1) * 4, cs));
+  if (has_seq) {
+    RC(S.seq_off64.ensure((nn + 1) * 8));
+    if (n) HIPCHK(hipMemcpyAsync(S.seq_off64.p, b->seq_off, (nn + 1) * 8, hipMemcpyHostToDevice, cs));
+    else HIPCHK(hipMemsetAsync(S.seq_off64.p, 0, 8, cs));
+    RC(h2d(S.seqs, (const uint8_t *)b->seqs, (size_t)n_seq, cs));
+  }
+  HIPCHK(hipEventRecord(S.ready, cs));
+  return BR_OK;
+}
+
+// The staged slot's input contract on the device (what br_batch_prepare / br_batch_seq_source compute on the host:
+// read-name groups src/core.cpp:347-380, mate index src/bramble.cpp:272-311, the group's shared sequence
+// src/core.cpp:353-378) and the device batch over it.
+static int prep_staged(br_ctx *c, const br_config *cfg, br_ctx::InSlot &S, hipStream_t st, br_device_batch *db) {
+  memset(db, 0, sizeof(*db));
+  const int64_t n = S.n;
+  const size_t nn = (size_t)n;
+  HIPCHK(hipStreamWaitEvent(st, S.ready, 0));
+  db->n_aln = n;
+  if (n == 0) return BR_OK;
+  RC(S.cigar_off.ensure((nn + 1) * 4)); RC(S.name_off.ensure((nn + 1) * 4)); RC(S.isnew.ensure(nn * 4));
+  RC(S.group_pre.ensure((nn + 1) * 4)); RC(S.mate_idx.ensure(nn * 4));
+  if (S.has_seq) { RC(S.seq_off.ensure((nn + 1) * 4)); RC(S.seq_src.ensure(nn * 4)); }
+  RC(c->p_small.ensure(64)); RC(c->p_big.ensure((nn / 96 + 2) * 4));
+  RC(c->tile_sums.ensure((size_t)std::max<int64_t>(scan_tiles_for(n + 1), 1) * 8 * 3));
+  RC(c->totals.ensure(16 * 8));
+  HIPCHK(hipMemsetAsync(c->p_small.p, 0, 64, st));
+  SoaArgs A{};
+  A.n = n; A.cigar_off64 = S.cigar_off64.as<uint64_t>(); A.name_off64 = S.name_off64.as<uint64_t>();
+  A.seq_off64 = S.has_seq ? S.seq_off64.as<uint64_t>() : nullptr;
+  A.cigar_off = S.cigar_off.as<uint32_t>(); A.name_off = S.name_off.as<uint32_t>(); A.seq_off = S.has_seq ? S.seq_off.as<uint32_t>() : nullptr;
+  A.names = S.names.as<uint8_t>(); A.cigar = S.cigar.as<uint32_t>(); A.isnew = S.isnew.as<uint32_t>(); A.maxima = c->p_small.as<uint32_t>();
+  launch_soa_fields(st, A);
+  uint64_t *d_tot = c->totals.as<uint64_t>();
+  ScanArgs SC{}; SC.n = n; SC.tile_sums = c->tile_sums.as<uint64_t>(); SC.src32 = A.isnew;
+  launch_scan(st, SC, 2, S.group_pre.p, false, d_tot + 9);
+  HIPCHK(hipMemcpyAsync(c->h_totals + 26, d_tot + 9, 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(c->h_totals + 27, c->p_small.p, 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  const uint64_t ng = c->h_totals[26];
+  const uint32_t max_nc = (uint32_t)(c->h_totals[27] & 0xffffffffu), max_clip = (uint32_t)(c->h_totals[27] >> 32);
+  RC(S.group_off.ensure(((size_t)ng + 1) * 4));
+  ParseArgs P{};
+  P.n = n; P.n_groups = (int64_t)ng; P.isnew = A.isnew; P.group_pre = S.group_pre.as<uint32_t>(); P.group_off = S.group_off.as<uint32_t>();
+  P.flags = S.flags.as<uint16_t>(); P.ref_id = S.ref_id.as<int32_t>(); P.ref_start = S.ref_start.as<int32_t>();
+  P.mate_ref_id = S.mate_ref.as<int32_t>(); P.mate_start = S.mate_start.as<int32_t>(); P.mate_idx = S.mate_idx.as<int32_t>();
+  P.n_big_groups = c->p_small.as<uint32_t>() + 2; P.big_groups = c->p_big.as<uint32_t>();
+  launch_group_off(st, P);
+  launch_mates(st, P);
+  db->n_groups = (int64_t)ng; db->ref_id = P.ref_id; db->ref_start = P.ref_start; db->flags = P.flags;
+  db->xs = S.xs.as<int8_t>(); db->ts = S.ts.as<int8_t>(); db->cigar_off = A.cigar_off; db->cigar = A.cigar;
+  db->mate_idx = P.mate_idx; db->group_off = P.group_off; db->l_qseq = S.lqseq.as<int32_t>();
+  db->n_cigar_words = (int64_t)S.n_words; db->max_n_cigar = (int32_t)max_nc;
+  db->name_off = A.name_off; db->names = A.names;
+  if (cfg->use_fasta && (cfg->lr || cfg->lr_hq)) {
+    if (!S.has_seq) return BR_ERR_INVALID_ARG;
+    P.seq_off = A.seq_off; P.seq_src = S.seq_src.as<int32_t>();
+    launch_seq_src(st, P);
+    db->seq_off = A.seq_off; db->seqs = S.seqs.as<uint8_t>(); db->seq_src = P.seq_src; db->max_soft_clip = (int32_t)max_clip;
+  }
+  return BR_OK;
+}
+
+extern "C" int br_project_staged(br_ctx *c, const br_config *cfg, int slot, br_host_rows *out) {
+  if (!c || !cfg || !out || slot < 0 || slot > 1) return BR_ERR_INVALID_ARG;
+  memset(out, 0, sizeof(*out));
+  br_ctx::InSlot &S = c->in_slot[slot];
+  if (!S.staged) return BR_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(c->ix->device));
+  RC(ensure_streams(c));
+  if (S.rows_pending) { HIPCHK(hipEventSynchronize(S.rows_home)); S.rows_pending = false; }  // the slot's pinned arrays are rewritten below
+  hipStream_t st = c->run_stream;
+  br_device_batch db;
+  RC(prep_staged(c, cfg, S, st, &db));
+  S.staged = false;
+  br_device_rows pr;
+  RC(run_device(c, cfg, &db, st, &pr));   // returns with the stream drained
+  const size_t nr = (size_t)pr.n_rows, nn = (size_t)S.n, np = (size_t)pr.n_pool_words;
+  hipStream_t ds = c->d2h_stream;
+  RC(d2h(S.h_a, pr.a, nr, ds)); RC(d2h(S.h_c, pr.cigar, nr, ds)); RC(d2h(S.h_pool, pr.pool, np, ds));
+  RC(S.h_row_off.resize(nn + 1));
+  if (nn) HIPCHK(hipMemcpyAsync(S.h_row_off.data(), pr.row_off, (nn + 1) * 8, hipMemcpyDeviceToHost, ds));
+  else S.h_row_off.p[0] = 0;
+  RC(d2h(S.h_mate, db.mate_idx, nn, ds));
+  if (c->host_detail) RC(d2h(S.h_x, pr.x, nr, ds));
+  if (pr.similarity_score) { RC(d2h(S.h_sim, pr.similarity_score, nr, ds)); RC(d2h(S.h_clip, pr.clip_score, nr, ds)); }
+  HIPCHK(hipEventRecord(S.rows_home, ds));
+  HIPCHK(hipEventRecord(c->rows_busy, ds));
+  c->rows_busy_set = true; S.rows_pending = true;
+  out->n_rows = pr.n_rows; out->n_aln = S.n; out->n_groups = db.n_groups; out->n_pool_words = pr.n_pool_words;
+  out->a = (const br_row_a *)S.h_a.data(); out->cigar = S.h_c.data(); out->pool = S.h_pool.data();
+  out->row_off = S.h_row_off.data(); out->mate_idx = S.h_mate.data();
+  out->x = c->host_detail ? (const br_row_x *)S.h_x.data() : nullptr;
+  out->similarity_score = pr.similarity_score ? S.h_sim.data() : nullptr;
+  out->clip_score = pr.similarity_score ? S.h_clip.data() : nullptr;
+  out->total_complete = pr.total_complete; out->total_unique = pr.total_unique;
+  out->dropped_reads = pr.dropped_reads; out->total_processed = pr.total_processed;
+  return BR_OK;
+}
+
+extern "C" int br_host_rows_wait(br_ctx *c, int slot) {
+  if (!c || slot < 0 || slot > 1) return BR_ERR_INVALID_ARG;
+  br_ctx::InSlot &S = c->in_slot[slot];
+  if (S.rows_pending) { HIPCHK(hipEventSynchronize(S.rows_home)); S.rows_pending = false; }
+  return BR_OK;
+}
+
+extern "C" int br_project_batch_packed(br_ctx *c, const br_config *cfg, const br_batch *b, br_host_rows *out) {
+  if (!c || !cfg || !b || !out) return BR_ERR_INVALID_ARG;
+  RC(br_batch_stage(c, b, 0));
+  RC(br_project_staged(c, cfg, 0, out));
+  return br_host_rows_wait(c, 0);
+}
+
+extern "C" int br_pin_host(void *p, size_t bytes) {
+  if (!p || !bytes) return BR_ERR_INVALID_ARG;
+  HIPCHK(hipHostRegister(p, bytes, hipHostRegisterDefault));
+  return BR_OK;
+}
+extern "C" int br_unpin_host(void *p) {
+  if (!p) return BR_ERR_INVALID_ARG;
+  HIPCHK(hipHostUnregister(p));
+  return BR_OK;
+}
+
+// The wide host rows (ABI version 1 layout): the same staging and device-side input contract, then the wide view
+// derived on the device and downloaded array by array.
 extern "C" int br_project_batch(br_ctx *c, const br_config *cfg, const br_batch *b, br_rows *out) {
   if (!c || !cfg || !b || !out) return BR_ERR_INVALID_ARG;
   memset(out, 0, sizeof(*out));
-  int64_t n = b->n_aln;
-  if (n < 0 || n >= 0x7fffffffll) return BR_ERR_CAPACITY;
-  uint64_t n_words = n ? b->cigar_off[n] : 0;
-  if (n_words >= 0xfffffff0ull - (uint64_t)n) return BR_ERR_CAPACITY;
-  HIPCHK(hipSetDevice(c->ix->device));
-  hipStream_t st = nullptr;
-
-  std::vector<int32_t> mate((size_t)std::max<int64_t>(n, 1));
-  std::vector<uint32_t> goff((size_t)n + 1);
-  int64_t ng = 0;
-  RC(br_batch_prepare(b, mate.data(), goff.data(), &ng));
-  std::vector<uint32_t> coff((size_t)n + 1);
-  uint32_t max_nc = 0;
-  for (int64_t i = 0; i <= n; i++) coff[i] = (uint32_t)(n ? b->cigar_off[i] : 0);
-  for (int64_t i = 0; i < n; i++) max_nc = std::max(max_nc, coff[i + 1] - coff[i]);
-
-  RC(h2d(c->b_ref_id, b->ref_id, (size_t)n, st)); RC(h2d(c->b_ref_start, b->ref_start, (size_t)n, st));
-  RC(h2d(c->b_flags, b->flags, (size_t)n, st)); RC(h2d(c->b_xs, b->xs, (size_t)n, st));
-  RC(h2d(c->b_ts, b->ts, (size_t)n, st)); RC(h2d(c->b_cigar_off, coff.data(), (size_t)n + 1, st));
-  RC(h2d(c->b_cigar, b->cigar, (size_t)n_words, st)); RC(h2d(c->b_mate_idx, mate.data(), (size_t)n, st));
-  RC(h2d(c->b_group_off, goff.data(), (size_t)ng + 1, st));
-  std::vector<int32_t> lq((size_t)std::max<int64_t>(n, 1), 0);
-  if (b->l_qseq) memcpy(lq.data(), b->l_qseq, (size_t)n * 4);
-  RC(h2d(c->b_lqseq, lq.data(), (size_t)n, st));
-  HIPCHK(hipStreamSynchronize(st));
-
-  br_device_batch db{};
-  if (cfg->use_fasta && (cfg->lr || cfg->lr_hq)) {
-    if (!b->seq_off || !b->seqs) return BR_ERR_INVALID_ARG;
-    uint64_t sbytes = n ? b->seq_off[n] : 0;
-    if (sbytes >= 0xfffffff0ull) return BR_ERR_CAPACITY;
-    std::vector<uint32_t> soff((size_t)n + 1);
-    for (int64_t i = 0; i <= n; i++) soff[i] = (uint32_t)b->seq_off[i];
-    std::vector<int32_t> src((size_t)std::max<int64_t>(n, 1), -1);
-    RC(br_batch_seq_source(b, goff.data(), ng, src.data()));
-    int32_t max_clip = 0;
-    for (int64_t i = 0; i < n; i++) {
-      uint32_t a0 = coff[i], a1 = coff[i + 1];
-      for (uint32_t k = a0; k < a1; k++) if ((b->cigar[k] & 0xf) == 4) max_clip = std::max<int32_t>(max_clip, (int32_t)(b->cigar[k] >> 4));
-    }
-    RC(h2d(c->b_seq_off, soff.data(), (size_t)n + 1, st)); RC(h2d(c->b_seqs, (const uint8_t *)b->seqs, (size_t)sbytes, st));
-    RC(h2d(c->b_seq_src, src.data(), (size_t)n, st));
-    HIPCHK(hipStreamSynchronize(st));
-    db.seq_off = c->b_seq_off.as<uint32_t>(); db.seqs = c->b_seqs.as<uint8_t>(); db.seq_src = c->b_seq_src.as<int32_t>();
-    db.max_soft_clip = max_clip;
-  }
-  {
-    uint64_t nbytes = n ? b->name_off[n] : 0;
-    if (nbytes >= 0xfffffff0ull) return BR_ERR_CAPACITY;
-    std::vector<uint32_t> noff((size_t)n + 1);
-    for (int64_t i = 0; i <= n; i++) noff[i] = (uint32_t)(n ? b->name_off[i] : 0);
-    RC(h2d(c->b_name_off, noff.data(), (size_t)n + 1, st)); RC(h2d(c->b_names, (const uint8_t *)b->names, (size_t)nbytes, st));
-    HIPCHK(hipStreamSynchronize(st));
-    db.name_off = c->b_name_off.as<uint32_t>(); db.names = c->b_names.as<uint8_t>();
-  }
-  db.n_aln = n; db.n_groups = ng; db.ref_id = c->b_ref_id.as<int32_t>(); db.ref_start = c->b_ref_start.as<int32_t>();
-  db.flags = c->b_flags.as<uint16_t>(); db.xs = c->b_xs.as<int8_t>(); db.ts = c->b_ts.as<int8_t>();
-  db.cigar_off = c->b_cigar_off.as<uint32_t>(); db.cigar = c->b_cigar.as<uint32_t>();
-  db.mate_idx = c->b_mate_idx.as<int32_t>(); db.group_off = c->b_group_off.as<uint32_t>();
-  db.l_qseq = c->b_lqseq.as<int32_t>(); db.n_cigar_words = (int64_t)n_words; db.max_n_cigar = (int32_t)max_nc;
-  br_device_rows dr;
-  RC(run_device(c, cfg, &db, st, &dr));
+  RC(br_batch_stage(c, b, 0));
+  br_ctx::InSlot &S = c->in_slot[0];
+  hipStream_t st = c->run_stream;
+  br_device_batch db;
+  RC(prep_staged(c, cfg, S, st, &db));
+  S.staged = false;
+  br_device_rows pr;
+  RC(run_device(c, cfg, &db, st, &pr));
+  br_device_wide_rows dr;
+  RC(expand_rows(c, st, &dr));
 
   size_t nr = (size_t)dr.n_rows;
   RC(d2h(c->h_input, dr.input_index, nr, st)); RC(d2h(c->h_tid, dr.transcript_id, nr, st));
@@ -1268,12 +1471,9 @@ extern "C" int br_project_batch(br_ctx *c, const br_config *cfg, const br_batch 
   RC(d2h(c->h_paired, dr.is_paired, nr, st)); RC(d2h(c->h_same, dr.same_transcript_as_mate, nr, st));
   RC(d2h(c->h_first, dr.is_first, nr, st)); RC(d2h(c->h_mate_tid, dr.mate_transcript_id, nr, st));
   RC(d2h(c->h_mate_pos, dr.mate_pos, nr, st)); RC(d2h(c->h_isize, dr.insert_size, nr, st));
-  RC(d2h(c->h_group, dr.group, nr, st));
+  RC(d2h(c->h_group, dr.group, nr, st)); RC(d2h(c->h_primary, dr.is_primary, nr, st));
   HIPCHK(hipStreamSynchronize(st));
   if (nr == 0) { RC(c->h_cigoff.resize(1)); c->h_cigoff.p[0] = 0; }
-
-  RC(d2h(c->h_primary, dr.is_primary, nr, st));
-  HIPCHK(hipStreamSynchronize(st));
 
   out->n_rows = (int64_t)nr;
   out->input_index = c->h_input.data(); out->transcript_id = c->h_tid.data(); out->pos = c->h_pos.data();
@@ -1284,8 +1484,8 @@ extern "C" int br_project_batch(br_ctx *c, const br_config *cfg, const br_batch 
   out->same_transcript_as_mate = c->h_same.data(); out->is_first = c->h_first.data();
   out->mate_transcript_id = c->h_mate_tid.data(); out->mate_pos = c->h_mate_pos.data();
   out->insert_size = c->h_isize.data(); out->group = c->h_group.data();
-  out->total_complete = dr.total_complete; out->total_unique = dr.total_unique;
-  out->dropped_reads = dr.dropped_reads; out->total_processed = dr.total_processed;
+  out->total_complete = pr.total_complete; out->total_unique = pr.total_unique;
+  out->dropped_reads = pr.dropped_reads; out->total_processed = pr.total_processed;
   return BR_OK;
 }
 
@@ -1350,7 +1550,12 @@ extern "C" uint32_t br_primary_pick(const char *name, size_t len, uint32_t n_tie
   return n_tied ? br::primary_pick((const uint8_t *)name, len, n_tied) : 0;
 }
 
-extern "C" const char *br_version(void) { return "bramble_amd 0.1.0 (gfx950)"; }
+extern "C" uint32_t br_row_mapq(uint32_t nh, int long_reads) {  // src/core.cpp:46-58
+  if (!long_reads) return nh == 1 ? 255u : nh == 2 ? 3u : (nh == 3 || nh == 4) ? 1u : 0u;
+  return nh > 1 ? 0u : 3u;
+}
+
+extern "C" const char *br_version(void) { return "bramble_amd 0.2.0 (gfx950, ABI 2)"; }
 extern "C" const char *br_strerror(int code) {
   switch (code) {
     case BR_OK: return "ok";

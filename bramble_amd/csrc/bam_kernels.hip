@@ -117,16 +117,16 @@ __device__ __forceinline__ uint32_t row_out_len(const BamArgs &B, int64_t r, con
   uint32_t ls = l_seq > 0 ? (uint32_t)l_seq : 0;
   uint32_t removed = x.len[0] + x.len[1] + x.len[2] + x.len[3];
   uint32_t added = 7u + 7u + (B.long_reads ? 7u : 0u);  // NH:i, HI:i, AS:i
-  return 4u + 32u + l_qname + 4u * B.r_ncig[r] + (ls + 1) / 2 + ls + (x.aux_len - removed) + added;
+  return 4u + 32u + l_qname + 4u * (((const uint32_t *)(B.r_a + r))[2] & RM_NCIG) + (ls + 1) / 2 + ls + (x.aux_len - removed) + added;
 }
 
 __global__ void __launch_bounds__(256) k_bam_size(BamArgs B) {
   int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= B.n_rows) return;
-  int32_t a = B.r_input[r];
+  int32_t a = (int32_t)((const uint32_t *)(B.r_x + r))[0];
   const uint8_t *rec = B.blob + B.rec_off[a];
   B.out_len[r] = row_out_len(B, r, rec, B.aux[a]);
-  if (B.r_ncig[r] > 65535u) *B.too_long = 1;  // would need htslib's CG:B,I spill-over; refused by the host
+  if ((((const uint32_t *)(B.r_a + r))[2] & RM_NCIG) > 65535u) *B.too_long = 1;  // would need htslib's CG:B,I spill-over; refused by the host
 }
 
 // 4-bit base complement of reverse_complement_bam (src/bam.cpp:658-667)
@@ -184,24 +184,35 @@ __device__ __forceinline__ void encode_row(const BamArgs &B, int64_t r, int lane
   uint32_t n_cig_in = x.c_b & 0xffffu, flag = x.c_b >> 16;
   int32_t l_seq = (int32_t)x.c_c;
   uint32_t ls = l_seq > 0 ? (uint32_t)l_seq : 0;
-  uint32_t n_cig = B.r_ncig[r];
-  bool minus = B.r_strand[r] == '-';
-  bool paired = B.r_paired[r], same = B.r_same[r];
+  // the packed row: {tid, pos, meta, NH}, {input, junc_hits, aligned_len, HI}; the pair's other record is the adjacent row
+  const uint4 ra = B.r_a[r];
+  const uint32_t meta = ra.z, nh = ra.w, hi = ((const uint32_t *)(B.r_x + r))[3];
+  uint32_t n_cig = meta & RM_NCIG;
+  bool minus = meta & RM_MINUS;
+  bool paired = meta & RM_PAIRED, same = meta & RM_SAME;
   // flags: secondary (src/core.cpp:142-143), reverse (bam.cpp:698), mate bits (bam.cpp:531-588)
-  if (B.r_primary[r]) flag &= ~0x100u; else flag |= 0x100u;
+  if (meta & RM_PRIMARY) flag &= ~0x100u; else flag |= 0x100u;
   if (minus) flag ^= 0x10u;
   int32_t mtid = -1, mpos = -1, tlen = 0;
   if (!paired) flag &= ~(0x1u | 0x2u | 0x20u);
   else {
     flag |= 0x1u;
     if (minus) flag |= 0x20u;  // both branches of bam.cpp:551-555 test the record's own transcript strand
-    mtid = B.r_mate_tid[r]; mpos = B.r_mate_pos[r];
-    if (same) { flag |= 0x2u; tlen = B.r_isize[r]; } else flag &= ~0x2u;
+    const uint4 rb = B.r_a[(meta & RM_FIRST) ? r + 1 : r - 1];
+    const int32_t my_pos = (int32_t)ra.y;
+    mpos = (int32_t)rb.y;
+    if (same) {
+      flag |= 0x2u; mtid = (int32_t)ra.x;
+      const int32_t lq = B.l_qseq[((const uint32_t *)(B.r_x + r))[0]];
+      tlen = (my_pos <= mpos) ? (mpos + lq) - my_pos : -((my_pos + lq) - mpos);
+    } else { flag &= ~0x2u; mtid = (int32_t)rb.x; }
   }
+  // get_mapq (src/core.cpp:46-58)
+  const uint32_t mapq = B.long_reads ? (nh > 1 ? 0u : 3u) : (nh == 1 ? 255u : nh == 2 ? 3u : (nh == 3 || nh == 4) ? 1u : 0u);
   // block_size + the 32 fixed bytes: nine dwords
   if (lane == 0) {
-    W4 h0; h0.a = total - 4u; h0.b = B.r_tid[r]; h0.c = B.r_pos[r];
-    h0.d = l_qname | ((B.r_mapq[r] & 0xffu) << 8) | (bin << 16);             // l_read_name, mapq, bin (kept)
+    W4 h0; h0.a = total - 4u; h0.b = ra.x; h0.c = ra.y;
+    h0.d = l_qname | (mapq << 8) | (bin << 16);                              // l_read_name, mapq, bin (kept)
     *(W4 *)out = h0;
   } else if (lane == 1) {
     W4 h1; h1.a = (n_cig & 0xffffu) | (flag << 16); h1.b = (uint32_t)l_seq; h1.c = (uint32_t)mtid; h1.d = (uint32_t)mpos;
@@ -213,8 +224,15 @@ __device__ __forceinline__ void encode_row(const BamArgs &B, int64_t r, int lane
   copy_fwd<G>(out + o, rec + 32, l_qname, lane);                            // read name
   o += l_qname;
   // rewritten CIGAR (op order reversed on '-', bam.cpp:688-695)
-  const uint32_t *cg = B.cigar + B.r_cigoff[r];
-  for (uint32_t k = lane; k < n_cig; k += G) *(u32u *)(out + o + 4 * k) = cg[minus ? n_cig - 1 - k : k];
+  {
+    const uint2 c = B.r_c[r];   // the ops themselves (<= 2), or their offset in the pool
+    if (n_cig <= 2u) {
+      if (lane < (int)n_cig) *(u32u *)(out + o + 4 * lane) = ((minus ? n_cig - 1 - lane : lane) == 0) ? c.x : c.y;
+    } else {
+      const uint32_t *cg = B.pool + (((uint64_t)c.y << 32) | c.x);
+      for (uint32_t k = lane; k < n_cig; k += G) *(u32u *)(out + o + 4 * k) = cg[minus ? n_cig - 1 - k : k];
+    }
+  }
   o += 4 * n_cig;
   // sequence: reverse-complemented nibbles on '-' (bam.cpp:671-678; the pad nibble of an odd length stays 0)
   const uint8_t *seq = rec + 32 + l_qname + 4 * n_cig_in;
@@ -263,9 +281,9 @@ __device__ __forceinline__ void encode_row(const BamArgs &B, int64_t r, int lane
     if (lane < n_tags) {
       const int kind = lane == 0 ? 0 : (lr ? (lane == 1 ? 1 : 2) : 2);  // 0 NH, 1 AS, 2 HI
       uint32_t val, t01;
-      if (kind == 0) { val = B.r_nh[r]; t01 = (uint32_t)'N' | ((uint32_t)'H' << 8); }
-      else if (kind == 2) { val = B.r_hi[r]; t01 = (uint32_t)'H' | ((uint32_t)'I' << 8); }
-      else { val = (uint32_t)(int32_t)(((double)x.as_val + (double)B.r_clip[r]) * B.r_sim[r]); t01 = (uint32_t)'A' | ((uint32_t)'S' << 8); }  // set_as_tag
+      if (kind == 0) { val = nh; t01 = (uint32_t)'N' | ((uint32_t)'H' << 8); }
+      else if (kind == 2) { val = hi; t01 = (uint32_t)'H' | ((uint32_t)'I' << 8); }
+      else { val = (uint32_t)(int32_t)(((double)x.as_val + (double)(B.r_clip ? B.r_clip[r] : 0)) * (B.r_sim ? B.r_sim[r] : 0.0)); t01 = (uint32_t)'A' | ((uint32_t)'S' << 8); }  // set_as_tag
       uint8_t *t = out + o + 7 * lane;
       *(u32u *)t = t01 | ((uint32_t)'i' << 16) | (val << 24);
       *(u32u *)(t + 3) = val;
@@ -278,7 +296,7 @@ __global__ void __launch_bounds__(256) k_bam_encode(BamArgs B) {
   const int lane = threadIdx.x & (G - 1);
   int64_t r = (int64_t)blockIdx.x * (256 / G) + (threadIdx.x / G);
   if (r >= B.n_rows) return;
-  int32_t a = B.r_input[r];
+  int32_t a = (int32_t)((const uint32_t *)(B.r_x + r))[0];
   encode_row<G>(B, r, lane, B.blob + B.rec_off[a], B.aux[a], B.out + B.out_off[r], (uint32_t)(B.out_off[r + 1] - B.out_off[r]));
 }
 

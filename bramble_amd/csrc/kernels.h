@@ -37,6 +37,8 @@ struct ProjectArgs {
   uint4 *m_b;            // {clip_score, 0, similarity lo, similarity hi}
   uint64_t *m_cigoff;
   uint32_t *cig_arena;
+  uint32_t *pool_cnt;    // [n_aln] words of the alignment's rewritten CIGARs that do not fit a row (> 2 ops), summed with
+                         // one atomic per such match by the emit kernels (zeroed per batch)
 };
 
 struct KswProb;
@@ -81,6 +83,19 @@ struct ScanArgs {
   int64_t n_tiles;            // scan3 only (set by the launcher)
 };
 
+// Packed row table: the product of the row stage (one row per emitted BAM record, rows of one read-name group
+// contiguous, a pair's two records adjacent).  Everything else a record carries follows from these words:
+//   NH = rows of the group, HI = rank inside the group (also stored), MAPQ = get_mapq(NH) (src/core.cpp:46-58),
+//   mate transcript / position / insert size = the adjacent row of the pair (set_mate_info, src/bam.cpp:531-588).
+//   r_a[r] = {transcript id, 0-based transcript position, meta, NH}
+//   r_c[r] = the rewritten CIGAR itself when it has <= 2 ops, else the 64-bit word offset of its ops in `pool`
+//   r_x[r] = {input alignment, junc_hits, aligned_len (ref_consumed), HI}
+#define RM_NCIG 0x00ffffffu      // meta bits 0..23: ops of the rewritten CIGAR
+#define RM_MINUS (1u << 24)      // transcript strand '-'
+#define RM_PAIRED (1u << 25)     // emitted together with its mate
+#define RM_SAME (1u << 26)       // ... on the same transcript
+#define RM_FIRST (1u << 27)      // the leader's own record (its mate's record follows)
+#define RM_PRIMARY (1u << 28)    // primary record of its read name
 struct PairArgs {
   int64_t n_groups, n_aln;
   int32_t long_reads;
@@ -91,30 +106,43 @@ struct PairArgs {
   const uint32_t *n_matches;
   const uint32_t *m_tid;
   const uint4 *m_a, *m_b;
-  const int32_t *l_qseq;
-  uint32_t *n_rows;         // count pass: records per leader alignment
-  uint64_t *pmask;          // [n_aln] count pass -> emit pass: list positions of a pair's common transcripts (lists <= 64)
-  const uint64_t *row_off;  // [n_aln + 1] emit pass
-  int32_t *r_input;
-  uint4 *r_rec;             // per record {match, mate match or ~0u, input alignment, RF_* flags}
-  uint32_t *r_nh, *r_hi, *r_mapq, *r_group;
-  int32_t *r_mate_tid, *r_mate_pos, *r_isize;
-  uint32_t *r_tid, *r_pos, *r_ncig;
-  int8_t *r_strand;
-  double *r_sim;
-  int32_t *r_clip, *r_junc, *r_refc;
-  uint8_t *r_paired, *r_same, *r_first;
-  uint64_t *counters;       // [4] total_complete, total_unique, dropped_reads, total_processed
-};
-
-struct RowArgs {
-  int64_t n_rows;
-  const uint4 *r_rec;
-  const uint32_t *r_ncig;
   const uint64_t *m_cigoff;
   const uint32_t *cig_arena;
-  const uint64_t *r_cigoff;  // [n_rows + 1]
-  uint32_t *cigar_out;
+  const uint32_t *pool_cnt;  // [n_aln] from the emit kernels
+  uint32_t *n_rows;         // count pass: records per leader alignment
+  uint32_t *n_pool;         // count pass: pool words reserved per leader alignment (its own + its mate's)
+  uint64_t *pmask;          // [n_aln] count pass -> emit pass: list positions of a pair's common transcripts (lists <= 64)
+  const uint64_t *row_off;  // [n_aln + 1] emit pass
+  const uint64_t *pool_off; // [n_aln + 1] emit pass
+  uint4 *r_a;
+  uint2 *r_c;
+  uint4 *r_x;
+  double *r_sim;            // aux presets only (similarity filter on)
+  int32_t *r_clip;
+  uint32_t *pool;
+  uint64_t *r_src;          // [n_rows] long-CIGAR mode: arena offset of each row's ops (k_pool_copy moves them)
+  uint64_t *counters;       // [4] total_complete, total_unique, dropped_reads, CIGAR too long for the meta word
+};
+
+// wide (one array per field) view of the packed rows: br_device_rows
+struct WideArgs {
+  int64_t n_rows, n_aln;
+  int32_t long_reads;
+  const uint4 *r_a; const uint2 *r_c; const uint4 *r_x;
+  const double *r_sim; const int32_t *r_clip;  // null: all zero
+  const uint32_t *pool;
+  const uint32_t *aln_group;
+  const int32_t *l_qseq;
+  int32_t *w_input;
+  uint32_t *w_nh, *w_hi, *w_mapq, *w_group;
+  int32_t *w_mate_tid, *w_mate_pos, *w_isize;
+  uint32_t *w_tid, *w_pos, *w_ncig;
+  int8_t *w_strand;
+  double *w_sim;
+  int32_t *w_clip, *w_junc, *w_refc;
+  uint8_t *w_paired, *w_same, *w_first, *w_primary;
+  const uint64_t *w_cigoff;  // [n_rows + 1] scan of w_ncig
+  uint32_t *w_cigar;         // dense rewritten CIGARs
 };
 
 struct StatsArgs {
@@ -146,14 +174,10 @@ struct BamArgs {
   const uint32_t *rec_len;   // [n_aln] or null: rec_off[i + 1] - rec_off[i]
   int8_t *xs_out, *ts_out;   // [n_aln] or null: tag_char1("XS") / tag_char1("ts") of every record
   BamAux *aux;               // [n_aln]
-  const int32_t *r_input;
-  const uint32_t *r_tid, *r_pos, *r_ncig, *r_nh, *r_hi, *r_mapq;
-  const int8_t *r_strand;
-  const uint8_t *r_paired, *r_same, *r_primary;
-  const int32_t *r_mate_tid, *r_mate_pos, *r_isize, *r_clip;
-  const double *r_sim;
-  const uint64_t *r_cigoff;
-  const uint32_t *cigar;
+  const uint4 *r_a; const uint2 *r_c; const uint4 *r_x;  // packed rows (PairArgs)
+  const double *r_sim; const int32_t *r_clip;              // null: all zero
+  const uint32_t *pool;
+  const int32_t *l_qseq;
   uint32_t *out_len;         // [n_rows]
   const uint64_t *out_off;   // [n_rows + 1]
   uint8_t *out;
@@ -201,7 +225,21 @@ struct ParseArgs {
   uint32_t *seq_len;
   const uint32_t *seq_off;
   uint8_t *seqs;
+  // flat (br_batch) input instead of records (blob == null): the pairing inputs come from these arrays
+  const int32_t *mate_ref_id, *mate_start;
 };
+// br_batch arrays as uploaded -> the input contract on the device (the same work br_batch_prepare /
+// br_batch_seq_source do on the host): 32-bit offsets, "starts a new read name" flags, batch maxima
+struct SoaArgs {
+  int64_t n;
+  const uint64_t *cigar_off64, *name_off64, *seq_off64;  // seq_off64 may be null
+  uint32_t *cigar_off, *name_off, *seq_off;
+  const uint8_t *names;
+  const uint32_t *cigar;
+  uint32_t *isnew;
+  uint32_t *maxima;  // [2] longest CIGAR, longest leading / trailing soft clip
+};
+void launch_soa_fields(hipStream_t st, const SoaArgs &S);
 void launch_rec_fields(hipStream_t st, const ParseArgs &P);
 void launch_group_off(hipStream_t st, const ParseArgs &P);
 void launch_rec_copy(hipStream_t st, const ParseArgs &P);
@@ -215,7 +253,8 @@ void launch_segment(hipStream_t st, int64_t n_aln, const int32_t *ref_id, const 
                     const uint16_t *flags, const int8_t *xs, const int8_t *ts, const uint32_t *cigar_off,
                     const uint32_t *cigar, const DevCfg &cfg, uint32_t n_refs, uint2 *seg, AlnMeta *meta,
                     uint4 *head, uint4 *head2, uint32_t *fast_flag);
-void launch_project(hipStream_t st, const ProjectArgs &A, bool emit, int group_lanes, int n_blocks);
+// part: see launch_project_g (0 = everything)
+void launch_project(hipStream_t st, const ProjectArgs &A, bool emit, int group_lanes, int n_blocks, int part = 0);
 void launch_project_fa(hipStream_t st, const ProjectArgs &A, const FaArgs &F, int mode, int n_blocks);
 void launch_ksw(hipStream_t st, const KswArgs &K, int n_blocks);
 size_t ksw_prob_bytes();
@@ -231,11 +270,14 @@ void launch_scan(hipStream_t st, const ScanArgs &S, int mode, void *out, bool ou
 void launch_group_ids(hipStream_t st, int64_t n_groups, const uint32_t *group_off, uint32_t *aln_group);
 void launch_scan3(hipStream_t st, ScanArgs S, uint32_t *match_off, uint64_t *cig_base, uint32_t *fast_pre,
                   uint64_t *total_out3);
-void launch_pair(hipStream_t st, const PairArgs &P, bool emit);
-// aux: the batch has clip / similarity scores (else the two row columns must already be zero)
-void launch_row_fill(hipStream_t st, const PairArgs &P, int64_t n_rows, bool aux);
-void launch_primary(hipStream_t st, const PairArgs &P, const uint32_t *name_off, const uint8_t *names, uint8_t *r_primary,
-                    bool has_scores);
-void launch_gather(hipStream_t st, const RowArgs &R, int64_t n_words);  // n_words: total rewritten-CIGAR words of the rows
+void launch_pair(hipStream_t st, const PairArgs &P);  // count pass: records and pool words per leader alignment
+// emit pass: the packed rows.  aux: the preset has clip / similarity scores; long_cigars: rows leave their ops in the arena
+// (r_src) for launch_pool_copy instead of copying them lane-serially
+void launch_rows(hipStream_t st, const PairArgs &P, bool aux, bool long_cigars);
+void launch_pool_copy(hipStream_t st, const PairArgs &P, int64_t n_rows);
+// primary record per read name (RM_PRIMARY) + the per-group counters; names may be null (no primary flags)
+void launch_primary(hipStream_t st, const PairArgs &P, const uint32_t *name_off, const uint8_t *names, bool has_scores);
+void launch_wide_fields(hipStream_t st, const WideArgs &W);
+void launch_wide_cigars(hipStream_t st, const WideArgs &W, int64_t n_words);
 
 }  // namespace br

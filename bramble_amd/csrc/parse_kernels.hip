@@ -127,6 +127,11 @@ __global__ void __launch_bounds__(256) k_rec_copy(ParseArgs P) {
 // first looks up its mate's position; when found the two are paired and the entry erased;
 // otherwise it stores its own position (overwriting an entry with the same key).
 __device__ __forceinline__ bool pair_eligible(const ParseArgs &P, int64_t k, int32_t &mate_start) {
+  if (!P.blob) {  // flat batch: br_batch_prepare's test on the caller's arrays
+    if (!(P.flags[k] & 1u) || P.ref_id[k] != P.mate_ref_id[k]) return false;
+    mate_start = P.mate_start[k];
+    return true;
+  }
   const uint8_t *rec = P.blob + P.rec_off[k];
   if (rec_length(P, k) < 32) return false;
   uint32_t flag = *(const u16u *)(rec + 14);
@@ -219,6 +224,11 @@ __global__ void __launch_bounds__(256) k_seq_src(ParseArgs P) {
   if (g >= P.n_groups) return;
   uint32_t a = P.group_off[g], b = P.group_off[g + 1];
   int32_t src = -1;
+  if (!P.blob) {  // flat batch (br_batch_seq_source): the sequences are already ASCII at seq_off
+    for (uint32_t k = a; k < b; k++) if (P.seq_off[k + 1] > P.seq_off[k]) { src = (int32_t)k; break; }
+    for (uint32_t k = a; k < b; k++) P.seq_src[k] = src;
+    return;
+  }
   for (uint32_t k = a; k < b; k++) if (P.l_qseq[k] > 0 && seq_fits(P, k)) { src = (int32_t)k; break; }
   for (uint32_t k = a; k < b; k++) { P.seq_src[k] = src; P.seq_len[k] = ((int32_t)k == src) ? (uint32_t)P.l_qseq[k] : 0u; }
 }
@@ -238,6 +248,48 @@ __global__ void __launch_bounds__(256) k_seq_ascii(ParseArgs P) {
   for (uint32_t k = lane; k < n; k += G) dst[k] = (uint8_t)tbl[(seq[k >> 1] >> ((~k & 1) << 2)) & 0xf];
 }
 
+// k_soa_fields: one lane per alignment of a flat batch (+ one for the closing offsets)
+__global__ void __launch_bounds__(256) k_soa_fields(SoaArgs S) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t ncig = 0, max_s = 0;
+  if (i <= S.n) {
+    const uint64_t c0 = S.cigar_off64[i], n0 = S.name_off64[i];
+    S.cigar_off[i] = (uint32_t)c0; S.name_off[i] = (uint32_t)n0;
+    if (S.seq_off64) S.seq_off[i] = (uint32_t)S.seq_off64[i];
+    if (i < S.n) {
+      const uint64_t c1 = S.cigar_off64[i + 1], n1 = S.name_off64[i + 1];
+      ncig = (uint32_t)(c1 - c0);
+      if (ncig) {   // leading / trailing soft clips (sizing of the rescue buffers), as k_rec_fields
+        const uint32_t *cg = S.cigar + c0;
+        uint32_t w = cg[0];
+        if ((w & 0xfu) == 5u && ncig > 1) w = cg[1];
+        if ((w & 0xfu) == 4u) max_s = w >> 4;
+        w = cg[ncig - 1];
+        if ((w & 0xfu) == 5u && ncig > 1) w = cg[ncig - 2];
+        if ((w & 0xfu) == 4u) max_s = max(max_s, w >> 4);
+      }
+      uint32_t isnew = 1;
+      if (i > 0) {
+        const uint64_t p0 = S.name_off64[i - 1];
+        const uint32_t nl = (uint32_t)(n1 - n0);
+        if ((uint32_t)(n0 - p0) == nl && (nl == 0 || same_bytes(S.names + p0, S.names + n0, nl))) isnew = 0;
+      }
+      S.isnew[i] = isnew;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    ncig = max(ncig, (uint32_t)__shfl_xor((int)ncig, o));
+    max_s = max(max_s, (uint32_t)__shfl_xor((int)max_s, o));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (ncig > __builtin_nontemporal_load(S.maxima)) atomicMax(S.maxima, ncig);
+    if (max_s > __builtin_nontemporal_load(S.maxima + 1)) atomicMax(S.maxima + 1, max_s);
+  }
+}
+
+void launch_soa_fields(hipStream_t st, const SoaArgs &S) {
+  hipLaunchKernelGGL(k_soa_fields, dim3((unsigned)((S.n + 1 + 255) / 256)), dim3(256), 0, st, S);
+}
 void launch_rec_fields(hipStream_t st, const ParseArgs &P) {
   if (P.n > 0) hipLaunchKernelGGL(k_rec_fields, dim3((unsigned)((P.n + 255) / 256)), dim3(256), 0, st, P);
 }

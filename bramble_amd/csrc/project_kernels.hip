@@ -937,6 +937,7 @@ __global__ void __launch_bounds__(256, EMIT ? 4 : 8) k_project(ProjectArgs A) {
             A.m_b[mi] = make_uint4((uint32_t)acc.clip_score, 0u, (uint32_t)sb64, (uint32_t)(sb64 >> 32));
           }
           A.m_cigoff[mi] = cig_ref;
+          if (n_out > 2u) atomicAdd(A.pool_cnt + a, n_out);
         }
       }
       if (EMIT && !have_mask && sweep == 0) __threadfence_block();  // m_aux[] written above is read below
@@ -1058,6 +1059,7 @@ __global__ void __launch_bounds__(256, CLS == 1 ? 8 : 6) k_emit_dense(ProjectArg
       cref = cbase + (uint64_t)rank * (1u + 2u * 6u);
       uint32_t *slot = A.cig_arena + cref;
       slot[0] = w0; slot[1] = w1; slot[2] = w2;
+      atomicAdd(A.pool_cnt + a, 3u);
     }
     uint32_t mo = moff + rank;
     A.m_tid[mo] = pay.x;
@@ -1114,6 +1116,7 @@ __global__ void __launch_bounds__(256, CLS == 1 ? 8 : 6) k_emit_dense(ProjectArg
     A.m_b[mo] = make_uint4((uint32_t)acc.clip_score, 0u, (uint32_t)sb64, (uint32_t)(sb64 >> 32));
   }
   A.m_cigoff[mo] = cig_ref;
+  if (n_out > 2u) atomicAdd(A.pool_cnt + a, n_out);
 }
 
 // ---------------------------------------------------------------------------
@@ -1340,133 +1343,210 @@ __global__ void __launch_bounds__(256) k_group_ids(int64_t n_groups, const uint3
   for (uint32_t i = group_off[g]; i < group_off[g + 1]; i++) aln_group[i] = (uint32_t)g;
 }
 
-// k_pair<EMIT>: one lane per alignment.  A "leader" (no mate, or its mate comes
+// k_pair (count pass): one lane per alignment.  A "leader" (no mate, or its mate comes
 // later in the group) emits for itself and its mate, exactly the calls
-// convert_reads makes (src/core.cpp:384-415).  EMIT=false counts the records,
-// EMIT=true writes (match, mate match, input, flags) per record at the scanned
-// offset; k_row_fill turns those into the row table.
-template <bool EMIT>
+// convert_reads makes (src/core.cpp:384-415).  Counts the records and reserves room
+// for their long (> 2 op) rewritten CIGARs; k_rows writes the rows at the scanned offsets.
 __global__ void __launch_bounds__(256) k_pair(PairArgs P) {
   int64_t i64 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i64 >= P.n_aln) return;
   uint32_t i = (uint32_t)i64;
-  uint32_t rows = 0;
+  uint32_t rows = 0, pool = 0;
   int32_t m = P.mate_idx[i];
   uint32_t g = P.aln_group[i];
   uint32_t a0 = P.group_off[g], a1 = P.group_off[g + 1];
   uint32_t mi0 = P.match_off[i], ni = P.n_matches[i];
   bool leader = !(m >= 0 && (uint32_t)m < i && (uint32_t)m >= a0);  // else: handled as the mate of an earlier leader
-  uint64_t r0 = EMIT ? P.row_off[i] : 0;
   if (leader && ni) {                          // a leader without matches drops the pair (mates.cpp:153)
     uint32_t nm = 0, mm0 = 0;
     if (m >= 0 && (uint32_t)m > i && (uint32_t)m < a1) { mm0 = P.match_off[m]; nm = P.n_matches[m]; }
     if (nm == 0) {
-      // unpaired emission: one record per transcript, ascending tid (mates.cpp:157-176)
-      if (EMIT)
-        for (uint32_t k = 0; k < ni; k++) {
-          P.r_rec[r0 + k] = make_uint4(mi0 + k, 0xffffffffu, i, RF_FIRST);
-        }
-      rows = ni;
+      rows = ni;                               // unpaired emission: one record per transcript (mates.cpp:157-176)
+      pool = P.pool_cnt[i];
     } else {
-      // both mates matched: sorted-set intersection (mates.cpp:204-231).  The count pass does the merge and leaves, per
-      // mate, the bit set of its list positions that are common (both lists ascend, so the k-th common position of one
-      // pairs with the k-th of the other); the emit pass only walks those bits -- no second merge over m_tid[].
+      // both mates matched: sorted-set intersection (mates.cpp:204-231).  The merge leaves, per mate, the bit set of
+      // its list positions that are common (both lists ascend, so the k-th common position of one pairs with the k-th
+      // of the other); the emit pass only walks those bits -- no second merge over m_tid[].
       uint32_t x = 0, y = 0, common = 0;
       const bool masked = ni <= 64u && nm <= 64u;
-      if (EMIT && masked) {
-        uint64_t ma = P.pmask[i], mb = P.pmask[m];
-        while (ma) {
-          uint32_t xx = (uint32_t)__builtin_ctzll(ma), yy = (uint32_t)__builtin_ctzll(mb);
-          ma &= ma - 1; mb &= mb - 1;
-          uint64_t r = r0 + 2ull * common;
-          P.r_rec[r] = make_uint4(mi0 + xx, mm0 + yy, i, RF_FIRST | RF_PAIRED | RF_SAME_TX);
-          P.r_rec[r + 1] = make_uint4(mm0 + yy, mi0 + xx, (uint32_t)m, RF_PAIRED | RF_SAME_TX);
-          common++;
-        }
-        x = ni;  // skip the merge
-      }
       uint64_t bits_a = 0, bits_b = 0;
       while (x < ni && y < nm) {
         uint32_t tx = P.m_tid[mi0 + x], ty = P.m_tid[mm0 + y];
         if (tx < ty) x++;
         else if (ty < tx) y++;
         else {
-          if (EMIT) {
-            uint64_t r = r0 + 2ull * common;
-            P.r_rec[r] = make_uint4(mi0 + x, mm0 + y, i, RF_FIRST | RF_PAIRED | RF_SAME_TX);
-            P.r_rec[r + 1] = make_uint4(mm0 + y, mi0 + x, (uint32_t)m, RF_PAIRED | RF_SAME_TX);
-          } else if (masked) { bits_a |= 1ull << x; bits_b |= 1ull << y; }
+          if (masked) { bits_a |= 1ull << x; bits_b |= 1ull << y; }
           common++; x++; y++;
         }
       }
-      if (!EMIT && masked) { P.pmask[i] = bits_a; P.pmask[m] = bits_b; }
+      if (masked) { P.pmask[i] = bits_a; P.pmask[m] = bits_b; }
       if (common) rows = 2 * common;
-      else if (ni == 1 && nm == 1) {  // one transcript each, different ones
-        if (EMIT) {
-          P.r_rec[r0] = make_uint4(mi0, mm0, i, RF_FIRST | RF_PAIRED);
-          P.r_rec[r0 + 1] = make_uint4(mm0, mi0, (uint32_t)m, RF_PAIRED);
-        }
-        rows = 2;
-      }
+      else if (ni == 1 && nm == 1) rows = 2;   // one transcript each, different ones
+      if (rows) pool = P.pool_cnt[i] + P.pool_cnt[m];   // a superset of the emitted records' ops: holes are allowed
     }
   }
-  if (!EMIT) P.n_rows[i] = rows;
+  P.n_rows[i] = rows; P.n_pool[i] = pool;
 }
 
-// k_row_fill: one lane per emitted record.  NH / HI / MAPQ of flush
-// (src/core.cpp:237-258,309-325), the match's fields, and the mate fields of
-// set_mate_info (src/bam.cpp:531-588).
-// AUX = false (presets without the similarity filter, hence without -S rescue): every clip score and similarity score
-// is 0; the two row columns were zero-filled once by the host side and m_b is neither written nor read.
-template <bool AUX>
-__global__ void __launch_bounds__(256) k_row_fill(PairArgs P, int64_t n_rows) {
-  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= n_rows) return;
-  uint4 rec = P.r_rec[r];
-  uint32_t x = rec.x, xm = rec.y;
-  int32_t input = (int32_t)rec.z;
-  uint8_t flags = (uint8_t)rec.w;
-  P.r_input[r] = input;
-  uint32_t g = P.aln_group[input];
-  uint64_t rs = P.row_off[P.group_off[g]], re = P.row_off[P.group_off[g + 1]];
-  uint32_t nh = (uint32_t)(re - rs);
-  uint4 ma = P.m_a[x];
-  uint32_t tid = P.m_tid[x];
-  int32_t mate_tid = -1, mate_pos = -1, isize = 0;
-  if (flags & RF_PAIRED) {
-    int32_t my_pos = (int32_t)ma.x;
-    mate_pos = (int32_t)P.m_a[xm].x;
-    if (flags & RF_SAME_TX) {
-      mate_tid = (int32_t)tid;
-      int32_t lq = P.l_qseq[input];
-      isize = (my_pos <= mate_pos) ? (mate_pos + lq) - my_pos : -((my_pos + lq) - mate_pos);
-    } else {
-      mate_tid = (int32_t)P.m_tid[xm];
-    }
+// one packed row from match x (see PairArgs).  CIGARs of more than two ops move from their arena slot to the dense
+// pool: lane-serially here (short reads: a few per cent of the rows, 3-6 words), or later by k_pool_copy (LONGC).
+template <bool AUX, bool LONGC>
+__device__ __forceinline__ void put_row(const PairArgs &P, uint64_t r, uint32_t x, uint32_t input, uint32_t fl,
+                                        uint32_t nh, uint32_t hi, uint64_t &pool_at, bool &too_long) {
+  const uint32_t tid = P.m_tid[x];
+  const uint4 ma = P.m_a[x];
+  const uint64_t cg = P.m_cigoff[x];
+  const uint32_t n = ma.y & 0x7fffffffu;
+  too_long |= n > RM_NCIG;
+  P.r_a[r] = make_uint4(tid, ma.x, (n & RM_NCIG) | ((ma.y >> 31) ? RM_MINUS : 0u) | fl, nh);
+  uint64_t c = cg;
+  if (n > 2u) {
+    c = pool_at;
+    if (LONGC) P.r_src[r] = cg;
+    else { const uint32_t *src = P.cig_arena + cg; uint32_t *dst = P.pool + pool_at; for (uint32_t k = 0; k < n; k++) dst[k] = src[k]; }
+    pool_at += n;
   }
-  P.r_nh[r] = nh; P.r_hi[r] = (uint32_t)(r - rs) + 1u; P.r_mapq[r] = mapq_of(nh, P.long_reads);
-  P.r_mate_tid[r] = mate_tid; P.r_mate_pos[r] = mate_pos; P.r_isize[r] = isize; P.r_group[r] = g;
-  P.r_tid[r] = tid; P.r_pos[r] = ma.x; P.r_strand[r] = (ma.y >> 31) ? (int8_t)'-' : (int8_t)'+';
-  P.r_ncig[r] = ma.y & 0x7fffffffu; P.r_junc[r] = (int32_t)ma.z; P.r_refc[r] = (int32_t)ma.w;
+  P.r_c[r] = make_uint2((uint32_t)c, (uint32_t)(c >> 32));
+  P.r_x[r] = make_uint4(input, ma.z, ma.w, hi);
   if (AUX) {
-    uint4 mb = P.m_b[x];
+    const uint4 mb = P.m_b[x];
     P.r_clip[r] = (int32_t)mb.x;
     P.r_sim[r] = __longlong_as_double((long long)(((unsigned long long)mb.w << 32) | mb.z));
   }
-  P.r_paired[r] = (flags & RF_PAIRED) ? 1 : 0; P.r_same[r] = (flags & RF_SAME_TX) ? 1 : 0;
-  P.r_first[r] = (flags & RF_FIRST) ? 1 : 0;
 }
 
-// k_group_stats: counters of src/bramble.cpp:729-736; grid-stride over groups,
-// one atomic per wave at the end.
-__global__ void __launch_bounds__(256) k_group_stats(PairArgs P) {
+// k_rows (emit pass): one lane per alignment; a leader writes its records and its mate's.  NH = records of the
+// read name (flush, src/core.cpp:250-258), HI = 1-based rank among them (:309-325).
+template <bool AUX, bool LONGC>
+__global__ void __launch_bounds__(256) k_rows(PairArgs P) {
+  int64_t i64 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i64 >= P.n_aln) return;
+  const uint32_t i = (uint32_t)i64;
+  const uint64_t r0 = P.row_off[i];
+  if (P.row_off[i + 1] == r0) return;          // not a leader, or nothing to emit
+  const int32_t m = P.mate_idx[i];
+  const uint32_t g = P.aln_group[i];
+  const uint32_t a0 = P.group_off[g], a1 = P.group_off[g + 1];
+  const uint64_t gs = P.row_off[a0];
+  const uint32_t nh = (uint32_t)(P.row_off[a1] - gs);
+  const uint32_t hi0 = (uint32_t)(r0 - gs) + 1u;
+  const uint32_t mi0 = P.match_off[i], ni = P.n_matches[i];
+  uint64_t pool_at = P.pool_off[i];
+  bool too_long = false;
+  uint32_t nm = 0, mm0 = 0;
+  if (m >= 0 && (uint32_t)m > i && (uint32_t)m < a1) { mm0 = P.match_off[m]; nm = P.n_matches[m]; }
+  if (nm == 0) {
+    for (uint32_t k = 0; k < ni; k++) put_row<AUX, LONGC>(P, r0 + k, mi0 + k, i, RM_FIRST, nh, hi0 + k, pool_at, too_long);
+  } else {
+    uint32_t common = 0;
+    const uint32_t fl = RM_PAIRED | RM_SAME;
+    if (ni <= 64u && nm <= 64u) {
+      uint64_t ma = P.pmask[i], mb = P.pmask[m];
+      while (ma) {
+        uint32_t xx = (uint32_t)__builtin_ctzll(ma), yy = (uint32_t)__builtin_ctzll(mb);
+        ma &= ma - 1; mb &= mb - 1;
+        put_row<AUX, LONGC>(P, r0 + 2ull * common, mi0 + xx, i, fl | RM_FIRST, nh, hi0 + 2u * common, pool_at, too_long);
+        put_row<AUX, LONGC>(P, r0 + 2ull * common + 1, mm0 + yy, (uint32_t)m, fl, nh, hi0 + 2u * common + 1u, pool_at, too_long);
+        common++;
+      }
+    } else {
+      uint32_t x = 0, y = 0;
+      while (x < ni && y < nm) {
+        uint32_t tx = P.m_tid[mi0 + x], ty = P.m_tid[mm0 + y];
+        if (tx < ty) x++;
+        else if (ty < tx) y++;
+        else {
+          put_row<AUX, LONGC>(P, r0 + 2ull * common, mi0 + x, i, fl | RM_FIRST, nh, hi0 + 2u * common, pool_at, too_long);
+          put_row<AUX, LONGC>(P, r0 + 2ull * common + 1, mm0 + y, (uint32_t)m, fl, nh, hi0 + 2u * common + 1u, pool_at, too_long);
+          common++; x++; y++;
+        }
+      }
+    }
+    if (!common) {   // one transcript each, different ones (the count pass reserved two records only in that case)
+      put_row<AUX, LONGC>(P, r0, mi0, i, RM_PAIRED | RM_FIRST, nh, hi0, pool_at, too_long);
+      put_row<AUX, LONGC>(P, r0 + 1, mm0, (uint32_t)m, RM_PAIRED, nh, hi0 + 1u, pool_at, too_long);
+    }
+  }
+  if (too_long) P.counters[3] = 1;
+}
+
+// k_pool_copy (long-CIGAR mode: hundreds of ops per record): 16 lanes move one record's ops from its arena slot
+__global__ void __launch_bounds__(256) k_pool_copy(PairArgs P, int64_t n_rows) {
+  const int lane = threadIdx.x & 15;
+  int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  if (r >= n_rows) return;
+  const uint32_t n = ((const uint32_t *)(P.r_a + r))[2] & RM_NCIG;
+  if (n <= 2u) return;
+  const uint2 c = P.r_c[r];
+  const uint32_t *src = P.cig_arena + P.r_src[r];
+  uint32_t *dst = P.pool + (((uint64_t)c.y << 32) | c.x);
+  for (uint32_t k = lane; k < n; k += 16) dst[k] = src[k];
+}
+
+// k_primary: one lane per read name.  Primary = the emitted record (pair) with the
+// best similarity score; ties are broken by get_rand(n_tied, std::hash(name))
+// (src/core.cpp:243-307), restated in primary_pick.h.  A leader's records are all paired or all
+// single, so its units follow from its record count and one flag word.
+// SCORES = false: presets without the similarity filter leave every score at 0.0 (src/evaluate.cpp:843-865), so
+// every emitted unit ties and r_sim need not be read at all.
+// Also the counters of src/bramble.cpp:729-736 (one atomic per wave at the end).
+template <bool SCORES>
+__global__ void __launch_bounds__(256) k_primary(PairArgs P, const uint32_t *__restrict__ name_off,
+                                                 const uint8_t *__restrict__ names) {
+  int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long uniq = 0, dropped = 0;
-  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < P.n_groups; g += (int64_t)gridDim.x * blockDim.x) {
-    uint32_t a0 = P.group_off[g], a1 = P.group_off[g + 1];
-    uniq += (P.row_off[a1] - P.row_off[a0]) == 1 ? 1 : 0;
+  if (g < P.n_groups) {
+    const uint32_t a0 = P.group_off[g], a1 = P.group_off[g + 1];
+    const uint64_t rs = P.row_off[a0], re = P.row_off[a1];
+    uniq = (re - rs) == 1 ? 1 : 0;
     uint32_t any = 0;
     for (uint32_t i = a0; i < a1; i++) any |= P.n_matches[i];
-    dropped += any ? 0 : 1;
+    dropped = any ? 0 : 1;
+    if (names && re > rs) {
+      uint32_t *meta = (uint32_t *)P.r_a + 2;   // meta word of row r: meta[4 * r]
+      uint64_t pick = rs;
+      if (!SCORES) {
+        uint32_t units = 0;
+        for (uint32_t i = a0; i < a1; i++) {
+          const uint64_t b = P.row_off[i]; const uint32_t n = (uint32_t)(P.row_off[i + 1] - b);
+          if (n) units += (meta[4 * b] & RM_PAIRED) ? n / 2 : n;
+        }
+        if (units > 1) {
+          uint32_t idx = primary_pick(names + name_off[a0], name_off[a0 + 1] - name_off[a0], units);
+          for (uint32_t i = a0; i < a1; i++) {
+            const uint64_t b = P.row_off[i]; const uint32_t n = (uint32_t)(P.row_off[i + 1] - b);
+            if (!n) continue;
+            const bool paired = meta[4 * b] & RM_PAIRED;
+            const uint32_t u = paired ? n / 2 : n;
+            if (idx < u) { pick = b + (paired ? 2ull * idx : idx); break; }
+            idx -= u;
+          }
+        }
+      } else {
+        double best = -__builtin_inf(); uint32_t at_best = 0;
+        for (uint64_t r = rs; r < re;) {
+          const bool paired = meta[4 * r] & RM_PAIRED;
+          double sc = P.r_sim[r];
+          if (paired) { double s2 = P.r_sim[r + 1]; sc = sc > s2 ? sc : s2; }   // std::max(pair_score, m_align score)
+          if (sc > best) { best = sc; pick = r; at_best = 1; } else if (sc == best) at_best++;
+          r += paired ? 2 : 1;
+        }
+        if (at_best > 1) {
+          uint32_t idx = primary_pick(names + name_off[a0], name_off[a0 + 1] - name_off[a0], at_best);
+          uint32_t seen = 0;
+          for (uint64_t r = rs; r < re;) {
+            const bool paired = meta[4 * r] & RM_PAIRED;
+            double sc = P.r_sim[r];
+            if (paired) { double s2 = P.r_sim[r + 1]; sc = sc > s2 ? sc : s2; }
+            if (sc == best) { if (seen == idx) { pick = r; break; } seen++; }
+            r += paired ? 2 : 1;
+          }
+        }
+      }
+      const uint32_t mw = meta[4 * pick];
+      meta[4 * pick] = mw | RM_PRIMARY;
+      if (mw & RM_PAIRED) meta[4 * (pick + 1)] |= RM_PRIMARY;
+    }
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) { uniq += __shfl_down(uniq, d, 64); dropped += __shfl_down(dropped, d, 64); }
@@ -1476,69 +1556,58 @@ __global__ void __launch_bounds__(256) k_group_stats(PairArgs P) {
   }
 }
 
-// k_primary: one lane per read name.  Primary = the emitted record (pair) with the
-// best similarity score; ties are broken by get_rand(n_tied, std::hash(name))
-// (src/core.cpp:243-307), restated in primary_pick.h.
-// SCORES = false: presets without the similarity filter leave every score at 0.0 (src/evaluate.cpp:843-865), so
-// every emitted unit ties and r_sim need not be read at all.
-template <bool SCORES>
-__global__ void __launch_bounds__(256) k_primary(PairArgs P, const uint32_t *__restrict__ name_off,
-                                                 const uint8_t *__restrict__ names, uint8_t *__restrict__ r_primary) {
-  int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= P.n_groups) return;
-  uint32_t a0 = P.group_off[g], a1 = P.group_off[g + 1];
-  uint64_t rs = P.row_off[a0], re = P.row_off[a1];
-  if (rs == re) return;
-  double best = SCORES ? -__builtin_inf() : 0.0; uint64_t best_r = rs; uint32_t at_best = 0;
-  for (uint64_t r = rs; r < re;) {
-    bool paired = P.r_paired[r];
-    if (SCORES) {
-      double sc = P.r_sim[r];
-      if (paired) { double s2 = P.r_sim[r + 1]; sc = sc > s2 ? sc : s2; }   // std::max(pair_score, m_align score)
-      if (sc > best) { best = sc; best_r = r; at_best = 1; } else if (sc == best) at_best++;
-    } else at_best++;
-    r += paired ? 2 : 1;
+// ---------------------------------------------------------------------------
+// wide view of the packed rows (br_device_rows / br_rows): one array per field.  Not part of the
+// projection itself: run on request (br_device_rows_expand).
+// k_wide_fields: one lane per row.  MAPQ of get_mapq, the mate fields of set_mate_info
+// (src/bam.cpp:531-588) from the pair's adjacent row.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_wide_fields(WideArgs W) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= W.n_rows) return;
+  const uint4 a = W.r_a[r], x = W.r_x[r];
+  const uint32_t meta = a.z;
+  const int32_t input = (int32_t)x.x;
+  int32_t mate_tid = -1, mate_pos = -1, isize = 0;
+  if (meta & RM_PAIRED) {
+    const uint4 b = W.r_a[(meta & RM_FIRST) ? r + 1 : r - 1];
+    const int32_t my_pos = (int32_t)a.y;
+    mate_pos = (int32_t)b.y;
+    if (meta & RM_SAME) {
+      mate_tid = (int32_t)a.x;
+      const int32_t lq = W.l_qseq[input];
+      isize = (my_pos <= mate_pos) ? (mate_pos + lq) - my_pos : -((my_pos + lq) - mate_pos);
+    } else mate_tid = (int32_t)b.x;
   }
-  uint64_t pick = best_r;
-  if (at_best > 1) {
-    uint32_t idx = primary_pick(names + name_off[a0], name_off[a0 + 1] - name_off[a0], at_best);
-    uint32_t seen = 0;
-    for (uint64_t r = rs; r < re;) {
-      bool paired = P.r_paired[r];
-      bool tied = true;
-      if (SCORES) {
-        double sc = P.r_sim[r];
-        if (paired) { double s2 = P.r_sim[r + 1]; sc = sc > s2 ? sc : s2; }
-        tied = sc == best;
-      }
-      if (tied) { if (seen == idx) { pick = r; break; } seen++; }
-      r += paired ? 2 : 1;
-    }
-  }
-  r_primary[pick] = 1;
-  if (P.r_paired[pick]) r_primary[pick + 1] = 1;
+  W.w_input[r] = input; W.w_nh[r] = a.w; W.w_hi[r] = x.w; W.w_mapq[r] = mapq_of(a.w, W.long_reads);
+  W.w_group[r] = W.aln_group[input];
+  W.w_mate_tid[r] = mate_tid; W.w_mate_pos[r] = mate_pos; W.w_isize[r] = isize;
+  W.w_tid[r] = a.x; W.w_pos[r] = a.y; W.w_ncig[r] = meta & RM_NCIG;
+  W.w_strand[r] = (meta & RM_MINUS) ? (int8_t)'-' : (int8_t)'+';
+  W.w_sim[r] = W.r_sim ? W.r_sim[r] : 0.0; W.w_clip[r] = W.r_clip ? W.r_clip[r] : 0;
+  W.w_junc[r] = (int32_t)x.y; W.w_refc[r] = (int32_t)x.z;
+  W.w_paired[r] = (meta & RM_PAIRED) ? 1 : 0; W.w_same[r] = (meta & RM_SAME) ? 1 : 0;
+  W.w_first[r] = (meta & RM_FIRST) ? 1 : 0; W.w_primary[r] = (meta & RM_PRIMARY) ? 1 : 0;
 }
 
-// k_gather: one lane per row copies its rewritten CIGAR to the dense pool
-// G lanes per row: 1 for short reads (one or two words per row), 16 for long reads (hundreds of words per row)
+// k_wide_cigars: G lanes per row copy its rewritten CIGAR to the dense per-row pool of the wide view
 template <int G>
-__global__ void __launch_bounds__(256) k_gather(RowArgs R) {
+__global__ void __launch_bounds__(256) k_wide_cigars(WideArgs W) {
   const int lane = threadIdx.x & (G - 1);
   int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
-  if (r >= R.n_rows) return;
-  uint32_t x = R.r_rec[r].x;
-  uint64_t ref = R.m_cigoff[x];
-  uint64_t d0 = R.r_cigoff[r];
-  uint32_t n = R.r_ncig[r];
-  if (n <= 2) {  // inline words
+  if (r >= W.n_rows) return;
+  const uint32_t n = ((const uint32_t *)(W.r_a + r))[2] & RM_NCIG;
+  const uint2 c = W.r_c[r];
+  const uint64_t d0 = W.w_cigoff[r];
+  if (n <= 2) {
     if (lane == 0) {
-      if (n > 0) R.cigar_out[d0] = (uint32_t)ref;
-      if (n > 1) R.cigar_out[d0 + 1] = (uint32_t)(ref >> 32);
+      if (n > 0) W.w_cigar[d0] = c.x;
+      if (n > 1) W.w_cigar[d0 + 1] = c.y;
     }
     return;
   }
-  const uint32_t *src = R.cig_arena + ref;
-  for (uint32_t k = lane; k < n; k += G) R.cigar_out[d0 + k] = src[k];
+  const uint32_t *src = W.pool + (((uint64_t)c.y << 32) | c.x);
+  for (uint32_t k = lane; k < n; k += G) W.w_cigar[d0 + k] = src[k];
 }
 
 // ---------------------------------------------------------------------------
@@ -1637,8 +1706,10 @@ void launch_segment(hipStream_t st, int64_t n_aln, const int32_t *ref_id, const 
                      xs, ts, cigar_off, cigar, cfg, n_refs, seg, meta, head, head2, fast_flag);
 }
 
+// part (count pass of the presets without the similarity filter, walk_list set): 0 = both kernels, 1 = the main one, 2 = the
+// one with the exon walk over the deferred alignments
 template <int G>
-static void launch_project_g(hipStream_t st, const ProjectArgs &A, bool emit, int n_blocks) {
+static void launch_project_g(hipStream_t st, const ProjectArgs &A, bool emit, int n_blocks, int part) {
   bool simf = A.cfg.filter_by_similarity != 0;
   if (emit) {
     if (simf) hipLaunchKernelGGL((k_project<G, true, true>), dim3(n_blocks), dim3(256), 0, st, A);
@@ -1646,14 +1717,15 @@ static void launch_project_g(hipStream_t st, const ProjectArgs &A, bool emit, in
   } else {
     if (simf) hipLaunchKernelGGL((k_project<G, false, true>), dim3(n_blocks), dim3(256), 0, st, A);
     else if (A.walk_list) {
-      hipLaunchKernelGGL((k_project<G, false, false, 1>), dim3(n_blocks), dim3(256), 0, st, A);
-      hipLaunchKernelGGL((k_project<G, false, false, 2>), dim3(n_blocks), dim3(256), 0, st, A);
+      if (part != 2) hipLaunchKernelGGL((k_project<G, false, false, 1>), dim3(n_blocks), dim3(256), 0, st, A);
+      if (part != 1) hipLaunchKernelGGL((k_project<G, false, false, 2>), dim3(n_blocks), dim3(256), 0, st, A);
     } else hipLaunchKernelGGL((k_project<G, false, false>), dim3(n_blocks), dim3(256), 0, st, A);
   }
 }
 
-void launch_project(hipStream_t st, const ProjectArgs &A, bool emit, int group_lanes, int n_blocks) {
-  if (!emit && A.ix.n_rows == 0) {  // empty annotation: nothing can match (and the kernel's clamped loads need one row)
+void launch_project(hipStream_t st, const ProjectArgs &A, bool emit, int group_lanes, int n_blocks, int part) {
+  if (!emit && A.ix.n_rows == 0) {
+    if (part == 2) return;  // empty annotation: nothing can match (and the kernel's clamped loads need one row)
     (void)hipMemsetAsync(A.n_matches, 0, (size_t)A.n_aln * 4, st);
     (void)hipMemsetAsync(A.mask, 0, (size_t)A.n_aln * 8, st);
     (void)hipMemsetAsync(A.ranges, 0, (size_t)A.n_aln * sizeof(uint4), st);
@@ -1666,10 +1738,10 @@ void launch_project(hipStream_t st, const ProjectArgs &A, bool emit, int group_l
   if (need < n_blocks) n_blocks = (int)need;
   if (n_blocks < 1) n_blocks = 1;
   switch (group_lanes) {
-    case 8: launch_project_g<8>(st, A, emit, n_blocks); break;
-    case 16: launch_project_g<16>(st, A, emit, n_blocks); break;
-    case 32: launch_project_g<32>(st, A, emit, n_blocks); break;
-    default: launch_project_g<64>(st, A, emit, n_blocks); break;
+    case 8: launch_project_g<8>(st, A, emit, n_blocks, part); break;
+    case 16: launch_project_g<16>(st, A, emit, n_blocks, part); break;
+    case 32: launch_project_g<32>(st, A, emit, n_blocks, part); break;
+    default: launch_project_g<64>(st, A, emit, n_blocks, part); break;
   }
 }
 
@@ -1732,31 +1804,36 @@ void launch_group_ids(hipStream_t st, int64_t n_groups, const uint32_t *group_of
   hipLaunchKernelGGL(k_group_ids, dim3(grid_for(n_groups, 256)), dim3(256), 0, st, n_groups, group_off, aln_group);
 }
 
-void launch_pair(hipStream_t st, const PairArgs &P, bool emit) {
+void launch_pair(hipStream_t st, const PairArgs &P) {
   if (P.n_aln <= 0) return;
-  if (emit) hipLaunchKernelGGL((k_pair<true>), dim3(grid_for(P.n_aln, 256)), dim3(256), 0, st, P);
-  else hipLaunchKernelGGL((k_pair<false>), dim3(grid_for(P.n_aln, 256)), dim3(256), 0, st, P);
+  hipLaunchKernelGGL(k_pair, dim3(grid_for(P.n_aln, 256)), dim3(256), 0, st, P);
 }
 
-void launch_row_fill(hipStream_t st, const PairArgs &P, int64_t n_rows, bool aux) {
-  if (n_rows > 0) {
-    if (aux) hipLaunchKernelGGL((k_row_fill<true>), dim3(grid_for(n_rows, 256)), dim3(256), 0, st, P, n_rows);
-    else hipLaunchKernelGGL((k_row_fill<false>), dim3(grid_for(n_rows, 256)), dim3(256), 0, st, P, n_rows);
-  }
-  if (P.n_groups > 0) hipLaunchKernelGGL(k_group_stats, dim3(std::min(grid_for(P.n_groups, 256), 1024)), dim3(256), 0, st, P);
+void launch_rows(hipStream_t st, const PairArgs &P, bool aux, bool long_cigars) {
+  if (P.n_aln <= 0) return;
+  dim3 g(grid_for(P.n_aln, 256)), b(256);
+  if (aux) { if (long_cigars) hipLaunchKernelGGL((k_rows<true, true>), g, b, 0, st, P); else hipLaunchKernelGGL((k_rows<true, false>), g, b, 0, st, P); }
+  else { if (long_cigars) hipLaunchKernelGGL((k_rows<false, true>), g, b, 0, st, P); else hipLaunchKernelGGL((k_rows<false, false>), g, b, 0, st, P); }
 }
 
-void launch_primary(hipStream_t st, const PairArgs &P, const uint32_t *name_off, const uint8_t *names, uint8_t *r_primary,
-                    bool has_scores) {
+void launch_pool_copy(hipStream_t st, const PairArgs &P, int64_t n_rows) {
+  if (n_rows > 0) hipLaunchKernelGGL(k_pool_copy, dim3(grid_for(n_rows * 16, 256)), dim3(256), 0, st, P, n_rows);
+}
+
+void launch_primary(hipStream_t st, const PairArgs &P, const uint32_t *name_off, const uint8_t *names, bool has_scores) {
   if (P.n_groups <= 0) return;
-  if (has_scores) hipLaunchKernelGGL((k_primary<true>), dim3(grid_for(P.n_groups, 256)), dim3(256), 0, st, P, name_off, names, r_primary);
-  else hipLaunchKernelGGL((k_primary<false>), dim3(grid_for(P.n_groups, 256)), dim3(256), 0, st, P, name_off, names, r_primary);
+  if (has_scores) hipLaunchKernelGGL((k_primary<true>), dim3(grid_for(P.n_groups, 256)), dim3(256), 0, st, P, name_off, names);
+  else hipLaunchKernelGGL((k_primary<false>), dim3(grid_for(P.n_groups, 256)), dim3(256), 0, st, P, name_off, names);
 }
 
-void launch_gather(hipStream_t st, const RowArgs &R, int64_t n_words) {
-  if (R.n_rows <= 0) return;
-  if (n_words > 8 * R.n_rows) hipLaunchKernelGGL((k_gather<16>), dim3(grid_for(R.n_rows * 16, 256)), dim3(256), 0, st, R);
-  else hipLaunchKernelGGL((k_gather<1>), dim3(grid_for(R.n_rows, 256)), dim3(256), 0, st, R);
+void launch_wide_fields(hipStream_t st, const WideArgs &W) {
+  if (W.n_rows > 0) hipLaunchKernelGGL(k_wide_fields, dim3(grid_for(W.n_rows, 256)), dim3(256), 0, st, W);
+}
+
+void launch_wide_cigars(hipStream_t st, const WideArgs &W, int64_t n_words) {
+  if (W.n_rows <= 0) return;
+  if (n_words > 8 * W.n_rows) hipLaunchKernelGGL((k_wide_cigars<16>), dim3(grid_for(W.n_rows * 16, 256)), dim3(256), 0, st, W);
+  else hipLaunchKernelGGL((k_wide_cigars<1>), dim3(grid_for(W.n_rows, 256)), dim3(256), 0, st, W);
 }
 
 }  // namespace br

@@ -69,8 +69,28 @@ class _DevArray:
 _TYPESTR = {"int8": "|i1", "uint8": "|u1", "int32": "<i4", "int64": "<i8", "float64": "<f8"}
 
 
-def rows_as_tensors(rows, device="cuda:0"):
-    """BrDeviceRows -> dict of torch tensors (unsigned 32/64-bit columns are viewed as signed)."""
+def packed_as_tensors(rows, n_aln, device="cuda:0"):
+    """BrDeviceRows (packed) -> dict of torch tensors: a int32 [n, 4] = {tid, pos, meta, nh}, cigar int64 [n],
+    x int32 [n, 4] = {input, junc_hits, aligned_len, hi}, pool int32, row_off int64 [n_aln + 1]."""
+    n = int(rows.n_rows)
+    out = {"n_rows": n, "row_off": torch.as_tensor(_DevArray(rows.row_off, n_aln + 1, "<i8"), device=device)}
+    if n == 0:
+        return out
+    out["a"] = torch.as_tensor(_DevArray(rows.a, 4 * n, "<i4"), device=device).view(n, 4)
+    out["x"] = torch.as_tensor(_DevArray(rows.x, 4 * n, "<i4"), device=device).view(n, 4)
+    out["cigar"] = torch.as_tensor(_DevArray(rows.cigar, n, "<i8"), device=device)
+    if int(rows.n_pool_words):
+        out["pool"] = torch.as_tensor(_DevArray(rows.pool, int(rows.n_pool_words), "<i4"), device=device)
+    if rows.similarity_score:
+        out["similarity_score"] = torch.as_tensor(_DevArray(rows.similarity_score, n, "<f8"), device=device)
+        out["clip_score"] = torch.as_tensor(_DevArray(rows.clip_score, n, "<i4"), device=device)
+    return out
+
+
+def rows_as_tensors(ctx, device="cuda:0", stream=0):
+    """Wide view of the context's last projection call (br_device_rows_expand) -> dict of torch tensors (unsigned
+    32/64-bit columns are viewed as signed)."""
+    rows = ctx.expand_rows(stream)
     n = int(rows.n_rows)
     spec = {"input_index": "int32", "transcript_id": "int32", "pos": "int32", "strand": "int8",
             "similarity_score": "float64", "clip_score": "int32", "junc_hits": "int32", "aligned_len": "int32",

@@ -12,11 +12,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbramble_amd.so")
 _P = C.POINTER
 
-K_SEGMENT, K_COUNT, K_EMIT, K_PAIR_COUNT, K_PAIR_EMIT, K_GATHER, K_SCAN, K_EMIT_AUX, K_KSW, K_BAM, K_PARSE, K_CODEC, K_EMIT_SIMPLE, K_PRIMARY, K_CIGAR_POOL, K_NUM = range(16)
-KERNEL_NAMES = ["k_segment", "k_project<G,false>", "k_emit_dense", "k_group_ids+k_pair<false>", "k_pair<true>",
-                "k_row_fill+k_group_stats", "k_scan_*", "k_expand+k_project<64,true>", "k_ksw", "k_bam_scan+k_bam_size+k_bam_encode",
+K_SEGMENT, K_COUNT, K_EMIT, K_PAIR_COUNT, K_PAIR_EMIT, K_GATHER, K_SCAN, K_EMIT_AUX, K_KSW, K_BAM, K_PARSE, K_CODEC, K_EMIT_SIMPLE, K_PRIMARY, K_CIGAR_POOL, K_COUNT_WALK, K_EXPAND, K_GROUP_IDS, K_NUM = range(19)
+KERNEL_NAMES = ["k_segment", "k_project<G,false,false,1>", "k_emit_dense<false,2>", "k_pair", "k_rows",
+                "(unused)", "k_scan_*", "k_project<64,true>", "k_ksw", "k_bam_scan+k_bam_size+k_bam_encode",
                 "k_rec_fields+k_group_off+k_rec_copy+k_mates+k_seq_*", "k_deflate_*+k_bgzf_compact",
-                "k_emit_dense<simple>", "k_primary", "k_gather"]
+                "k_emit_dense<false,1>", "k_primary", "k_pool_copy", "k_project<G,false,false,2>", "k_expand", "k_group_ids"]
 
 
 class BrambleError(RuntimeError):
@@ -83,9 +83,27 @@ class BrDeviceBatch(C.Structure):
 
 
 class BrDeviceRows(C.Structure):
-    _fields_ = [("n_rows", C.c_int64), ("n_matches", C.c_int64), ("n_cigar_words", C.c_int64)] + \
-               [(n, C.c_void_p) for n, _ in _ROW_FIELDS] + [(n, C.c_void_p) for n, _ in _ROW_TAIL] + _COUNTERS + \
+    """Packed rows (ABI version 2): a = {tid, pos, meta, nh}, cigar = inline ops or pool offset, x = {input, junc_hits,
+    aligned_len, hi}."""
+    _fields_ = [("n_rows", C.c_int64), ("n_matches", C.c_int64), ("n_pool_words", C.c_int64),
+                ("a", C.c_void_p), ("cigar", C.c_void_p), ("x", C.c_void_p), ("similarity_score", C.c_void_p),
+                ("clip_score", C.c_void_p), ("pool", C.c_void_p), ("row_off", C.c_void_p)] + _COUNTERS
+
+
+class BrDeviceWideRows(C.Structure):
+    _fields_ = [("n_rows", C.c_int64), ("n_cigar_words", C.c_int64)] + \
+               [(n, C.c_void_p) for n, _ in _ROW_FIELDS] + [(n, C.c_void_p) for n, _ in _ROW_TAIL] + \
                [("is_primary", C.c_void_p)]
+
+
+class BrHostRows(C.Structure):
+    _fields_ = [("n_rows", C.c_int64), ("n_aln", C.c_int64), ("n_groups", C.c_int64), ("n_pool_words", C.c_int64),
+                ("a", C.c_void_p), ("cigar", C.c_void_p), ("pool", C.c_void_p), ("row_off", C.c_void_p),
+                ("mate_idx", C.c_void_p), ("x", C.c_void_p), ("similarity_score", C.c_void_p),
+                ("clip_score", C.c_void_p)] + _COUNTERS
+
+
+ROW_MINUS, ROW_PAIRED, ROW_SAME_TX, ROW_FIRST, ROW_PRIMARY = 1 << 24, 1 << 25, 1 << 26, 1 << 27, 1 << 28
 
 
 class BrDeviceRecords(C.Structure):
@@ -109,10 +127,11 @@ class BrDeviceBam(C.Structure):
 EXPORTS = ["br_index_build", "br_index_build_flat", "br_index_free", "br_index_num_transcripts", "br_index_transcript_name",
            "br_index_transcript_len", "br_index_num_refs", "br_index_num_intervals", "br_index_device_bytes", "br_config_short_read",
            "br_config_long_read", "br_config_resolve", "br_batch_prepare", "br_batch_seq_source", "br_ctx_new", "br_ctx_free",
-           "br_project_batch", "br_project_batch_device", "br_project_group", "br_bam_encode_device", "br_project_bam_device", "br_project_bam_bundle", "br_bam_bundle_stage", "br_project_bam_staged", "br_bam_split", "br_annotation_load", "br_annotation_free",
+           "br_project_batch", "br_project_batch_device", "br_device_rows_expand", "br_batch_stage", "br_project_staged", "br_host_rows_wait", "br_project_batch_packed",
+           "br_pin_host", "br_unpin_host", "br_project_group", "br_bam_encode_device", "br_project_bam_device", "br_project_bam_bundle", "br_bam_bundle_stage", "br_project_bam_staged", "br_bam_split", "br_annotation_load", "br_annotation_free",
            "br_annotation_num_transcripts", "br_annotation_transcripts", "br_annotation_num_refs", "br_annotation_refnames", "br_cli_main", "br_bgzf_write_file", "br_bgzf_read_file",
            "br_free_buffer", "br_bgzf_codec", "br_bgzf_deflate_device", "br_ctx_set_profiling",
-           "br_ctx_set_param", "br_ctx_kernel_ms", "br_ctx_collect_counters", "br_ctx_last_counters", "br_ctx_rescue_stats", "br_primary_pick", "br_version", "br_strerror"]
+           "br_ctx_set_param", "br_ctx_kernel_ms", "br_ctx_collect_counters", "br_ctx_last_counters", "br_ctx_rescue_stats", "br_primary_pick", "br_row_mapq", "br_version", "br_strerror"]
 
 _LIB = None
 
@@ -170,6 +189,15 @@ def lib():
         L.br_project_batch.argtypes = [C.c_void_p, _P(BrConfig), _P(BrBatch), _P(BrRows)]
         L.br_project_batch_device.argtypes = [C.c_void_p, _P(BrConfig), _P(BrDeviceBatch), C.c_void_p,
                                               _P(BrDeviceRows)]
+        L.br_batch_stage.argtypes = [C.c_void_p, _P(BrBatch), C.c_int]
+        L.br_project_staged.argtypes = [C.c_void_p, _P(BrConfig), C.c_int, _P(BrHostRows)]
+        L.br_host_rows_wait.argtypes = [C.c_void_p, C.c_int]
+        L.br_project_batch_packed.argtypes = [C.c_void_p, _P(BrConfig), _P(BrBatch), _P(BrHostRows)]
+        L.br_pin_host.argtypes = [C.c_void_p, C.c_size_t]
+        L.br_unpin_host.argtypes = [C.c_void_p]
+        L.br_row_mapq.restype = C.c_uint32
+        L.br_row_mapq.argtypes = [C.c_uint32, C.c_int]
+        L.br_device_rows_expand.argtypes = [C.c_void_p, C.c_void_p, _P(BrDeviceWideRows)]
         L.br_bam_encode_device.argtypes = [C.c_void_p, _P(BrConfig), _P(BrDeviceRecords), C.c_void_p, _P(BrDeviceBam)]
         L.br_project_bam_device.argtypes = [C.c_void_p, _P(BrConfig), _P(BrDeviceRecords), C.c_void_p, C.c_int32, C.c_void_p,
                                             _P(BrDeviceRows), _P(BrDeviceBam)]
@@ -354,6 +382,79 @@ def _view(ptr, n, dtype):
     return np.frombuffer(buf, dtype=dtype, count=n).copy()
 
 
+def host_rows_to_numpy(r):
+    """BrHostRows -> dict of numpy copies: a uint32 [n, 4] = {tid, pos, meta, nh}, cigar uint64 [n], pool uint32,
+    row_off uint64 [n_aln + 1], mate_idx int32 [n_aln], optional x / similarity_score / clip_score."""
+    n, na = int(r.n_rows), int(r.n_aln)
+    out = {"n_rows": n, "n_aln": na, "n_groups": int(r.n_groups),
+           "a": _view(r.a, 4 * n, np.uint32).reshape(n, 4), "cigar": _view(r.cigar, n, np.uint64),
+           "pool": _view(r.pool, int(r.n_pool_words), np.uint32), "row_off": _view(r.row_off, na + 1, np.uint64),
+           "mate_idx": _view(r.mate_idx, na, np.int32)}
+    if r.x:
+        out["x"] = _view(r.x, 4 * n, np.uint32).reshape(n, 4)
+    if r.similarity_score:
+        out["similarity_score"] = _view(r.similarity_score, n, np.float64)
+        out["clip_score"] = _view(r.clip_score, n, np.int32)
+    for name, _ in _COUNTERS:
+        out[name] = int(getattr(r, name))
+    return out
+
+
+def unpack_host_rows(p, l_qseq, long_reads=False):
+    """Packed host rows (host_rows_to_numpy, with the x array) -> the wide dict project_batch returns (minus `group`),
+    derived on the host exactly as include/bramble_amd.h documents: HI / MAPQ / mate fields / insert size."""
+    n = p["n_rows"]
+    a, x = p["a"], p["x"]
+    meta = a[:, 2]
+    ncig = (meta & 0xffffff).astype(np.int64)
+    w = {"n_rows": n, "transcript_id": a[:, 0].copy(), "pos": a[:, 1].copy(), "nh": a[:, 3].copy(),
+         "strand": np.where(meta & ROW_MINUS, ord("-"), ord("+")).astype(np.int8),
+         "is_paired": ((meta & ROW_PAIRED) != 0).astype(np.uint8),
+         "same_transcript_as_mate": ((meta & ROW_SAME_TX) != 0).astype(np.uint8),
+         "is_first": ((meta & ROW_FIRST) != 0).astype(np.uint8), "is_primary": ((meta & ROW_PRIMARY) != 0).astype(np.uint8),
+         "input_index": x[:, 0].astype(np.int32), "junc_hits": x[:, 1].astype(np.int32),
+         "aligned_len": x[:, 2].astype(np.int32), "hi": x[:, 3].copy()}
+    nh = w["nh"]
+    if long_reads:
+        w["mapq"] = np.where(nh > 1, 0, 3).astype(np.uint32)
+    else:
+        w["mapq"] = np.select([nh == 1, nh == 2, (nh == 3) | (nh == 4)], [255, 3, 1], 0).astype(np.uint32)
+    coff = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum(ncig, out=coff[1:])
+    cig = np.zeros(int(coff[-1]), dtype=np.uint32)
+    c = p["cigar"]
+    one = np.nonzero(ncig >= 1)[0]
+    inl = ncig <= 2
+    i1 = np.nonzero(inl & (ncig >= 1))[0]
+    cig[coff[i1].astype(np.int64)] = (c[i1] & np.uint64(0xffffffff)).astype(np.uint32)
+    i2 = np.nonzero(ncig == 2)[0]
+    cig[coff[i2].astype(np.int64) + 1] = (c[i2] >> np.uint64(32)).astype(np.uint32)
+    for r in np.nonzero(~inl)[0]:
+        o = int(c[r])
+        cig[int(coff[r]):int(coff[r + 1])] = p["pool"][o:o + int(ncig[r])]
+    del one
+    w["cigar_off"], w["cigar"] = coff, cig
+    paired = w["is_paired"].astype(bool)
+    first = w["is_first"].astype(bool)
+    idx = np.arange(n)
+    nb = np.where(first, idx + 1, idx - 1)
+    nb = np.where(paired, nb, idx)
+    mate_pos = np.where(paired, a[nb, 1].astype(np.int64), -1)
+    same = w["same_transcript_as_mate"].astype(bool)
+    mate_tid = np.where(paired, np.where(same, a[:, 0].astype(np.int64), a[nb, 0].astype(np.int64)), -1)
+    lq = np.asarray(l_qseq, dtype=np.int64)[w["input_index"]] if n else np.zeros(0, np.int64)
+    my = a[:, 1].astype(np.int64)
+    isz = np.where(my <= mate_pos, (mate_pos + lq) - my, -((my + lq) - mate_pos))
+    w["mate_transcript_id"] = mate_tid.astype(np.int32)
+    w["mate_pos"] = mate_pos.astype(np.int32)
+    w["insert_size"] = np.where(paired & same, isz, 0).astype(np.int32)
+    w["similarity_score"] = p.get("similarity_score", np.zeros(n))
+    w["clip_score"] = p.get("clip_score", np.zeros(n, np.int32))
+    for k in ("total_complete", "total_unique", "dropped_reads", "total_processed"):
+        w[k] = p[k]
+    return w
+
+
 class Context:
     """ProjectionContext: device scratch + stream-ordered pipeline for one index."""
 
@@ -487,9 +588,23 @@ class Context:
         check(lib().br_ctx_rescue_stats(self.h, out), "br_ctx_rescue_stats")
         return dict(zip(("problems", "dp_cells", "rescued", "seq_bytes"), [int(v) for v in out]))
 
+    def project_batch_packed(self, cfg, batch):
+        """Host batch in, packed host rows (dict of numpy arrays copied out of the context's pinned buffers) out."""
+        keep = []
+        b = _batch_struct(batch, keep)
+        r = BrHostRows()
+        check(lib().br_project_batch_packed(self.h, C.byref(cfg), C.byref(b), C.byref(r)), "br_project_batch_packed")
+        return host_rows_to_numpy(r)
+
+    def expand_rows(self, stream=0):
+        """Wide (one array per field) view of the last projection call's rows: BrDeviceWideRows."""
+        out = BrDeviceWideRows()
+        check(lib().br_device_rows_expand(self.h, C.c_void_p(stream), C.byref(out)), "br_device_rows_expand")
+        return out
+
     def project_batch_device(self, cfg, dev_batch, stream=0):
         """dev_batch: dict of torch CUDA tensors (see bramble_amd.device.upload_batch).  Returns the
-        BrDeviceRows struct (device pointers owned by the context)."""
+        BrDeviceRows struct (packed rows; device pointers owned by the context)."""
         db = self._device_batch_struct(dev_batch)
         out = BrDeviceRows()
         check(lib().br_project_batch_device(self.h, C.byref(cfg), C.byref(db), C.c_void_p(stream), C.byref(out)),

@@ -207,11 +207,59 @@ typedef struct br_device_batch {
   const uint8_t *names;
 } br_device_batch;
 
-/* Rows as device pointers (same field meaning as br_rows; is_primary is filled
- * when the batch carries read names).
- * Valid until the next projection call on the context. */
+/* ABI version 2: the rows of the device-resident entry points are PACKED (24 bytes + 16 bytes of detail per emitted
+ * record instead of 22 separate arrays): the row stage of the pipeline is bound by the bytes it writes, and a host
+ * that downloads rows pays for them a second time over PCIe.  The wide one-array-per-field view (ABI version 1's
+ * br_device_rows, now br_device_wide_rows) is derived from the packed table on request. */
+#define BR_ABI_VERSION 2
+
+/* One emitted BAM record (ProjectedAlignment, bramble-rs/src/api.rs:135-176; the fields write_to_bam sets,
+ * src/core.cpp:96-212).  Rows of one read name are contiguous and a pair's two records are adjacent (the leader's own
+ * record first), so
+ *   HI   = 1-based rank of the row among its read name's rows (also stored in br_row_x),
+ *   MAPQ = br_row_mapq(nh, long_reads)                                    (get_mapq, src/core.cpp:46-58),
+ *   mate transcript / position = the adjacent row's, insert size from the two positions and the read length
+ *                                                                         (set_mate_info, src/bam.cpp:531-588). */
+typedef struct br_row_a {
+  uint32_t transcript_id;
+  uint32_t pos;   /* 0-based transcript position (fwpos / rcpos by strand) */
+  uint32_t meta;  /* BR_ROW_* bits */
+  uint32_t nh;    /* records emitted for the read name (NH tag) */
+} br_row_a;
+#define BR_ROW_NCIGAR(meta) ((meta) & 0xffffffu) /* ops of the rewritten CIGAR */
+#define BR_ROW_MINUS (1u << 24)                  /* transcript strand '-' */
+#define BR_ROW_PAIRED (1u << 25)                 /* emitted together with its mate (the adjacent row) */
+#define BR_ROW_SAME_TX (1u << 26)                /* ... on the same transcript */
+#define BR_ROW_FIRST (1u << 27)                  /* the leading record of the pair / an unpaired record; its input
+                                                  * alignment is the leader of row_off[], the other row's is the mate */
+#define BR_ROW_PRIMARY (1u << 28)                /* primary record of the read name (src/core.cpp:243-307) */
+typedef struct br_row_x {
+  uint32_t input_index; /* alignment of the batch this record rewrites */
+  uint32_t junc_hits;
+  uint32_t aligned_len; /* ref_consumed: transcript bases spanned */
+  uint32_t hi;          /* HI tag */
+} br_row_x;
+uint32_t br_row_mapq(uint32_t nh, int long_reads); /* get_mapq, src/core.cpp:46-58 */
+
+/* Packed rows as device pointers; valid until the next projection call on the context.
+ * cigar[r]: the rewritten CIGAR (update_cigar, src/bam.cpp:502-528) itself when it has <= 2 ops (op 0 in the low
+ * word, op 1 in the high word), else the offset of its ops in pool[].  row_off[i] .. row_off[i + 1] are the rows
+ * emitted by alignment i as the leader (for itself and, alternating, its mate). */
 typedef struct br_device_rows {
-  int64_t n_rows, n_matches, n_cigar_words;
+  int64_t n_rows, n_matches, n_pool_words;
+  const br_row_a *a;
+  const uint64_t *cigar;
+  const br_row_x *x;
+  const double *similarity_score; /* NULL unless the preset filters by similarity (then every score is 0.0) */
+  const int32_t *clip_score;      /* NULL likewise (0) */
+  const uint32_t *pool;
+  const uint64_t *row_off;        /* n_aln + 1 */
+  uint64_t total_complete, total_unique, dropped_reads, total_processed;
+} br_device_rows;
+
+/* The wide view: same field meaning as br_rows; is_primary is filled when the batch carries read names. */
+typedef struct br_device_wide_rows {
+  int64_t n_rows, n_cigar_words;
   const int32_t *input_index;
   const uint32_t *transcript_id, *pos;
   const int8_t *strand;
@@ -223,12 +271,52 @@ typedef struct br_device_rows {
   const uint8_t *is_paired, *same_transcript_as_mate, *is_first;
   const int32_t *mate_transcript_id, *mate_pos, *insert_size;
   const uint32_t *group;
-  uint64_t total_complete, total_unique, dropped_reads, total_processed;
   const uint8_t *is_primary;
-} br_device_rows;
+} br_device_wide_rows;
 
 int br_project_batch_device(br_ctx *, const br_config *, const br_device_batch *, void *stream,
                             br_device_rows *out);
+/* Derives the wide view of the LAST projection call's rows on the device (arrays owned by the context, valid until
+ * the next projection call). */
+int br_device_rows_expand(br_ctx *, void *stream, br_device_wide_rows *out);
+
+/* ---- flat batches over PCIe: packed rows home, uploads / downloads overlapped with the projection ------------- */
+
+/* Packed rows in pinned host memory owned by the context (one set per staging slot).  The per-record fields are
+ * those of br_device_rows; x (detail) is NULL unless br_ctx_set_param("host_detail", 1).  mate_idx is the mate index
+ * the device computed for the batch (process_pairs, src/bramble.cpp:272-311): the input alignment of a row of leader
+ * i is i when BR_ROW_FIRST is set, else mate_idx[i]. */
+typedef struct br_host_rows {
+  int64_t n_rows, n_aln, n_groups, n_pool_words;
+  const br_row_a *a;
+  const uint64_t *cigar;
+  const uint32_t *pool;
+  const uint64_t *row_off;  /* n_aln + 1 */
+  const int32_t *mate_idx;  /* n_aln */
+  const br_row_x *x;
+  const double *similarity_score;
+  const int32_t *clip_score;
+  uint64_t total_complete, total_unique, dropped_reads, total_processed;
+} br_host_rows;
+
+/* convert_reads minus BAM writing for a flat host batch in three steps, so that batch k + 1 uploads and batch
+ * k - 1 downloads while batch k is projected (one host thread suffices):
+ *   br_batch_stage(ctx, batch, slot)      queues the uploads of `batch` on the context's copy stream (slot 0 / 1);
+ *                                         the arrays must stay valid, and should be pinned (br_pin_host), until
+ *                                         br_project_staged(slot) has returned;
+ *   br_project_staged(ctx, cfg, slot, out) computes the input contract on the device (read-name groups, mate index,
+ *                                         the group's shared sequence: what br_batch_prepare / br_batch_seq_source
+ *                                         do on the host), projects, and queues the download of the packed rows;
+ *   br_host_rows_wait(ctx, slot)          returns when that slot's rows are in host memory; they stay valid until
+ *                                         the slot's next br_project_staged.
+ * br_project_batch_packed = the three in sequence on slot 0. */
+int br_batch_stage(br_ctx *, const br_batch *, int slot);
+int br_project_staged(br_ctx *, const br_config *, int slot, br_host_rows *out);
+int br_host_rows_wait(br_ctx *, int slot);
+int br_project_batch_packed(br_ctx *, const br_config *, const br_batch *, br_host_rows *out);
+/* Page-locks caller memory for asynchronous transfers (hipHostRegister / hipHostUnregister behind plain C). */
+int br_pin_host(void *p, size_t bytes);
+int br_unpin_host(void *p);
 
 /* AoS convenience mirroring project_group_with (bramble-rs/src/api.rs:285-290):
  * all alignments of ONE query name in, one br_projected per emitted record out
@@ -385,21 +473,24 @@ const char *br_bgzf_codec(void); /* "libdeflate" (bound at run time when present
 
 /* Kernel names reported by br_ctx_kernel_ms / rocprof. */
 #define BR_K_SEGMENT 0    /* k_segment */
-#define BR_K_COUNT 1      /* k_project<G,false> (both kernels of the split count pass) */
+#define BR_K_COUNT 1      /* k_project<G,false> (count pass; with "count_split" the main kernel, without the exon walk) */
 #define BR_K_EMIT 2       /* k_emit_dense (general class; the whole list for long-read presets) */
-#define BR_K_PAIR_COUNT 3 /* k_group_ids + k_pair<false> */
-#define BR_K_PAIR_EMIT 4  /* k_pair<true> */
-#define BR_K_GATHER 5     /* k_row_fill + k_group_stats */
+#define BR_K_PAIR_COUNT 3 /* k_pair */
+#define BR_K_PAIR_EMIT 4  /* k_rows (the packed row table) */
+#define BR_K_GATHER 5     /* unused since ABI version 2 (k_row_fill + k_group_stats folded into k_rows / k_primary) */
 #define BR_K_SCAN 6       /* k_scan_* */
-#define BR_K_EMIT_AUX 7   /* k_expand + k_project<64,true> (alignments with > 64 candidate rows) */
+#define BR_K_EMIT_AUX 7   /* k_project<64,true> (alignments with > 64 candidate rows) */
 #define BR_K_KSW 8        /* k_ksw (-S clip rescue DP) */
 #define BR_K_BAM 9        /* k_bam_scan + k_bam_size + k_bam_encode */
 #define BR_K_PARSE 10     /* k_rec_fields + k_group_off + k_rec_copy + k_mates* + k_seq_* */
 #define BR_K_CODEC 11     /* k_deflate_dynamic | k_deflate_fixed, k_bgzf_compact */
 #define BR_K_EMIT_SIMPLE 12 /* k_emit_dense, simple class (one read exon from a single M op) */
-#define BR_K_PRIMARY 13   /* k_primary */
-#define BR_K_CIGAR_POOL 14 /* k_gather */
-#define BR_K_NUM 15
+#define BR_K_PRIMARY 13   /* k_primary (+ the per-read-name counters) */
+#define BR_K_CIGAR_POOL 14 /* k_pool_copy (long-read CIGARs only) */
+#define BR_K_COUNT_WALK 15 /* k_project<G,false,false,2>: the deferred alignments of the split count pass, with the exon walk */
+#define BR_K_EXPAND 16    /* k_expand (emit work list) */
+#define BR_K_GROUP_IDS 17 /* k_group_ids */
+#define BR_K_NUM 18
 /* When enabled, every launch is bracketed by hipEvents on the launch stream. */
 int br_ctx_set_profiling(br_ctx *, int enabled);
 /* Launch tuning: "group_lanes" (8|16|32|64 lanes cooperating on one alignment),

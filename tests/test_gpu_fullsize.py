@@ -44,7 +44,7 @@ def test_full_size_properties(setup):
     cfg = lib.make_config()
     db = brdev.upload_batch(batch, "cuda:0")
     rows = ctx.project_batch_device(cfg, db, 0)
-    t = brdev.rows_as_tensors(rows)
+    t = brdev.rows_as_tensors(ctx)
     n = t["n_rows"]
     assert n > 5 * PAIRS and rows.total_processed == batch["n_aln"]
 
@@ -72,7 +72,7 @@ def test_full_size_properties(setup):
     cs1 = _checksums(t)
     # idempotence
     rows2 = ctx.project_batch_device(cfg, db, 0)
-    assert _checksums(brdev.rows_as_tensors(rows2)) == cs1
+    assert _checksums(brdev.rows_as_tensors(ctx)) == cs1
     del t, rows, rows2
 
     # shard additivity
@@ -94,7 +94,7 @@ def test_full_size_properties(setup):
     for r in range(2):
         sub, lo = shard.shard_batch(batch, r, 2, starts=starts)
         rs = ctx.project_batch_device(cfg, brdev.upload_batch(sub, "cuda:0"), 0)
-        cs = _checksums(brdev.rows_as_tensors(rs))
+        cs = _checksums(brdev.rows_as_tensors(ctx))
         for k, v in cs.items():
             total[k] = total.get(k, 0) + v
     assert total == cs1
@@ -128,7 +128,7 @@ def test_full_size_bam_bundle_stream_properties():
     off_d = torch.from_numpy(roff.view(np.int64)).cuda()
     len_d = torch.from_numpy(rlen.view(np.int32)).cuda()
     rows, bam = ctx.project_bam_device(cfg, blob, off_d, len_d, np.arange(ann.flat["n_refs"], dtype=np.int32), 0)
-    t = brdev.rows_as_tensors(rows)
+    t = brdev.rows_as_tensors(ctx)
     n = t["n_rows"]
     assert n > 5 * PAIRS and int(bam.n_rows) == n
     out = torch.as_tensor(brdev._DevArray(bam.data, int(bam.n_bytes), "|u1"), device="cuda:0")
@@ -160,7 +160,7 @@ def test_full_size_bam_bundle_stream_properties():
     # the flat-batch path on the same alignments gives the same rows
     db = brdev.upload_batch(batch, "cuda:0")
     rows2 = ctx.project_batch_device(cfg, db, 0)
-    assert _checksums(brdev.rows_as_tensors(rows2)) == cs_bundle
+    assert _checksums(brdev.rows_as_tensors(ctx)) == cs_bundle
     del db
 
     # device deflate of the whole stream; inflate a sample of blocks on the host
