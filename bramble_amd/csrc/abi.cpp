@@ -430,7 +430,8 @@ struct br_ctx {
   int count_split = 1;   // count pass as two kernels: the main one without the exon walk, a second one for the alignments that need it
   DevBuf walk_list, pmask;
   // packed row table (the product of the row stage) and what its kernels need
-  DevBuf pk_a, pk_c, pk_x, pk_sim, pk_clip, pk_src, pool, pool_cnt, n_pool, pool_off;
+  DevBuf r_rec, pk_a, pk_c, pk_x, pk_sim, pk_clip;
+  DevBuf pool, pool_sizes, pool_off, pk_ch;   // dense long-CIGAR pool + rewritten references for host downloads
   bool last_aux_cols = false;           // the last call's rows carry similarity / clip scores
   bool wide_valid = false;              // the wide view below matches the last call's rows
   const int32_t *last_l_qseq = nullptr; // the last batch's l_qseq (device; insert sizes of the wide view / the encoder)
@@ -492,7 +493,7 @@ extern "C" void br_ctx_free(br_ctx *c) {
                     &c->m_cigoff, &c->cig_arena, &c->big_list, &c->n_big, &c->m_aln,
                     &c->bam_aux, &c->bam_len, &c->bam_off, &c->bam_out, &c->z_slots, &c->z_sizes, &c->z_off, &c->z_dense, &c->z_tabs, &c->z_tokens, &c->p_ncig, &c->p_name_len, &c->p_isnew, &c->p_group_pre, &c->p_small, &c->p_big, &c->p_seq_len, &c->p_ref_map, &c->fa_stats, &c->fa_n_prob, &c->fa_seq_bytes, &c->fa_prob_off, &c->fa_seqarena_off, &c->fa_probs, &c->fa_results,
                     &c->fa_seq_arena, &c->fa_clip_ops, &c->fa_ideal_cap, &c->fa_scratch, &c->b_seq_off, &c->b_seqs, &c->b_seq_src,
-                    &c->pk_a, &c->pk_c, &c->pk_x, &c->pk_sim, &c->pk_clip, &c->pk_src, &c->pool, &c->pool_cnt, &c->n_pool, &c->pool_off,
+                    &c->r_rec, &c->pk_a, &c->pk_c, &c->pk_x, &c->pk_sim, &c->pk_clip, &c->pool, &c->pool_sizes, &c->pool_off, &c->pk_ch,
                     &c->n_rows, &c->row_off, &c->aln_group, &c->r_input, &c->r_nh, &c->r_hi, &c->r_mapq,
                     &c->r_group, &c->r_mate_tid, &c->r_mate_pos, &c->r_isize, &c->r_tid, &c->r_pos,
                     &c->r_ncig, &c->r_strand, &c->r_sim, &c->r_clip, &c->r_junc, &c->r_refc, &c->r_cigoff,
@@ -641,9 +642,7 @@ static int run_device_impl(br_ctx *c, const br_config *cfg, const br_device_batc
   A.match_off = c->match_off.as<uint32_t>(); A.cig_base = c->cig_base.as<uint64_t>();
   RC(c->big_list.ensure((size_t)n * 4)); RC(c->n_big.ensure(16));
   HIPCHK(hipMemsetAsync(c->n_big.p, 0, 8, st));
-  RC(c->pool_cnt.ensure((size_t)n * 4));
-  HIPCHK(hipMemsetAsync(c->pool_cnt.p, 0, (size_t)n * 4, st));
-  A.pool_cnt = c->pool_cnt.as<uint32_t>();
+
   A.big_list = c->big_list.as<uint32_t>(); A.n_big = c->n_big.as<uint32_t>();
   if (c->count_split) { RC(c->walk_list.ensure((size_t)n * 4)); A.walk_list = c->walk_list.as<uint32_t>(); A.n_walk = c->n_big.as<uint32_t>() + 1; }
   int n_blocks = c->n_cu * c->blocks_per_cu;
@@ -771,7 +770,6 @@ static int run_device_impl(br_ctx *c, const br_config *cfg, const br_device_batc
   // (a buffer that a queued packed download still reads must not be reallocated under it)
   if (c->rows_busy_set && c->row_off.cap < (size_t)(n + 1) * 8) HIPCHK(hipEventSynchronize(c->rows_busy));
   RC(c->n_rows.ensure((size_t)n * 4)); RC(c->row_off.ensure((size_t)(n + 1) * 8)); RC(c->aln_group.ensure((size_t)n * 4));
-  RC(c->n_pool.ensure((size_t)n * 4)); RC(c->pool_off.ensure((size_t)(n + 1) * 8));
   RC(pf.begin(BR_K_GROUP_IDS));
   launch_group_ids(st, ng, b->group_off, c->aln_group.as<uint32_t>());
   RC(pf.end());
@@ -780,12 +778,12 @@ static int run_device_impl(br_ctx *c, const br_config *cfg, const br_device_batc
   P.n_groups = ng; P.n_aln = n; P.long_reads = dc.long_reads; P.group_off = b->group_off; P.mate_idx = b->mate_idx;
   P.aln_group = c->aln_group.as<uint32_t>();
   P.match_off = c->match_off.as<uint32_t>(); P.n_matches = c->n_matches.as<uint32_t>(); P.m_tid = A.m_tid; P.m_a = A.m_a; P.m_b = A.m_b;
-  P.m_cigoff = A.m_cigoff; P.cig_arena = A.cig_arena; P.pool_cnt = A.pool_cnt;
-  P.n_rows = c->n_rows.as<uint32_t>(); P.n_pool = c->n_pool.as<uint32_t>();
-  P.row_off = c->row_off.as<uint64_t>(); P.pool_off = c->pool_off.as<uint64_t>(); P.counters = c->counters_d.as<uint64_t>();
+  P.m_cigoff = A.m_cigoff;
+  P.n_rows = c->n_rows.as<uint32_t>();
+  P.row_off = c->row_off.as<uint64_t>(); P.counters = c->counters_d.as<uint64_t>();
   RC(c->pmask.ensure((size_t)n * 8)); P.pmask = c->pmask.as<uint64_t>();
   RC(pf.begin(BR_K_PAIR_COUNT));
-  launch_pair(st, P);
+  launch_pair(st, P, false);
   RC(pf.end());
   ScanArgs S2{};
   S2.n = n; S2.src32 = c->n_rows.as<uint32_t>(); S2.tile_sums = c->tile_sums.as<uint64_t>();
@@ -793,43 +791,36 @@ static int run_device_impl(br_ctx *c, const br_config *cfg, const br_device_batc
   if (c->rows_busy_set) { HIPCHK(hipStreamWaitEvent(st, c->rows_busy, 0)); }
   RC(pf.begin(BR_K_SCAN));
   launch_scan(st, S2, 2, c->row_off.p, true, d_tot + 2);
-  S2.src32 = c->n_pool.as<uint32_t>();
-  launch_scan(st, S2, 2, c->pool_off.p, true, d_tot + 3);
   RC(pf.end());
-  HIPCHK(hipMemcpyAsync(c->h_totals + 2, d_tot + 2, 16, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(c->h_totals + 2, d_tot + 2, 8, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
-  const uint64_t n_rows = c->h_totals[2], n_pool = c->h_totals[3];
-  out->n_rows = (int64_t)n_rows; out->n_pool_words = (int64_t)n_pool;
+  const uint64_t n_rows = c->h_totals[2];
+  out->n_rows = (int64_t)n_rows; out->n_pool_words = (int64_t)n_cig_arena;
 
   const size_t nr = (size_t)std::max<uint64_t>(n_rows, 1);
   // clip score / similarity score columns exist only when the preset filters by similarity (long reads): else all zero
   const bool aux_cols = dc.filter_by_similarity != 0;
-  if (c->rows_busy_set && (c->pk_a.cap < nr * sizeof(uint4) || c->pk_x.cap < nr * sizeof(uint4) || c->pk_c.cap < nr * sizeof(uint2) ||
-                           c->pool.cap < (size_t)std::max<uint64_t>(n_pool, 1) * 4 ||
-                           (aux_cols && (c->pk_sim.cap < nr * 8 || c->pk_clip.cap < nr * 4))))
+  if (c->rows_busy_set && (c->pk_a.cap < nr * sizeof(uint4) || (aux_cols && (c->pk_sim.cap < nr * 8 || c->pk_clip.cap < nr * 4))))
     HIPCHK(hipEventSynchronize(c->rows_busy));
+  RC(c->r_rec.ensure(nr * sizeof(uint4)));
   RC(c->pk_a.ensure(nr * sizeof(uint4))); RC(c->pk_c.ensure(nr * sizeof(uint2))); RC(c->pk_x.ensure(nr * sizeof(uint4)));
-  RC(c->pool.ensure((size_t)std::max<uint64_t>(n_pool, 1) * 4));
   if (aux_cols) { RC(c->pk_sim.ensure(nr * 8)); RC(c->pk_clip.ensure(nr * 4)); }
-  // records with hundreds of ops (long reads): the ops move to the pool 16 lanes per record instead of lane-serially
-  const bool long_cigars = n_pool > 8 * n_rows;
-  if (long_cigars) RC(c->pk_src.ensure(nr * 8));
+  P.n_rows_total = (int64_t)n_rows; P.r_rec = c->r_rec.as<uint4>();
   P.r_a = c->pk_a.as<uint4>(); P.r_c = c->pk_c.as<uint2>(); P.r_x = c->pk_x.as<uint4>();
   P.r_sim = aux_cols ? c->pk_sim.as<double>() : nullptr; P.r_clip = aux_cols ? c->pk_clip.as<int32_t>() : nullptr;
-  P.pool = c->pool.as<uint32_t>(); P.r_src = long_cigars ? c->pk_src.as<uint64_t>() : nullptr;
   if (n_rows) {
     RC(pf.begin(BR_K_PAIR_EMIT));
-    launch_rows(st, P, aux_cols, long_cigars);
+    launch_pair(st, P, true);
     RC(pf.end());
-    if (long_cigars) {
-      RC(pf.begin(BR_K_CIGAR_POOL));
-      launch_pool_copy(st, P, (int64_t)n_rows);
-      RC(pf.end());
-    }
   }
   RC(pf.begin(BR_K_PRIMARY));
   launch_primary(st, P, b->name_off, (b->names && b->name_off) ? b->names : nullptr, aux_cols);  // + per-group counters
   RC(pf.end());
+  if (n_rows) {
+    RC(pf.begin(BR_K_ROWS));
+    launch_rows(st, P, aux_cols);
+    RC(pf.end());
+  }
   HIPCHK(hipMemcpyAsync(c->h_totals + 4, c->counters_d.p, 4 * 8, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   if (!keep_events) RC(pf.collect());
@@ -840,9 +831,9 @@ static int run_device_impl(br_ctx *c, const br_config *cfg, const br_device_batc
   out->a = (const br_row_a *)c->pk_a.p; out->cigar = (const uint64_t *)c->pk_c.p; out->x = (const br_row_x *)c->pk_x.p;
   out->similarity_score = aux_cols ? c->pk_sim.as<double>() : nullptr;
   out->clip_score = aux_cols ? c->pk_clip.as<int32_t>() : nullptr;
-  out->pool = c->pool.as<uint32_t>(); out->row_off = c->row_off.as<uint64_t>();
+  out->pool = c->cig_arena.as<uint32_t>(); out->row_off = c->row_off.as<uint64_t>();
   c->counters[6] = n_matches;
-  c->last_n_rows = (int64_t)n_rows; c->last_n_aln = n; c->last_n_pool = (int64_t)n_pool;
+  c->last_n_rows = (int64_t)n_rows; c->last_n_aln = n; c->last_n_pool = (int64_t)n_cig_arena;
   c->last_aux_cols = aux_cols; c->wide_valid = false; c->last_l_qseq = b->l_qseq; c->last_long_reads = dc.long_reads;
   return BR_OK;
 }
@@ -867,7 +858,7 @@ static int expand_rows(br_ctx *c, hipStream_t st, br_device_wide_rows *out) {
     W.n_rows = (int64_t)n_rows; W.n_aln = c->last_n_aln; W.long_reads = c->last_long_reads;
     W.r_a = c->pk_a.as<uint4>(); W.r_c = c->pk_c.as<uint2>(); W.r_x = c->pk_x.as<uint4>();
     W.r_sim = c->last_aux_cols ? c->pk_sim.as<double>() : nullptr; W.r_clip = c->last_aux_cols ? c->pk_clip.as<int32_t>() : nullptr;
-    W.pool = c->pool.as<uint32_t>(); W.aln_group = c->aln_group.as<uint32_t>(); W.l_qseq = c->last_l_qseq;
+    W.pool = c->cig_arena.as<uint32_t>(); W.aln_group = c->aln_group.as<uint32_t>(); W.l_qseq = c->last_l_qseq;
     W.w_input = c->r_input.as<int32_t>(); W.w_nh = c->r_nh.as<uint32_t>(); W.w_hi = c->r_hi.as<uint32_t>();
     W.w_mapq = c->r_mapq.as<uint32_t>(); W.w_group = c->r_group.as<uint32_t>(); W.w_mate_tid = c->r_mate_tid.as<int32_t>();
     W.w_mate_pos = c->r_mate_pos.as<int32_t>(); W.w_isize = c->r_isize.as<int32_t>(); W.w_tid = c->r_tid.as<uint32_t>();
@@ -955,7 +946,7 @@ static int bam_encode_impl(br_ctx *c, const br_config *cfg, const br_device_reco
   B.aux = (BamAux *)c->bam_aux.p;
   B.r_a = c->pk_a.as<uint4>(); B.r_c = c->pk_c.as<uint2>(); B.r_x = c->pk_x.as<uint4>();
   B.r_sim = c->last_aux_cols ? c->pk_sim.as<double>() : nullptr; B.r_clip = c->last_aux_cols ? c->pk_clip.as<int32_t>() : nullptr;
-  B.pool = c->pool.as<uint32_t>(); B.l_qseq = c->last_l_qseq;
+  B.pool = c->cig_arena.as<uint32_t>(); B.l_qseq = c->last_l_qseq;
   B.out_len = c->bam_len.as<uint32_t>(); B.out_off = c->bam_off.as<uint64_t>();
   RC(c->tile_sums.ensure((size_t)std::max<int64_t>(scan_tiles_for(nr + 1), 1) * 8 * 3));
   RC(c->totals.ensure(16 * 8));
@@ -1397,9 +1388,28 @@ extern "C" int br_project_staged(br_ctx *c, const br_config *cfg, int slot, br_h
   S.staged = false;
   br_device_rows pr;
   RC(run_device(c, cfg, &db, st, &pr));   // returns with the stream drained
-  const size_t nr = (size_t)pr.n_rows, nn = (size_t)S.n, np = (size_t)pr.n_pool_words;
+  const size_t nr = (size_t)pr.n_rows, nn = (size_t)S.n;
+  // the long (> 2 op) rewritten CIGARs sit in the sparse arena: a dense copy for the host (sizes -> scan -> copy)
+  size_t np = 0;
+  if (nr) {
+    RC(c->pool_sizes.ensure(nr * 4)); RC(c->pool_off.ensure((nr + 1) * 8)); RC(c->pk_ch.ensure(nr * sizeof(uint2)));
+    RC(c->tile_sums.ensure((size_t)std::max<int64_t>(scan_tiles_for((int64_t)nr + 1), 1) * 8 * 3));
+    PoolArgs Q{};
+    Q.n_rows = (int64_t)nr; Q.r_a = c->pk_a.as<uint4>(); Q.r_c = c->pk_c.as<uint2>(); Q.arena = c->cig_arena.as<uint32_t>();
+    Q.sizes = c->pool_sizes.as<uint32_t>(); Q.off = c->pool_off.as<uint64_t>(); Q.c_out = c->pk_ch.as<uint2>();
+    launch_pool_sizes(st, Q);
+    ScanArgs SP{}; SP.n = (int64_t)nr; SP.src32 = Q.sizes; SP.tile_sums = c->tile_sums.as<uint64_t>();
+    launch_scan(st, SP, 2, c->pool_off.p, true, c->totals.as<uint64_t>() + 10);
+    HIPCHK(hipMemcpyAsync(c->h_totals + 28, c->totals.as<uint64_t>() + 10, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    np = (size_t)c->h_totals[28];
+    RC(c->pool.ensure(std::max<size_t>(np, 1) * 4));
+    Q.pool = c->pool.as<uint32_t>();
+    launch_pool_copy(st, Q, np > 8 * nr);
+    HIPCHK(hipStreamSynchronize(st));
+  }
   hipStream_t ds = c->d2h_stream;
-  RC(d2h(S.h_a, pr.a, nr, ds)); RC(d2h(S.h_c, pr.cigar, nr, ds)); RC(d2h(S.h_pool, pr.pool, np, ds));
+  RC(d2h(S.h_a, pr.a, nr, ds)); RC(d2h(S.h_c, c->pk_ch.p, nr, ds)); RC(d2h(S.h_pool, c->pool.p, np, ds));
   RC(S.h_row_off.resize(nn + 1));
   if (nn) HIPCHK(hipMemcpyAsync(S.h_row_off.data(), pr.row_off, (nn + 1) * 8, hipMemcpyDeviceToHost, ds));
   else S.h_row_off.p[0] = 0;
@@ -1409,7 +1419,7 @@ extern "C" int br_project_staged(br_ctx *c, const br_config *cfg, int slot, br_h
   HIPCHK(hipEventRecord(S.rows_home, ds));
   HIPCHK(hipEventRecord(c->rows_busy, ds));
   c->rows_busy_set = true; S.rows_pending = true;
-  out->n_rows = pr.n_rows; out->n_aln = S.n; out->n_groups = db.n_groups; out->n_pool_words = pr.n_pool_words;
+  out->n_rows = pr.n_rows; out->n_aln = S.n; out->n_groups = db.n_groups; out->n_pool_words = (int64_t)np;
   out->a = (const br_row_a *)S.h_a.data(); out->cigar = S.h_c.data(); out->pool = S.h_pool.data();
   out->row_off = S.h_row_off.data(); out->mate_idx = S.h_mate.data();
   out->x = c->host_detail ? (const br_row_x *)S.h_x.data() : nullptr;
@@ -1496,11 +1506,16 @@ extern "C" int br_project_group(br_ctx *c, const br_config *cfg, const br_alignm
   *out = nullptr; *n_out = 0;
   std::vector<int32_t> ref_id(n), ref_start(n), mate_ref(n), mate_start(n), lq(n);
   std::vector<uint16_t> flags(n); std::vector<int8_t> xs(n), ts(n);
-  std::vector<uint64_t> coff(n + 1, 0), noff(n + 1, 0);
-  std::vector<uint32_t> cig; std::string names;
-  std::string name0 = n ? (alns[0].query_name ? alns[0].query_name : "") : "";
+  std::vector<uint64_t> coff(n + 1, 0), noff(n + 1, 0), soff(n + 1, 0);
+  std::vector<uint32_t> cig; std::string names, seqs;
+  const char *name0 = n ? (alns[0].query_name ? alns[0].query_name : "") : "";
+  bool any_seq = false;
   for (size_t i = 0; i < n; i++) {
     const br_alignment &a = alns[i];
+    // one call = one query name (GenomicAlignment::query_name: "shared by all alignments in the group", api.rs:74-75)
+    if (strcmp(a.query_name ? a.query_name : "", name0) != 0) return BR_ERR_INVALID_ARG;
+    if (a.ref_start < 0 || a.ref_start > 0x7fffffffll || a.mate_ref_start < 0 || a.mate_ref_start > 0x7fffffffll) return BR_ERR_INVALID_ARG;
+    if ((a.n_cigar && !a.cigar) || (a.sequence_len && !a.sequence)) return BR_ERR_INVALID_ARG;
     ref_id[i] = a.ref_id; ref_start[i] = (int32_t)a.ref_start;
     uint16_t f = 0;
     if (a.is_paired) { f |= 0x1; if (a.mate_is_unmapped) f |= 0x8; f |= a.is_first_in_pair ? 0x40 : 0x80; }
@@ -1508,14 +1523,19 @@ extern "C" int br_project_group(br_ctx *c, const br_config *cfg, const br_alignm
     flags[i] = f; xs[i] = (int8_t)a.xs_strand; ts[i] = (int8_t)a.ts_strand;
     mate_ref[i] = a.mate_ref_id; mate_start[i] = (int32_t)a.mate_ref_start;
     cig.insert(cig.end(), a.cigar, a.cigar + a.n_cigar); coff[i + 1] = cig.size();
-    names += name0; noff[i + 1] = names.size();  // one group: every alignment carries the group's name
-    lq[i] = (int32_t)(a.read_len ? a.read_len : a.sequence_len);
+    names += name0; noff[i + 1] = names.size();
+    // sequence: Option<Vec<u8>> (api.rs:91-95); the clip rescue shares the first one of the group (api.rs:308-312, src/core.cpp:353-378)
+    if (a.sequence && a.sequence_len) { seqs.append(a.sequence, a.sequence_len); any_seq = true; }
+    soff[i + 1] = seqs.size();
+    lq[i] = (int32_t)(a.read_len ? a.read_len : a.sequence_len);   // api.rs:345-349
   }
   br_batch b{};
   b.n_aln = (int64_t)n; b.ref_id = ref_id.data(); b.ref_start = ref_start.data(); b.flags = flags.data();
   b.xs = xs.data(); b.ts = ts.data(); b.cigar_off = coff.data(); b.cigar = cig.data();
   b.mate_ref_id = mate_ref.data(); b.mate_start = mate_start.data(); b.name_off = noff.data();
   b.names = names.data(); b.l_qseq = lq.data();
+  if (any_seq) { b.seq_off = soff.data(); b.seqs = seqs.data(); }
+  else if (cfg->use_fasta && (cfg->lr || cfg->lr_hq)) { seqs.assign(1, 'N'); b.seq_off = soff.data(); b.seqs = seqs.data(); }  // no sequence: nothing to rescue
   br_rows rows;
   RC(br_project_batch(c, cfg, &b, &rows));
   c->h_proj.resize((size_t)rows.n_rows);

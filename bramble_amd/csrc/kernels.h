@@ -37,8 +37,6 @@ struct ProjectArgs {
   uint4 *m_b;            // {clip_score, 0, similarity lo, similarity hi}
   uint64_t *m_cigoff;
   uint32_t *cig_arena;
-  uint32_t *pool_cnt;    // [n_aln] words of the alignment's rewritten CIGARs that do not fit a row (> 2 ops), summed with
-                         // one atomic per such match by the emit kernels (zeroed per batch)
 };
 
 struct KswProb;
@@ -88,7 +86,7 @@ struct ScanArgs {
 //   NH = rows of the group, HI = rank inside the group (also stored), MAPQ = get_mapq(NH) (src/core.cpp:46-58),
 //   mate transcript / position / insert size = the adjacent row of the pair (set_mate_info, src/bam.cpp:531-588).
 //   r_a[r] = {transcript id, 0-based transcript position, meta, NH}
-//   r_c[r] = the rewritten CIGAR itself when it has <= 2 ops, else the 64-bit word offset of its ops in `pool`
+//   r_c[r] = the rewritten CIGAR itself when it has <= 2 ops, else the 64-bit word offset of its ops in the CIGAR arena
 //   r_x[r] = {input alignment, junc_hits, aligned_len (ref_consumed), HI}
 #define RM_NCIG 0x00ffffffu      // meta bits 0..23: ops of the rewritten CIGAR
 #define RM_MINUS (1u << 24)      // transcript strand '-'
@@ -97,7 +95,7 @@ struct ScanArgs {
 #define RM_FIRST (1u << 27)      // the leader's own record (its mate's record follows)
 #define RM_PRIMARY (1u << 28)    // primary record of its read name
 struct PairArgs {
-  int64_t n_groups, n_aln;
+  int64_t n_groups, n_aln, n_rows_total;
   int32_t long_reads;
   const uint32_t *group_off;
   const uint32_t *aln_group;  // [n_aln] group of each alignment (k_group_ids)
@@ -107,21 +105,34 @@ struct PairArgs {
   const uint32_t *m_tid;
   const uint4 *m_a, *m_b;
   const uint64_t *m_cigoff;
-  const uint32_t *cig_arena;
-  const uint32_t *pool_cnt;  // [n_aln] from the emit kernels
   uint32_t *n_rows;         // count pass: records per leader alignment
-  uint32_t *n_pool;         // count pass: pool words reserved per leader alignment (its own + its mate's)
   uint64_t *pmask;          // [n_aln] count pass -> emit pass: list positions of a pair's common transcripts (lists <= 64)
   const uint64_t *row_off;  // [n_aln + 1] emit pass
-  const uint64_t *pool_off; // [n_aln + 1] emit pass
+  // per record {match, input alignment, NH, HI | RR_* bits}: written by k_pair_emit (one lane per alignment), flagged by
+  // k_primary, turned into the packed row by k_rows (one lane per record)
+  uint4 *r_rec;
   uint4 *r_a;
   uint2 *r_c;
   uint4 *r_x;
   double *r_sim;            // aux presets only (similarity filter on)
   int32_t *r_clip;
+  uint64_t *counters;       // [4] total_complete, total_unique, dropped_reads, a field overflowed its packed width
+};
+#define RR_HI 0x0fffffffu        // r_rec.w bits 0..27: HI
+#define RR_PRIMARY (1u << 28)
+#define RR_PAIRED (1u << 29)
+#define RR_SAME (1u << 30)
+#define RR_FIRST (1u << 31)
+
+// dense copy of the long (> 2 op) rewritten CIGARs for the host (the device rows point into the sparse arena)
+struct PoolArgs {
+  int64_t n_rows;
+  const uint4 *r_a; const uint2 *r_c;
+  const uint32_t *arena;
+  uint32_t *sizes;          // [n_rows] ops of a long CIGAR, else 0
+  const uint64_t *off;      // [n_rows + 1] scan of sizes
+  uint2 *c_out;             // [n_rows] r_c with the arena offsets replaced by pool offsets
   uint32_t *pool;
-  uint64_t *r_src;          // [n_rows] long-CIGAR mode: arena offset of each row's ops (k_pool_copy moves them)
-  uint64_t *counters;       // [4] total_complete, total_unique, dropped_reads, CIGAR too long for the meta word
 };
 
 // wide (one array per field) view of the packed rows: br_device_rows
@@ -270,13 +281,12 @@ void launch_scan(hipStream_t st, const ScanArgs &S, int mode, void *out, bool ou
 void launch_group_ids(hipStream_t st, int64_t n_groups, const uint32_t *group_off, uint32_t *aln_group);
 void launch_scan3(hipStream_t st, ScanArgs S, uint32_t *match_off, uint64_t *cig_base, uint32_t *fast_pre,
                   uint64_t *total_out3);
-void launch_pair(hipStream_t st, const PairArgs &P);  // count pass: records and pool words per leader alignment
-// emit pass: the packed rows.  aux: the preset has clip / similarity scores; long_cigars: rows leave their ops in the arena
-// (r_src) for launch_pool_copy instead of copying them lane-serially
-void launch_rows(hipStream_t st, const PairArgs &P, bool aux, bool long_cigars);
-void launch_pool_copy(hipStream_t st, const PairArgs &P, int64_t n_rows);
-// primary record per read name (RM_PRIMARY) + the per-group counters; names may be null (no primary flags)
+void launch_pair(hipStream_t st, const PairArgs &P, bool emit);  // count pass: records per leader alignment; emit pass: r_rec
+// primary record per read name (RR_PRIMARY) + the per-group counters; names may be null (no primary flags)
 void launch_primary(hipStream_t st, const PairArgs &P, const uint32_t *name_off, const uint8_t *names, bool has_scores);
+void launch_rows(hipStream_t st, const PairArgs &P, bool aux);  // r_rec + match table -> packed rows
+void launch_pool_sizes(hipStream_t st, const PoolArgs &Q);
+void launch_pool_copy(hipStream_t st, const PoolArgs &Q, bool long_cigars);
 void launch_wide_fields(hipStream_t st, const WideArgs &W);
 void launch_wide_cigars(hipStream_t st, const WideArgs &W, int64_t n_words);
 

@@ -937,7 +937,6 @@ __global__ void __launch_bounds__(256, EMIT ? 4 : 8) k_project(ProjectArgs A) {
             A.m_b[mi] = make_uint4((uint32_t)acc.clip_score, 0u, (uint32_t)sb64, (uint32_t)(sb64 >> 32));
           }
           A.m_cigoff[mi] = cig_ref;
-          if (n_out > 2u) atomicAdd(A.pool_cnt + a, n_out);
         }
       }
       if (EMIT && !have_mask && sweep == 0) __threadfence_block();  // m_aux[] written above is read below
@@ -1059,7 +1058,6 @@ __global__ void __launch_bounds__(256, CLS == 1 ? 8 : 6) k_emit_dense(ProjectArg
       cref = cbase + (uint64_t)rank * (1u + 2u * 6u);
       uint32_t *slot = A.cig_arena + cref;
       slot[0] = w0; slot[1] = w1; slot[2] = w2;
-      atomicAdd(A.pool_cnt + a, 3u);
     }
     uint32_t mo = moff + rank;
     A.m_tid[mo] = pay.x;
@@ -1116,7 +1114,6 @@ __global__ void __launch_bounds__(256, CLS == 1 ? 8 : 6) k_emit_dense(ProjectArg
     A.m_b[mo] = make_uint4((uint32_t)acc.clip_score, 0u, (uint32_t)sb64, (uint32_t)(sb64 >> 32));
   }
   A.m_cigoff[mo] = cig_ref;
-  if (n_out > 2u) atomicAdd(A.pool_cnt + a, n_out);
 }
 
 // ---------------------------------------------------------------------------
@@ -1343,210 +1340,147 @@ __global__ void __launch_bounds__(256) k_group_ids(int64_t n_groups, const uint3
   for (uint32_t i = group_off[g]; i < group_off[g + 1]; i++) aln_group[i] = (uint32_t)g;
 }
 
-// k_pair (count pass): one lane per alignment.  A "leader" (no mate, or its mate comes
+// k_pair<EMIT>: one lane per alignment.  A "leader" (no mate, or its mate comes
 // later in the group) emits for itself and its mate, exactly the calls
-// convert_reads makes (src/core.cpp:384-415).  Counts the records and reserves room
-// for their long (> 2 op) rewritten CIGARs; k_rows writes the rows at the scanned offsets.
+// convert_reads makes (src/core.cpp:384-415).  EMIT=false counts the records,
+// EMIT=true writes {match, input, NH, HI | flags} per record at the scanned
+// offset: NH = records of the read name (flush, src/core.cpp:250-258), HI = 1-based rank among them (:309-325).
+// k_rows turns those into the packed rows, one lane per record.
+template <bool EMIT>
 __global__ void __launch_bounds__(256) k_pair(PairArgs P) {
   int64_t i64 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i64 >= P.n_aln) return;
   uint32_t i = (uint32_t)i64;
-  uint32_t rows = 0, pool = 0;
+  uint32_t rows = 0;
+  uint64_t r0 = 0;
+  if (EMIT) { r0 = P.row_off[i]; if (P.row_off[i + 1] == r0) return; }   // not a leader, or nothing to emit
   int32_t m = P.mate_idx[i];
   uint32_t g = P.aln_group[i];
   uint32_t a0 = P.group_off[g], a1 = P.group_off[g + 1];
   uint32_t mi0 = P.match_off[i], ni = P.n_matches[i];
   bool leader = !(m >= 0 && (uint32_t)m < i && (uint32_t)m >= a0);  // else: handled as the mate of an earlier leader
+  uint32_t nh = 0, hi0 = 0;
+  uint4 *__restrict__ rec = P.r_rec;
+  if (EMIT) {
+    const uint64_t gs = P.row_off[a0];
+    const uint64_t gn = P.row_off[a1] - gs;
+    nh = (uint32_t)gn; hi0 = (uint32_t)(r0 - gs) + 1u;
+    if (gn > (uint64_t)RR_HI) P.counters[3] = 1;   // HI does not fit its 28 bits
+  }
   if (leader && ni) {                          // a leader without matches drops the pair (mates.cpp:153)
     uint32_t nm = 0, mm0 = 0;
     if (m >= 0 && (uint32_t)m > i && (uint32_t)m < a1) { mm0 = P.match_off[m]; nm = P.n_matches[m]; }
     if (nm == 0) {
-      rows = ni;                               // unpaired emission: one record per transcript (mates.cpp:157-176)
-      pool = P.pool_cnt[i];
+      // unpaired emission: one record per transcript, ascending tid (mates.cpp:157-176)
+      if (EMIT)
+        for (uint32_t k = 0; k < ni; k++) rec[r0 + k] = make_uint4(mi0 + k, i, nh, (hi0 + k) | RR_FIRST);
+      rows = ni;
     } else {
-      // both mates matched: sorted-set intersection (mates.cpp:204-231).  The merge leaves, per mate, the bit set of
-      // its list positions that are common (both lists ascend, so the k-th common position of one pairs with the k-th
-      // of the other); the emit pass only walks those bits -- no second merge over m_tid[].
+      // both mates matched: sorted-set intersection (mates.cpp:204-231).  The count pass does the merge and leaves, per
+      // mate, the bit set of its list positions that are common (both lists ascend, so the k-th common position of one
+      // pairs with the k-th of the other); the emit pass only walks those bits -- no second merge over m_tid[].
       uint32_t x = 0, y = 0, common = 0;
       const bool masked = ni <= 64u && nm <= 64u;
+      if (EMIT && masked) {
+        uint64_t ma = P.pmask[i], mb = P.pmask[m];
+        while (ma) {
+          uint32_t xx = (uint32_t)__builtin_ctzll(ma), yy = (uint32_t)__builtin_ctzll(mb);
+          ma &= ma - 1; mb &= mb - 1;
+          uint64_t r = r0 + 2ull * common;
+          rec[r] = make_uint4(mi0 + xx, i, nh, (hi0 + 2u * common) | RR_FIRST | RR_PAIRED | RR_SAME);
+          rec[r + 1] = make_uint4(mm0 + yy, (uint32_t)m, nh, (hi0 + 2u * common + 1u) | RR_PAIRED | RR_SAME);
+          common++;
+        }
+        x = ni;  // skip the merge
+      }
       uint64_t bits_a = 0, bits_b = 0;
       while (x < ni && y < nm) {
         uint32_t tx = P.m_tid[mi0 + x], ty = P.m_tid[mm0 + y];
         if (tx < ty) x++;
         else if (ty < tx) y++;
         else {
-          if (masked) { bits_a |= 1ull << x; bits_b |= 1ull << y; }
+          if (EMIT) {
+            uint64_t r = r0 + 2ull * common;
+            rec[r] = make_uint4(mi0 + x, i, nh, (hi0 + 2u * common) | RR_FIRST | RR_PAIRED | RR_SAME);
+            rec[r + 1] = make_uint4(mm0 + y, (uint32_t)m, nh, (hi0 + 2u * common + 1u) | RR_PAIRED | RR_SAME);
+          } else if (masked) { bits_a |= 1ull << x; bits_b |= 1ull << y; }
           common++; x++; y++;
         }
       }
-      if (masked) { P.pmask[i] = bits_a; P.pmask[m] = bits_b; }
+      if (!EMIT && masked) { P.pmask[i] = bits_a; P.pmask[m] = bits_b; }
       if (common) rows = 2 * common;
-      else if (ni == 1 && nm == 1) rows = 2;   // one transcript each, different ones
-      if (rows) pool = P.pool_cnt[i] + P.pool_cnt[m];   // a superset of the emitted records' ops: holes are allowed
-    }
-  }
-  P.n_rows[i] = rows; P.n_pool[i] = pool;
-}
-
-// one packed row from match x (see PairArgs).  CIGARs of more than two ops move from their arena slot to the dense
-// pool: lane-serially here (short reads: a few per cent of the rows, 3-6 words), or later by k_pool_copy (LONGC).
-template <bool AUX, bool LONGC>
-__device__ __forceinline__ void put_row(const PairArgs &P, uint64_t r, uint32_t x, uint32_t input, uint32_t fl,
-                                        uint32_t nh, uint32_t hi, uint64_t &pool_at, bool &too_long) {
-  const uint32_t tid = P.m_tid[x];
-  const uint4 ma = P.m_a[x];
-  const uint64_t cg = P.m_cigoff[x];
-  const uint32_t n = ma.y & 0x7fffffffu;
-  too_long |= n > RM_NCIG;
-  P.r_a[r] = make_uint4(tid, ma.x, (n & RM_NCIG) | ((ma.y >> 31) ? RM_MINUS : 0u) | fl, nh);
-  uint64_t c = cg;
-  if (n > 2u) {
-    c = pool_at;
-    if (LONGC) P.r_src[r] = cg;
-    else { const uint32_t *src = P.cig_arena + cg; uint32_t *dst = P.pool + pool_at; for (uint32_t k = 0; k < n; k++) dst[k] = src[k]; }
-    pool_at += n;
-  }
-  P.r_c[r] = make_uint2((uint32_t)c, (uint32_t)(c >> 32));
-  P.r_x[r] = make_uint4(input, ma.z, ma.w, hi);
-  if (AUX) {
-    const uint4 mb = P.m_b[x];
-    P.r_clip[r] = (int32_t)mb.x;
-    P.r_sim[r] = __longlong_as_double((long long)(((unsigned long long)mb.w << 32) | mb.z));
-  }
-}
-
-// k_rows (emit pass): one lane per alignment; a leader writes its records and its mate's.  NH = records of the
-// read name (flush, src/core.cpp:250-258), HI = 1-based rank among them (:309-325).
-template <bool AUX, bool LONGC>
-__global__ void __launch_bounds__(256) k_rows(PairArgs P) {
-  int64_t i64 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i64 >= P.n_aln) return;
-  const uint32_t i = (uint32_t)i64;
-  const uint64_t r0 = P.row_off[i];
-  if (P.row_off[i + 1] == r0) return;          // not a leader, or nothing to emit
-  const int32_t m = P.mate_idx[i];
-  const uint32_t g = P.aln_group[i];
-  const uint32_t a0 = P.group_off[g], a1 = P.group_off[g + 1];
-  const uint64_t gs = P.row_off[a0];
-  const uint32_t nh = (uint32_t)(P.row_off[a1] - gs);
-  const uint32_t hi0 = (uint32_t)(r0 - gs) + 1u;
-  const uint32_t mi0 = P.match_off[i], ni = P.n_matches[i];
-  uint64_t pool_at = P.pool_off[i];
-  bool too_long = false;
-  uint32_t nm = 0, mm0 = 0;
-  if (m >= 0 && (uint32_t)m > i && (uint32_t)m < a1) { mm0 = P.match_off[m]; nm = P.n_matches[m]; }
-  if (nm == 0) {
-    for (uint32_t k = 0; k < ni; k++) put_row<AUX, LONGC>(P, r0 + k, mi0 + k, i, RM_FIRST, nh, hi0 + k, pool_at, too_long);
-  } else {
-    uint32_t common = 0;
-    const uint32_t fl = RM_PAIRED | RM_SAME;
-    if (ni <= 64u && nm <= 64u) {
-      uint64_t ma = P.pmask[i], mb = P.pmask[m];
-      while (ma) {
-        uint32_t xx = (uint32_t)__builtin_ctzll(ma), yy = (uint32_t)__builtin_ctzll(mb);
-        ma &= ma - 1; mb &= mb - 1;
-        put_row<AUX, LONGC>(P, r0 + 2ull * common, mi0 + xx, i, fl | RM_FIRST, nh, hi0 + 2u * common, pool_at, too_long);
-        put_row<AUX, LONGC>(P, r0 + 2ull * common + 1, mm0 + yy, (uint32_t)m, fl, nh, hi0 + 2u * common + 1u, pool_at, too_long);
-        common++;
-      }
-    } else {
-      uint32_t x = 0, y = 0;
-      while (x < ni && y < nm) {
-        uint32_t tx = P.m_tid[mi0 + x], ty = P.m_tid[mm0 + y];
-        if (tx < ty) x++;
-        else if (ty < tx) y++;
-        else {
-          put_row<AUX, LONGC>(P, r0 + 2ull * common, mi0 + x, i, fl | RM_FIRST, nh, hi0 + 2u * common, pool_at, too_long);
-          put_row<AUX, LONGC>(P, r0 + 2ull * common + 1, mm0 + y, (uint32_t)m, fl, nh, hi0 + 2u * common + 1u, pool_at, too_long);
-          common++; x++; y++;
+      else if (ni == 1 && nm == 1) {  // one transcript each, different ones
+        if (EMIT) {
+          rec[r0] = make_uint4(mi0, i, nh, hi0 | RR_FIRST | RR_PAIRED);
+          rec[r0 + 1] = make_uint4(mm0, (uint32_t)m, nh, (hi0 + 1u) | RR_PAIRED);
         }
+        rows = 2;
       }
     }
-    if (!common) {   // one transcript each, different ones (the count pass reserved two records only in that case)
-      put_row<AUX, LONGC>(P, r0, mi0, i, RM_PAIRED | RM_FIRST, nh, hi0, pool_at, too_long);
-      put_row<AUX, LONGC>(P, r0 + 1, mm0, (uint32_t)m, RM_PAIRED, nh, hi0 + 1u, pool_at, too_long);
-    }
   }
-  if (too_long) P.counters[3] = 1;
+  if (!EMIT) P.n_rows[i] = rows;
 }
 
-// k_pool_copy (long-CIGAR mode: hundreds of ops per record): 16 lanes move one record's ops from its arena slot
-__global__ void __launch_bounds__(256) k_pool_copy(PairArgs P, int64_t n_rows) {
-  const int lane = threadIdx.x & 15;
-  int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-  if (r >= n_rows) return;
-  const uint32_t n = ((const uint32_t *)(P.r_a + r))[2] & RM_NCIG;
-  if (n <= 2u) return;
-  const uint2 c = P.r_c[r];
-  const uint32_t *src = P.cig_arena + P.r_src[r];
-  uint32_t *dst = P.pool + (((uint64_t)c.y << 32) | c.x);
-  for (uint32_t k = lane; k < n; k += 16) dst[k] = src[k];
-}
-
-// k_primary: one lane per read name.  Primary = the emitted record (pair) with the
+// k_primary: one lane per read name (grid-stride).  Primary = the emitted record (pair) with the
 // best similarity score; ties are broken by get_rand(n_tied, std::hash(name))
 // (src/core.cpp:243-307), restated in primary_pick.h.  A leader's records are all paired or all
 // single, so its units follow from its record count and one flag word.
 // SCORES = false: presets without the similarity filter leave every score at 0.0 (src/evaluate.cpp:843-865), so
-// every emitted unit ties and r_sim need not be read at all.
+// every emitted unit ties and the scores need not be read at all.
 // Also the counters of src/bramble.cpp:729-736 (one atomic per wave at the end).
 template <bool SCORES>
 __global__ void __launch_bounds__(256) k_primary(PairArgs P, const uint32_t *__restrict__ name_off,
                                                  const uint8_t *__restrict__ names) {
-  int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long uniq = 0, dropped = 0;
-  if (g < P.n_groups) {
+  uint32_t *flagw = (uint32_t *)P.r_rec + 3;   // flag word of record r: flagw[4 * r]
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < P.n_groups; g += (int64_t)gridDim.x * blockDim.x) {
     const uint32_t a0 = P.group_off[g], a1 = P.group_off[g + 1];
     const uint64_t rs = P.row_off[a0], re = P.row_off[a1];
-    uniq = (re - rs) == 1 ? 1 : 0;
+    uniq += (re - rs) == 1 ? 1 : 0;
     uint32_t any = 0;
     for (uint32_t i = a0; i < a1; i++) any |= P.n_matches[i];
-    dropped = any ? 0 : 1;
-    if (names && re > rs) {
-      uint32_t *meta = (uint32_t *)P.r_a + 2;   // meta word of row r: meta[4 * r]
-      uint64_t pick = rs;
-      if (!SCORES) {
+    dropped += any ? 0 : 1;
+    if (!names || re == rs) continue;
+    uint64_t pick = rs;
+    if (!SCORES) {
+      if (re - rs > 1) {
         uint32_t units = 0;
-        for (uint32_t i = a0; i < a1; i++) {
-          const uint64_t b = P.row_off[i]; const uint32_t n = (uint32_t)(P.row_off[i + 1] - b);
-          if (n) units += (meta[4 * b] & RM_PAIRED) ? n / 2 : n;
-        }
+        for (uint64_t r = rs; r < re;) { const bool paired = flagw[4 * r] & RR_PAIRED; units++; r += paired ? 2 : 1; }
         if (units > 1) {
           uint32_t idx = primary_pick(names + name_off[a0], name_off[a0 + 1] - name_off[a0], units);
-          for (uint32_t i = a0; i < a1; i++) {
-            const uint64_t b = P.row_off[i]; const uint32_t n = (uint32_t)(P.row_off[i + 1] - b);
-            if (!n) continue;
-            const bool paired = meta[4 * b] & RM_PAIRED;
-            const uint32_t u = paired ? n / 2 : n;
-            if (idx < u) { pick = b + (paired ? 2ull * idx : idx); break; }
-            idx -= u;
-          }
-        }
-      } else {
-        double best = -__builtin_inf(); uint32_t at_best = 0;
-        for (uint64_t r = rs; r < re;) {
-          const bool paired = meta[4 * r] & RM_PAIRED;
-          double sc = P.r_sim[r];
-          if (paired) { double s2 = P.r_sim[r + 1]; sc = sc > s2 ? sc : s2; }   // std::max(pair_score, m_align score)
-          if (sc > best) { best = sc; pick = r; at_best = 1; } else if (sc == best) at_best++;
-          r += paired ? 2 : 1;
-        }
-        if (at_best > 1) {
-          uint32_t idx = primary_pick(names + name_off[a0], name_off[a0 + 1] - name_off[a0], at_best);
-          uint32_t seen = 0;
-          for (uint64_t r = rs; r < re;) {
-            const bool paired = meta[4 * r] & RM_PAIRED;
-            double sc = P.r_sim[r];
-            if (paired) { double s2 = P.r_sim[r + 1]; sc = sc > s2 ? sc : s2; }
-            if (sc == best) { if (seen == idx) { pick = r; break; } seen++; }
-            r += paired ? 2 : 1;
-          }
+          uint64_t r = rs;
+          for (; idx; idx--) r += (flagw[4 * r] & RR_PAIRED) ? 2 : 1;
+          pick = r;
         }
       }
-      const uint32_t mw = meta[4 * pick];
-      meta[4 * pick] = mw | RM_PRIMARY;
-      if (mw & RM_PAIRED) meta[4 * (pick + 1)] |= RM_PRIMARY;
+    } else {
+      auto score_of = [&](uint64_t r) -> double {  // similarity of the record's match
+        const uint4 mb = P.m_b[P.r_rec[r].x];
+        return __longlong_as_double((long long)(((unsigned long long)mb.w << 32) | mb.z));
+      };
+      double best = -__builtin_inf(); uint32_t at_best = 0;
+      for (uint64_t r = rs; r < re;) {
+        const bool paired = flagw[4 * r] & RR_PAIRED;
+        double sc = score_of(r);
+        if (paired) { double s2 = score_of(r + 1); sc = sc > s2 ? sc : s2; }   // std::max(pair_score, m_align score)
+        if (sc > best) { best = sc; pick = r; at_best = 1; } else if (sc == best) at_best++;
+        r += paired ? 2 : 1;
+      }
+      if (at_best > 1) {
+        uint32_t idx = primary_pick(names + name_off[a0], name_off[a0 + 1] - name_off[a0], at_best);
+        uint32_t seen = 0;
+        for (uint64_t r = rs; r < re;) {
+          const bool paired = flagw[4 * r] & RR_PAIRED;
+          double sc = score_of(r);
+          if (paired) { double s2 = score_of(r + 1); sc = sc > s2 ? sc : s2; }
+          if (sc == best) { if (seen == idx) { pick = r; break; } seen++; }
+          r += paired ? 2 : 1;
+        }
+      }
     }
+    const uint32_t fw = flagw[4 * pick];
+    flagw[4 * pick] = fw | RR_PRIMARY;
+    if (fw & RR_PAIRED) flagw[4 * (pick + 1)] |= RR_PRIMARY;
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) { uniq += __shfl_down(uniq, d, 64); dropped += __shfl_down(dropped, d, 64); }
@@ -1554,6 +1488,53 @@ __global__ void __launch_bounds__(256) k_primary(PairArgs P, const uint32_t *__r
     if (uniq) atomicAdd((unsigned long long *)&P.counters[1], uniq);
     if (dropped) atomicAdd((unsigned long long *)&P.counters[2], dropped);
   }
+}
+
+// k_rows: one lane per emitted record: r_rec + its match's record -> the packed row (see PairArgs).  Rewritten
+// CIGARs of more than two ops stay in their arena slot; the row carries the slot's offset.
+template <bool AUX>
+__global__ void __launch_bounds__(256) k_rows(PairArgs P) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= P.n_rows_total) return;
+  const uint4 rec = P.r_rec[r];
+  const uint32_t x = rec.x;
+  const uint32_t tid = P.m_tid[x];
+  const uint4 ma = P.m_a[x];
+  const uint64_t cg = P.m_cigoff[x];
+  const uint32_t n = ma.y & 0x7fffffffu;
+  if (n > RM_NCIG) P.counters[3] = 1;
+  const uint32_t f = rec.w;
+  const uint32_t meta = (n & RM_NCIG) | ((ma.y >> 31) ? RM_MINUS : 0u) | ((f & RR_PAIRED) ? RM_PAIRED : 0u) |
+                        ((f & RR_SAME) ? RM_SAME : 0u) | ((f & RR_FIRST) ? RM_FIRST : 0u) | ((f & RR_PRIMARY) ? RM_PRIMARY : 0u);
+  P.r_a[r] = make_uint4(tid, ma.x, meta, rec.z);
+  P.r_c[r] = make_uint2((uint32_t)cg, (uint32_t)(cg >> 32));
+  P.r_x[r] = make_uint4(rec.y, ma.z, ma.w, f & RR_HI);
+  if (AUX) {
+    const uint4 mb = P.m_b[x];
+    P.r_clip[r] = (int32_t)mb.x;
+    P.r_sim[r] = __longlong_as_double((long long)(((unsigned long long)mb.w << 32) | mb.z));
+  }
+}
+
+// dense pool of the long rewritten CIGARs (host downloads only): sizes -> scan -> copy
+__global__ void __launch_bounds__(256) k_pool_sizes(PoolArgs Q) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= Q.n_rows) return;
+  const uint32_t n = ((const uint32_t *)(Q.r_a + r))[2] & RM_NCIG;
+  Q.sizes[r] = n > 2u ? n : 0u;
+}
+template <int G>
+__global__ void __launch_bounds__(256) k_pool_copy(PoolArgs Q) {
+  const int lane = threadIdx.x & (G - 1);
+  int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+  if (r >= Q.n_rows) return;
+  const uint32_t n = ((const uint32_t *)(Q.r_a + r))[2] & RM_NCIG;
+  const uint2 c = Q.r_c[r];
+  if (n <= 2u) { if (lane == 0) Q.c_out[r] = c; return; }
+  const uint64_t d0 = Q.off[r];
+  if (lane == 0) Q.c_out[r] = make_uint2((uint32_t)d0, (uint32_t)(d0 >> 32));
+  const uint32_t *src = Q.arena + (((uint64_t)c.y << 32) | c.x);
+  for (uint32_t k = lane; k < n; k += G) Q.pool[d0 + k] = src[k];
 }
 
 // ---------------------------------------------------------------------------
@@ -1804,26 +1785,34 @@ void launch_group_ids(hipStream_t st, int64_t n_groups, const uint32_t *group_of
   hipLaunchKernelGGL(k_group_ids, dim3(grid_for(n_groups, 256)), dim3(256), 0, st, n_groups, group_off, aln_group);
 }
 
-void launch_pair(hipStream_t st, const PairArgs &P) {
+void launch_pair(hipStream_t st, const PairArgs &P, bool emit) {
   if (P.n_aln <= 0) return;
-  hipLaunchKernelGGL(k_pair, dim3(grid_for(P.n_aln, 256)), dim3(256), 0, st, P);
-}
-
-void launch_rows(hipStream_t st, const PairArgs &P, bool aux, bool long_cigars) {
-  if (P.n_aln <= 0) return;
-  dim3 g(grid_for(P.n_aln, 256)), b(256);
-  if (aux) { if (long_cigars) hipLaunchKernelGGL((k_rows<true, true>), g, b, 0, st, P); else hipLaunchKernelGGL((k_rows<true, false>), g, b, 0, st, P); }
-  else { if (long_cigars) hipLaunchKernelGGL((k_rows<false, true>), g, b, 0, st, P); else hipLaunchKernelGGL((k_rows<false, false>), g, b, 0, st, P); }
-}
-
-void launch_pool_copy(hipStream_t st, const PairArgs &P, int64_t n_rows) {
-  if (n_rows > 0) hipLaunchKernelGGL(k_pool_copy, dim3(grid_for(n_rows * 16, 256)), dim3(256), 0, st, P, n_rows);
+  if (emit) hipLaunchKernelGGL((k_pair<true>), dim3(grid_for(P.n_aln, 256)), dim3(256), 0, st, P);
+  else hipLaunchKernelGGL((k_pair<false>), dim3(grid_for(P.n_aln, 256)), dim3(256), 0, st, P);
 }
 
 void launch_primary(hipStream_t st, const PairArgs &P, const uint32_t *name_off, const uint8_t *names, bool has_scores) {
   if (P.n_groups <= 0) return;
-  if (has_scores) hipLaunchKernelGGL((k_primary<true>), dim3(grid_for(P.n_groups, 256)), dim3(256), 0, st, P, name_off, names);
-  else hipLaunchKernelGGL((k_primary<false>), dim3(grid_for(P.n_groups, 256)), dim3(256), 0, st, P, name_off, names);
+  dim3 g(std::min(grid_for(P.n_groups, 256), 4096)), b(256);
+  if (has_scores) hipLaunchKernelGGL((k_primary<true>), g, b, 0, st, P, name_off, names);
+  else hipLaunchKernelGGL((k_primary<false>), g, b, 0, st, P, name_off, names);
+}
+
+void launch_rows(hipStream_t st, const PairArgs &P, bool aux) {
+  if (P.n_rows_total <= 0) return;
+  dim3 g(grid_for(P.n_rows_total, 256)), b(256);
+  if (aux) hipLaunchKernelGGL((k_rows<true>), g, b, 0, st, P);
+  else hipLaunchKernelGGL((k_rows<false>), g, b, 0, st, P);
+}
+
+void launch_pool_sizes(hipStream_t st, const PoolArgs &Q) {
+  if (Q.n_rows > 0) hipLaunchKernelGGL(k_pool_sizes, dim3(grid_for(Q.n_rows, 256)), dim3(256), 0, st, Q);
+}
+
+void launch_pool_copy(hipStream_t st, const PoolArgs &Q, bool long_cigars) {
+  if (Q.n_rows <= 0) return;
+  if (long_cigars) hipLaunchKernelGGL((k_pool_copy<16>), dim3(grid_for(Q.n_rows * 16, 256)), dim3(256), 0, st, Q);
+  else hipLaunchKernelGGL((k_pool_copy<1>), dim3(grid_for(Q.n_rows, 256)), dim3(256), 0, st, Q);
 }
 
 void launch_wide_fields(hipStream_t st, const WideArgs &W) {

@@ -13,10 +13,10 @@ LIB_PATH = os.path.join(_HERE, "libbramble_amd.so")
 _P = C.POINTER
 
 K_SEGMENT, K_COUNT, K_EMIT, K_PAIR_COUNT, K_PAIR_EMIT, K_GATHER, K_SCAN, K_EMIT_AUX, K_KSW, K_BAM, K_PARSE, K_CODEC, K_EMIT_SIMPLE, K_PRIMARY, K_CIGAR_POOL, K_COUNT_WALK, K_EXPAND, K_GROUP_IDS, K_NUM = range(19)
-KERNEL_NAMES = ["k_segment", "k_project<G,false,false,1>", "k_emit_dense<false,2>", "k_pair", "k_rows",
-                "(unused)", "k_scan_*", "k_project<64,true>", "k_ksw", "k_bam_scan+k_bam_size+k_bam_encode",
+KERNEL_NAMES = ["k_segment", "k_project<G,false,false,1>", "k_emit_dense<false,2>", "k_pair<false>", "k_pair<true>",
+                "k_rows", "k_scan_*", "k_project<64,true>", "k_ksw", "k_bam_scan+k_bam_size+k_bam_encode",
                 "k_rec_fields+k_group_off+k_rec_copy+k_mates+k_seq_*", "k_deflate_*+k_bgzf_compact",
-                "k_emit_dense<false,1>", "k_primary", "k_pool_copy", "k_project<G,false,false,2>", "k_expand", "k_group_ids"]
+                "k_emit_dense<false,1>", "k_primary", "(unused)", "k_project<G,false,false,2>", "k_expand", "k_group_ids"]
 
 
 class BrambleError(RuntimeError):
@@ -94,6 +94,23 @@ class BrDeviceWideRows(C.Structure):
     _fields_ = [("n_rows", C.c_int64), ("n_cigar_words", C.c_int64)] + \
                [(n, C.c_void_p) for n, _ in _ROW_FIELDS] + [(n, C.c_void_p) for n, _ in _ROW_TAIL] + \
                [("is_primary", C.c_void_p)]
+
+
+class BrAlignment(C.Structure):  # br_alignment = GenomicAlignment (bramble-rs/src/api.rs:73-126)
+    _fields_ = [("query_name", C.c_char_p), ("ref_id", C.c_int32), ("ref_start", C.c_int64),
+                ("is_reverse", C.c_uint8), ("is_paired", C.c_uint8), ("is_first_in_pair", C.c_uint8),
+                ("mate_is_unmapped", C.c_uint8), ("xs_strand", C.c_char), ("ts_strand", C.c_char),
+                ("hit_index", C.c_int32), ("mate_ref_id", C.c_int32), ("mate_ref_start", C.c_int64),
+                ("cigar", C.c_void_p), ("n_cigar", C.c_uint32), ("sequence", C.c_char_p), ("sequence_len", C.c_uint32),
+                ("read_len", C.c_uint32)]
+
+
+class BrProjected(C.Structure):  # br_projected = ProjectedAlignment (api.rs:135-176) + mapq + rewritten CIGAR
+    _fields_ = [("transcript_id", C.c_uint32), ("transcript_start", C.c_uint32), ("transcript_end", C.c_uint32),
+                ("aligned_len", C.c_uint32), ("query_aligned_len", C.c_uint32), ("is_reverse", C.c_uint8),
+                ("similarity_score", C.c_double), ("nh", C.c_uint32), ("hi", C.c_uint32), ("is_primary", C.c_uint8),
+                ("same_transcript_as_mate", C.c_uint8), ("is_paired_out", C.c_uint8), ("insert_size", C.c_int32),
+                ("input_index", C.c_uint64), ("mapq", C.c_uint32), ("cigar", _P(C.c_uint32)), ("n_cigar", C.c_uint32)]
 
 
 class BrHostRows(C.Structure):
@@ -189,6 +206,8 @@ def lib():
         L.br_project_batch.argtypes = [C.c_void_p, _P(BrConfig), _P(BrBatch), _P(BrRows)]
         L.br_project_batch_device.argtypes = [C.c_void_p, _P(BrConfig), _P(BrDeviceBatch), C.c_void_p,
                                               _P(BrDeviceRows)]
+        L.br_project_group.argtypes = [C.c_void_p, _P(BrConfig), _P(BrAlignment), C.c_size_t, _P(_P(BrProjected)),
+                                       _P(C.c_size_t)]
         L.br_batch_stage.argtypes = [C.c_void_p, _P(BrBatch), C.c_int]
         L.br_project_staged.argtypes = [C.c_void_p, _P(BrConfig), C.c_int, _P(BrHostRows)]
         L.br_host_rows_wait.argtypes = [C.c_void_p, C.c_int]
@@ -595,6 +614,49 @@ class Context:
         r = BrHostRows()
         check(lib().br_project_batch_packed(self.h, C.byref(cfg), C.byref(b), C.byref(r)), "br_project_batch_packed")
         return host_rows_to_numpy(r)
+
+    def project_group(self, cfg, alns):
+        """project_group_with (bramble-rs/src/api.rs:285-290): alns = list of dicts with the GenomicAlignment fields
+        (query_name, ref_id, ref_start, cigar [uint32 BAM-packed] and optional is_reverse, is_paired, is_first_in_pair,
+        mate_is_unmapped, xs_strand, ts_strand, hit_index, mate_ref_id, mate_ref_start, sequence, read_len) -> list of
+        dicts with the br_projected fields.  Raises BrambleError(BR_ERR_INVALID_ARG) when the query names differ."""
+        n = len(alns)
+        arr = (BrAlignment * max(n, 1))()
+        keep = []
+        for i, a in enumerate(alns):
+            cg = np.ascontiguousarray(a["cigar"], dtype=np.uint32)
+            keep.append(cg)
+            x = arr[i]
+            x.query_name = a["query_name"].encode()
+            x.ref_id = int(a["ref_id"])
+            x.ref_start = int(a["ref_start"])
+            x.is_reverse = int(bool(a.get("is_reverse")))
+            x.is_paired = int(bool(a.get("is_paired")))
+            x.is_first_in_pair = int(bool(a.get("is_first_in_pair")))
+            x.mate_is_unmapped = int(bool(a.get("mate_is_unmapped")))
+            x.xs_strand = (a.get("xs_strand") or "\0").encode()
+            x.ts_strand = (a.get("ts_strand") or "\0").encode()
+            x.hit_index = int(a.get("hit_index", 0))
+            x.mate_ref_id = int(a.get("mate_ref_id", -1))
+            x.mate_ref_start = int(a.get("mate_ref_start", 0))
+            x.cigar = cg.ctypes.data if len(cg) else None
+            x.n_cigar = len(cg)
+            sq = a.get("sequence")
+            if sq:
+                sb = sq.encode() if isinstance(sq, str) else bytes(sq)
+                keep.append(sb)
+                x.sequence = sb
+                x.sequence_len = len(sb)
+            x.read_len = int(a.get("read_len", 0))
+        out, n_out = _P(BrProjected)(), C.c_size_t()
+        check(lib().br_project_group(self.h, C.byref(cfg), arr, n, C.byref(out), C.byref(n_out)), "br_project_group")
+        res = []
+        for k in range(n_out.value):
+            p = out[k]
+            d = {f: getattr(p, f) for f, _ in BrProjected._fields_ if f != "cigar"}
+            d["cigar"] = np.array([p.cigar[j] for j in range(p.n_cigar)], dtype=np.uint32)
+            res.append(d)
+        return res
 
     def expand_rows(self, stream=0):
         """Wide (one array per field) view of the last projection call's rows: BrDeviceWideRows."""

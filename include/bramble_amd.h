@@ -243,7 +243,8 @@ uint32_t br_row_mapq(uint32_t nh, int long_reads); /* get_mapq, src/core.cpp:46-
 
 /* Packed rows as device pointers; valid until the next projection call on the context.
  * cigar[r]: the rewritten CIGAR (update_cigar, src/bam.cpp:502-528) itself when it has <= 2 ops (op 0 in the low
- * word, op 1 in the high word), else the offset of its ops in pool[].  row_off[i] .. row_off[i + 1] are the rows
+ * word, op 1 in the high word), else the offset of its ops in pool[] (on the device: the sparse CIGAR arena the emit
+ * pass wrote; the host entry points compact it).  row_off[i] .. row_off[i + 1] are the rows
  * emitted by alignment i as the leader (for itself and, alternating, its mate). */
 typedef struct br_device_rows {
   int64_t n_rows, n_matches, n_pool_words;
@@ -476,8 +477,8 @@ const char *br_bgzf_codec(void); /* "libdeflate" (bound at run time when present
 #define BR_K_COUNT 1      /* k_project<G,false> (count pass; with "count_split" the main kernel, without the exon walk) */
 #define BR_K_EMIT 2       /* k_emit_dense (general class; the whole list for long-read presets) */
 #define BR_K_PAIR_COUNT 3 /* k_pair */
-#define BR_K_PAIR_EMIT 4  /* k_rows (the packed row table) */
-#define BR_K_GATHER 5     /* unused since ABI version 2 (k_row_fill + k_group_stats folded into k_rows / k_primary) */
+#define BR_K_PAIR_EMIT 4  /* k_pair<true> (per-record {match, input, NH, HI | flags}) */
+#define BR_K_ROWS 5       /* k_rows (the packed row table) */
 #define BR_K_SCAN 6       /* k_scan_* */
 #define BR_K_EMIT_AUX 7   /* k_project<64,true> (alignments with > 64 candidate rows) */
 #define BR_K_KSW 8        /* k_ksw (-S clip rescue DP) */
@@ -486,7 +487,7 @@ const char *br_bgzf_codec(void); /* "libdeflate" (bound at run time when present
 #define BR_K_CODEC 11     /* k_deflate_dynamic | k_deflate_fixed, k_bgzf_compact */
 #define BR_K_EMIT_SIMPLE 12 /* k_emit_dense, simple class (one read exon from a single M op) */
 #define BR_K_PRIMARY 13   /* k_primary (+ the per-read-name counters) */
-#define BR_K_CIGAR_POOL 14 /* k_pool_copy (long-read CIGARs only) */
+#define BR_K_CIGAR_POOL 14 /* unused since ABI version 2 */
 #define BR_K_COUNT_WALK 15 /* k_project<G,false,false,2>: the deferred alignments of the split count pass, with the exon walk */
 #define BR_K_EXPAND 16    /* k_expand (emit work list) */
 #define BR_K_GROUP_IDS 17 /* k_group_ids */

@@ -97,7 +97,7 @@ def test_device_input_contract_equals_host_prepare():
     p = ctx.project_batch_packed(lib.make_config(), b)
     assert p["n_groups"] == len(goff) - 1
     assert np.array_equal(p["mate_idx"], mate)
-    assert (mate[n0:] >= 0).sum() > 200
+    assert (mate[n0:] >= 0).sum() > 150
     ctx.close()
     idx.close()
 
