@@ -96,6 +96,13 @@ static int build_index_flat(size_t n_tx, const int32_t *tx_ref, const int8_t *tx
     }
     uint32_t tlen = 0;
     for (auto &e : ex) tlen += e.end - e.start;
+    if (tlen == 0) {
+      // the reference writes no @SQ line for a transcript of length 0 (src/bramble.cpp:588-596) while tids keep counting
+      // every guide: its header and its records would disagree.  GTF coordinates are inclusive, so a loader never makes
+      // one; refuse it here instead of numbering around it.
+      fprintf(stderr, "[bramble_amd] transcript '%s' has no exonic bases\n", ix->names[t].c_str());
+      delete ix; return BR_ERR_ANNOTATION;
+    }
     ix->lengths.push_back(tlen);
     ix->tx_first.push_back((uint32_t)ix->tx_ex.size());
     char strand = (char)tx_strand[t];
@@ -1031,6 +1038,7 @@ extern "C" int br_project_bam_device(br_ctx *c, const br_config *cfg, const br_d
   BamArgs B{};
   B.n_aln = n; B.long_reads = dc.long_reads ? 1 : 0; B.blob = recs->blob; B.rec_off = recs->rec_off; B.rec_len = recs->rec_len;
   B.aux = (BamAux *)c->bam_aux.p; B.xs_out = c->b_xs.as<int8_t>(); B.ts_out = c->b_ts.as<int8_t>();
+  B.cg_flag = c->p_small.as<uint32_t>() + 3;
 
   RC(pf.begin(BR_K_PARSE));
   launch_rec_fields(st, P);
@@ -1046,8 +1054,9 @@ extern "C" int br_project_bam_device(br_ctx *c, const br_config *cfg, const br_d
   S.src32 = P.isnew;    launch_scan(st, S, 2, c->p_group_pre.p, false, d_tot + 2);
   RC(pf.end());
   HIPCHK(hipMemcpyAsync(c->h_totals + 16, d_tot, 3 * 8, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipMemcpyAsync(c->h_totals + 20, c->p_small.p, 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(c->h_totals + 20, c->p_small.p, 16, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
+  if (c->h_totals[21] >> 32) { pf.collect(); return BR_ERR_UNSUPPORTED; }  // a CIGAR spilled into a CG:B,I tag (> 65535 ops)
   uint64_t n_words = c->h_totals[16], name_bytes = c->h_totals[17], ng = c->h_totals[18];
   uint32_t max_nc = (uint32_t)(c->h_totals[20] & 0xffffffffu), max_clip = (uint32_t)(c->h_totals[20] >> 32);
   if (n_words >= 0xffffffffull - (uint64_t)n || name_bytes >= 0xfffffff0ull) { pf.collect(); return BR_ERR_CAPACITY; }

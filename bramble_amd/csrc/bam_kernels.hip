@@ -68,10 +68,12 @@ __global__ void __launch_bounds__(256) k_bam_scan(BamArgs B) {
       const uint8_t *s = rec + start, *end = rec + rlen;
       // slots: 0 NH, 1 XS (short) / ts (long), 2 HI, 3 AS (long reads only)
       bool have[4] = {false, false, false, false};
+      bool have_cg = false;
       while (end - s >= 3) {
         uint8_t t0 = s[0], t1 = s[1], ty = s[2];
         int64_t vl = aux_value_len(ty, s + 3, end);
         if (vl < 0 || s + 3 + vl > end) break;  // malformed: htslib stops here too
+        if (t0 == 'C' && t1 == 'G' && ty == 'B' && s[3] == 'I') have_cg = true;
         // tag_char1 (gclib/GSam.cpp:310-318): first value byte of the first XS / ts tag when A or Z
         if (t0 == 'X' && t1 == 'S' && !have_xs) { have_xs = true; if (ty == 'A' || ty == 'Z') xs_c = (int8_t)s[3]; }
         if (t0 == 't' && t1 == 's' && !have_ts) { have_ts = true; if (ty == 'A' || ty == 'Z') ts_c = (int8_t)s[3]; }
@@ -98,6 +100,13 @@ __global__ void __launch_bounds__(256) k_bam_scan(BamArgs B) {
           }
         }
         s += 3 + vl;
+      }
+      // A CIGAR of more than 65535 ops lives in a CG:B,I tag behind the placeholder <l_seq>S<ref_len>N (SAM spec 4.2.2);
+      // htslib's bam_read1 restores it for the reference, this reader does not: the bundle is refused.
+      if (have_cg && n_cig == 2 && B.cg_flag) {
+        const uint8_t *cg = rec + 32 + l_qname;
+        const uint32_t w0 = ld_u32(cg), w1 = ld_u32(cg + 4);
+        if ((w0 & 0xfu) == 4u && (w0 >> 4) == (uint32_t)l_seq && (w1 & 0xfu) == 3u) *B.cg_flag = 1u;
       }
       // sort the (at most four) removal intervals by offset: a tiny insertion sort
       for (int i = 1; i < 4; i++)

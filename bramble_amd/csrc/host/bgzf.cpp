@@ -282,4 +282,10 @@ bool BgzfWriter::close() {
   return ok;
 }
 
+void BgzfWriter::abandon() {
+  if (!f_) return;
+  if (f_ == stdout) fflush(f_); else fclose(f_);
+  f_ = nullptr; pending_.clear();
+}
+
 }  // namespace brio

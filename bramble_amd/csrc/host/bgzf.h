@@ -72,6 +72,7 @@ class BgzfWriter {
   // closes the pending partial block, then appends bytes that already ARE complete BGZF blocks (device deflate)
   bool write_raw(const uint8_t *p, size_t n);
   bool close();  // flushes and appends the 28-byte EOF block
+  void abandon();  // closes the file without the EOF block (a failed run must not leave a stream that looks complete)
   const std::string &error() const { return err_; }
   uint64_t bytes_out() const { return bytes_out_; }
 

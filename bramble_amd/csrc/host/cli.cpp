@@ -39,7 +39,8 @@ using brio::BgzfWriter;
 struct Options {
   std::string in_bam, out_bam, gff, fasta;
   br_config cfg;
-  int threads = 1, level = 6, device = 0;
+  int threads = 1, level = 6;
+  std::vector<int> devices{0};  // --device N / --devices a,b,...: one worker (index replica + context + host threads) per entry
   int64_t bundle_records = 2000000;
   bool quiet = false;
   bool device_deflate = true;   // BGZF blocks made on the GPU unless a host level is asked for
@@ -52,10 +53,12 @@ void usage(FILE *f) {
           " [--help] [--version] [--quiet] [--fr] [--rf] [--lr] [--lr-hq] [--strict]\n"
           " [--max-soft-clip N] [--max-junction-insertion N] [--max-junction-deletion N]\n"
           " [--max-error-exon N] [--similarity-threshold X]\n"
-          " [--device-deflate | --host-deflate | --compression-level 0-9] [--bundle-size N] [--device N]\n\n"
+          " [--device-deflate | --host-deflate | --compression-level 0-9] [--bundle-size N] [--device N | --devices a,b,...]\n\n"
           "Project spliced genomic alignments into transcriptomic space.\n"
           "The output BGZF blocks are deflated on the GPU by default (per-block Huffman codes); --host-deflate or\n"
-          "--compression-level N use the host codec (libdeflate / zlib, level 6 like the reference unless N is given).\n");
+          "--compression-level N use the host codec (libdeflate / zlib, level 6 like the reference unless N is given).\n"
+          "--devices 0,1,...: bundles are dealt to one worker per listed GPU (an index replica each, no exchange between them);\n"
+          "the output keeps the input order.\n");
 }
 
 bool parse_u32(const char *s, uint32_t &v) { char *e; unsigned long x = strtoul(s, &e, 10); if (e == s || *e) return false; v = (uint32_t)x; return true; }
@@ -93,7 +96,13 @@ int parse_args(int argc, char **argv, Options &o) {
     else if (a == "--host-deflate") o.device_deflate = false;
     else if (a == "--bundle-size") { const char *v = value(); if (!v) return -1; o.bundle_records = atoll(v); if (o.bundle_records < 1) return -1; }
     else if (a == "--device-deflate") o.device_deflate = true;
-    else if (a == "--device") { const char *v = value(); if (!v) return -1; o.device = atoi(v); }
+    else if (a == "--device") { const char *v = value(); if (!v) return -1; o.devices.assign(1, atoi(v)); }
+    else if (a == "--devices") {
+      const char *v = value(); if (!v) return -1;
+      o.devices.clear();
+      for (const char *q = v; *q;) { char *e; long d = strtol(q, &e, 10); if (e == q || d < 0) return -1; o.devices.push_back((int)d); q = *e == ',' ? e + 1 : e; if (*e && *e != ',') return -1; }
+      if (o.devices.empty() || o.devices.size() > 64) return -1;
+    }
     else if (!a.empty() && a[0] == '-' && a != "-") { fprintf(stderr, "unknown option %s\n", a.c_str()); return -1; }
     else if (o.in_bam.empty()) o.in_bam = a;
     else { fprintf(stderr, "unexpected argument %s\n", a.c_str()); return -1; }
@@ -229,8 +238,8 @@ struct Slot {  // bounded FIFO between two pipeline stages
   void release() { std::unique_lock<std::mutex> l(m); q.pop_front(); cv.notify_all(); }
 };
 
-struct Bundle { brio::ByteBuf blob; std::vector<uint64_t> off; std::vector<uint32_t> len; };
-struct OutChunk { const uint8_t *data; uint64_t n; };
+struct Bundle { brio::ByteBuf blob; std::vector<uint64_t> off; std::vector<uint32_t> len; uint64_t seq = 0; };
+struct OutChunk { const uint8_t *data; uint64_t n; int worker; };
 
 const uint8_t *rec_name(const brio::ByteBuf &b, uint64_t off, uint32_t &l) { l = b[off + 8]; return b.data() + off + 32; }
 
@@ -253,14 +262,13 @@ extern "C" int br_cli_main(int argc, char **argv) {
   brio::ByteBuf buf; size_t pos = 0;
   BamHeader hdr; std::string err;
   if (!read_header(rd, buf, pos, hdr, err)) { fprintf(stderr, "error: %s: %s\n", o.in_bam.c_str(), err.c_str()); return 1; }
-  Slot<Bundle> to_gpu(4);      // the reader runs ahead while the guides are parsed and the index is built
-  Slot<OutChunk> to_writer(1); // exactly one: the two pinned download buffers alternate
+  Slot<Bundle> to_gpu(4);      // the reader runs ahead while the guides are parsed and the indexes are built
   // consumed bundle buffers go back to the reader: their pages are already faulted in
   std::mutex pool_m; std::vector<std::unique_ptr<brio::ByteBuf>> pool;
-  uint64_t total_reads = 0, unmapped_reads = 0;
+  uint64_t total_reads = 0, unmapped_reads = 0, next_seq = 0;
   std::string reader_err, writer_err;
   std::atomic<bool> cancel{false};
-  double t_inflate = 0, t_split = 0, t_copy = 0, t_deflate = 0, t_wait_gpu_in = 0;
+  double t_inflate = 0, t_split = 0, t_copy = 0, t_deflate = 0;
   auto now = []() { return std::chrono::steady_clock::now(); };
   auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
 
@@ -336,6 +344,7 @@ extern "C" int br_cli_main(int argc, char **argv) {
         for (auto &x : noff) x -= byte_end;
         off.swap(noff); len.swap(nlen);
         t_copy += secs(tc0, now());
+        b->seq = next_seq++;   // the writer restores this order whatever worker projects the bundle
         to_gpu.put(std::move(b));
       }
       if (cut < 0 && eof) break;
@@ -343,7 +352,7 @@ extern "C" int br_cli_main(int argc, char **argv) {
     to_gpu.finish();
   });
 
-  // the reader is already inflating while the guides are parsed and the index is built
+  // the reader is already inflating while the guides are parsed and the indexes are built
   auto stop_reader = [&]() -> int { cancel = true; while (to_gpu.take()) {} reader.join(); return 1; };
   br_annotation *ann = nullptr;
   int rc = br_annotation_load(o.gff.c_str(), &ann);
@@ -353,7 +362,7 @@ extern "C" int br_cli_main(int argc, char **argv) {
   Fasta fa;
   std::vector<br_fasta_seq> fseqs;
   if (o.cfg.use_fasta) {
-    if (!load_fasta(o.fasta.c_str(), fa)) { fprintf(stderr, "error: could not open genome %s\n", o.fasta.c_str()); return stop_reader(); }
+    if (!load_fasta(o.fasta.c_str(), fa)) { fprintf(stderr, "error: could not open genome %s\n", o.fasta.c_str()); br_annotation_free(ann); return stop_reader(); }
     for (size_t i = 0; i < fa.names.size(); i++) fseqs.push_back({fa.names[i].c_str(), fa.seqs[i].data(), fa.seqs[i].size()});
   }
   if (!o.quiet) {
@@ -361,16 +370,45 @@ extern "C" int br_cli_main(int argc, char **argv) {
     if (o.cfg.lr) printf("[bramble] using long-read mode (--lr)\n");
     else if (o.cfg.lr_hq) printf("[bramble] using long-read mode (--lr-hq)\n");
     else printf("[bramble] using short-read mode (have long reads? try running with --lr or --lr-hq)\n");
-    printf("[bramble] building g2t index\n");
+    printf("[bramble] building g2t index%s\n", o.devices.size() > 1 ? " (one replica per device)" : "");
   }
-  br_index *ix = nullptr;
-  rc = br_index_build(br_annotation_transcripts(ann), n_tx, refnames, n_refs, fseqs.empty() ? nullptr : fseqs.data(), fseqs.size(),
-                      o.device, &ix);
-  if (rc) { fprintf(stderr, "error: index build failed: %s\n", br_strerror(rc)); br_annotation_free(ann); return stop_reader(); }
-  fa = Fasta();  // the index holds the exon sequences now
-  br_ctx *ctx = nullptr;
-  rc = br_ctx_new(ix, &ctx);
-  if (rc) { fprintf(stderr, "error: %s\n", br_strerror(rc)); br_index_free(ix); br_annotation_free(ann); return stop_reader(); }
+
+  // One worker per listed device: its own index replica and context (the reference's workers share one read-only tree,
+  // src/threads.cpp:114-162; here every GPU holds a copy), an uploader thread and a projecting thread.  Workers take
+  // bundles from the reader's queue as they become free -- no exchange between them; the writer restores bundle order
+  // (bramble-cli/src/pipeline.rs:226-240 keeps a BTreeMap for the same purpose).
+  struct Staged { std::unique_ptr<Bundle> b; int slot; int rc; };
+  struct Worker {
+    int id = 0, device = 0;
+    br_index *ix = nullptr; br_ctx *ctx = nullptr;
+    int build_rc = 0;
+    std::unique_ptr<Slot<Staged>> to_main;
+    std::mutex permit_m; std::condition_variable permit_cv; int permits = 3;   // three device staging slots
+    std::mutex done_m; std::condition_variable done_cv; uint64_t produced = 0, written = 0;  // chunks handed to / finished by the writer
+    std::thread uploader, runner;
+    uint64_t total_complete = 0, total_unique = 0, dropped = 0, n_bundles = 0;
+    double gpu_seconds = 0, t_upload = 0, t_wait_in = 0;
+  };
+  const size_t n_workers = o.devices.size();
+  std::vector<std::unique_ptr<Worker>> workers;
+  for (size_t w = 0; w < n_workers; w++) { workers.emplace_back(new Worker()); workers[w]->id = (int)w; workers[w]->device = o.devices[w]; workers[w]->to_main.reset(new Slot<Staged>(2)); }
+  auto free_all = [&]() {
+    for (auto &w : workers) { if (w->ctx) br_ctx_free(w->ctx); if (w->ix) br_index_free(w->ix); w->ctx = nullptr; w->ix = nullptr; }
+    if (ann) br_annotation_free(ann);
+    ann = nullptr;
+  };
+  {
+    std::vector<std::thread> builders;
+    for (auto &wp : workers) builders.emplace_back([&, w = wp.get()]() {
+      w->build_rc = br_index_build(br_annotation_transcripts(ann), n_tx, refnames, n_refs, fseqs.empty() ? nullptr : fseqs.data(), fseqs.size(), w->device, &w->ix);
+      if (!w->build_rc) w->build_rc = br_ctx_new(w->ix, &w->ctx);
+    });
+    for (auto &t : builders) t.join();
+  }
+  for (auto &w : workers)
+    if (w->build_rc) { fprintf(stderr, "error: index build failed on device %d: %s\n", w->device, br_strerror(w->build_rc)); free_all(); return stop_reader(); }
+  fa = Fasta();  // the indexes hold the exon sequences now
+  const br_index *ix0 = workers[0]->ix;
 
   // input refID -> annotation reference index; names the annotation lacks get ids past its table
   // (gseqs.addName, src/bramble.cpp:384: a new id with no interval tree behind it)
@@ -380,83 +418,116 @@ extern "C" int br_cli_main(int argc, char **argv) {
   int32_t extra = (int32_t)n_refs;
   for (size_t r = 0; r < hdr.ref_names.size(); r++) { auto it = ref_of.find(hdr.ref_names[r]); ref_map[r] = it != ref_of.end() ? it->second : extra++; }
 
+  // the output goes to a temporary name next to the target and is renamed on success: a failed run leaves no file that
+  // looks complete (a truncated stream with a valid EOF block)
+  const bool to_stdout = o.out_bam == "-";
+  const std::string out_tmp = to_stdout ? o.out_bam : o.out_bam + ".tmp-bramble";
   BgzfWriter wr;
-  if (!wr.open(o.out_bam.c_str(), o.threads, o.level)) { fprintf(stderr, "error: %s\n", wr.error().c_str()); return stop_reader(); }
+  if (!wr.open(out_tmp.c_str(), o.threads, o.level)) { fprintf(stderr, "error: %s\n", wr.error().c_str()); free_all(); return stop_reader(); }
   {
-    std::vector<uint8_t> h = make_bam_header(make_header_text(hdr.text, ix, cl, o.gff), ix);
-    if (!wr.write(h.data(), h.size()) ) { fprintf(stderr, "error: %s\n", wr.error().c_str()); return stop_reader(); }
+    std::vector<uint8_t> h = make_bam_header(make_header_text(hdr.text, ix0, cl, o.gff), ix0);
+    if (!wr.write(h.data(), h.size())) { fprintf(stderr, "error: %s\n", wr.error().c_str()); wr.abandon(); if (!to_stdout) remove(out_tmp.c_str()); free_all(); return stop_reader(); }
   }
   if (!o.quiet) printf("[bramble] processing alignments :-)\n");
   double t_setup = since();
 
+  // ordered writer: chunks arrive tagged with their bundle's sequence number
+  std::mutex out_m; std::condition_variable out_cv; std::map<uint64_t, OutChunk> out_map; uint64_t out_next = 0; bool out_done = false;
   std::thread writer([&]() {
     for (;;) {
-      OutChunk *c = to_writer.hold();
-      if (!c) break;
+      OutChunk c;
+      {
+        std::unique_lock<std::mutex> l(out_m);
+        out_cv.wait(l, [&] { return out_map.count(out_next) || out_done; });
+        auto it = out_map.find(out_next);
+        if (it == out_map.end()) break;   // done, and the next chunk never came (a worker failed): stop here
+        c = it->second; out_map.erase(it); out_next++;
+      }
       auto td0 = now();
-      if (writer_err.empty() && c->n && !(o.device_deflate ? wr.write_raw(c->data, (size_t)c->n) : wr.write(c->data, (size_t)c->n))) writer_err = wr.error();
+      if (writer_err.empty() && c.n && !(o.device_deflate ? wr.write_raw(c.data, (size_t)c.n) : wr.write(c.data, (size_t)c.n))) writer_err = wr.error();
       t_deflate += secs(td0, now());
-      to_writer.release();
+      Worker *w = workers[(size_t)c.worker].get();
+      { std::lock_guard<std::mutex> l(w->done_m); w->written++; }
+      w->done_cv.notify_all();
     }
   });
 
-  uint64_t total_complete = 0, total_unique = 0, dropped = 0, n_bundles = 0;
-  double gpu_seconds = 0, t_upload = 0;
-  int fail = 0;
-  // uploader thread: stages bundle k into device slot k % 3 on the context's copy stream while the main thread
-  // projects an earlier one; three permits = three slots, a permit returns when a slot's projection is done
-  struct Staged { std::unique_ptr<Bundle> b; int slot; int rc; };
-  Slot<Staged> to_main(2);
-  std::mutex permit_m; std::condition_variable permit_cv; int permits = 3;
-  std::thread uploader([&]() {
-    int64_t seq = 0;
-    for (;;) {
-      auto b = to_gpu.take();
-      if (!b) break;
-      { std::unique_lock<std::mutex> l(permit_m); permit_cv.wait(l, [&] { return permits > 0; }); permits--; }
-      auto st = std::make_unique<Staged>();
-      st->slot = (int)(seq++ % 3);
-      br_bam_bundle bb{b->blob.data(), b->blob.size(), b->off.data(), b->len.data(), (int64_t)b->off.size(), ref_map.data(), (int32_t)ref_map.size(), o.device_deflate ? 1 : 0};
-      auto t0 = now();
-      st->rc = br_bam_bundle_stage(ctx, &bb, st->slot);
-      t_upload += secs(t0, now());
-      st->b = std::move(b);
-      to_main.put(std::move(st));
-    }
-    to_main.finish();
-  });
-  for (;;) {
-    auto tw0 = now();
-    auto st = to_main.take();
-    t_wait_gpu_in += secs(tw0, now());
-    if (!st) break;
-    auto &b = st->b;
-    if (!fail && st->rc) { fprintf(stderr, "error: upload failed: %s\n", br_strerror(st->rc)); fail = 1; }
-    br_host_bam hb;
-    memset(&hb, 0, sizeof(hb));
-    if (!fail) {
-      br_bam_bundle bb{b->blob.data(), b->blob.size(), b->off.data(), b->len.data(), (int64_t)b->off.size(), ref_map.data(), (int32_t)ref_map.size(), o.device_deflate ? 1 : 0};
-      auto t0 = now();
-      rc = br_project_bam_staged(ctx, &o.cfg, &bb, st->slot, &hb);
-      gpu_seconds += secs(t0, now());
-      if (rc) { fprintf(stderr, "error: projection failed: %s\n", br_strerror(rc)); fail = 1; }
-    }
-    { auto spare = std::make_unique<brio::ByteBuf>(); spare->swap(b->blob); std::lock_guard<std::mutex> l(pool_m); pool.push_back(std::move(spare)); }
-    { std::lock_guard<std::mutex> l(permit_m); permits++; }
-    permit_cv.notify_all();
-    if (fail) continue;  // drain
-    total_complete += hb.total_complete; total_unique += hb.total_unique; dropped += hb.dropped_reads; n_bundles++;
-    auto c = std::make_unique<OutChunk>(); c->data = hb.data; c->n = hb.n_bytes;
-    to_writer.put(std::move(c));  // returns once the writer has FINISHED the previous chunk: the two pinned buffers alternate
+  std::atomic<int> fail{0};
+  for (auto &wp : workers) {
+    Worker *w = wp.get();
+    // uploader: stages bundle k of this worker into device slot k % 3 on the context's copy stream while the runner
+    // projects an earlier one; three permits = three slots, a permit returns when a slot's projection is done
+    w->uploader = std::thread([&, w]() {
+      int64_t k = 0;
+      for (;;) {
+        auto b = to_gpu.take();
+        if (!b) break;
+        { std::unique_lock<std::mutex> l(w->permit_m); w->permit_cv.wait(l, [&] { return w->permits > 0; }); w->permits--; }
+        auto st = std::make_unique<Staged>();
+        st->slot = (int)(k++ % 3);
+        br_bam_bundle bb{b->blob.data(), b->blob.size(), b->off.data(), b->len.data(), (int64_t)b->off.size(), ref_map.data(), (int32_t)ref_map.size(), o.device_deflate ? 1 : 0};
+        auto t0 = now();
+        st->rc = fail ? 0 : br_bam_bundle_stage(w->ctx, &bb, st->slot);
+        w->t_upload += secs(t0, now());
+        st->b = std::move(b);
+        w->to_main->put(std::move(st));
+      }
+      w->to_main->finish();
+    });
+    w->runner = std::thread([&, w]() {
+      for (;;) {
+        auto tw0 = now();
+        auto st = w->to_main->take();
+        w->t_wait_in += secs(tw0, now());
+        if (!st) break;
+        auto &b = st->b;
+        if (!fail && st->rc) { fprintf(stderr, "error: upload failed on device %d: %s\n", w->device, br_strerror(st->rc)); fail = 1; }
+        br_host_bam hb;
+        memset(&hb, 0, sizeof(hb));
+        if (!fail) {
+          // the context's two pinned result buffers alternate: chunk j - 2 of this worker must be on disk before call j
+          { std::unique_lock<std::mutex> l(w->done_m); w->done_cv.wait(l, [&] { return w->written + 2 > w->produced || fail; }); }
+          br_bam_bundle bb{b->blob.data(), b->blob.size(), b->off.data(), b->len.data(), (int64_t)b->off.size(), ref_map.data(), (int32_t)ref_map.size(), o.device_deflate ? 1 : 0};
+          auto t0 = now();
+          int prc2 = fail ? 0 : br_project_bam_staged(w->ctx, &o.cfg, &bb, st->slot, &hb);
+          w->gpu_seconds += secs(t0, now());
+          if (prc2) { fprintf(stderr, "error: projection failed on device %d: %s\n", w->device, br_strerror(prc2)); fail = 1; }
+        }
+        const uint64_t seq = b->seq;
+        { auto spare = std::make_unique<brio::ByteBuf>(); spare->swap(b->blob); std::lock_guard<std::mutex> l(pool_m); pool.push_back(std::move(spare)); }
+        { std::lock_guard<std::mutex> l(w->permit_m); w->permits++; }
+        w->permit_cv.notify_all();
+        if (fail) { for (auto &x : workers) x->done_cv.notify_all(); continue; }  // drain
+        w->total_complete += hb.total_complete; w->total_unique += hb.total_unique; w->dropped += hb.dropped_reads; w->n_bundles++;
+        { std::lock_guard<std::mutex> l(w->done_m); w->produced++; }
+        { std::lock_guard<std::mutex> l(out_m); out_map[seq] = OutChunk{hb.data, hb.n_bytes, w->id}; }
+        out_cv.notify_all();
+      }
+    });
   }
-  uploader.join();
-  to_writer.finish();
+  for (auto &w : workers) { w->uploader.join(); w->runner.join(); }
+  { std::lock_guard<std::mutex> l(out_m); out_done = true; }
+  out_cv.notify_all();
   reader.join(); writer.join();
-  if (!reader_err.empty()) { fprintf(stderr, "error: %s: %s\n", o.in_bam.c_str(), reader_err.c_str()); fail = 1; }
-  if (!writer_err.empty()) { fprintf(stderr, "error: %s: %s\n", o.out_bam.c_str(), writer_err.c_str()); fail = 1; }
-  if (!wr.close()) { fprintf(stderr, "error: %s: %s\n", o.out_bam.c_str(), wr.error().c_str()); fail = 1; }
+  int failed = fail.load();
+  if (!reader_err.empty()) { fprintf(stderr, "error: %s: %s\n", o.in_bam.c_str(), reader_err.c_str()); failed = 1; }
+  if (!writer_err.empty()) { fprintf(stderr, "error: %s: %s\n", o.out_bam.c_str(), writer_err.c_str()); failed = 1; }
+  if (!failed && out_next != next_seq) { fprintf(stderr, "error: %s: output incomplete\n", o.out_bam.c_str()); failed = 1; }
+  if (failed) {
+    wr.abandon();                          // no EOF block: the stream must not look complete
+    if (!to_stdout) remove(out_tmp.c_str());
+  } else {
+    if (!wr.close()) { fprintf(stderr, "error: %s: %s\n", o.out_bam.c_str(), wr.error().c_str()); failed = 1; if (!to_stdout) remove(out_tmp.c_str()); }
+    else if (!to_stdout && rename(out_tmp.c_str(), o.out_bam.c_str()) != 0) { fprintf(stderr, "error: could not rename %s to %s\n", out_tmp.c_str(), o.out_bam.c_str()); failed = 1; }
+  }
   double t_done = since();
-  br_ctx_free(ctx); br_index_free(ix); br_annotation_free(ann);
+  uint64_t total_complete = 0, total_unique = 0, dropped = 0, n_bundles = 0;
+  double gpu_seconds = 0, t_upload = 0, t_wait_gpu_in = 0;
+  for (auto &w : workers) {
+    total_complete += w->total_complete; total_unique += w->total_unique; dropped += w->dropped; n_bundles += w->n_bundles;
+    gpu_seconds += w->gpu_seconds; t_upload += w->t_upload; t_wait_gpu_in += w->t_wait_in;
+  }
+  free_all();
   double t_freed = since();
   if (!o.quiet) {  // src/bramble.cpp:727-736
     printf("\n[bramble] final report:\n");
@@ -465,13 +536,13 @@ extern "C" int br_cli_main(int argc, char **argv) {
     printf("# dropped alignments: %llu\n", (unsigned long long)dropped);
     printf("# total alignments:   %llu\n", (unsigned long long)total_complete);
     printf("# unique alignments:  %llu\n\n", (unsigned long long)total_unique);
-    printf("[bramble] %llu bundles, %.2fs on the device path (upload + kernels + download), %.2fs wall (setup %.2fs, codec %s)\n",
-           (unsigned long long)n_bundles, gpu_seconds, since(), t_setup, brio::codec_name());
+    printf("[bramble] %llu bundles on %zu device worker(s), %.2fs on the device path (upload + kernels + download, summed), %.2fs wall (setup %.2fs, codec %s)\n",
+           (unsigned long long)n_bundles, n_workers, gpu_seconds, since(), t_setup, brio::codec_name());
     printf("[bramble] release of device / pinned memory: %.2fs\n", t_freed - t_done);
     printf("[bramble] stage busy time: inflate %.2fs, split %.2fs, bundle copy %.2fs, upload %.2fs, device %.2fs (waited for input %.2fs), deflate+write %.2fs\n",
            t_inflate, t_split, t_copy, t_upload, gpu_seconds, t_wait_gpu_in, t_deflate);
   }
-  return fail;
+  return failed;
 }
 
 // ---- BGZF utilities (host only) -------------------------------------------------------------------

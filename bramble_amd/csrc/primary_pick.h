@@ -12,7 +12,7 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define BR_HD __host__ __device__ __forceinline__
 #else
 #define BR_HD inline

@@ -1444,13 +1444,46 @@ __global__ void __launch_bounds__(256) k_primary(PairArgs P, const uint32_t *__r
     uint64_t pick = rs;
     if (!SCORES) {
       if (re - rs > 1) {
-        uint32_t units = 0;
-        for (uint64_t r = rs; r < re;) { const bool paired = flagw[4 * r] & RR_PAIRED; units++; r += paired ? 2 : 1; }
-        if (units > 1) {
-          uint32_t idx = primary_pick(names + name_off[a0], name_off[a0 + 1] - name_off[a0], units);
-          uint64_t r = rs;
-          for (; idx; idx--) r += (flagw[4 * r] & RR_PAIRED) ? 2 : 1;
-          pick = r;
+        // units per leader = its record count, halved when they are pairs (the flag of its first record): a chain of
+        // three dependent stages (group -> row offsets -> flags) instead of one load per unit.  Up to four alignments
+        // per name (nearly every group) with every stage's loads issued together.
+        const uint32_t na = a1 - a0;
+        if (na <= 4u) {
+          uint64_t ro[5]; uint32_t fl[4], un[4];
+#pragma unroll
+          for (int k = 0; k < 5; k++) ro[k] = P.row_off[a0 + ((uint32_t)k < na ? (uint32_t)k : na)];
+#pragma unroll
+          for (int k = 0; k < 4; k++) fl[k] = flagw[4 * (ro[k + 1] > ro[k] ? ro[k] : rs)];   // spent slots re-read a valid record
+          uint32_t units = 0;
+#pragma unroll
+          for (int k = 0; k < 4; k++) { const uint32_t n = (uint32_t)(ro[k + 1] - ro[k]); un[k] = (fl[k] & RR_PAIRED) ? n / 2 : n; units += un[k]; }
+          if (units > 1) {
+            uint32_t idx = primary_pick(names + name_off[a0], name_off[a0 + 1] - name_off[a0], units);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              const bool here = idx < un[k];
+              if (here) pick = ro[k] + ((fl[k] & RR_PAIRED) ? 2ull * idx : idx);
+              idx = here ? 0xffffffffu : idx - un[k];   // 0xffffffff: found (no later leader can match)
+              un[k] = here ? 0u : un[k];
+            }
+          }
+        } else {
+          uint32_t units = 0;
+          for (uint32_t i = a0; i < a1; i++) {
+            const uint64_t b = P.row_off[i]; const uint32_t n = (uint32_t)(P.row_off[i + 1] - b);
+            if (n) units += (flagw[4 * b] & RR_PAIRED) ? n / 2 : n;
+          }
+          if (units > 1) {
+            uint32_t idx = primary_pick(names + name_off[a0], name_off[a0 + 1] - name_off[a0], units);
+            for (uint32_t i = a0; i < a1; i++) {
+              const uint64_t b = P.row_off[i]; const uint32_t n = (uint32_t)(P.row_off[i + 1] - b);
+              if (!n) continue;
+              const bool paired = flagw[4 * b] & RR_PAIRED;
+              const uint32_t u = paired ? n / 2 : n;
+              if (idx < u) { pick = b + (paired ? 2ull * idx : idx); break; }
+              idx -= u;
+            }
+          }
         }
       }
     } else {

@@ -1,7 +1,9 @@
-"""N>1 path on CPU: world_size-2 gloo.  Each rank takes its shard of read-name groups
-(bramble_amd.shard), projects it independently (here with the oracle standing in for
-the per-rank GPU, since this box has none) and the concatenation over ranks must equal
-the unsharded result -- the property that makes the path collective-free."""
+"""N>1 path: world_size-2 gloo.  Each rank takes its shard of read-name groups
+(bramble_amd.shard), projects it independently and the concatenation over ranks must equal
+the unsharded result -- the property that makes the path collective-free.  On a box without
+a GPU the oracle stands in for the per-rank device (test_sharded_equals_unsharded); on the GPU
+box the ranks call the HIP path through the C ABI (test_sharded_hip_ranks_equal_unsharded_oracle,
+marked gpu: both ranks share the one card, each with its own index replica and context)."""
 import os
 import socket
 import sys
@@ -23,17 +25,28 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, use_hip=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from bramble_amd import shard, synth
-    from oracle import oracle_binding as ob
     ann = synth.Annotation("S")
     batch = ann.reads(3000, "pe")
     sub, lo = shard.shard_batch(batch, rank, world)
-    rows, _, _ = ob.run(ob.OracleIndex(ann.as_dict()), ob.make_flags(), sub, want_matches=False)
+    if use_hip:
+        from bramble_amd import lib
+        ndev = max(torch.cuda.device_count(), 1)
+        idx = lib.Index(ann.as_dict(), device=rank % ndev)   # this rank's index replica
+        ctx = lib.Context(idx)
+        w = ctx.project_batch(lib.make_config(), sub)
+        rows = {"n_rows": w["n_rows"], "tid": w["transcript_id"], "pos": w["pos"], "nh": w["nh"], "input_index": w["input_index"],
+                "cigar": w["cigar"], "total_unique": w["total_unique"], "dropped_reads": w["dropped_reads"]}
+        ctx.close()
+        idx.close()
+    else:
+        from oracle import oracle_binding as ob
+        rows, _, _ = ob.run(ob.OracleIndex(ann.as_dict()), ob.make_flags(), sub, want_matches=False)
     # the only cross-rank traffic: counters (5 integers summed) -- never the data path
     cnt = torch.tensor([rows["n_rows"], rows["total_unique"], rows["dropped_reads"], sub["n_aln"]], dtype=torch.int64)
     dist.all_reduce(cnt)
@@ -43,10 +56,10 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_sharded_equals_unsharded(tmp_path):
+def _check_sharded(tmp_path, use_hip):
     world = 2
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), use_hip), nprocs=world, join=True)
     sys.path.insert(0, ROOT)
     from bramble_amd import synth
     from oracle import oracle_binding as ob
@@ -57,6 +70,15 @@ def test_sharded_equals_unsharded(tmp_path):
     for key, fk in (("tid", "tid"), ("pos", "pos"), ("nh", "nh"), ("input_index", "input_index"), ("cigar", "cigar")):
         assert np.array_equal(np.concatenate([p[key] for p in parts]), full[fk]), key
     assert parts[0]["total"].tolist() == [full["n_rows"], full["total_unique"], full["dropped_reads"], batch["n_aln"]]
+
+
+def test_sharded_equals_unsharded(tmp_path):
+    _check_sharded(tmp_path, False)
+
+
+@pytest.mark.gpu
+def test_sharded_hip_ranks_equal_unsharded_oracle(tmp_path):
+    _check_sharded(tmp_path, True)
 
 
 def test_shards_never_split_a_name_group():

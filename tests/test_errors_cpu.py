@@ -23,6 +23,16 @@ def test_unknown_seqname_and_overlapping_exons_are_annotation_errors():
         lib.Index(bad, device=-1)
 
 
+def test_transcript_without_exonic_bases_is_an_annotation_error():
+    """The reference writes no @SQ line for a transcript of length 0 (src/bramble.cpp:588-596) while its tids count every
+    guide: header and records would disagree, so the index refuses such a transcript instead of numbering around it."""
+    for exons in ([[100, 100]], []):
+        bad = {"refnames": ["chr1"], "transcripts": [{"id": "ok", "ref_id": 0, "strand": "+", "exons": [[10, 20]]},
+                                                     {"id": "empty", "ref_id": 0, "strand": "+", "exons": exons}]}
+        with pytest.raises(lib.BrambleError, match="annotation"):
+            lib.Index(bad, device=-1)
+
+
 def test_host_only_index_has_accessors_but_no_context():
     idx = lib.Index(ANN, device=-1)
     assert idx.num_transcripts() == 1 and idx.transcript_len(0) == 200 and idx.transcript_name(0) == "t1"

@@ -190,3 +190,53 @@ def test_cli_errors(tmp_path):
     gtf.write_text('chr1\tx\texon\t10\t50\t.\t+\t.\tgene_id "g"; transcript_id "t";\n')
     r = subprocess.run([BIN, str(notbam), "-G", str(gtf), "-o", str(tmp_path / "o.bam")], capture_output=True, text=True)
     assert r.returncode != 0 and "BGZF" in r.stderr
+
+
+def test_cli_several_device_workers_give_the_single_device_stream(tmp_path):
+    """--devices a,b,...: one reader deals bundles to one worker per listed device (index replica + context + host
+    threads each, as src/threads.cpp:114-162 feeds N workers from one reader), the writer restores bundle order.  The GPU
+    box has one card, so the same device is listed two and three times: every worker is a separate context / replica,
+    which is all the path knows about a device.  The record stream must be byte-identical to the single-worker run."""
+    ann = synth.Annotation("G", n_genes=900, n_refs=3)
+    annd = ann.as_dict()
+    b = ann.reads(12000, "pe", with_records=1, p_multimap=0.1)
+    stream = framed_stream(b)
+    gtf, in_bam = str(tmp_path / "g.gtf"), str(tmp_path / "in.bam")
+    bamio.write_gtf(gtf, annd)
+    bamio.write_bam(in_bam, "@HD\tVN:1.6\n", [(n, 1000000) for n in annd["refnames"]], stream.tobytes())
+    outs, reports = [], []
+    for k, extra in enumerate((["--device", "0"], ["--devices", "0,0"], ["--devices", "0,0,0", "--host-deflate"])):
+        out_bam = str(tmp_path / ("o%d.bam" % k))
+        r = subprocess.run([BIN, in_bam, "-G", gtf, "-o", out_bam, "-p", "4", "--bundle-size", "900"] + extra,
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr + r.stdout
+        assert not os.path.exists(out_bam + ".tmp-bramble")
+        outs.append(bamio.read_bam(out_bam))
+        reports.append([l for l in r.stdout.splitlines() if l.startswith("# ")])
+        assert ("on %d device worker(s)" % (k + 1)) in r.stdout
+    assert len(outs[0][2]) > 500000
+    for o in outs[1:]:
+        assert o[1] == outs[0][1] and np.array_equal(o[2], outs[0][2])
+    assert reports[1] == reports[0] and reports[2] == reports[0]
+
+
+def test_cli_failed_run_leaves_no_output_file(tmp_path):
+    """A run that fails mid-stream (here: a BGZF block whose payload is corrupt, after several good bundles) must exit
+    non-zero and leave neither the output nor a complete-looking temporary behind."""
+    ann = synth.Annotation("G", n_genes=300, n_refs=2)
+    annd = ann.as_dict()
+    b = ann.reads(6000, "pe", with_records=1)
+    stream = framed_stream(b)
+    gtf, in_bam, out_bam = str(tmp_path / "g.gtf"), str(tmp_path / "in.bam"), str(tmp_path / "out.bam")
+    bamio.write_gtf(gtf, annd)
+    bamio.write_bam(in_bam, "@HD\tVN:1.6\n", [(n, 1000000) for n in annd["refnames"]], stream.tobytes(), block=30000)
+    raw = bytearray(open(in_bam, "rb").read())
+    sizes = bamio.bgzf_block_sizes(in_bam)
+    at = sum(sizes[:len(sizes) * 2 // 3]) + 30      # inside the deflate payload of a block two thirds in
+    for k in range(8):
+        raw[at + k] ^= 0x5a
+    open(in_bam, "wb").write(bytes(raw))
+    r = subprocess.run([BIN, in_bam, "-G", gtf, "-o", out_bam, "-p", "2", "--bundle-size", "500", "--devices", "0,0"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "error" in r.stderr
+    assert not os.path.exists(out_bam) and not os.path.exists(out_bam + ".tmp-bramble")
