@@ -1579,6 +1579,61 @@ extern "C" uint32_t br_primary_pick(const char *name, size_t len, uint32_t n_tie
   return n_tied ? br::primary_pick((const uint8_t *)name, len, n_tied) : 0;
 }
 
+// Diagnostic: the -S rescue DP alone.  Runs k_ksw on n (target, query) pairs as right-side problems and returns, per
+// pair, whether the rescue is accepted, the maximum, and the raw traceback CIGAR (forward order, BAM-packed M / I / D).
+extern "C" int br_ctx_ksw_pairs(br_ctx *c, int64_t n, const char *const *tseq, const char *const *qseq, int32_t *ok,
+                                int32_t *max, uint32_t *n_cigar, uint32_t *cigar, uint32_t cigar_cap) {
+  if (!c || n < 0 || (n && (!tseq || !qseq || !ok || !max || !n_cigar || !cigar)) || !cigar_cap) return BR_ERR_INVALID_ARG;
+  if (n == 0) return BR_OK;
+  HIPCHK(hipSetDevice(c->ix->device));
+  hipStream_t st = nullptr;
+  struct HProb { uint32_t qlen, tlen, side, pad; uint64_t seq_off; };
+  if (ksw_prob_bytes() != sizeof(HProb)) return BR_ERR_UNSUPPORTED;
+  std::vector<HProb> probs((size_t)n);
+  std::vector<uint8_t> arena;
+  auto code = [](char ch) -> uint8_t { switch (ch) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 4; } };
+  uint64_t qmax = 0, tmaxv = 0;
+  for (int64_t p = 0; p < n; p++) {
+    size_t ql = strlen(qseq[p]), tl = strlen(tseq[p]);
+    probs[(size_t)p] = HProb{(uint32_t)ql, (uint32_t)tl, 1u, 0u, (uint64_t)arena.size()};
+    for (size_t k = 0; k < ql; k++) arena.push_back(code(qseq[p][k]));
+    for (size_t k = 0; k < tl; k++) arena.push_back(code(tseq[p][k]));
+    qmax = std::max<uint64_t>(qmax, ql); tmaxv = std::max<uint64_t>(tmaxv, tl);
+  }
+  DevBuf d_probs, d_res, d_arena, d_ops, d_raw, d_rawn, d_max, d_scratch;
+  auto cleanup = [&]() { d_probs.release(); d_res.release(); d_arena.release(); d_ops.release(); d_raw.release(); d_rawn.release(); d_max.release(); d_scratch.release(); };
+  int rc = BR_OK;
+  struct HRes { int32_t ok, score, refc; uint32_t n_ops; };
+  std::vector<HRes> res((size_t)n);
+  do {
+    if ((rc = d_probs.ensure((size_t)n * sizeof(HProb))) || (rc = d_res.ensure((size_t)n * ksw_res_bytes())) ||
+        (rc = d_arena.ensure(arena.size() + 16)) || (rc = d_ops.ensure((arena.size() + (size_t)n + 1) * 4)) ||
+        (rc = d_raw.ensure((size_t)n * cigar_cap * 4)) || (rc = d_rawn.ensure((size_t)n * 4)) || (rc = d_max.ensure((size_t)n * 4))) break;
+    KswArgs K{};
+    K.n_prob = n; K.probs = (const KswProb *)d_probs.p; K.results = (KswRes *)d_res.p; K.seq_arena = d_arena.as<uint8_t>();
+    K.clip_ops = d_ops.as<uint32_t>(); K.tmax = (uint32_t)std::max<uint64_t>(tmaxv, 1);
+    K.pmat_bytes = (size_t)(((qmax + tmaxv) * std::max<uint64_t>(tmaxv, 1) + 15) & ~15ull);
+    K.raw_words = (size_t)((qmax + tmaxv + 4 + 3) & ~3ull);
+    K.scratch_per_wave = K.pmat_bytes + K.raw_words * 4 + ((4 * tmaxv + 15) & ~15ull);
+    int kb = (int)std::min<int64_t>((n + 3) / 4, (int64_t)c->n_cu * 4);
+    if ((rc = d_scratch.ensure((size_t)kb * 4 * K.scratch_per_wave))) break;
+    K.scratch = d_scratch.as<uint8_t>(); K.stats = nullptr;
+    K.raw_out = d_raw.as<uint32_t>(); K.raw_n = d_rawn.as<uint32_t>(); K.max_out = d_max.as<int32_t>(); K.raw_cap = cigar_cap;
+    if (hipMemsetAsync(d_max.p, 0, (size_t)n * 4, st) != hipSuccess || hipMemsetAsync(d_rawn.p, 0, (size_t)n * 4, st) != hipSuccess ||
+        hipMemcpyAsync(d_probs.p, probs.data(), (size_t)n * sizeof(HProb), hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(d_arena.p, arena.data(), arena.size(), hipMemcpyHostToDevice, st) != hipSuccess) { rc = BR_ERR_HIP; break; }
+    launch_ksw(st, K, kb);
+    if (hipMemcpyAsync(res.data(), d_res.p, (size_t)n * sizeof(HRes), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(max, d_max.p, (size_t)n * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(n_cigar, d_rawn.p, (size_t)n * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(cigar, d_raw.p, (size_t)n * cigar_cap * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) { rc = BR_ERR_HIP; break; }
+    for (int64_t p = 0; p < n; p++) ok[p] = res[(size_t)p].ok;
+  } while (0);
+  cleanup();
+  return rc;
+}
+
 extern "C" uint32_t br_row_mapq(uint32_t nh, int long_reads) {  // src/core.cpp:46-58
   if (!long_reads) return nh == 1 ? 255u : nh == 2 ? 3u : (nh == 3 || nh == 4) ? 1u : 0u;
   return nh > 1 ? 0u : 3u;

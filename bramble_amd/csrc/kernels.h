@@ -68,6 +68,8 @@ struct KswArgs {
   size_t scratch_per_wave, pmat_bytes, raw_words;
   uint32_t tmax;
   uint64_t *stats;  // [2] DP cells, accepted rescues (may be null)
+  // diagnostic (br_ctx_ksw_pairs): the raw traceback CIGAR (forward order) and the maximum of every problem; null otherwise
+  uint32_t *raw_out, *raw_n; int32_t *max_out; uint32_t raw_cap;
 };
 
 struct ScanArgs {

@@ -148,7 +148,7 @@ EXPORTS = ["br_index_build", "br_index_build_flat", "br_index_free", "br_index_n
            "br_pin_host", "br_unpin_host", "br_project_group", "br_bam_encode_device", "br_project_bam_device", "br_project_bam_bundle", "br_bam_bundle_stage", "br_project_bam_staged", "br_bam_split", "br_annotation_load", "br_annotation_free",
            "br_annotation_num_transcripts", "br_annotation_transcripts", "br_annotation_num_refs", "br_annotation_refnames", "br_cli_main", "br_bgzf_write_file", "br_bgzf_read_file",
            "br_free_buffer", "br_bgzf_codec", "br_bgzf_deflate_device", "br_ctx_set_profiling",
-           "br_ctx_set_param", "br_ctx_kernel_ms", "br_ctx_collect_counters", "br_ctx_last_counters", "br_ctx_rescue_stats", "br_primary_pick", "br_row_mapq", "br_version", "br_strerror"]
+           "br_ctx_set_param", "br_ctx_kernel_ms", "br_ctx_collect_counters", "br_ctx_last_counters", "br_ctx_rescue_stats", "br_ctx_ksw_pairs", "br_primary_pick", "br_row_mapq", "br_version", "br_strerror"]
 
 _LIB = None
 
@@ -232,6 +232,8 @@ def lib():
         L.br_ctx_collect_counters.argtypes = [C.c_void_p, _P(BrDeviceBatch), C.c_void_p]
         L.br_ctx_last_counters.argtypes = [C.c_void_p, C.c_void_p]
         L.br_ctx_rescue_stats.argtypes = [C.c_void_p, C.c_void_p]
+        L.br_ctx_ksw_pairs.argtypes = [C.c_void_p, C.c_int64, _P(C.c_char_p), _P(C.c_char_p), C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_uint32]
         L.br_primary_pick.restype = C.c_uint32
         L.br_primary_pick.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32]
         L.br_version.restype = C.c_char_p
@@ -601,6 +603,20 @@ class Context:
         check(lib().br_bam_encode_device(self.h, C.byref(cfg), C.byref(recs), C.c_void_p(stream), C.byref(out)),
               "br_bam_encode_device")
         return out
+
+    def ksw_pairs(self, pairs, cap=None):
+        """Diagnostic: k_ksw alone on [(target, query)] -> (ok int32[n], max int32[n], [cigar uint32[] per pair])."""
+        n = len(pairs)
+        cap = int(cap or max([len(t) + len(q) + 4 for t, q in pairs] + [8]))
+        ts = (C.c_char_p * max(n, 1))(*[t.encode() for t, _ in pairs])
+        qs = (C.c_char_p * max(n, 1))(*[q.encode() for _, q in pairs])
+        ok = np.zeros(max(n, 1), np.int32)
+        mx = np.zeros(max(n, 1), np.int32)
+        nc = np.zeros(max(n, 1), np.uint32)
+        cig = np.zeros(max(n, 1) * cap, np.uint32)
+        check(lib().br_ctx_ksw_pairs(self.h, n, ts, qs, ok.ctypes.data, mx.ctypes.data, nc.ctypes.data, cig.ctypes.data, cap),
+              "br_ctx_ksw_pairs")
+        return ok[:n], mx[:n], [cig[p * cap:p * cap + int(nc[p])].copy() for p in range(n)]
 
     def rescue_stats(self):
         out = (C.c_uint64 * 4)()

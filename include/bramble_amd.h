@@ -515,6 +515,13 @@ int br_ctx_last_counters(br_ctx *, uint64_t out[8]);
  * out[2] = accepted rescues, out[3] = coded sequence bytes. */
 int br_ctx_rescue_stats(br_ctx *, uint64_t out[4]);
 
+/* Diagnostic: the -S rescue DP alone (k_ksw = ksw_extz2_sse as src/evaluate.cpp:296-313 calls it, on the device).
+ * n (target, query) ASCII pairs in; per pair: ok[p] = the rescue would be accepted (max >= 10 and the walk reached the
+ * last cell, src/evaluate.cpp:484,643), max[p], and -- when ok -- the traceback CIGAR in forward order (BAM-packed
+ * M / I / D) at cigar[p * cigar_cap ...], n_cigar[p] ops. */
+int br_ctx_ksw_pairs(br_ctx *, int64_t n, const char *const *tseq, const char *const *qseq, int32_t *ok, int32_t *max,
+                     uint32_t *n_cigar, uint32_t *cigar, uint32_t cigar_cap);
+
 /* The reference's primary tie-break (src/core.cpp:214-218,298-299):
  * uniform_int_distribution<uint32_t>(0, n_tied-1)(mt19937_64(std::hash<std::string>(name))),
  * restated bit-exactly for libstdc++ (GCC 11, x86-64). */

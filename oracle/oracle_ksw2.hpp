@@ -2,10 +2,15 @@
 // TEST INFRASTRUCTURE ONLY -- scalar restatement of ksw_extz2_sse as bramble
 // calls it (see oracle_core.hpp header for the oracle's role and pinning).
 //
-// PARITY UNPINNED: follows subprojects/packagefiles/ksw2/ksw2_extz2_sse.cpp
-// (in /root/reference) for the DP; ksw2.h helpers (absent from the reference
-// tree; lh3/ksw2@289609b per subprojects/ksw2.wrap) are restated from the
-// published upstream header.  No reference test exercises this path.
+// Follows subprojects/packagefiles/ksw2/ksw2_extz2_sse.cpp (in /root/reference)
+// for the DP; ksw2.h helpers (absent from the reference tree; lh3/ksw2@289609b per
+// subprojects/ksw2.wrap) are restated from the published upstream header.  No
+// reference test exercises this path, so there is no reference-held vector for it.
+// PINNED INDEPENDENTLY instead: tests/ksw2_gotoh.c is a differently structured
+// implementation (full-matrix int32 Gotoh, traceback by comparing matrix values,
+// derived from the in-tree kernel source alone) and tests/test_ksw2_pinned.py
+// demands equal score / max / end cell / CIGAR on 10^5 random rescue-shaped pairs
+// and on the committed vectors tests/golden/ksw2_cases.json.
 // ============================================================================
 #pragma once
 #include <cstdint>

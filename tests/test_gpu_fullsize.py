@@ -189,3 +189,152 @@ def test_full_size_bam_bundle_stream_properties():
     assert b == nblk and p == len(zh)
     ctx.close()
     idx.close()
+
+
+# ---- configs[2] (1 M ONT-like reads, --lr -S) and configs[4] (5 M HiFi-like reads, --lr-hq --strict
+# --similarity-threshold 0.95) at BASELINE.json's full sizes ----------------------------------------------------
+
+def _name_group_starts(batch):
+    """Alignment indices where a new read name starts (+ n_aln), vectorised (shard.group_starts is a Python loop)."""
+    n = int(batch["n_aln"])
+    noff = batch["name_off"].astype(np.int64)
+    ln_ = np.diff(noff)
+    names = batch["names"]
+    same = np.zeros(n, dtype=bool)
+    cand = np.nonzero(ln_[1:] == ln_[:-1])[0] + 1
+    for L in np.unique(ln_[cand]):
+        idxs = cand[ln_[cand] == L]
+        a = names[(noff[idxs][:, None] + np.arange(L)[None, :])]
+        b = names[(noff[idxs - 1][:, None] + np.arange(L)[None, :])]
+        same[idxs] = (a == b).all(axis=1)
+    return np.concatenate([np.nonzero(~same)[0], [n]]).astype(np.int64)
+
+
+def _long_read_properties(ctx, cfg, batch, min_rows, sim_thr=None, need_rescues=False):
+    """The size-independent properties of the module docstring for a long-read batch, plus: every emitted similarity
+    score is that of a match that passed the filter (score > 0 <=> similarity > (double)threshold_f32, evaluate.cpp:
+    843-865 gives passing matches x^2 * (junc_hits + 1) with x > 0), and rescued clips are present when asked for."""
+    db = brdev.upload_batch(batch, "cuda:0")
+    rows = ctx.project_batch_device(cfg, db, 0)
+    t = brdev.rows_as_tensors(ctx)
+    n = t["n_rows"]
+    assert n > min_rows and rows.total_processed == batch["n_aln"]
+    w = t["cigar"].to(torch.int64) & 0xFFFFFFFF
+    op = w & 0xF
+    ln = w >> 4
+    assert bool((op <= 8).all())   # no private override op (10..13) survives the merge
+    consumes = (op == 0) | (op == 1) | (op == 4) | (op == 7) | (op == 8)
+    qcum = torch.cat([torch.zeros(1, dtype=torch.int64, device=w.device), torch.cumsum(torch.where(consumes, ln, torch.zeros_like(ln)), 0)])
+    off = t["cigar_off"]
+    lq = torch.from_numpy(batch["l_qseq"].astype(np.int64)).cuda()
+    assert bool(((qcum[off[1:]] - qcum[off[:-1]]) == lq[t["input_index"].to(torch.int64)]).all())
+    g = t["group"].to(torch.int64)
+    per_group = torch.bincount(g, minlength=int(g.max().item()) + 1)
+    assert bool((t["nh"].to(torch.int64) == per_group[g]).all())
+    first_row = torch.cumsum(per_group, 0) - per_group
+    assert bool((t["hi"].to(torch.int64) == torch.arange(n, device=g.device) - first_row[g] + 1).all())
+    # long-read MAPQ (get_mapq, src/core.cpp:46-58): 3 when unique, 0 otherwise; one primary record per read name
+    assert bool((t["mapq"].to(torch.int64) == torch.where(t["nh"].to(torch.int64) > 1, 0, 3)).all())
+    assert int(t["is_primary"].to(torch.int64).sum().item()) == int((per_group > 0).sum().item())
+    sim = t["similarity_score"]
+    assert bool((sim > 0).all()) and bool(torch.isfinite(sim).all())
+    if need_rescues:
+        assert int((t["clip_score"] != 0).sum().item()) > n // 100
+    cs1 = _checksums(t)
+    cs1["sim"] = float(sim.sum().item())
+    rows2 = ctx.project_batch_device(cfg, db, 0)
+    t2 = brdev.rows_as_tensors(ctx)
+    cs2 = _checksums(t2)
+    cs2["sim"] = float(t2["similarity_score"].sum().item())
+    assert cs2 == cs1   # idempotence, doubles included (same order of summation: bit-equal)
+    del t, t2, rows, rows2, db, w, op, ln, qcum
+    # shard additivity: the two halves, cut at a read-name boundary, give exactly the rows of the whole
+    starts = _name_group_starts(batch)
+    total = {}
+    for r in range(2):
+        sub, lo = shard.shard_batch(batch, r, 2, starts=starts)
+        ctx.project_batch_device(cfg, brdev.upload_batch(sub, "cuda:0"), 0)
+        ts = brdev.rows_as_tensors(ctx)
+        cs = _checksums(ts)
+        for k, v in cs.items():
+            total[k] = total.get(k, 0) + v
+        del ts
+    cs1.pop("sim")
+    assert total == cs1
+    return starts
+
+
+def _oracle_head(ann, batch, starts, flags, n_groups, with_seq):
+    """The first n_groups read names against the oracle (cut at a name boundary)."""
+    from oracle import oracle_binding as ob
+    from tests.parity import assert_rows_equal
+    cut = int(starts[n_groups])
+    sub = {"n_aln": cut}
+    for k in ("ref_id", "ref_start", "flags", "xs", "ts", "mate_ref_id", "mate_start", "l_qseq"):
+        sub[k] = batch[k][:cut]
+    for ok_, pk in (("cigar_off", "cigar"), ("name_off", "names")) + ((("seq_off", "seqs"),) if with_seq else ()):
+        sub[ok_] = batch[ok_][:cut + 1]
+        sub[pk] = batch[pk][:int(sub[ok_][-1])]
+    if not with_seq:
+        sub["seq_off"] = None
+        sub["seqs"] = None
+    return sub
+
+
+def test_full_size_config2_ont_with_clip_rescue():
+    """configs[2]: 1 M ONT-like reads, --lr -S (clip rescue: k_project_fa + k_ksw at full size)."""
+    from oracle import oracle_binding as ob
+    from tests.parity import assert_rows_equal
+    ann = synth.Annotation("G", n_genes=6000, n_refs=5, with_genome=True)
+    idx = lib.Index.from_flat(ann.flat, device=0)
+    ctx = lib.Context(idx)
+    batch = ann.reads(1_000_000, "ont", with_seq=1)
+    flags = {"lr": 1, "use_fasta": 1}
+    cfg = lib.make_config(**flags)
+    starts = _long_read_properties(ctx, cfg, batch, 1_000_000, need_rescues=True)
+    st = ctx.rescue_stats()
+    assert st["problems"] > 100_000 and st["rescued"] > 10_000
+    # oracle comparison on a 20 k-read head
+    sub = _oracle_head(ann, batch, starts, flags, 20000, True)
+    prod = ctx.project_batch(cfg, sub)
+    annd = ann.as_dict()
+    orc, _, _ = ob.run(ob.OracleIndex(annd), ob.make_flags(**flags), sub, want_matches=False)
+    assert_rows_equal(prod, orc)
+    ctx.close()
+    idx.close()
+
+
+def test_full_size_config4_hifi_similarity_filter():
+    """configs[4] on one GPU: 5 M HiFi-like reads, --lr-hq --strict --similarity-threshold 0.95 vs the GENCODE-shaped
+    annotation (on 8 GPUs the same batch is sharded by read name: the additivity property below is that sharding)."""
+    from oracle import oracle_binding as ob
+    from tests.parity import assert_rows_equal
+    ann = synth.Annotation("G")
+    idx = lib.Index.from_flat(ann.flat, device=0)
+    ctx = lib.Context(idx)
+    batch = ann.reads(5_000_000, "hifi")
+    flags = {"lr_hq": 1, "strict": 1, "sim_thr": 0.95}
+    cfg = lib.make_config(**flags)
+    starts = _long_read_properties(ctx, cfg, batch, 5_000_000)
+    sub = _oracle_head(ann, batch, starts, flags, 20000, False)
+    prod = ctx.project_batch(cfg, sub)
+    f = ann.flat
+    oi = ob.OracleIndex.__new__(ob.OracleIndex)
+    L = ob.lib()
+    oi.h = L.orc_index_new()
+    exs = np.stack([f["ex_start"], f["ex_end"]], axis=1).astype(np.uint32)
+    off = f["tx_exon_off"].astype(np.int64)
+    for tx in range(len(f["tx_ref"])):
+        e = np.ascontiguousarray(exs[off[tx]:off[tx + 1]]).reshape(-1)
+        L.orc_index_add_transcript(oi.h, int(f["tx_ref"][tx]), bytes([int(f["tx_strand"][tx])]), b"", e.ctypes.data, len(e) // 2, None, 0)
+    L.orc_index_finish(oi.h)
+    orc, _, _ = ob.run(oi, ob.make_flags(**flags), sub, want_matches=False)
+    assert orc["n_rows"] > 10000
+    assert_rows_equal(prod, orc)
+    # every emitted score belongs to a match above the threshold: the oracle's rows are exactly the filtered set, and
+    # the raw similarity behind a score x^2 (junc_hits + 1) is thr + x (1 - thr) > thr
+    thr = float(np.float32(0.95))
+    x = np.sqrt(prod["similarity_score"] / (prod["junc_hits"].astype(np.float64) + 1.0))
+    assert (thr + x * (1.0 - thr) > thr).all()
+    ctx.close()
+    idx.close()
