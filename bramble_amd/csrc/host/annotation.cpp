@@ -12,8 +12,11 @@
 //     added to the exons in finalize, :2123-2130)
 //   * an exonless transcript gets one exon spanning it (finalize :2079-2086; bramble.cpp:568-576)
 //   * transcript bounds become the exon span (:2192-2201)
-//   * order: reference NAME (strcmp), start, level (0 for every transcript), end, strcmp(ID)
-//     (gfo_cmpByLoc, :75-90)
+//   * order: reference NAME (strcmp), start, level, end, strcmp(ID) (gfo_cmpByLoc, :75-90).  level = depth below
+//     the features that were on file BEFORE it and that it names as its parent (updateParent, :1436-1441): a GFF3
+//     transcript with Parent=<gene or transcript seen earlier> is one below that parent; a GTF `transcript` line whose
+//     gene_id names an earlier `gene` line is at level 1 (GffLine sets Parent = gene_id for it, :733-741); a transcript
+//     known only from its exon lines, or whose parent comes later or not at all, stays at level 0
 // Out of the restated subset (documented in DESIGN.md): BED / TLF input, "*_gene_segment"
 // redistribution, discontinuous features that reuse one ID, Ensembl id/version merging
 // (procEnsemblID is off in bramble), non-transcript parents promoted by their exon children.
@@ -46,6 +49,7 @@ struct Tx {
   char strand = '.';
   uint32_t start = 0, end = 0;                   // feature line coordinates (used when exonless)
   bool has_line = false;
+  int level = 0;                                 // GffObj::gff_level
   std::vector<std::pair<uint32_t, uint32_t>> segs;  // sorted, merged, 1-based inclusive
 };
 
@@ -133,7 +137,7 @@ extern "C" int br_annotation_load(const char *path, br_annotation **out) {
   gzbuffer(f, 1 << 20);
   std::vector<Tx> txs;
   std::unordered_map<std::string, size_t> by_key;       // id + '\t' + seqname + strand
-  std::unordered_map<std::string, char> gene_ids;       // GFF3: ids of gene features (exon children -> implicit transcript)
+  std::unordered_map<std::string, int> feat_level;      // ids of the gene / transcript features read so far -> gff_level
   std::vector<std::string> refnames;
   std::unordered_map<std::string, int> ref_of;
   int fmt = 0;  // 0 unknown, 1 GFF3, 2 GTF
@@ -187,11 +191,28 @@ extern "C" int br_annotation_load(const char *path, br_annotation **out) {
       }
     }
     if (fmt == 1) {
-      if (kind == K_GENE) { if (!id.empty()) gene_ids[id] = strand; continue; }
+      // level of a gene / transcript feature: one below the last of its parents that was read before it
+      auto level_under = [&](const std::string &parents) -> int {
+        int lv = 0;
+        size_t a = 0;
+        while (a <= parents.size() && !parents.empty()) {
+          size_t b = parents.find(',', a);
+          if (b == std::string::npos) b = parents.size();
+          std::string pid = parents.substr(a, b - a);
+          while (!pid.empty() && pid.back() == ' ') pid.pop_back();
+          auto it = feat_level.find(pid);
+          if (it != feat_level.end()) lv = it->second + 1;
+          a = b + 1;
+        }
+        return lv;
+      };
+      if (kind == K_GENE) { if (!id.empty()) feat_level.emplace(id, level_under(parent)); continue; }
       if (kind == K_TRANSCRIPT) {
         if (id.empty()) continue;
         Tx &tx = get_tx(id, t[0], strand);
         tx.has_line = true; tx.strand = strand; tx.start = (uint32_t)fs; tx.end = (uint32_t)fe;
+        tx.level = level_under(parent);
+        feat_level[id] = tx.level;
       } else if (kind == K_EXONLIKE) {
         if (parent.empty()) continue;
         size_t a = 0;
@@ -209,10 +230,19 @@ extern "C" int br_annotation_load(const char *path, br_annotation **out) {
         }
       }
     } else {  // GTF: unrecognised features are dropped when only transcripts are loaded (gff.cpp:696-698)
-      if (kind == K_GENE || kind == K_OTHER) continue;
+      if (kind == K_OTHER) continue;
+      if (kind == K_GENE) {   // its ID is the transcript_id when it has one, else the gene_id (gff.cpp:704-721)
+        std::string gid;
+        if ((gtf_attr(info, "transcript_id", gid) && !gid.empty()) || (gtf_attr(info, "gene_id", gid) && !gid.empty())) feat_level.emplace(gid, 0);
+        continue;
+      }
       if (!gtf_attr(info, "transcript_id", id) || id.empty()) continue;
       Tx &tx = get_tx(id, t[0], strand);
-      if (kind == K_TRANSCRIPT) { tx.has_line = true; tx.strand = strand; tx.start = (uint32_t)fs; tx.end = (uint32_t)fe; }
+      if (kind == K_TRANSCRIPT) {
+        tx.has_line = true; tx.strand = strand; tx.start = (uint32_t)fs; tx.end = (uint32_t)fe;
+        std::string gid;   // a `transcript` line names its gene as parent (gff.cpp:733-741)
+        if (gtf_attr(info, "gene_id", gid)) { auto it = feat_level.find(gid); if (it != feat_level.end()) tx.level = it->second + 1; }
+      }
       else { if (!tx.has_line && tx.segs.empty()) tx.strand = strand; add_segment(tx.segs, (uint32_t)fs, (uint32_t)fe); }
     }
   }
@@ -229,6 +259,7 @@ extern "C" int br_annotation_load(const char *path, br_annotation **out) {
     int c = strcmp(a->seqname.c_str(), b->seqname.c_str());
     if (c) return c < 0;
     if (a->start != b->start) return a->start < b->start;
+    if (a->level != b->level) return a->level < b->level;
     if (a->end != b->end) return a->end < b->end;
     return strcmp(a->id.c_str(), b->id.c_str()) < 0;
   });

@@ -129,3 +129,58 @@ def test_missing_file_and_empty_annotation(tmp_path):
     p.write_text("# nothing\n")
     with pytest.raises(lib.BrambleError):
         load(p)
+
+
+def test_guide_order_level_comes_before_end(tmp_path):
+    """gfo_cmpByLoc (gclib/gff.cpp:75-90) compares start, then the feature LEVEL, then end, then the ID.  The level is
+    one below the parent a feature names if that parent was on file before it (updateParent, gff.cpp:1436-1441;
+    GffLine sets Parent = gene_id for a GTF `transcript` line, :733-741).  Orders below are derived by hand from those
+    lines: wherever two transcripts start together, the shallower one comes first even when it ends later."""
+    # GFF3: a transcript without a parent (level 0) before a same-start transcript under a gene (level 1), although it
+    # is longer; a primary_transcript (level 1) before the miRNA it parents (level 2), although the miRNA is shorter
+    gff = tmp_path / "levels.gff3"
+    gff.write_text("\n".join([
+        "##gff-version 3",
+        "chr1\tx\tgene\t100\t500\t.\t+\t.\tID=gene1",
+        "chr1\tx\tmRNA\t100\t300\t.\t+\t.\tID=A_under_gene;Parent=gene1",
+        "chr1\tx\texon\t100\t300\t.\t+\t.\tParent=A_under_gene",
+        "chr1\tx\tncRNA\t100\t400\t.\t+\t.\tID=B_no_parent",
+        "chr1\tx\texon\t100\t400\t.\t+\t.\tParent=B_no_parent",
+        "chr1\tx\tgene\t1000\t1200\t.\t-\t.\tID=gene2",
+        "chr1\tx\tprimary_transcript\t1000\t1200\t.\t-\t.\tID=P_pre;Parent=gene2",
+        "chr1\tx\texon\t1000\t1200\t.\t-\t.\tParent=P_pre",
+        "chr1\tx\tmiRNA\t1000\t1020\t.\t-\t.\tID=M_mature;Parent=P_pre",
+        "chr1\tx\texon\t1000\t1020\t.\t-\t.\tParent=M_mature",
+        # same start, same level (both under a gene): end decides, then the ID
+        "chr1\tx\tmRNA\t2000\t2300\t.\t+\t.\tID=Z_long;Parent=gene1",
+        "chr1\tx\texon\t2000\t2300\t.\t+\t.\tParent=Z_long",
+        "chr1\tx\tmRNA\t2000\t2100\t.\t+\t.\tID=Y_short;Parent=gene1",
+        "chr1\tx\texon\t2000\t2100\t.\t+\t.\tParent=Y_short",
+        "chr1\tx\tmRNA\t2000\t2100\t.\t+\t.\tID=X_short;Parent=gene1",
+        "chr1\tx\texon\t2000\t2100\t.\t+\t.\tParent=X_short",
+        # a parent that comes AFTER its child is not found when the child is read: the child stays at level 0
+        "chr1\tx\tmRNA\t3000\t3300\t.\t+\t.\tID=C_early_child;Parent=gene3",
+        "chr1\tx\texon\t3000\t3300\t.\t+\t.\tParent=C_early_child",
+        "chr1\tx\tgene\t3000\t3400\t.\t+\t.\tID=gene3",
+        "chr1\tx\tmRNA\t3000\t3100\t.\t+\t.\tID=D_late_child;Parent=gene3",
+        "chr1\tx\texon\t3000\t3100\t.\t+\t.\tParent=D_late_child",
+    ]) + "\n")
+    txs, _ = load(gff)
+    assert [t[0] for t in txs] == ["B_no_parent", "A_under_gene", "P_pre", "M_mature", "X_short", "Y_short", "Z_long",
+                                   "C_early_child", "D_late_child"]
+    # GTF: `transcript` lines under an earlier `gene` line are at level 1; a transcript known only from its exon lines, or
+    # whose gene line is missing, is at level 0 and goes first at equal starts
+    gtf = tmp_path / "levels.gtf"
+    g = lambda gid, tid: 'gene_id "%s"; transcript_id "%s";' % (gid, tid)   # noqa: E731
+    gtf.write_text("\n".join([
+        "chr2\tx\tgene\t100\t900\t.\t+\t.\tgene_id \"G1\";",
+        "chr2\tx\ttranscript\t100\t300\t.\t+\t.\t" + g("G1", "t_with_line"),
+        "chr2\tx\texon\t100\t300\t.\t+\t.\t" + g("G1", "t_with_line"),
+        "chr2\tx\texon\t100\t600\t.\t+\t.\t" + g("G1", "t_exons_only"),
+        "chr2\tx\ttranscript\t100\t700\t.\t+\t.\t" + g("G_absent", "t_gene_line_missing"),
+        "chr2\tx\texon\t100\t700\t.\t+\t.\t" + g("G_absent", "t_gene_line_missing"),
+        "chr2\tx\ttranscript\t100\t200\t.\t+\t.\t" + g("G1", "t_short_with_line"),
+        "chr2\tx\texon\t100\t200\t.\t+\t.\t" + g("G1", "t_short_with_line"),
+    ]) + "\n")
+    txs, _ = load(gtf)
+    assert [t[0] for t in txs] == ["t_exons_only", "t_gene_line_missing", "t_short_with_line", "t_with_line"]
