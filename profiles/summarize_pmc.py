@@ -5,9 +5,10 @@ usage: summarize_pmc.py FETCH_counter_collection.csv WRITE_counter_collection.cs
 
 FETCH_SIZE / WRITE_SIZE are collected in separate `rocprofv3 --pmc X --kernel-trace` passes of
 `python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline` (MI355X_MICROARCH.md, HBM section).
-Per dispatch the counter is in KiB; on gfx950 FETCH_SIZE counts 32-byte requests as if they were
-64 bytes wide only half of the time -- the guide's correction is bytes = 2 * FETCH_SIZE * 1024 for
-reads and WRITE_SIZE * 1024 for writes.  Everything here is averaged PER LAUNCH (sum over the
+Per dispatch the counter is in KiB.  FETCH_SIZE = TCC_EA0_RDREQ x 64 B, but on gfx950 every L2->fabric read request is
+128 bytes wide -- for coalesced streams and for random 4/16/32/64-byte gathers alike (TCC_EA0_RDREQ_128B == TCC_EA0_RDREQ,
+the 32B / 64B request counters stay at zero: profiles/r02/pmc_calibration.json, profiles/calib_fetch.hip) -- so
+bytes = 2 * FETCH_SIZE * 1024 for reads of every kernel here, and WRITE_SIZE * 1024 for writes.  Everything here is averaged PER LAUNCH (sum over the
 dispatches of a kernel / number of dispatches), the same normalisation bench.py uses for
 `roofline.achieved`.
 """
@@ -53,28 +54,33 @@ def main():
             "FETCH_SIZE_KB_per_launch": f,
             "WRITE_SIZE_KB_per_launch": w,
             "hbm_bytes_corrected": int((2.0 * f + w) * 1024.0),
+            "correction": "reads 2 x FETCH_SIZE (all read requests are 128 B: r02/pmc_calibration.json), writes WRITE_SIZE as is",
         }
     json.dump(full, open(os.path.join(out_dir, "pmc_summary.json"), "w"), indent=1)
-    # the table bench.py reads: template arguments folded so that the name is stable
+    # the table bench.py reads: keyed like br_ctx kernel timers (bench.py's kernel_ms_per_step)
+    def bench_key(k):
+        k = k.replace(", ", ",")
+        m = re.match(r"k_project<(\d+),(true|false),(true|false),(\d)>", k)
+        if m:
+            return "k_project<64,true>" if m.group(2) == "true" else "k_project<G,%s,%s,%s>" % (m.group(2), m.group(3), m.group(4))
+        if k.startswith("k_scan"):
+            return "k_scan_*"
+        if re.match(r"k_(rows|primary)<", k):
+            return re.sub(r"<.*>$", "", k)
+        return k
     kern = {}
     for k, v in full.items():
-        key = re.sub(r"<.*>$", "", k)
-        if key in ("k_project", "k_emit_dense"):
-            # count and emit instantiations of k_project are different kernels
-            if key == "k_project":
-                key = "k_project<64,true>" if re.search(r"<\d+, true", k) else "k_project<G,false>"  # bench.py's bucket names
-            elif re.search(r"<(true|false), 1>", k):
-                key = "k_emit_dense<simple>"
-            if key == "k_project<G,false>" and key in kern:
-                # the count pass of the short-read presets is two kernels (main + the alignments that need the exon
-                # walk): one launch of the path runs both, so their per-launch figures add up
-                t = dict(kern[key])
-                for f in ("FETCH_SIZE_KB_per_launch", "WRITE_SIZE_KB_per_launch", "hbm_bytes_corrected"):
-                    t[f] = t[f] + v[f]
-                t["kernels_summed"] = t.get("kernels_summed", 1) + 1
-                kern[key] = t
-            elif key not in kern or v["hbm_bytes_corrected"] > kern[key]["hbm_bytes_corrected"]:
-                kern[key] = v
+        if k in ("k_stats", "k_sum_ncig"):
+            continue   # diagnostics outside the timed step
+        key = bench_key(k)
+        if key in kern:
+            t = dict(kern[key])
+            for f in ("FETCH_SIZE_KB_per_launch", "WRITE_SIZE_KB_per_launch", "hbm_bytes_corrected"):
+                t[f] = t[f] + v[f]
+            t["kernels_summed"] = t.get("kernels_summed", 1) + 1
+            kern[key] = t
+        else:
+            kern[key] = dict(v)
     traffic = {
         "pairs": pairs,
         "note": "per launch; rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of "
