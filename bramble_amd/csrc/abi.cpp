@@ -450,6 +450,12 @@ struct br_ctx {
   int64_t last_n_rows = 0, last_n_aln = 0;
   DevBuf fa_stats, fa_n_prob, fa_seq_bytes, fa_prob_off, fa_seqarena_off, fa_probs, fa_results, fa_seq_arena, fa_clip_ops,
       fa_ideal_cap, fa_scratch, b_seq_off, b_seqs, b_seq_src;
+  // the streamed -S DP (ksw_kernels.hip): per-bin descriptors, per-problem DP results, leftovers, counters, group
+  // rows / offsets, the direction tape, raw traceback ops
+  DevBuf ksw_desc, ksw_dp, ksw_left, ksw_cnt, ksw_group, ksw_tape, ksw_raw;
+  int ksw_fast = 1;            // 0: every problem through the general kernel k_ksw
+  int64_t ksw_tape_mb = 49152; // HBM set aside for the direction tape; larger batches go through in pieces
+  uint64_t ksw_diag[8] = {0};  // last call: pieces, problems per bin [4], leftovers before the DP, tape bytes (largest piece), spare
   DevBuf n_rows, row_off, aln_group;
   // wide view of the rows (br_device_rows_expand): one array per field
   DevBuf r_input, r_nh, r_hi, r_mapq, r_group, r_mate_tid, r_mate_pos,
@@ -506,7 +512,8 @@ extern "C" void br_ctx_free(br_ctx *c) {
                     &c->r_ncig, &c->r_strand, &c->r_sim, &c->r_clip, &c->r_junc, &c->r_refc, &c->r_cigoff,
                     &c->cigar_out, &c->r_paired, &c->r_same, &c->r_first, &c->r_primary, &c->b_name_off, &c->b_names, &c->b_ref_id, &c->b_ref_start,
                     &c->b_flags, &c->b_xs, &c->b_ts, &c->b_cigar_off, &c->b_cigar, &c->b_mate_idx,
-                    &c->b_group_off, &c->b_lqseq, &c->walk_list, &c->pmask};
+                    &c->b_group_off, &c->b_lqseq, &c->walk_list, &c->pmask,
+                    &c->ksw_desc, &c->ksw_dp, &c->ksw_left, &c->ksw_cnt, &c->ksw_group, &c->ksw_tape, &c->ksw_raw};
   for (DevBuf *b : bufs) b->release();
   for (auto &e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if (c->h_totals) (void)hipHostFree(c->h_totals);
@@ -541,6 +548,8 @@ extern "C" int br_ctx_set_param(br_ctx *c, const char *key, int64_t v) {
   if (!strcmp(key, "count_split")) { c->count_split = v != 0; return BR_OK; }
   if (!strcmp(key, "deflate_dynamic")) { c->deflate_dynamic = v != 0; return BR_OK; }
   if (!strcmp(key, "bam_lanes")) { if (v != 4 && v != 8 && v != 16 && v != 32 && v != 64) return BR_ERR_INVALID_ARG; c->bam_lanes = (int)v; return BR_OK; }
+  if (!strcmp(key, "ksw_fast")) { c->ksw_fast = v != 0; return BR_OK; }
+  if (!strcmp(key, "ksw_tape_mb")) { if (v < 1) return BR_ERR_INVALID_ARG; c->ksw_tape_mb = v; return BR_OK; }
   if (!strcmp(key, "host_detail")) { c->host_detail = v != 0; return BR_OK; }
   if (!strcmp(key, "blocks_per_cu")) { if (v < 1 || v > 64) return BR_ERR_INVALID_ARG; c->blocks_per_cu = (int)v; return BR_OK; }
   return BR_ERR_INVALID_ARG;
@@ -551,6 +560,15 @@ extern "C" int br_ctx_kernel_ms(br_ctx *c, int which, double *ms, int32_t *launc
   if (launches) *launches = c->k_launches[which];
   return BR_OK;
 }
+// Diagnostic: how the last -S call's DP problems were routed (pieces, problems per array shape, leftovers handed to the
+// general kernel before the DP, tape bytes of the largest piece, leftovers of the last piece after the DP).
+extern "C" int br_ctx_ksw_diag(br_ctx *c, uint64_t out[8]) {
+  if (!c || !out) return BR_ERR_INVALID_ARG;
+  memcpy(out, c->ksw_diag, sizeof(c->ksw_diag));
+  out[7] = (uint32_t)c->h_totals[24];
+  return BR_OK;
+}
+
 extern "C" int br_ctx_rescue_stats(br_ctx *c, uint64_t out[4]) {
   if (!c || !out) return BR_ERR_INVALID_ARG;
   memcpy(out, c->rescue_stats, sizeof(c->rescue_stats));
@@ -598,6 +616,99 @@ struct Prof {
 };
 
 #define RC(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+
+// The -S rescue DP over n_prob problems.  Problems whose target fits a register array go
+// through the streamed kernels piece by piece (a piece = a range of problems whose direction tape fits the budget):
+// k_ksw_bin -> [host reads the bin sizes] -> k_ksw_plan -> k_ksw_dp per bin -> k_ksw over the leftovers -> k_ksw_trace.
+struct KswRun {
+  int64_t n_prob; const KswProb *probs; KswRes *results; const uint8_t *seq_arena; uint32_t *clip_ops;
+  uint64_t seq_total, qmax, tmax; uint64_t *stats;
+  uint32_t *raw_out, *raw_n; int32_t *max_out; uint32_t raw_cap;
+};
+
+static int run_ksw(br_ctx *c, hipStream_t st, const KswRun &R) {
+  if (R.n_prob <= 0) return BR_OK;
+  const uint64_t n_all = (uint64_t)R.n_prob;
+  const uint64_t qmax = std::max<uint64_t>(R.qmax, 1), tmax = std::max<uint64_t>(R.tmax, 1);
+  KswArgs K{};
+  K.n_prob = R.n_prob; K.probs = R.probs; K.results = R.results; K.seq_arena = R.seq_arena; K.clip_ops = R.clip_ops;
+  K.tmax = (uint32_t)tmax; K.stats = R.stats;
+  K.raw_out = R.raw_out; K.raw_n = R.raw_n; K.max_out = R.max_out; K.raw_cap = R.raw_cap;
+  K.pmat_bytes = (size_t)(((qmax + tmax) * tmax + 15) & ~15ull);
+  K.raw_words = (size_t)((qmax + tmax + 4 + 3) & ~3ull);
+  K.scratch_per_wave = K.pmat_bytes + K.raw_words * 4 + ((4 * tmax + 15) & ~15ull);
+  const uint64_t budget = 16ull << 30;  // HBM set aside for the general kernel's direction matrices
+  auto general = [&](uint64_t n_work, const uint32_t *list, const uint32_t *n_list) -> int {
+    uint64_t waves = std::min<uint64_t>({(uint64_t)c->n_cu * 4 * 4, std::max<uint64_t>(budget / K.scratch_per_wave, 4), (n_work + 3) / 4 * 4});
+    int kb = (int)std::max<uint64_t>(waves / 4, 1);
+    RC(c->fa_scratch.ensure((size_t)kb * 4 * K.scratch_per_wave));
+    K.scratch = c->fa_scratch.as<uint8_t>(); K.list = list; K.n_list = n_list;
+    launch_ksw(st, K, kb);
+    return BR_OK;
+  };
+  memset(c->ksw_diag, 0, sizeof(c->ksw_diag));
+  c->h_totals[24] = 0;
+  if (!c->ksw_fast) return general(n_all, nullptr, nullptr);
+
+  RC(c->ksw_raw.ensure((size_t)(R.seq_total + n_all + 1) * 4));
+  RC(c->ksw_cnt.ensure(64));
+  uint32_t *h_cnt = (uint32_t *)(c->h_totals + 16);   // 16 words of the pinned totals
+  const uint64_t tape_budget = (uint64_t)c->ksw_tape_mb << 20;
+  // groups a bin may run at once: 16 waves per CU
+  uint32_t max_groups[KSW_N_BINS];
+  for (int b = 0; b < KSW_N_BINS; b++) max_groups[b] = (uint32_t)c->n_cu * 16u * (64u / (uint32_t)KSW_BIN_G(b));
+  std::vector<std::pair<uint64_t, uint64_t>> todo;   // [p0, p1)
+  todo.emplace_back(0, n_all);
+  while (!todo.empty()) {
+    const uint64_t p0 = todo.back().first, p1 = todo.back().second, n = p1 - p0;
+    todo.pop_back();
+    RC(c->ksw_desc.ensure((size_t)n * sizeof(KswDesc) * KSW_N_BINS));
+    RC(c->ksw_dp.ensure((size_t)n * sizeof(KswDp)));
+    RC(c->ksw_left.ensure((size_t)n * 4));
+    KswFastArgs A{};
+    A.p0 = (int64_t)p0; A.n = (int64_t)n; A.probs = R.probs; A.results = R.results; A.seq_arena = R.seq_arena;
+    A.clip_ops = R.clip_ops; A.raw_ops = c->ksw_raw.as<uint32_t>();
+    for (int b = 0; b < KSW_N_BINS; b++) A.desc[b] = c->ksw_desc.as<KswDesc>() + (size_t)b * n;
+    A.counters = c->ksw_cnt.as<uint32_t>(); A.leftover = c->ksw_left.as<uint32_t>(); A.dp = c->ksw_dp.as<KswDp>();
+    A.stats = R.stats; A.raw_out = R.raw_out; A.raw_n = R.raw_n; A.max_out = R.max_out; A.raw_cap = R.raw_cap;
+    HIPCHK(hipMemsetAsync(c->ksw_cnt.p, 0, 64, st));
+    launch_ksw_bin(st, A);
+    HIPCHK(hipMemcpyAsync(h_cnt, c->ksw_cnt.p, 64, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const uint64_t *h_rows = (const uint64_t *)(h_cnt + 8);
+    uint64_t tape_bytes = 0; uint32_t n_groups_total = 0;
+    for (int b = 0; b < KSW_N_BINS; b++) {
+      A.n_bin[b] = h_cnt[b];
+      A.n_groups[b] = std::min<uint32_t>(max_groups[b], h_cnt[b]);
+      A.group_base[b] = n_groups_total;
+      n_groups_total += A.n_groups[b];
+      tape_bytes += (h_rows[b] + (uint64_t)A.n_groups[b] * (KSW_BIN_W(b) + KSW_TAIL_ROWS)) * (uint64_t)KSW_BIN_ROWBYTES(b);
+    }
+    if (tape_bytes > tape_budget && n >= 2048) {
+      uint64_t mid = p0 + n / 2;
+      todo.emplace_back(mid, p1); todo.emplace_back(p0, mid);
+      continue;
+    }
+    const uint32_t n_left = h_cnt[KSW_N_BINS];
+    c->ksw_diag[0]++;
+    for (int b = 0; b < KSW_N_BINS; b++) c->ksw_diag[1 + b] += h_cnt[b];
+    c->ksw_diag[5] += n_left; c->ksw_diag[6] = std::max<uint64_t>(c->ksw_diag[6], tape_bytes);
+    if (n_groups_total) {
+      RC(c->ksw_group.ensure((size_t)n_groups_total * 16));
+      RC(c->ksw_tape.ensure((size_t)tape_bytes + 256));
+      A.group_rows = c->ksw_group.as<uint64_t>(); A.group_off = A.group_rows + n_groups_total;
+      A.tape = c->ksw_tape.as<uint8_t>();
+      launch_ksw_plan(st, A);
+      for (int b = 0; b < KSW_N_BINS; b++) launch_ksw_dp(st, A, b);
+    }
+    // what the arrays do not take: targets beyond the widest array, and (never seen outside tests) groups whose tape ran out
+    RC(general(n_left ? n_left : 64, A.leftover, A.counters + KSW_N_BINS));
+    launch_ksw_trace(st, A);
+    // leftovers after the DP (those of the last piece; read by br_ctx_ksw_diag once the stream has been synchronised)
+    HIPCHK(hipMemcpyAsync((uint32_t *)(c->h_totals + 24), A.counters + KSW_N_BINS, 4, hipMemcpyDeviceToHost, st));
+  }
+  return BR_OK;
+}
 
 // The HIP pipeline over a device-resident batch.
 static int run_device_impl(br_ctx *c, const br_config *cfg, const br_device_batch *b, hipStream_t st, br_device_rows *out,
@@ -697,7 +808,7 @@ static int run_device_impl(br_ctx *c, const br_config *cfg, const br_device_batc
     if (n_prob >= 0xffffffffull) return BR_ERR_CAPACITY;
     RC(c->fa_probs.ensure(std::max<size_t>(n_prob, 1) * ksw_prob_bytes()));
     RC(c->fa_results.ensure(std::max<size_t>(n_prob, 1) * ksw_res_bytes()));
-    RC(c->fa_seq_arena.ensure(std::max<size_t>(seq_total, 16)));
+    RC(c->fa_seq_arena.ensure((size_t)seq_total + 1024));   // the streamed DP reads whole dwords past a problem's last base
     RC(c->fa_clip_ops.ensure((std::max<size_t>(seq_total + n_prob, 1)) * 4));
     F.probs = (KswProb *)c->fa_probs.p; F.results = (KswRes *)c->fa_results.p;
     F.seq_arena = c->fa_seq_arena.as<uint8_t>(); F.clip_ops = c->fa_clip_ops.as<uint32_t>();
@@ -705,22 +816,12 @@ static int run_device_impl(br_ctx *c, const br_config *cfg, const br_device_batc
       RC(pf.begin(BR_K_COUNT));
       launch_project_fa(st, A, F, 1, n_blocks);
       RC(pf.end());
-      // ksw2: per-wave scratch = direction matrix + raw traceback ops + (large targets) u/v/x/y
       uint64_t qmax = (uint64_t)std::max(b->max_soft_clip, 0) + std::max(dc.max_clip, dc.max_junc_ins);
-      uint64_t tmax = qmax + 40;
-      KswArgs K{};
-      K.n_prob = (int64_t)n_prob; K.probs = F.probs; K.results = F.results; K.seq_arena = F.seq_arena;
-      K.clip_ops = F.clip_ops; K.tmax = (uint32_t)tmax;
-      K.pmat_bytes = (size_t)(((qmax + tmax) * tmax + 15) & ~15ull);
-      K.raw_words = (size_t)((qmax + tmax + 4 + 3) & ~3ull);
-      K.scratch_per_wave = K.pmat_bytes + K.raw_words * 4 + ((4 * tmax + 15) & ~15ull);
-      const uint64_t budget = 16ull << 30;  // HBM set aside for direction matrices
-      uint64_t waves = std::min<uint64_t>({(uint64_t)c->n_cu * 4 * 4, std::max<uint64_t>(budget / K.scratch_per_wave, 4), (n_prob + 3) / 4 * 4});
-      int kb = (int)std::max<uint64_t>(waves / 4, 1);
-      RC(c->fa_scratch.ensure((size_t)kb * 4 * K.scratch_per_wave));
-      K.scratch = c->fa_scratch.as<uint8_t>(); K.stats = c->fa_stats.as<uint64_t>();
+      KswRun R{};
+      R.n_prob = (int64_t)n_prob; R.probs = F.probs; R.results = F.results; R.seq_arena = F.seq_arena; R.clip_ops = F.clip_ops;
+      R.seq_total = seq_total; R.qmax = qmax; R.tmax = qmax + 40; R.stats = c->fa_stats.as<uint64_t>();
       RC(pf.begin(BR_K_KSW));
-      launch_ksw(st, K, kb);
+      RC(run_ksw(c, st, R));
       RC(pf.end());
       HIPCHK(hipMemcpyAsync(c->h_totals + 8, c->fa_stats.p, 16, hipMemcpyDeviceToHost, st));
     }
@@ -1600,29 +1701,23 @@ extern "C" int br_ctx_ksw_pairs(br_ctx *c, int64_t n, const char *const *tseq, c
     for (size_t k = 0; k < tl; k++) arena.push_back(code(tseq[p][k]));
     qmax = std::max<uint64_t>(qmax, ql); tmaxv = std::max<uint64_t>(tmaxv, tl);
   }
-  DevBuf d_probs, d_res, d_arena, d_ops, d_raw, d_rawn, d_max, d_scratch;
-  auto cleanup = [&]() { d_probs.release(); d_res.release(); d_arena.release(); d_ops.release(); d_raw.release(); d_rawn.release(); d_max.release(); d_scratch.release(); };
+  DevBuf d_probs, d_res, d_arena, d_ops, d_raw, d_rawn, d_max;
+  auto cleanup = [&]() { d_probs.release(); d_res.release(); d_arena.release(); d_ops.release(); d_raw.release(); d_rawn.release(); d_max.release(); };
   int rc = BR_OK;
   struct HRes { int32_t ok, score, refc; uint32_t n_ops; };
   std::vector<HRes> res((size_t)n);
   do {
     if ((rc = d_probs.ensure((size_t)n * sizeof(HProb))) || (rc = d_res.ensure((size_t)n * ksw_res_bytes())) ||
-        (rc = d_arena.ensure(arena.size() + 16)) || (rc = d_ops.ensure((arena.size() + (size_t)n + 1) * 4)) ||
+        (rc = d_arena.ensure(arena.size() + 1024)) || (rc = d_ops.ensure((arena.size() + (size_t)n + 1) * 4)) ||
         (rc = d_raw.ensure((size_t)n * cigar_cap * 4)) || (rc = d_rawn.ensure((size_t)n * 4)) || (rc = d_max.ensure((size_t)n * 4))) break;
-    KswArgs K{};
-    K.n_prob = n; K.probs = (const KswProb *)d_probs.p; K.results = (KswRes *)d_res.p; K.seq_arena = d_arena.as<uint8_t>();
-    K.clip_ops = d_ops.as<uint32_t>(); K.tmax = (uint32_t)std::max<uint64_t>(tmaxv, 1);
-    K.pmat_bytes = (size_t)(((qmax + tmaxv) * std::max<uint64_t>(tmaxv, 1) + 15) & ~15ull);
-    K.raw_words = (size_t)((qmax + tmaxv + 4 + 3) & ~3ull);
-    K.scratch_per_wave = K.pmat_bytes + K.raw_words * 4 + ((4 * tmaxv + 15) & ~15ull);
-    int kb = (int)std::min<int64_t>((n + 3) / 4, (int64_t)c->n_cu * 4);
-    if ((rc = d_scratch.ensure((size_t)kb * 4 * K.scratch_per_wave))) break;
-    K.scratch = d_scratch.as<uint8_t>(); K.stats = nullptr;
-    K.raw_out = d_raw.as<uint32_t>(); K.raw_n = d_rawn.as<uint32_t>(); K.max_out = d_max.as<int32_t>(); K.raw_cap = cigar_cap;
+    KswRun R{};
+    R.n_prob = n; R.probs = (const KswProb *)d_probs.p; R.results = (KswRes *)d_res.p; R.seq_arena = d_arena.as<uint8_t>();
+    R.clip_ops = d_ops.as<uint32_t>(); R.seq_total = arena.size(); R.qmax = qmax; R.tmax = tmaxv; R.stats = nullptr;
+    R.raw_out = d_raw.as<uint32_t>(); R.raw_n = d_rawn.as<uint32_t>(); R.max_out = d_max.as<int32_t>(); R.raw_cap = cigar_cap;
     if (hipMemsetAsync(d_max.p, 0, (size_t)n * 4, st) != hipSuccess || hipMemsetAsync(d_rawn.p, 0, (size_t)n * 4, st) != hipSuccess ||
         hipMemcpyAsync(d_probs.p, probs.data(), (size_t)n * sizeof(HProb), hipMemcpyHostToDevice, st) != hipSuccess ||
         hipMemcpyAsync(d_arena.p, arena.data(), arena.size(), hipMemcpyHostToDevice, st) != hipSuccess) { rc = BR_ERR_HIP; break; }
-    launch_ksw(st, K, kb);
+    if ((rc = run_ksw(c, st, R))) break;
     if (hipMemcpyAsync(res.data(), d_res.p, (size_t)n * sizeof(HRes), hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipMemcpyAsync(max, d_max.p, (size_t)n * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipMemcpyAsync(n_cigar, d_rawn.p, (size_t)n * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||

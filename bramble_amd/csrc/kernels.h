@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "device_types.h"
+#include "ksw_types.h"
 
 namespace br {
 
@@ -39,8 +40,6 @@ struct ProjectArgs {
   uint32_t *cig_arena;
 };
 
-struct KswProb;
-struct KswRes;
 
 // -S clip rescue (rescue_kernels.inc)
 struct FaArgs {
@@ -69,6 +68,28 @@ struct KswArgs {
   uint32_t tmax;
   uint64_t *stats;  // [2] DP cells, accepted rescues (may be null)
   // diagnostic (br_ctx_ksw_pairs): the raw traceback CIGAR (forward order) and the maximum of every problem; null otherwise
+  uint32_t *raw_out, *raw_n; int32_t *max_out; uint32_t raw_cap;
+  // when set: only the problems list[0 .. *n_list) (the ones the streamed DP leaves to this kernel)
+  const uint32_t *list; const uint32_t *n_list;
+};
+
+// The streamed DP over one range of problems [p0, p0 + n): k_ksw_bin -> k_ksw_plan -> k_ksw_group_scan -> k_ksw_dp<G,K> per
+// bin -> k_ksw (the listed leftovers) -> k_ksw_trace.  counters: [0..3] problems per bin, [4] leftovers, [5] groups
+// (scan total, unused), u64 view [4..7] tape rows per bin.
+struct KswFastArgs {
+  int64_t p0, n;
+  const KswProb *probs;
+  KswRes *results;
+  const uint8_t *seq_arena;
+  uint32_t *clip_ops, *raw_ops;
+  KswDesc *desc[KSW_N_BINS];       // [n] each
+  uint32_t *counters;
+  uint32_t *leftover;              // [n] problem indices for k_ksw
+  KswDp *dp;                       // [n], indexed by p - p0
+  uint64_t *group_rows, *group_off;  // per group (all bins, bin b's groups from group_base[b]): tape rows / byte offset
+  uint8_t *tape;
+  uint32_t n_bin[KSW_N_BINS], n_groups[KSW_N_BINS], group_base[KSW_N_BINS];
+  uint64_t *stats;
   uint32_t *raw_out, *raw_n; int32_t *max_out; uint32_t raw_cap;
 };
 
@@ -271,6 +292,10 @@ void launch_segment(hipStream_t st, int64_t n_aln, const int32_t *ref_id, const 
 void launch_project(hipStream_t st, const ProjectArgs &A, bool emit, int group_lanes, int n_blocks, int part = 0);
 void launch_project_fa(hipStream_t st, const ProjectArgs &A, const FaArgs &F, int mode, int n_blocks);
 void launch_ksw(hipStream_t st, const KswArgs &K, int n_blocks);
+void launch_ksw_bin(hipStream_t st, const KswFastArgs &A);
+void launch_ksw_plan(hipStream_t st, const KswFastArgs &A);       // group rows + the scan of their byte sizes
+void launch_ksw_dp(hipStream_t st, const KswFastArgs &A, int bin);
+void launch_ksw_trace(hipStream_t st, const KswFastArgs &A);
 size_t ksw_prob_bytes();
 size_t ksw_res_bytes();
 void launch_expand(hipStream_t st, const ProjectArgs &A);

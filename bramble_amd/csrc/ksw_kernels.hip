@@ -1,0 +1,615 @@
+// ksw_extz2 for the -S soft-clip rescue (rows a9 / a10 of SURVEY.md 8a) on gfx950.
+//
+//   subprojects/packagefiles/ksw2/ksw2_extz2_sse.cpp:37-318 (anti-diagonal u/v/x/y difference recurrence, approximate
+//   maximum, z-drop), ksw2.h ksw_backtrack, src/evaluate.cpp:284-317,397-448,548-598 (acceptance, clip segment).
+//   Scores as src/evaluate.cpp:296-313: match 1, mismatch -4, N -1, gap open 4, extend 1, z-drop 40, full band,
+//   EXTZ_ONLY | APPROX_MAX | APPROX_DROP.
+//
+// k_ksw_dp<G,K>: a systolic array in registers.  A group of G lanes owns G*K target columns (K consecutive columns per
+// lane, two 16-bit cells per VGPR, packed-16 arithmetic); the query streams through the columns one column per step, so
+// that column c holds cell (r, c) of anti-diagonal r with query base r - c.  A cell needs x, v of column c-1 from the
+// step before (one wave_shr DPP move per stream and lane, v_alignbit inside the lane) and its own u, y: no LDS, no
+// loads in the recurrence.  Problems follow each other through the array back to back: while problem A's band leaves
+// the low columns, problem B's first anti-diagonals already use them, which removes the two idle triangles of an
+// anti-diagonal sweep.  The first base of a problem carries a flag; a column that sees it resets its u / y and takes
+// the next problem's target base.  Values are kept x4 with a 2-bit tag in the low bits (match 2 > deletion 1 >
+// insertion 0), so that one packed max gives the winner and ksw2's tie order at once.  Per step every lane stores the
+// 4-bit directions of its K columns as one dword of a per-group tape (row = step); k_ksw_trace walks the tape with one
+// lane per problem.  The approximate-maximum / z-drop bookkeeping (one scalar chain per problem in ksw2) runs in the
+// lanes of the group, one problem per lane, on the u / v values the columns publish to LDS.
+// k_ksw: the general kernel (any size; one wave per problem, state in LDS / HBM) for what does not fit the arrays.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_types.h"
+#include "kernels.h"
+
+namespace br {
+
+#define KSW_NEG_INF (-0x40000000)
+
+// ---------------------------------------------------------------------------
+// traceback + clip segment, shared by k_ksw and k_ksw_trace
+// ---------------------------------------------------------------------------
+struct RawSink {
+  uint32_t *raw; uint32_t n;
+  __device__ __forceinline__ void push(uint32_t op, int len) {
+    if (n == 0 || op != (raw[n - 1] & 0xf)) raw[n++] = ((uint32_t)len << 4) | op;
+    else raw[n - 1] += (uint32_t)len << 4;
+  }
+};
+
+// raw[] = the forward CIGAR reversed (forward op k = raw[n-1-k]); build_left/right_clip_segment (src/evaluate.cpp:397-448,548-598)
+__device__ __forceinline__ KswRes clip_segment(const uint32_t *raw, uint32_t n, const KswProb &pr, int ez_max, uint32_t *dst) {
+  int query_consumed = 0, ref_consumed = 0;
+  for (uint32_t k = 0; k < n; k++) {
+    uint32_t op = raw[k] & 0xf, len = raw[k] >> 4;
+    if (op == 0 || op == 1) query_consumed += (int)len;
+    if (op == 0 || op == 2) ref_consumed += (int)len;
+  }
+  int rest = (int)pr.qlen - query_consumed;  // unaligned remainder -> CLIP_OVERRIDE
+  uint32_t m = 0;
+  auto add = [&](uint32_t len, uint32_t op) {
+    if (m && (dst[m - 1] & 0xf) == op) dst[m - 1] = (((dst[m - 1] >> 4) + len) << 4) | op;
+    else dst[m++] = (len << 4) | op;
+  };
+  auto emit = [&](uint32_t wv, bool outermost) {
+    uint32_t op = wv & 0xf, len = wv >> 4;  // 0 M, 1 I, 2 D
+    if (outermost && op == 2) return;
+    if (outermost && op == 1) { add(len, OP_CLIP_OVR); return; }
+    add(len, op == 2 ? OP_DEL_OVR : op == 1 ? OP_INS_OVR : OP_MATCH_OVR);
+  };
+  if (pr.side == 0) {
+    // left: sequences were reversed, so walk the forward CIGAR backwards (= raw order)
+    if (rest > 0) add((uint32_t)rest, OP_CLIP_OVR);
+    for (uint32_t k = 0; k < n; k++) emit(raw[k], k == 0);
+  } else {
+    for (uint32_t k = 0; k < n; k++) emit(raw[n - 1 - k], k == n - 1);
+    if (rest > 0) add((uint32_t)rest, OP_CLIP_OVR);
+  }
+  KswRes rs; rs.ok = 1; rs.score = ez_max; rs.refc = ref_consumed; rs.n_ops = m;
+  return rs;
+}
+
+// ---------------------------------------------------------------------------
+// k_ksw: one wave per rescue problem, grid-stride.  Per-wave HBM scratch: direction matrix
+// p[(qlen+tlen-1) x tlen], raw traceback ops.
+// ---------------------------------------------------------------------------
+#define KSW_LDS_T 2048  // u/v/x/y live in LDS up to this target length, else in HBM scratch
+
+__global__ void __launch_bounds__(256) k_ksw(KswArgs K) {
+  __shared__ uint32_t sh_uvxy[4][KSW_LDS_T];   // u | v << 8 | x << 16 | y << 24 per target position: one LDS word per cell
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t waves_total = (int64_t)gridDim.x * 4;
+  const int64_t wid = (int64_t)blockIdx.x * 4 + w;
+  uint8_t *pmat = K.scratch + (size_t)wid * K.scratch_per_wave;
+  uint32_t *raw = (uint32_t *)(pmat + K.pmat_bytes);
+  uint32_t *gl_uvxy = (uint32_t *)(raw + K.raw_words);
+  const int8_t q = 4, e = 1; const int qe = 5; const int8_t qe2 = 10;
+  const int8_t sc_mch = 1, sc_mis = -4, sc_N = -1, max_sc_v = 11;
+  const int zdrop = 40;
+  unsigned long long cells = 0, rescued = 0;
+  const int64_t n_work = K.list ? (int64_t)*K.n_list : K.n_prob;
+
+  for (int64_t pi = wid; pi < n_work; pi += waves_total) {
+    const int64_t p = K.list ? (int64_t)K.list[pi] : pi;
+    KswProb pr = K.probs[p];
+    int qlen = (int)pr.qlen, tlen = (int)pr.tlen;
+    const uint8_t *query = K.seq_arena + pr.seq_off, *target = query + qlen;
+    KswRes rs; rs.ok = 0; rs.score = 0; rs.refc = 0; rs.n_ops = 0;
+    if (qlen <= 0 || tlen <= 0) { if (lane == 0) K.results[p] = rs; continue; }
+    cells += (unsigned long long)qlen * (unsigned long long)tlen;
+    uint32_t *cell = tlen <= KSW_LDS_T ? &sh_uvxy[w][0] : gl_uvxy;
+    auto U = [](uint32_t c) { return (int8_t)c; };
+    auto V = [](uint32_t c) { return (int8_t)(c >> 8); };
+    auto X = [](uint32_t c) { return (int8_t)(c >> 16); };
+    auto Y = [](uint32_t c) { return (int8_t)(c >> 24); };
+    auto PACK = [](int8_t u8, int8_t v8, int8_t x8, int8_t y8) {
+      return (uint32_t)(uint8_t)u8 | ((uint32_t)(uint8_t)v8 << 8) | ((uint32_t)(uint8_t)x8 << 16) | ((uint32_t)(uint8_t)y8 << 24);
+    };
+    for (int t = lane; t < tlen; t += 64) cell[t] = 0;
+    __builtin_amdgcn_wave_barrier();
+    int32_t ez_max = 0, ez_max_t = -1, ez_max_q = -1, ez_score = KSW_NEG_INF; bool zdropped = false;
+    int32_t H0 = 0, last_H0_t = 0;
+    int last_st = -1, last_en = -1;
+    int n_rows = qlen + tlen - 1;
+    for (int r = 0; r < n_rows; ++r) {
+      int st0 = r - qlen + 1 > 0 ? r - qlen + 1 : 0;
+      int en0 = r < tlen - 1 ? r : tlen - 1;
+      if (tlen > KSW_LDS_T) __threadfence_block();  // cells of the previous row were written by other lanes
+      if (en0 >= r && lane == 0) { uint32_t c0 = cell[r]; cell[r] = PACK(r ? q : 0, V(c0), X(c0), 0); }
+      if (tlen > KSW_LDS_T) __threadfence_block();
+      __builtin_amdgcn_wave_barrier();
+      int8_t cx, cv;  // x[r-1][t-1], v[r-1][t-1] for the first cell of the next chunk
+      if (st0 > 0) { if (st0 - 1 >= last_st && st0 - 1 <= last_en) { uint32_t c1 = cell[st0 - 1]; cx = X(c1); cv = V(c1); } else { cx = 0; cv = 0; } }
+      else { cx = 0; cv = r ? q : 0; }
+      uint8_t *prow = pmat + (size_t)r * (size_t)tlen;
+      for (int c = st0; c <= en0; c += 64) {
+        int t = c + lane;
+        bool act = t <= en0;
+        int8_t ox = 0, ov = 0, ut = 0, yt = 0;
+        if (act) { uint32_t cw = cell[t]; ox = X(cw); ov = V(cw); ut = U(cw); yt = Y(cw); }
+        int8_t xt1 = (int8_t)__shfl_up((int)ox, 1, 64), vt1 = (int8_t)__shfl_up((int)ov, 1, 64);
+        if (lane == 0) { xt1 = cx; vt1 = cv; }
+        cx = (int8_t)__shfl((int)ox, 63, 64); cv = (int8_t)__shfl((int)ov, 63, 64);
+        if (act) {
+          uint8_t sq = target[t], sqr = query[r - t];
+          int8_t sc = (sq == 4 || sqr == 4) ? sc_N : (sq == sqr ? sc_mch : sc_mis);
+          int8_t z = (int8_t)(sc + qe2);
+          int8_t a = (int8_t)(xt1 + vt1);
+          int8_t b = (int8_t)(yt + ut);
+          uint8_t d = (a > z) ? 1 : 0;
+          z = z > a ? z : a;
+          if (b > z) d = 2;
+          z = (int8_t)((uint8_t)z > (uint8_t)b ? (uint8_t)z : (uint8_t)b);
+          z = (int8_t)((uint8_t)z < (uint8_t)max_sc_v ? (uint8_t)z : (uint8_t)max_sc_v);
+          int8_t nu = (int8_t)(z - vt1), nv = (int8_t)(z - ut), nx = 0, ny = 0;
+          z = (int8_t)(z - q);
+          a = (int8_t)(a - z);
+          b = (int8_t)(b - z);
+          if (a > 0) { nx = a; d |= 0x08; }
+          if (b > 0) { ny = b; d |= 0x10; }
+          cell[t] = PACK(nu, nv, nx, ny);
+          prow[t] = d;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      // approximate max + z-drop (wave-uniform: every lane reads the same cells)
+      if (tlen > KSW_LDS_T) __threadfence_block();
+      bool stop = false;
+      if (r > 0) {
+        if (last_H0_t >= st0 && last_H0_t <= en0 && last_H0_t + 1 >= st0 && last_H0_t + 1 <= en0) {
+          int32_t d0 = (int32_t)(uint8_t)V(cell[last_H0_t]) - qe, d1 = (int32_t)(uint8_t)U(cell[last_H0_t + 1]) - qe;
+          if (d0 > d1) H0 += d0; else { H0 += d1; ++last_H0_t; }
+        } else if (last_H0_t >= st0 && last_H0_t <= en0) {
+          H0 += (int32_t)(uint8_t)V(cell[last_H0_t]) - qe;
+        } else {
+          ++last_H0_t; H0 += (int32_t)(uint8_t)U(cell[last_H0_t]) - qe;
+        }
+        // ksw_apply_zdrop (rotated form)
+        int tt = last_H0_t;
+        if (H0 > ez_max) { ez_max = H0; ez_max_t = tt; ez_max_q = r - tt; }
+        else if (tt >= ez_max_t && r - tt >= ez_max_q) {
+          int tl = tt - ez_max_t, ql = (r - tt) - ez_max_q, l = tl > ql ? tl - ql : ql - tl;
+          if (zdrop >= 0 && ez_max - H0 > zdrop + l * e) { zdropped = true; stop = true; }
+        }
+      } else { H0 = (int32_t)(uint8_t)V(cell[0]) - qe - qe; last_H0_t = 0; }
+      if (stop) break;
+      if (r == qlen + tlen - 2 && en0 == tlen - 1) ez_score = H0;
+      last_st = st0; last_en = en0;
+    }
+    (void)zdropped;
+    // acceptance: max >= 10 and the DP reached the last cell (src/evaluate.cpp:484,643)
+    if (K.max_out && lane == 0) { K.max_out[p] = ez_max; K.raw_n[p] = 0; }
+    if (ez_max < 10 || ez_score == KSW_NEG_INF || ez_max_t < 0 || ez_max_q < 0) { if (lane == 0) K.results[p] = rs; continue; }
+    __threadfence_block();
+    if (lane == 0) {
+      // ksw_backtrack (is_rot): ops pushed from the end to the start into raw[]
+      int i = ez_max_t, j = ez_max_q, state = 0;
+      RawSink sk{raw, 0};
+      while (i >= 0 && j >= 0) {
+        int r = i + j;
+        uint32_t tmp = pmat[(size_t)r * (size_t)tlen + (size_t)i];
+        if (state == 0) state = tmp & 7;
+        else if (!(tmp >> (state + 2) & 1)) state = 0;
+        if (state == 0) state = tmp & 7;
+        if (state == 0) { sk.push(0, 1); --i; --j; }
+        else if (state == 1 || state == 3) { sk.push(2, 1); --i; }
+        else { sk.push(1, 1); --j; }
+      }
+      if (i >= 0) sk.push(2, i + 1);
+      if (j >= 0) sk.push(1, j + 1);
+      uint32_t n = sk.n;
+      if (K.raw_out) { K.raw_n[p] = n; for (uint32_t k = 0; k < n && k < K.raw_cap; k++) K.raw_out[(size_t)p * K.raw_cap + k] = raw[n - 1 - k]; }
+      K.results[p] = clip_segment(raw, n, pr, ez_max, K.clip_ops + (pr.seq_off + (uint64_t)p));
+      rescued++;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (lane == 0 && K.stats) {
+    atomicAdd((unsigned long long *)&K.stats[0], cells);     // DP cells (qlen x tlen summed)
+    atomicAdd((unsigned long long *)&K.stats[1], rescued);   // accepted rescues
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_ksw_bin: one lane per problem: its array shape (by target length), a slot in that bin's descriptor array,
+// the bin's tape rows.  Degenerate problems get their (empty) result here.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int ksw_bin_of(uint32_t qlen, uint32_t tlen) {
+  if (qlen > 0xffffu) return KSW_N_BINS;
+  if (tlen <= (uint32_t)KSW_BIN_W(0)) return 0;
+  if (tlen <= (uint32_t)KSW_BIN_W(1)) return 1;
+  if (tlen <= (uint32_t)KSW_BIN_W(2)) return 2;
+  if (tlen <= (uint32_t)KSW_BIN_W(3)) return 3;
+  return KSW_N_BINS;
+}
+
+// rows a problem occupies on its group's tape: its query bases, at least K steps between two first bases
+__device__ __forceinline__ uint32_t ksw_rows_of(uint32_t qlen, int K) { return (qlen > (uint32_t)K ? qlen : (uint32_t)K) + 1u; }
+
+__global__ void __launch_bounds__(256) k_ksw_bin(KswFastArgs A) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  int bin = -1; KswProb pr; pr.qlen = pr.tlen = pr.side = pr.pad = 0; pr.seq_off = 0;
+  if (i < A.n) {
+    pr = A.probs[A.p0 + i];
+    KswDp d; d.max = 0; d.max_t = d.max_q = -1; d.flags = 0; d.tape = 0;
+    A.dp[i] = d;
+    if (pr.qlen == 0 || pr.tlen == 0) {
+      KswRes rs; rs.ok = 0; rs.score = 0; rs.refc = 0; rs.n_ops = 0;
+      A.results[A.p0 + i] = rs;
+      if (A.max_out) { A.max_out[A.p0 + i] = 0; A.raw_n[A.p0 + i] = 0; }
+    } else bin = ksw_bin_of(pr.qlen, pr.tlen);
+  }
+#pragma unroll
+  for (int b = 0; b <= KSW_N_BINS; b++) {
+    uint64_t m = __ballot(bin == b);
+    if (!m) continue;
+    uint32_t base = 0;
+    const int leader = __ffsll((unsigned long long)m) - 1;
+    if (lane == leader) base = atomicAdd(&A.counters[b], (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, leader, 64);
+    if (bin == b) {
+      uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      if (b < KSW_N_BINS) { KswDesc d; d.qt = pr.qlen | (pr.tlen << 16); d.prob = (uint32_t)(A.p0 + i); d.seq_off = pr.seq_off; A.desc[b][pos] = d; }
+      else A.leftover[pos] = (uint32_t)(A.p0 + i);
+    }
+  }
+  // tape rows of every bin (the host sizes the tape from them)
+  unsigned long long *rows64 = (unsigned long long *)(A.counters + 8);
+#pragma unroll
+  for (int b = 0; b < KSW_N_BINS; b++) {
+    unsigned long long rws = bin == b ? (unsigned long long)ksw_rows_of(pr.qlen, KSW_BIN_K(b)) : 0ull;
+    for (int d = 32; d >= 1; d >>= 1) rws += (unsigned long long)__shfl_xor((long long)rws, d, 64);
+    if (lane == 0 && rws) atomicAdd(&rows64[b], rws);
+  }
+}
+
+// k_ksw_plan: one lane per group (all bins): the tape rows of the group's problems (group g of a bin with NG groups
+// takes problems g, g + NG, g + 2 NG, ...).
+__global__ void __launch_bounds__(256) k_ksw_plan(KswFastArgs A, uint32_t n_groups_total) {
+  const uint32_t gg = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gg >= n_groups_total) return;
+  int b = 0;
+#pragma unroll
+  for (int k = 1; k < KSW_N_BINS; k++) if (gg >= A.group_base[k]) b = k;
+  const uint32_t g = gg - A.group_base[b], NG = A.n_groups[b], n = A.n_bin[b];
+  const int K = KSW_BIN_K(b);
+  uint64_t rows = 0;
+  for (uint32_t k = g; k < n; k += NG) rows += ksw_rows_of(A.desc[b][k].qt & 0xffffu, K);
+  rows += (uint64_t)KSW_BIN_W(b) + KSW_TAIL_ROWS;
+  A.group_rows[gg] = rows;
+  A.group_off[gg] = rows * (uint64_t)KSW_BIN_ROWBYTES(b);
+}
+
+// exclusive scan of group_off in place, one block
+__global__ void __launch_bounds__(1024) k_ksw_group_scan(uint64_t *v, uint32_t n) {
+  __shared__ uint64_t sh[1024];
+  const uint32_t per = (n + 1023u) / 1024u, lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+  uint64_t s = 0;
+  for (uint32_t i = lo; i < hi; i++) s += v[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    uint64_t y = threadIdx.x >= (uint32_t)d ? sh[threadIdx.x - d] : 0;
+    __syncthreads();
+    sh[threadIdx.x] += y;
+    __syncthreads();
+  }
+  uint64_t run = sh[threadIdx.x] - s;
+  for (uint32_t i = lo; i < hi; i++) { uint64_t x = v[i]; v[i] = run; run += x; }
+}
+
+// ---------------------------------------------------------------------------
+// k_ksw_dp
+// ---------------------------------------------------------------------------
+typedef short ksw_s2 __attribute__((ext_vector_type(2)));
+typedef unsigned short ksw_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(ksw_s2, a) + __builtin_bit_cast(ksw_s2, b)); }
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(ksw_s2, a) - __builtin_bit_cast(ksw_s2, b)); }
+__device__ __forceinline__ uint32_t pk_max_i(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(ksw_s2, a), __builtin_bit_cast(ksw_s2, b))); }
+__device__ __forceinline__ uint32_t pk_min_u(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(ksw_u2, a), __builtin_bit_cast(ksw_u2, b))); }
+__device__ __forceinline__ uint32_t pk_sign(uint32_t a) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(ksw_s2, a) >> (ksw_s2)(15)); }
+__device__ __forceinline__ uint32_t bfi32(uint32_t m, uint32_t a, uint32_t b) { return (m & a) | (~m & b); }
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xf, 0xf, false); }
+
+// lanes of one wave exchange data through LDS: program order is enough for the hardware, the fence keeps the compiler from
+// moving the accesses
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
+// scaled constants (values x4, tag in the low two bits)
+#define KSW4_Q 0x00100010u       // gap open 4
+#define KSW4_ZMAX 0x002c002cu    // max_sc_v 11
+#define KSW4_ZN 0x00260026u      // N against anything: (-1 + 10) * 4 + tag 2
+#define KSW_LUT_LO 0x1a1a1a2eu   // t ^ q = 0: match (1 + 10) * 4 + 2 = 46; 1..3: mismatch (-4 + 10) * 4 + 2 = 26
+#define KSW_LUT_HI 0x26262626u   // 4..7: the query base is N
+
+struct KswDpArgs {
+  const KswDesc *desc; uint32_t n, n_groups;
+  const uint64_t *group_rows, *group_off;   // already offset to the bin's first group
+  uint8_t *tape; const uint8_t *seq_arena;
+  KswDp *dp; int64_t p0;
+  uint32_t *leftover, *n_leftover;
+  uint32_t bin;
+};
+
+template <int G, int K>
+__global__ void __launch_bounds__(256) k_ksw_dp(KswDpArgs A) {
+  constexpr int P = K / 2, W = G * K, GPW = 64 / G;
+  __shared__ uint32_t sh_pub[4][2][64 * P];     // [wave][v | u][column pair]: what the columns hold after the step
+  __shared__ uint32_t sh_mb[4][64];             // per bookkeeping lane: 0 = free, else first step of its problem + 1
+  __shared__ uint32_t sh_cx[4][GPW];            // per group: sequence number + 1 of a problem that z-dropped
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int gl = lane & (G - 1), grp = lane / G;
+  const uint32_t g = ((uint32_t)blockIdx.x * 4u + (uint32_t)w) * GPW + (uint32_t)grp;
+  const uint32_t NG = A.n_groups;
+  const uint32_t cnt = (g < NG && A.n > g) ? (A.n - g + NG - 1u) / NG : 0u;   // problems of this group: g, g + NG, ...
+  const uint32_t rows_alloc = g < NG ? (uint32_t)A.group_rows[g] : 0u;
+  uint8_t *tape_g = A.tape + (g < NG ? A.group_off[g] : 0ull) + (size_t)gl * 4u;
+  const uint64_t tape_off_g = g < NG ? A.group_off[g] : 0ull;
+  const uint32_t c0 = (uint32_t)gl * K;
+  auto load_desc = [&](uint32_t k) { KswDesc d; d.qt = 0; d.prob = 0; d.seq_off = 0; if (k < cnt) d = A.desc[g + k * NG]; return d; };
+  auto load8 = [&](uint64_t off) { uint2 v; __builtin_memcpy(&v, A.seq_arena + off, 8); return v; };
+
+  sh_mb[w][lane] = 0;
+  if (gl == 0) sh_cx[w][grp] = 0;
+  wave_sync();
+
+  // ---- column state: pair p = columns c0 + 2p (low half), c0 + 2p + 1 (high half)
+  uint32_t U[P], Y[P], V[P], S[P], Q[P], T[P], TN[P], TX[P], TNX[P];
+  uint32_t initu0 = (gl == 0) ? 0x00100000u : KSW4_Q;     // u of a problem's diagonal cell: q, 0 in column 0
+#pragma unroll
+  for (int p = 0; p < P; p++) { U[p] = Y[p] = V[p] = Q[p] = 0; S[p] = 0x00010001u; T[p] = TX[p] = 0x0c000c00u; TN[p] = TNX[p] = 0; }
+  auto make_t = [&](uint2 raw, uint32_t *t, uint32_t *tn) {
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+      const int j0 = 2 * p, j1 = 2 * p + 1;
+      const uint32_t b0 = ((j0 < 4 ? raw.x : raw.y) >> (8 * (j0 & 3))) & 7u, b1 = ((j1 < 4 ? raw.x : raw.y) >> (8 * (j1 & 3))) & 7u;
+      t[p] = 0x0c000c00u | b0 | (b1 << 16);
+      tn[p] = (b0 == 4u ? 0xffffu : 0u) | (b1 == 4u ? 0xffff0000u : 0u);
+    }
+  };
+  // the target bases of the problems to come: TX = next first base to arrive (problem kl), txx = the one after, dd = the
+  // descriptor after that (its target is fetched when txx moves up)
+  uint32_t kl = 0;
+  uint2 txx = make_uint2(0, 0);
+  KswDesc dd;
+  {
+    KswDesc d0 = load_desc(0), d1 = load_desc(1);
+    dd = load_desc(2);
+    if (cnt > 0) make_t(load8(d0.seq_off + (d0.qt & 0xffffu) + c0), TX, TNX);
+    if (cnt > 1) txx = load8(d1.seq_off + (d1.qt & 0xffffu) + c0);
+  }
+  // ---- feeder (lane 0 of the group)
+  int32_t fk = -1; uint32_t fi = 0, fq = 0, fgap = K;
+  uint64_t fbuf = 0, fnext = 0, fqn = 0, fqoff = 0;
+  KswDesc fdn, fdn2;
+  fdn.qt = fdn2.qt = 0; fdn.prob = fdn2.prob = 0; fdn.seq_off = fdn2.seq_off = 0;
+  if (gl == 0) {
+    fdn = load_desc(0); fdn2 = load_desc(1);
+    if (cnt > 0) { uint2 v = load8(fdn.seq_off); fqn = (uint64_t)v.x | ((uint64_t)v.y << 32); }
+  }
+  // ---- bookkeeping lane: problems gl, gl + G, ... of the group
+  uint32_t tk = (uint32_t)gl; KswDesc td = load_desc(tk);
+  bool tr_on = false; int32_t tS = 0, tq = 0, tt = 0, H0 = 0, lastT = 0, emax = 0, emax_t = -1, emax_q = -1;
+  const uint16_t *pubV = (const uint16_t *)&sh_pub[w][0][0] + grp * W, *pubU = (const uint16_t *)&sh_pub[w][1][0] + grp * W;
+
+  for (uint32_t s = 0;; s++) {
+    // the tape of a group holds rows_alloc steps; a group that would run past it (a queue of very short problems
+    // waiting for bookkeeping lanes) hands what it has not finished to k_ksw
+    if (s >= rows_alloc) {
+      if (tr_on) { A.leftover[atomicAdd(A.n_leftover, 1u)] = td.prob; tr_on = false; }
+      if (gl == 0) { for (uint32_t k = (uint32_t)(fk + 1); k < cnt; k++) A.leftover[atomicAdd(A.n_leftover, 1u)] = A.desc[g + k * NG].prob; fk = (int32_t)cnt; fi = fq = 0; }
+    }
+    bool busy = tr_on || (gl == 0 && (uint32_t)(fk + 1) < cnt);
+    if (!__any(busy)) break;
+
+    // ---- feeder: the base that enters column 0 now
+    uint32_t qin = 0, vin = 0;
+    if (gl == 0 && s < rows_alloc) {
+      bool feeding = fk >= 0 && fi < fq && sh_cx[w][grp] != (uint32_t)(fk + 1);
+      if (!feeding && (uint32_t)(fk + 1) < cnt && fgap >= (uint32_t)K && sh_mb[w][grp * G + ((uint32_t)(fk + 1) & (G - 1))] == 0) {
+        fk++;
+        fq = fdn.qt & 0xffffu; fi = 0; fqoff = fdn.seq_off; fbuf = fqn;
+        { uint2 v = load8(fqoff + 8); fnext = (uint64_t)v.x | ((uint64_t)v.y << 32); }
+        fdn = fdn2;
+        if ((uint32_t)(fk + 1) < cnt) { uint2 v = load8(fdn.seq_off); fqn = (uint64_t)v.x | ((uint64_t)v.y << 32); }
+        fdn2 = load_desc((uint32_t)(fk + 2));
+        sh_mb[w][grp * G + ((uint32_t)fk & (G - 1))] = s + 1u;
+        feeding = true; fgap = 0;
+      }
+      if (feeding) {
+        uint32_t ch = (uint32_t)(fbuf >> (8u * (fi & 7u))) & 7u;
+        qin = ch | (fi == 0 ? 0x8000u : 0u); vin = fi ? 16u : 0u;
+        fi++;
+        if ((fi & 7u) == 0) { fbuf = fnext; uint2 v = load8(fqoff + fi + 8); fnext = (uint64_t)v.x | ((uint64_t)v.y << 32); }
+      }
+      fgap++;
+    }
+    wave_sync();
+
+    // ---- the three streams move one column
+    uint32_t qp = wave_shr1(Q[P - 1]), vp = wave_shr1(V[P - 1]), sp = wave_shr1(S[P - 1]);
+    if (gl == 0) { qp = qin << 16; vp = vin << 16; sp = (vin + 1u) << 16; }
+    uint32_t Qn[P], V1[P], S1[P];
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+      Qn[p] = __builtin_amdgcn_alignbit(Q[p], p ? Q[p - 1] : qp, 16);
+      V1[p] = __builtin_amdgcn_alignbit(V[p], p ? V[p - 1] : vp, 16);
+      S1[p] = __builtin_amdgcn_alignbit(S[p], p ? S[p - 1] : sp, 16);
+    }
+    // ---- cells
+    uint32_t D[P];
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+      const uint32_t fm = pk_sign(Qn[p]);                       // first base of a problem: new target base, u = q, y = 0
+      T[p] = bfi32(fm, TX[p], T[p]); TN[p] = bfi32(fm, TNX[p], TN[p]);
+      const uint32_t ue = bfi32(fm, p == 0 ? initu0 : KSW4_Q, U[p]), ye = Y[p] & ~fm;
+      uint32_t z = __builtin_amdgcn_perm(KSW_LUT_HI, KSW_LUT_LO, T[p] ^ Qn[p]) & 0x00ff00ffu;
+      z = bfi32(TN[p], KSW4_ZN, z);
+      const uint32_t a = S1[p], b = pk_add(ye, ue);
+      const uint32_t wv = pk_max_i(pk_max_i(z, a), b);          // tags: ties go to match, then deletion
+      const uint32_t zc = pk_min_u(wv & 0xfffcfffcu, KSW4_ZMAX);
+      const uint32_t nv = pk_sub(zc, ue);
+      U[p] = pk_sub(zc, V1[p]);
+      const uint32_t zq = pk_sub(zc, KSW4_Q);
+      const uint32_t xt = pk_max_i(pk_sub(a, zq), 0x00010001u);  // x * 4 + 1: the deletion tag of the next column's a
+      const uint32_t yn = pk_max_i(pk_sub(b, zq), 0u);
+      V[p] = nv; Y[p] = yn; S[p] = pk_add(xt, nv);
+      // direction nibble: winner tag | x continues << 2 | y continues << 3
+      uint32_t d = (pk_min_u(xt, 0x00050005u) & 0x00040004u) | (wv & 0x00030003u);
+      D[p] = (pk_min_u(yn, 0x00040004u) << 1) | d;
+      Q[p] = Qn[p];
+    }
+    uint32_t word = D[0];
+#pragma unroll
+    for (int p = 1; p < P; p++) word |= D[p] << (4 * p);
+    if (s < rows_alloc) *(uint32_t *)(tape_g + (size_t)s * (G * 4u)) = word;
+
+    // ---- a first base leaves the lane: the next problem's target moves up
+    if (Qn[P - 1] >> 31) {
+      make_t(txx, TX, TNX);
+      kl++;
+      if (kl + 1 < cnt) txx = load8(dd.seq_off + (dd.qt & 0xffffu) + c0);
+      dd = load_desc(kl + 2);
+    }
+
+    // ---- publish v, u; approximate maximum and z-drop of the problems in flight
+#pragma unroll
+    for (int p = 0; p < P; p++) { sh_pub[w][0][lane * P + p] = V[p]; sh_pub[w][1][lane * P + p] = U[p]; }
+    wave_sync();
+    if (!tr_on) {
+      uint32_t mb = sh_mb[w][lane];
+      if (mb) { tr_on = true; tS = (int32_t)(mb - 1u); tq = (int32_t)(td.qt & 0xffffu); tt = (int32_t)(td.qt >> 16); H0 = 0; lastT = 0; emax = 0; emax_t = emax_q = -1; }
+    }
+    if (tr_on) {
+      const int r = (int32_t)s - tS;
+      const int st0 = r - tq + 1 > 0 ? r - tq + 1 : 0, en0 = r < tt - 1 ? r : tt - 1;
+      bool stop = false;
+      if (r == 0) { H0 = (int32_t)(pubV[0] >> 2) - 10; lastT = 0; }
+      else {
+        const bool in0 = lastT >= st0 && lastT <= en0, in1 = lastT + 1 >= st0 && lastT + 1 <= en0;
+        const int t1 = lastT + 1 < W ? lastT + 1 : W - 1;
+        const int32_t d0 = (int32_t)(pubV[lastT] >> 2) - 5, d1 = (int32_t)(pubU[t1] >> 2) - 5;
+        if (in0 && in1) { if (d0 > d1) H0 += d0; else { H0 += d1; ++lastT; } }
+        else if (in0) H0 += d0;
+        else { ++lastT; H0 += d1; }
+        const int tc = lastT;
+        if (H0 > emax) { emax = H0; emax_t = tc; emax_q = r - tc; }
+        else if (tc >= emax_t && r - tc >= emax_q) {
+          int tl = tc - emax_t, ql = (r - tc) - emax_q, l = tl > ql ? tl - ql : ql - tl;
+          if (emax - H0 > 40 + l) stop = true;
+        }
+      }
+      const bool last = r == tq + tt - 2;
+      if (stop || last) {
+        KswDp d; d.max = emax; d.max_t = emax_t; d.max_q = emax_q;
+        d.flags = 1u | ((last && !stop) ? 2u : 0u) | (A.bin << 8);
+        d.tape = tape_off_g + (uint64_t)(uint32_t)tS * (G * 4u);
+        A.dp[(int64_t)td.prob - A.p0] = d;
+        if (stop) sh_cx[w][grp] = tk + 1u;
+        sh_mb[w][lane] = 0;
+        tr_on = false; tk += G; td = load_desc(tk);
+      }
+    }
+    wave_sync();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_ksw_trace: one lane per problem: acceptance (src/evaluate.cpp:484,643), ksw_backtrack over the tape, clip segment
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_ksw_trace(KswFastArgs A) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  unsigned long long rescued = 0, cells = 0;
+  if (i < A.n) {
+    const KswDp d = A.dp[i];
+    if (d.flags & 1u) {
+      const int64_t p = A.p0 + i;
+      const KswProb pr = A.probs[p];
+      cells = (unsigned long long)pr.qlen * pr.tlen;
+      KswRes rs; rs.ok = 0; rs.score = 0; rs.refc = 0; rs.n_ops = 0;
+      if (A.max_out) { A.max_out[p] = d.max; A.raw_n[p] = 0; }
+      if (d.max < 10 || !(d.flags & 2u) || d.max_t < 0 || d.max_q < 0) A.results[p] = rs;
+      else {
+        const int b = (int)(d.flags >> 8);
+        const uint32_t K = (uint32_t)KSW_BIN_K(b), rb = (uint32_t)KSW_BIN_ROWBYTES(b);
+        const uint8_t *tp = A.tape + d.tape;
+        uint32_t *raw = A.raw_ops + (pr.seq_off + (uint64_t)p);
+        int ci = d.max_t, cj = d.max_q, state = 0;
+        RawSink sk{raw, 0};
+        while (ci >= 0 && cj >= 0) {
+          const uint32_t r = (uint32_t)(ci + cj), ln = (uint32_t)ci / K, jj = (uint32_t)ci - ln * K;
+          const uint32_t word = *(const uint32_t *)(tp + (size_t)r * rb + (size_t)ln * 4u);
+          const uint32_t nib = (word >> (((jj & 1u) ? 16u : 0u) + 2u * (jj & ~1u))) & 0xfu;
+          const uint32_t tmp = (2u - (nib & 3u)) | ((nib & 0xcu) << 1);
+          if (state == 0) state = tmp & 7;
+          else if (!(tmp >> (state + 2) & 1)) state = 0;
+          if (state == 0) state = tmp & 7;
+          if (state == 0) { sk.push(0, 1); --ci; --cj; }
+          else if (state == 1 || state == 3) { sk.push(2, 1); --ci; }
+          else { sk.push(1, 1); --cj; }
+        }
+        if (ci >= 0) sk.push(2, ci + 1);
+        if (cj >= 0) sk.push(1, cj + 1);
+        const uint32_t n = sk.n;
+        if (A.raw_out) { A.raw_n[p] = n; for (uint32_t k = 0; k < n && k < A.raw_cap; k++) A.raw_out[(size_t)p * A.raw_cap + k] = raw[n - 1 - k]; }
+        A.results[p] = clip_segment(raw, n, pr, d.max, A.clip_ops + (pr.seq_off + (uint64_t)p));
+        rescued = 1;
+      }
+    }
+  }
+  uint64_t m = __ballot(rescued != 0);
+  if (lane == 0 && m && A.stats) atomicAdd((unsigned long long *)&A.stats[1], (unsigned long long)__popcll(m));
+  for (int d = 32; d >= 1; d >>= 1) cells += (unsigned long long)__shfl_xor((long long)cells, d, 64);   // qlen x tlen of the stats line
+  if (lane == 0 && cells && A.stats) atomicAdd((unsigned long long *)&A.stats[0], cells);
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+size_t ksw_prob_bytes() { return sizeof(KswProb); }
+size_t ksw_res_bytes() { return sizeof(KswRes); }
+
+void launch_ksw(hipStream_t st, const KswArgs &K, int n_blocks) {
+  if (K.n_prob <= 0 || n_blocks <= 0) return;
+  hipLaunchKernelGGL(k_ksw, dim3(n_blocks), dim3(256), 0, st, K);
+}
+
+void launch_ksw_bin(hipStream_t st, const KswFastArgs &A) {
+  if (A.n <= 0) return;
+  hipLaunchKernelGGL(k_ksw_bin, dim3((unsigned)((A.n + 255) / 256)), dim3(256), 0, st, A);
+}
+
+void launch_ksw_plan(hipStream_t st, const KswFastArgs &A) {
+  uint32_t total = A.group_base[KSW_N_BINS - 1] + A.n_groups[KSW_N_BINS - 1];
+  if (!total) return;
+  hipLaunchKernelGGL(k_ksw_plan, dim3((total + 255) / 256), dim3(256), 0, st, A, total);
+  hipLaunchKernelGGL(k_ksw_group_scan, dim3(1), dim3(1024), 0, st, A.group_off, total);
+}
+
+void launch_ksw_dp(hipStream_t st, const KswFastArgs &A, int bin) {
+  if (!A.n_bin[bin] || !A.n_groups[bin]) return;
+  KswDpArgs D{};
+  D.desc = A.desc[bin]; D.n = A.n_bin[bin]; D.n_groups = A.n_groups[bin];
+  D.group_rows = A.group_rows + A.group_base[bin]; D.group_off = A.group_off + A.group_base[bin];
+  D.tape = A.tape; D.seq_arena = A.seq_arena; D.dp = A.dp; D.p0 = A.p0;
+  D.leftover = A.leftover; D.n_leftover = A.counters + KSW_N_BINS; D.bin = (uint32_t)bin;
+  const uint32_t gpw = 64u / (uint32_t)KSW_BIN_G(bin);
+  const uint32_t blocks = (A.n_groups[bin] + 4u * gpw - 1u) / (4u * gpw);
+  switch (bin) {
+    case 0: hipLaunchKernelGGL((k_ksw_dp<KSW_BIN_G(0), KSW_BIN_K(0)>), dim3(blocks), dim3(256), 0, st, D); break;
+    case 1: hipLaunchKernelGGL((k_ksw_dp<KSW_BIN_G(1), KSW_BIN_K(1)>), dim3(blocks), dim3(256), 0, st, D); break;
+    case 2: hipLaunchKernelGGL((k_ksw_dp<KSW_BIN_G(2), KSW_BIN_K(2)>), dim3(blocks), dim3(256), 0, st, D); break;
+    default: hipLaunchKernelGGL((k_ksw_dp<KSW_BIN_G(3), KSW_BIN_K(3)>), dim3(blocks), dim3(256), 0, st, D); break;
+  }
+}
+
+void launch_ksw_trace(hipStream_t st, const KswFastArgs &A) {
+  if (A.n <= 0) return;
+  hipLaunchKernelGGL(k_ksw_trace, dim3((unsigned)((A.n + 255) / 256)), dim3(256), 0, st, A);
+}
+
+}  // namespace br

@@ -1686,9 +1686,6 @@ __global__ void __launch_bounds__(256) k_sum_ncig(const uint4 *m_a, int64_t n, u
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
-size_t ksw_prob_bytes() { return sizeof(KswProb); }
-size_t ksw_res_bytes() { return sizeof(KswRes); }
-
 void launch_project_fa(hipStream_t st, const ProjectArgs &A, const FaArgs &F, int mode, int n_blocks) {
   if (A.n_aln <= 0) return;
   constexpr int FG = FA_GROUP_LANES;
@@ -1702,11 +1699,6 @@ void launch_project_fa(hipStream_t st, const ProjectArgs &A, const FaArgs &F, in
     case 2: hipLaunchKernelGGL((k_project_fa<2, FG>), g, b, 0, st, A, F); break;
     default: hipLaunchKernelGGL((k_project_fa<3, FG>), g, b, 0, st, A, F); break;
   }
-}
-
-void launch_ksw(hipStream_t st, const KswArgs &K, int n_blocks) {
-  if (K.n_prob <= 0) return;
-  hipLaunchKernelGGL(k_ksw, dim3(n_blocks), dim3(256), 0, st, K);
 }
 
 static inline int grid_for(int64_t n, int per_block) { return (int)((n + per_block - 1) / per_block); }

@@ -514,6 +514,11 @@ int br_ctx_last_counters(br_ctx *, uint64_t out[8]);
 /* -S runs: out[0] = rescue problems of the last call, out[1] = ksw2 DP cells (sum of qlen x tlen),
  * out[2] = accepted rescues, out[3] = coded sequence bytes. */
 int br_ctx_rescue_stats(br_ctx *, uint64_t out[4]);
+/* Diagnostic: routing of the last call's rescue DP problems: pieces, problems per register-array shape (64 / 128 / 256 /
+ * 384 target columns), problems left to the general kernel before the DP, direction-tape bytes of the largest piece, 0,
+ * leftovers of the last piece after the DP.  Keys of br_ctx_set_param: "ksw_fast" (0 = general kernel only),
+ * "ksw_tape_mb" (tape budget; larger batches are processed in pieces). */
+int br_ctx_ksw_diag(br_ctx *, uint64_t out[8]);
 
 /* Diagnostic: the -S rescue DP alone (k_ksw = ksw_extz2_sse as src/evaluate.cpp:296-313 calls it, on the device).
  * n (target, query) ASCII pairs in; per pair: ok[p] = the rescue would be accepted (max >= 10 and the walk reached the

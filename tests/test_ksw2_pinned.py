@@ -110,3 +110,74 @@ def test_k_ksw_reproduces_the_golden_vectors_and_the_checker_on_random_pairs():
     assert n_ok > 5000
     ctx.close()
     idx.close()
+
+
+def _long_pair(rng, ql):
+    """A rescue-shaped pair with a query of ql bases (beyond random_pair's 160): a copy with a few edits, or unrelated."""
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    q = acgt[rng.randint(0, 4, ql)].copy()
+    if rng.randint(0, 5) == 0:
+        t = acgt[rng.randint(0, 4, int(rng.randint(1, ql + 41)))].copy()
+    else:
+        t = list(q)
+        for _ in range(int(rng.randint(0, 1 + ql // 12))):
+            k = int(rng.randint(0, len(t)))
+            u = rng.randint(0, 3)
+            if u == 0:
+                t[k] = acgt[rng.randint(0, 4)]
+            elif u == 1 and len(t) > 1:
+                del t[k]
+            else:
+                t.insert(k, acgt[rng.randint(0, 4)])
+        t = np.array(t + list(acgt[rng.randint(0, 4, int(rng.randint(0, 41)))]), dtype=np.uint8)[:ql + 40]
+        if rng.randint(0, 4) == 0 and len(t) > 40:
+            cut = int(rng.randint(20, len(t)))
+            t[cut:] = acgt[rng.randint(0, 4, len(t) - cut)]
+    if rng.randint(0, 6) == 0:
+        t[int(rng.randint(0, len(t)))] = ord("N")
+        q[int(rng.randint(0, len(q)))] = ord("N")
+    return bytes(t).decode(), bytes(q).decode()
+
+
+@pytest.mark.gpu
+def test_streamed_dp_every_array_shape_leftovers_and_pieces():
+    """k_ksw_dp (the register arrays of 64 / 128 / 256 / 384 target columns), the problems it leaves to k_ksw (targets
+    beyond 384 columns) and a tape budget small enough to force several pieces: every problem against the full-matrix
+    checker, and the general kernel alone (ksw_fast = 0) gives the same answers."""
+    from bramble_amd import lib, synth
+    ann = synth.Annotation("S")
+    idx = lib.Index(ann.as_dict(), device=0)
+    ctx = lib.Context(idx)
+    rng = np.random.RandomState(23)
+    pairs = [ksw2_check.random_pair(rng) for _ in range(3000)]
+    pairs += [_long_pair(rng, int(rng.randint(150, 520))) for _ in range(1500)]
+    # very short problems in a row (first bases closer than a lane's column count), targets shorter than the query
+    pairs += [("ACGTACGTAC"[:int(rng.randint(1, 11))], "ACGTTGCA"[:int(rng.randint(1, 9))]) for _ in range(300)]
+    pairs += [(p[0][:int(rng.randint(1, 30))], p[1]) for p in (_long_pair(rng, int(rng.randint(60, 300))) for _ in range(300))]
+    order = rng.permutation(len(pairs))
+    pairs = [pairs[k] for k in order]
+    want = [ksw2_check.gotoh(t, q) for t, q in pairs]
+
+    def check(ok, mx, cigs):
+        n_ok = 0
+        for p, g in enumerate(want):
+            accept = g["max"] >= 10 and g["score"] != ksw2_check.NEG_INF
+            assert bool(ok[p]) == accept, (pairs[p], int(ok[p]), g)
+            assert int(mx[p]) == g["max"], (pairs[p], int(mx[p]), g)
+            if accept:
+                assert ksw2_check.cigar_text(cigs[p]) == ksw2_check.cigar_text(g["cigar"]), (pairs[p],)
+                n_ok += 1
+        return n_ok
+
+    assert check(*ctx.ksw_pairs(pairs)) > 1500
+    d = ctx.ksw_diag()
+    assert d["pieces"] == 1 and all(n > 100 for n in d["per_shape"]) and d["leftover_before"] > 50, d
+    assert d["leftover_after"] == d["leftover_before"], d       # no group ran out of tape
+    ctx.set_param("ksw_tape_mb", 1)
+    check(*ctx.ksw_pairs(pairs))
+    assert ctx.ksw_diag()["pieces"] > 1
+    ctx.set_param("ksw_fast", 0)
+    check(*ctx.ksw_pairs(pairs))
+    assert ctx.ksw_diag()["pieces"] == 0
+    ctx.close()
+    idx.close()
