@@ -172,6 +172,8 @@ def main():
         label = "%d ONT-like reads (median 900 bp, clips <= 300) --lr -S vs a 6000-gene annotation with synthetic genome" % n
     idx = lib.Index.from_flat(ann.flat, device=0)
     ctx = lib.Context(idx)
+    if os.environ.get("KSW_FAST") is not None:
+        ctx.set_param("ksw_fast", int(os.environ["KSW_FAST"]))
     db = brdev.upload_batch(batch, "cuda:0")
     stream = torch.cuda.current_stream().cuda_stream
     for _ in range(args.warmup):
@@ -194,6 +196,7 @@ def main():
         st = ctx.rescue_stats()
         ksw_ms = kms.get("k_ksw", 0.0) / args.steps
         out["rescue"] = st
+        out["ksw_routing"] = ctx.ksw_diag()
         out["k_ksw_GCUPS"] = st["dp_cells"] / (ksw_ms * 1e-3) / 1e9 if ksw_ms else None
     print(json.dumps(out))
 

@@ -454,8 +454,9 @@ struct br_ctx {
   // rows / offsets, the direction tape, raw traceback ops
   DevBuf ksw_desc, ksw_dp, ksw_left, ksw_cnt, ksw_group, ksw_tape, ksw_raw;
   int ksw_fast = 1;            // 0: every problem through the general kernel k_ksw
+  uint32_t ksw_groups[KSW_N_BINS] = {0};
   int64_t ksw_tape_mb = 49152; // HBM set aside for the direction tape; larger batches go through in pieces
-  uint64_t ksw_diag[8] = {0};  // last call: pieces, problems per bin [4], leftovers before the DP, tape bytes (largest piece), spare
+  uint64_t ksw_diag[16] = {0};  // last call: pieces, problems per bin [4], leftovers before the DP, tape bytes (largest piece), spare, tape rows per bin [4]
   DevBuf n_rows, row_off, aln_group;
   // wide view of the rows (br_device_rows_expand): one array per field
   DevBuf r_input, r_nh, r_hi, r_mapq, r_group, r_mate_tid, r_mate_pos,
@@ -562,7 +563,7 @@ extern "C" int br_ctx_kernel_ms(br_ctx *c, int which, double *ms, int32_t *launc
 }
 // Diagnostic: how the last -S call's DP problems were routed (pieces, problems per array shape, leftovers handed to the
 // general kernel before the DP, tape bytes of the largest piece, leftovers of the last piece after the DP).
-extern "C" int br_ctx_ksw_diag(br_ctx *c, uint64_t out[8]) {
+extern "C" int br_ctx_ksw_diag(br_ctx *c, uint64_t out[16]) {
   if (!c || !out) return BR_ERR_INVALID_ARG;
   memcpy(out, c->ksw_diag, sizeof(c->ksw_diag));
   out[7] = (uint32_t)c->h_totals[24];
@@ -654,9 +655,12 @@ static int run_ksw(br_ctx *c, hipStream_t st, const KswRun &R) {
   RC(c->ksw_cnt.ensure(64));
   uint32_t *h_cnt = (uint32_t *)(c->h_totals + 16);   // 16 words of the pinned totals
   const uint64_t tape_budget = (uint64_t)c->ksw_tape_mb << 20;
-  // groups a bin may run at once: 16 waves per CU
+  // groups of a bin = what is resident at once (one wave of blocks: every group runs from the first cycle)
   uint32_t max_groups[KSW_N_BINS];
-  for (int b = 0; b < KSW_N_BINS; b++) max_groups[b] = (uint32_t)c->n_cu * 16u * (64u / (uint32_t)KSW_BIN_G(b));
+  for (int b = 0; b < KSW_N_BINS; b++) {
+    if (!c->ksw_groups[b]) c->ksw_groups[b] = ksw_dp_resident_groups(b, c->n_cu);
+    max_groups[b] = c->ksw_groups[b];
+  }
   std::vector<std::pair<uint64_t, uint64_t>> todo;   // [p0, p1)
   todo.emplace_back(0, n_all);
   while (!todo.empty()) {
@@ -693,6 +697,7 @@ static int run_ksw(br_ctx *c, hipStream_t st, const KswRun &R) {
     c->ksw_diag[0]++;
     for (int b = 0; b < KSW_N_BINS; b++) c->ksw_diag[1 + b] += h_cnt[b];
     c->ksw_diag[5] += n_left; c->ksw_diag[6] = std::max<uint64_t>(c->ksw_diag[6], tape_bytes);
+    for (int b = 0; b < KSW_N_BINS; b++) c->ksw_diag[8 + b] += h_rows[b];
     if (n_groups_total) {
       RC(c->ksw_group.ensure((size_t)n_groups_total * 16));
       RC(c->ksw_tape.ensure((size_t)tape_bytes + 256));
@@ -1698,7 +1703,7 @@ extern "C" int br_ctx_ksw_pairs(br_ctx *c, int64_t n, const char *const *tseq, c
     size_t ql = strlen(qseq[p]), tl = strlen(tseq[p]);
     probs[(size_t)p] = HProb{(uint32_t)ql, (uint32_t)tl, 1u, 0u, (uint64_t)arena.size()};
     for (size_t k = 0; k < ql; k++) arena.push_back(code(qseq[p][k]));
-    for (size_t k = 0; k < tl; k++) arena.push_back(code(tseq[p][k]));
+    for (size_t k = 0; k < tl; k++) { uint8_t cd = code(tseq[p][k]); probs[(size_t)p].pad |= cd >> 2; arena.push_back(cd); }
     qmax = std::max<uint64_t>(qmax, ql); tmaxv = std::max<uint64_t>(tmaxv, tl);
   }
   DevBuf d_probs, d_res, d_arena, d_ops, d_raw, d_rawn, d_max;

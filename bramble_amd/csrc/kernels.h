@@ -296,6 +296,7 @@ void launch_ksw_bin(hipStream_t st, const KswFastArgs &A);
 void launch_ksw_plan(hipStream_t st, const KswFastArgs &A);       // group rows + the scan of their byte sizes
 void launch_ksw_dp(hipStream_t st, const KswFastArgs &A, int bin);
 void launch_ksw_trace(hipStream_t st, const KswFastArgs &A);
+uint32_t ksw_dp_resident_groups(int bin, int n_cu);
 size_t ksw_prob_bytes();
 size_t ksw_res_bytes();
 void launch_expand(hipStream_t st, const ProjectArgs &A);

@@ -231,7 +231,7 @@ __device__ __forceinline__ uint32_t ksw_rows_of(uint32_t qlen, int K) { return (
 __global__ void __launch_bounds__(256) k_ksw_bin(KswFastArgs A) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
-  int bin = -1; KswProb pr; pr.qlen = pr.tlen = pr.side = pr.pad = 0; pr.seq_off = 0;
+  int bin = -1; KswProb pr; pr.qlen = pr.tlen = pr.side = pr.t_has_n = 0; pr.seq_off = 0;
   if (i < A.n) {
     pr = A.probs[A.p0 + i];
     KswDp d; d.max = 0; d.max_t = d.max_q = -1; d.flags = 0; d.tape = 0;
@@ -240,7 +240,7 @@ __global__ void __launch_bounds__(256) k_ksw_bin(KswFastArgs A) {
       KswRes rs; rs.ok = 0; rs.score = 0; rs.refc = 0; rs.n_ops = 0;
       A.results[A.p0 + i] = rs;
       if (A.max_out) { A.max_out[A.p0 + i] = 0; A.raw_n[A.p0 + i] = 0; }
-    } else bin = ksw_bin_of(pr.qlen, pr.tlen);
+    } else bin = pr.t_has_n ? KSW_N_BINS : ksw_bin_of(pr.qlen, pr.tlen);   // the arrays score a target base by t ^ q: no N
   }
 #pragma unroll
   for (int b = 0; b <= KSW_N_BINS; b++) {
@@ -321,7 +321,6 @@ __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SE
 // scaled constants (values x4, tag in the low two bits)
 #define KSW4_Q 0x00100010u       // gap open 4
 #define KSW4_ZMAX 0x002c002cu    // max_sc_v 11
-#define KSW4_ZN 0x00260026u      // N against anything: (-1 + 10) * 4 + tag 2
 #define KSW_LUT_LO 0x1a1a1a2eu   // t ^ q = 0: match (1 + 10) * 4 + 2 = 46; 1..3: mismatch (-4 + 10) * 4 + 2 = 26
 #define KSW_LUT_HI 0x26262626u   // 4..7: the query base is N
 
@@ -337,7 +336,9 @@ struct KswDpArgs {
 template <int G, int K>
 __global__ void __launch_bounds__(256) k_ksw_dp(KswDpArgs A) {
   constexpr int P = K / 2, W = G * K, GPW = 64 / G;
-  __shared__ uint32_t sh_pub[4][2][64 * P];     // [wave][v | u][column pair]: what the columns hold after the step
+  // column layout of a lane: pair j = columns c0 + j (low half) and c0 + j + P (high half), so that the left neighbours
+  // of both halves of pair j are the two halves of pair j - 1: only pair 0 needs a shifted operand
+  __shared__ uint32_t sh_pub[4][2][64 * P];     // [wave][v | u][lane * P + pair]: what the columns hold after the step
   __shared__ uint32_t sh_mb[4][64];             // per bookkeeping lane: 0 = free, else first step of its problem + 1
   __shared__ uint32_t sh_cx[4][GPW];            // per group: sequence number + 1 of a problem that z-dropped
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -346,40 +347,43 @@ __global__ void __launch_bounds__(256) k_ksw_dp(KswDpArgs A) {
   const uint32_t NG = A.n_groups;
   const uint32_t cnt = (g < NG && A.n > g) ? (A.n - g + NG - 1u) / NG : 0u;   // problems of this group: g, g + NG, ...
   const uint32_t rows_alloc = g < NG ? (uint32_t)A.group_rows[g] : 0u;
-  uint8_t *tape_g = A.tape + (g < NG ? A.group_off[g] : 0ull) + (size_t)gl * 4u;
   const uint64_t tape_off_g = g < NG ? A.group_off[g] : 0ull;
+  uint8_t *tape_g = A.tape + tape_off_g + (size_t)gl * 8u;
   const uint32_t c0 = (uint32_t)gl * K;
   auto load_desc = [&](uint32_t k) { KswDesc d; d.qt = 0; d.prob = 0; d.seq_off = 0; if (k < cnt) d = A.desc[g + k * NG]; return d; };
   auto load8 = [&](uint64_t off) { uint2 v; __builtin_memcpy(&v, A.seq_arena + off, 8); return v; };
+  auto load16 = [&](uint64_t off) { uint4 v; __builtin_memcpy(&v, A.seq_arena + off, 16); return v; };
 
   sh_mb[w][lane] = 0;
   if (gl == 0) sh_cx[w][grp] = 0;
   wave_sync();
 
-  // ---- column state: pair p = columns c0 + 2p (low half), c0 + 2p + 1 (high half)
-  uint32_t U[P], Y[P], V[P], S[P], Q[P], T[P], TN[P], TX[P], TNX[P];
-  uint32_t initu0 = (gl == 0) ? 0x00100000u : KSW4_Q;     // u of a problem's diagonal cell: q, 0 in column 0
+  uint32_t U[P], Y[P], V[P], S[P], Q[P], T[P], TX[P];
+  const uint32_t initu0 = (gl == 0) ? 0x00100000u : KSW4_Q;     // u of a problem's diagonal cell: q, 0 in column 0
 #pragma unroll
-  for (int p = 0; p < P; p++) { U[p] = Y[p] = V[p] = Q[p] = 0; S[p] = 0x00010001u; T[p] = TX[p] = 0x0c000c00u; TN[p] = TNX[p] = 0; }
-  auto make_t = [&](uint2 raw, uint32_t *t, uint32_t *tn) {
+  for (int p = 0; p < P; p++) { U[p] = Y[p] = V[p] = Q[p] = 0; S[p] = 0x00010001u; T[p] = TX[p] = 0x0c000c00u; }
+  // target codes of the lane's columns c0 .. c0 + K - 1 (16 raw bytes) -> per pair the perm selector halves 0x0c00 | code
+  auto make_t = [&](uint4 raw, uint32_t *t) {
+    const uint32_t wd[4] = {raw.x, raw.y, raw.z, raw.w};
 #pragma unroll
     for (int p = 0; p < P; p++) {
-      const int j0 = 2 * p, j1 = 2 * p + 1;
-      const uint32_t b0 = ((j0 < 4 ? raw.x : raw.y) >> (8 * (j0 & 3))) & 7u, b1 = ((j1 < 4 ? raw.x : raw.y) >> (8 * (j1 & 3))) & 7u;
-      t[p] = 0x0c000c00u | b0 | (b1 << 16);
-      tn[p] = (b0 == 4u ? 0xffffu : 0u) | (b1 == 4u ? 0xffff0000u : 0u);
+      const int j0 = p, j1 = p + P;   // bytes j0 -> bits 0..7, j1 -> bits 16..23
+      const uint32_t sel = (uint32_t)((j0 & 3) + ((j0 >> 2) == (j1 >> 2) ? 0 : 4)) | 0x0c00u | ((uint32_t)(j1 & 3) << 16) | 0x0c000000u;
+      // v_perm_b32 {hi dword, lo dword}: bytes 0-3 = the second operand; j1's dword goes there, j0's (when different) above it
+      const uint32_t lo = wd[j1 >> 2], hi = wd[j0 >> 2];
+      t[p] = __builtin_amdgcn_perm(hi, lo, sel) | 0x0c000c00u;
     }
   };
   // the target bases of the problems to come: TX = next first base to arrive (problem kl), txx = the one after, dd = the
   // descriptor after that (its target is fetched when txx moves up)
   uint32_t kl = 0;
-  uint2 txx = make_uint2(0, 0);
+  uint4 txx = make_uint4(0, 0, 0, 0);
   KswDesc dd;
   {
     KswDesc d0 = load_desc(0), d1 = load_desc(1);
     dd = load_desc(2);
-    if (cnt > 0) make_t(load8(d0.seq_off + (d0.qt & 0xffffu) + c0), TX, TNX);
-    if (cnt > 1) txx = load8(d1.seq_off + (d1.qt & 0xffffu) + c0);
+    if (cnt > 0) make_t(load16(d0.seq_off + (d0.qt & 0xffffu) + c0), TX);
+    if (cnt > 1) txx = load16(d1.seq_off + (d1.qt & 0xffffu) + c0);
   }
   // ---- feeder (lane 0 of the group)
   int32_t fk = -1; uint32_t fi = 0, fq = 0, fgap = K;
@@ -394,6 +398,8 @@ __global__ void __launch_bounds__(256) k_ksw_dp(KswDpArgs A) {
   uint32_t tk = (uint32_t)gl; KswDesc td = load_desc(tk);
   bool tr_on = false; int32_t tS = 0, tq = 0, tt = 0, H0 = 0, lastT = 0, emax = 0, emax_t = -1, emax_q = -1;
   const uint16_t *pubV = (const uint16_t *)&sh_pub[w][0][0] + grp * W, *pubU = (const uint16_t *)&sh_pub[w][1][0] + grp * W;
+  // u16 index of group column t in a published array
+  auto pub_idx = [&](int t) { const uint32_t ut = (uint32_t)t, ln = ut / K, jj = ut - ln * K, hf = jj >= (uint32_t)P ? 1u : 0u; return ln * K + 2u * (jj - hf * P) + hf; };
 
   for (uint32_t s = 0;; s++) {
     // the tape of a group holds rows_alloc steps; a group that would run past it (a queue of very short problems
@@ -429,49 +435,53 @@ __global__ void __launch_bounds__(256) k_ksw_dp(KswDpArgs A) {
     }
     wave_sync();
 
-    // ---- the three streams move one column
+    // ---- what enters pair 0: low half from the lane before (or the feeder), high half from this lane's pair P - 1
     uint32_t qp = wave_shr1(Q[P - 1]), vp = wave_shr1(V[P - 1]), sp = wave_shr1(S[P - 1]);
     if (gl == 0) { qp = qin << 16; vp = vin << 16; sp = (vin + 1u) << 16; }
-    uint32_t Qn[P], V1[P], S1[P];
-#pragma unroll
-    for (int p = 0; p < P; p++) {
-      Qn[p] = __builtin_amdgcn_alignbit(Q[p], p ? Q[p - 1] : qp, 16);
-      V1[p] = __builtin_amdgcn_alignbit(V[p], p ? V[p - 1] : vp, 16);
-      S1[p] = __builtin_amdgcn_alignbit(S[p], p ? S[p - 1] : sp, 16);
-    }
-    // ---- cells
+    const uint32_t qb = __builtin_amdgcn_alignbit(Q[P - 1], qp, 16), vb = __builtin_amdgcn_alignbit(V[P - 1], vp, 16),
+                   sb = __builtin_amdgcn_alignbit(S[P - 1], sp, 16);
+    const bool leaving = (Q[P - 2 >= 0 ? P - 2 : 0] >> 31) != 0;   // a first base reaches the lane's last column in this step
+    // ---- cells, pairs in descending order: pair j reads what pair j - 1 held after the step before
     uint32_t D[P];
+    uint32_t m3 = 0x00030003u;
+    asm("" : "+v"(m3));   // a register mask keeps the tag merge one v_bfi_b32 (a literal is taken apart into and / and / or)
 #pragma unroll
-    for (int p = 0; p < P; p++) {
-      const uint32_t fm = pk_sign(Qn[p]);                       // first base of a problem: new target base, u = q, y = 0
-      T[p] = bfi32(fm, TX[p], T[p]); TN[p] = bfi32(fm, TNX[p], TN[p]);
+    for (int p = P - 1; p >= 0; p--) {
+      const uint32_t qn = p ? Q[p - 1] : qb, v1 = p ? V[p - 1] : vb, a = p ? S[p - 1] : sb;
+      uint32_t fm = pk_sign(qn);                                 // first base of a problem: new target base, u = q, y = 0
+      asm("" : "+v"(fm));                                        // keeps the selects below as v_bfi_b32 (else: per-half compares + cndmasks)
+      T[p] = bfi32(fm, TX[p], T[p]);
       const uint32_t ue = bfi32(fm, p == 0 ? initu0 : KSW4_Q, U[p]), ye = Y[p] & ~fm;
-      uint32_t z = __builtin_amdgcn_perm(KSW_LUT_HI, KSW_LUT_LO, T[p] ^ Qn[p]) & 0x00ff00ffu;
-      z = bfi32(TN[p], KSW4_ZN, z);
-      const uint32_t a = S1[p], b = pk_add(ye, ue);
+      const uint32_t z = __builtin_amdgcn_perm(KSW_LUT_HI, KSW_LUT_LO, T[p] ^ qn) & 0x00ff00ffu;
+      const uint32_t b = pk_add(ye, ue);
       const uint32_t wv = pk_max_i(pk_max_i(z, a), b);          // tags: ties go to match, then deletion
       const uint32_t zc = pk_min_u(wv & 0xfffcfffcu, KSW4_ZMAX);
       const uint32_t nv = pk_sub(zc, ue);
-      U[p] = pk_sub(zc, V1[p]);
+      U[p] = pk_sub(zc, v1);
       const uint32_t zq = pk_sub(zc, KSW4_Q);
       const uint32_t xt = pk_max_i(pk_sub(a, zq), 0x00010001u);  // x * 4 + 1: the deletion tag of the next column's a
       const uint32_t yn = pk_max_i(pk_sub(b, zq), 0u);
       V[p] = nv; Y[p] = yn; S[p] = pk_add(xt, nv);
       // direction nibble: winner tag | x continues << 2 | y continues << 3
-      uint32_t d = (pk_min_u(xt, 0x00050005u) & 0x00040004u) | (wv & 0x00030003u);
-      D[p] = (pk_min_u(yn, 0x00040004u) << 1) | d;
-      Q[p] = Qn[p];
+      D[p] = (pk_min_u(yn, 0x00040004u) << 1) | bfi32(m3, wv, pk_min_u(xt, 0x00050005u));
+      Q[p] = qn;
     }
-    uint32_t word = D[0];
+    if (s < rows_alloc) {
+      uint2 word;
+      word.x = D[0];
 #pragma unroll
-    for (int p = 1; p < P; p++) word |= D[p] << (4 * p);
-    if (s < rows_alloc) *(uint32_t *)(tape_g + (size_t)s * (G * 4u)) = word;
+      for (int p = 1; p < 4 && p < P; p++) word.x |= D[p] << (4 * p);
+      word.y = P > 4 ? D[4] : 0u;
+#pragma unroll
+      for (int p = 5; p < P; p++) word.y |= D[p] << (4 * (p - 4));
+      *(uint2 *)(tape_g + (size_t)s * (G * 8u)) = word;
+    }
 
     // ---- a first base leaves the lane: the next problem's target moves up
-    if (Qn[P - 1] >> 31) {
-      make_t(txx, TX, TNX);
+    if (leaving) {
+      make_t(txx, TX);
       kl++;
-      if (kl + 1 < cnt) txx = load8(dd.seq_off + (dd.qt & 0xffffu) + c0);
+      if (kl + 1 < cnt) txx = load16(dd.seq_off + (dd.qt & 0xffffu) + c0);
       dd = load_desc(kl + 2);
     }
 
@@ -491,7 +501,7 @@ __global__ void __launch_bounds__(256) k_ksw_dp(KswDpArgs A) {
       else {
         const bool in0 = lastT >= st0 && lastT <= en0, in1 = lastT + 1 >= st0 && lastT + 1 <= en0;
         const int t1 = lastT + 1 < W ? lastT + 1 : W - 1;
-        const int32_t d0 = (int32_t)(pubV[lastT] >> 2) - 5, d1 = (int32_t)(pubU[t1] >> 2) - 5;
+        const int32_t d0 = (int32_t)(pubV[pub_idx(lastT)] >> 2) - 5, d1 = (int32_t)(pubU[pub_idx(t1)] >> 2) - 5;
         if (in0 && in1) { if (d0 > d1) H0 += d0; else { H0 += d1; ++lastT; } }
         else if (in0) H0 += d0;
         else { ++lastT; H0 += d1; }
@@ -506,7 +516,7 @@ __global__ void __launch_bounds__(256) k_ksw_dp(KswDpArgs A) {
       if (stop || last) {
         KswDp d; d.max = emax; d.max_t = emax_t; d.max_q = emax_q;
         d.flags = 1u | ((last && !stop) ? 2u : 0u) | (A.bin << 8);
-        d.tape = tape_off_g + (uint64_t)(uint32_t)tS * (G * 4u);
+        d.tape = tape_off_g + (uint64_t)(uint32_t)tS * (G * 8u);
         A.dp[(int64_t)td.prob - A.p0] = d;
         if (stop) sh_cx[w][grp] = tk + 1u;
         sh_mb[w][lane] = 0;
@@ -535,15 +545,16 @@ __global__ void __launch_bounds__(256) k_ksw_trace(KswFastArgs A) {
       if (d.max < 10 || !(d.flags & 2u) || d.max_t < 0 || d.max_q < 0) A.results[p] = rs;
       else {
         const int b = (int)(d.flags >> 8);
-        const uint32_t K = (uint32_t)KSW_BIN_K(b), rb = (uint32_t)KSW_BIN_ROWBYTES(b);
+        const uint32_t K = (uint32_t)KSW_BIN_K(b), P = K / 2, rb = (uint32_t)KSW_BIN_ROWBYTES(b);
         const uint8_t *tp = A.tape + d.tape;
         uint32_t *raw = A.raw_ops + (pr.seq_off + (uint64_t)p);
         int ci = d.max_t, cj = d.max_q, state = 0;
         RawSink sk{raw, 0};
         while (ci >= 0 && cj >= 0) {
-          const uint32_t r = (uint32_t)(ci + cj), ln = (uint32_t)ci / K, jj = (uint32_t)ci - ln * K;
-          const uint32_t word = *(const uint32_t *)(tp + (size_t)r * rb + (size_t)ln * 4u);
-          const uint32_t nib = (word >> (((jj & 1u) ? 16u : 0u) + 2u * (jj & ~1u))) & 0xfu;
+          // column ci = lane ci / K, pair (ci % K) % P, half (ci % K) / P; pairs 0-3 sit in the lane's first dword
+          const uint32_t r = (uint32_t)(ci + cj), ln = (uint32_t)ci / K, jj = (uint32_t)ci - ln * K, hf = jj >= P ? 1u : 0u, pj = jj - hf * P;
+          const uint32_t word = *(const uint32_t *)(tp + (size_t)r * rb + (size_t)ln * 8u + (pj >> 2) * 4u);
+          const uint32_t nib = (word >> (hf * 16u + 4u * (pj & 3u))) & 0xfu;
           const uint32_t tmp = (2u - (nib & 3u)) | ((nib & 0xcu) << 1);
           if (state == 0) state = tmp & 7;
           else if (!(tmp >> (state + 2) & 1)) state = 0;
@@ -605,6 +616,20 @@ void launch_ksw_dp(hipStream_t st, const KswFastArgs &A, int bin) {
     case 2: hipLaunchKernelGGL((k_ksw_dp<KSW_BIN_G(2), KSW_BIN_K(2)>), dim3(blocks), dim3(256), 0, st, D); break;
     default: hipLaunchKernelGGL((k_ksw_dp<KSW_BIN_G(3), KSW_BIN_K(3)>), dim3(blocks), dim3(256), 0, st, D); break;
   }
+}
+
+// groups of a bin that are resident at once (blocks per CU from the occupancy query x 4 waves x groups per wave)
+uint32_t ksw_dp_resident_groups(int bin, int n_cu) {
+  int blocks = 0;
+  hipError_t e;
+  switch (bin) {
+    case 0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_ksw_dp<KSW_BIN_G(0), KSW_BIN_K(0)>, 256, 0); break;
+    case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_ksw_dp<KSW_BIN_G(1), KSW_BIN_K(1)>, 256, 0); break;
+    case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_ksw_dp<KSW_BIN_G(2), KSW_BIN_K(2)>, 256, 0); break;
+    default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_ksw_dp<KSW_BIN_G(3), KSW_BIN_K(3)>, 256, 0); break;
+  }
+  if (e != hipSuccess || blocks < 1) blocks = 3;
+  return (uint32_t)blocks * (uint32_t)n_cu * 4u * (64u / (uint32_t)KSW_BIN_G(bin));
 }
 
 void launch_ksw_trace(hipStream_t st, const KswFastArgs &A) {

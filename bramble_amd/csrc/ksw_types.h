@@ -4,7 +4,7 @@
 
 namespace br {
 
-struct KswProb { uint32_t qlen, tlen; uint32_t side; uint32_t pad; uint64_t seq_off; };   // q codes, then t codes
+struct KswProb { uint32_t qlen, tlen; uint32_t side; uint32_t t_has_n; uint64_t seq_off; };   // q codes, then t codes; t_has_n: an N among the target codes
 struct KswRes { int32_t ok, score, refc; uint32_t n_ops; };                              // ops at clip_ops[seq_off + p]
 
 // Streamed DP (k_ksw_dp): problems are binned by target length into four array shapes; a bin's problems sit in a
@@ -16,11 +16,11 @@ struct KswDesc { uint32_t qt; uint32_t prob; uint64_t seq_off; };   // qlen | tl
 struct KswDp { int32_t max, max_t, max_q; uint32_t flags; uint64_t tape; };
 
 #define KSW_N_BINS 4
-// lanes per group / target columns per lane of every bin (columns = product); a lane stores 4 tape bytes per step
-#define KSW_BIN_G(b) ((b) == 0 ? 8 : (b) == 1 ? 16 : (b) == 2 ? 32 : 64)
-#define KSW_BIN_K(b) ((b) == 3 ? 6 : 8)
+// lanes per group / target columns per lane of every bin (columns = product); a lane stores 8 tape bytes per step
+#define KSW_BIN_G(b) ((b) == 0 ? 8 : (b) == 1 ? 8 : (b) == 2 ? 16 : 32)
+#define KSW_BIN_K(b) ((b) == 0 ? 8 : (b) == 3 ? 12 : 16)
 #define KSW_BIN_W(b) (KSW_BIN_G(b) * KSW_BIN_K(b))      // 64, 128, 256, 384 target columns
-#define KSW_BIN_ROWBYTES(b) (KSW_BIN_G(b) * 4)
+#define KSW_BIN_ROWBYTES(b) (KSW_BIN_G(b) * 8)
 #define KSW_TAIL_ROWS 64                                 // slack rows behind a group's last problem
 
 }  // namespace br

@@ -625,10 +625,11 @@ class Context:
         return dict(zip(("problems", "dp_cells", "rescued", "seq_bytes"), [int(v) for v in out]))
 
     def ksw_diag(self):
-        out = (C.c_uint64 * 8)()
+        out = (C.c_uint64 * 16)()
         check(lib().br_ctx_ksw_diag(self.h, out), "br_ctx_ksw_diag")
         v = [int(x) for x in out]
-        return {"pieces": v[0], "per_shape": v[1:5], "leftover_before": v[5], "tape_bytes": v[6], "leftover_after": v[7]}
+        return {"pieces": v[0], "per_shape": v[1:5], "leftover_before": v[5], "tape_bytes": v[6], "leftover_after": v[7],
+                "rows_per_shape": v[8:12]}
 
     def project_batch_packed(self, cfg, batch):
         """Host batch in, packed host rows (dict of numpy arrays copied out of the context's pinned buffers) out."""
