@@ -449,7 +449,7 @@ struct br_ctx {
   uint8_t *h_bam[2] = {nullptr, nullptr}; size_t h_bam_cap[2] = {0, 0}; int h_bam_next = 0;  // pinned download buffers of br_project_bam_bundle (alternating)
   int64_t last_n_rows = 0, last_n_aln = 0;
   DevBuf fa_stats, fa_n_prob, fa_seq_bytes, fa_prob_off, fa_seqarena_off, fa_probs, fa_results, fa_seq_arena, fa_clip_ops,
-      fa_ideal_cap, fa_scratch, b_seq_off, b_seqs, b_seq_src;
+      fa_ideal_cap, fa_scratch, fa_srcs, b_seq_off, b_seqs, b_seq_src;
   // the streamed -S DP (ksw_kernels.hip): per-bin descriptors, per-problem DP results, leftovers, counters, group
   // rows / offsets, the direction tape, raw traceback ops
   DevBuf ksw_desc, ksw_dp, ksw_left, ksw_cnt, ksw_group, ksw_tape, ksw_raw;
@@ -514,7 +514,7 @@ extern "C" void br_ctx_free(br_ctx *c) {
                     &c->cigar_out, &c->r_paired, &c->r_same, &c->r_first, &c->r_primary, &c->b_name_off, &c->b_names, &c->b_ref_id, &c->b_ref_start,
                     &c->b_flags, &c->b_xs, &c->b_ts, &c->b_cigar_off, &c->b_cigar, &c->b_mate_idx,
                     &c->b_group_off, &c->b_lqseq, &c->walk_list, &c->pmask,
-                    &c->ksw_desc, &c->ksw_dp, &c->ksw_left, &c->ksw_cnt, &c->ksw_group, &c->ksw_tape, &c->ksw_raw};
+                    &c->fa_srcs, &c->ksw_desc, &c->ksw_dp, &c->ksw_left, &c->ksw_cnt, &c->ksw_group, &c->ksw_tape, &c->ksw_raw};
   for (DevBuf *b : bufs) b->release();
   for (auto &e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if (c->h_totals) (void)hipHostFree(c->h_totals);
@@ -815,11 +815,13 @@ static int run_device_impl(br_ctx *c, const br_config *cfg, const br_device_batc
     RC(c->fa_results.ensure(std::max<size_t>(n_prob, 1) * ksw_res_bytes()));
     RC(c->fa_seq_arena.ensure((size_t)seq_total + 1024));   // the streamed DP reads whole dwords past a problem's last base
     RC(c->fa_clip_ops.ensure((std::max<size_t>(seq_total + n_prob, 1)) * 4));
-    F.probs = (KswProb *)c->fa_probs.p; F.results = (KswRes *)c->fa_results.p;
+    RC(c->fa_srcs.ensure(std::max<size_t>(n_prob, 1) * sizeof(FaSrc)));
+    F.probs = (KswProb *)c->fa_probs.p; F.results = (KswRes *)c->fa_results.p; F.srcs = c->fa_srcs.as<FaSrc>();
     F.seq_arena = c->fa_seq_arena.as<uint8_t>(); F.clip_ops = c->fa_clip_ops.as<uint32_t>();
     if (n_prob) {
       RC(pf.begin(BR_K_COUNT));
       launch_project_fa(st, A, F, 1, n_blocks);
+      launch_fa_fill(st, A, F, (int64_t)n_prob);
       RC(pf.end());
       uint64_t qmax = (uint64_t)std::max(b->max_soft_clip, 0) + std::max(dc.max_clip, dc.max_junc_ins);
       KswRun R{};

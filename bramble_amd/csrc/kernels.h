@@ -51,6 +51,7 @@ struct FaArgs {
   const uint32_t *prob_off;    // [n_aln + 1]
   const uint64_t *seqarena_off;  // [n_aln + 1]
   KswProb *probs;
+  FaSrc *srcs;                 // [n_prob] where the sequences of a problem come from
   KswRes *results;
   uint8_t *seq_arena;          // query / target codes of every problem
   uint32_t *clip_ops;          // clip-segment CIGARs: problem p at seq_off(p) + p
@@ -291,6 +292,7 @@ void launch_segment(hipStream_t st, int64_t n_aln, const int32_t *ref_id, const 
 // part: see launch_project_g (0 = everything)
 void launch_project(hipStream_t st, const ProjectArgs &A, bool emit, int group_lanes, int n_blocks, int part = 0);
 void launch_project_fa(hipStream_t st, const ProjectArgs &A, const FaArgs &F, int mode, int n_blocks);
+void launch_fa_fill(hipStream_t st, const ProjectArgs &A, const FaArgs &F, int64_t n_prob);   // coded sequences of every problem
 void launch_ksw(hipStream_t st, const KswArgs &K, int n_blocks);
 void launch_ksw_bin(hipStream_t st, const KswFastArgs &A);
 void launch_ksw_plan(hipStream_t st, const KswFastArgs &A);       // group rows + the scan of their byte sizes

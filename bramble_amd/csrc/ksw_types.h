@@ -5,6 +5,9 @@
 namespace br {
 
 struct KswProb { uint32_t qlen, tlen; uint32_t side; uint32_t t_has_n; uint64_t seq_off; };   // q codes, then t codes; t_has_n: an N among the target codes
+// where a problem's sequences come from (written by k_project_fa<1>, read by k_fa_fill): the alignment, its transcript's
+// first tx_ex row, the first neighbour exon of the target window
+struct FaSrc { uint32_t aln, e_base, i_from, pad; };
 struct KswRes { int32_t ok, score, refc; uint32_t n_ops; };                              // ops at clip_ops[seq_off + p]
 
 // Streamed DP (k_ksw_dp): problems are binned by target length into four array shapes; a bin's problems sit in a

@@ -1701,6 +1701,12 @@ void launch_project_fa(hipStream_t st, const ProjectArgs &A, const FaArgs &F, in
   }
 }
 
+void launch_fa_fill(hipStream_t st, const ProjectArgs &A, const FaArgs &F, int64_t n_prob) {
+  if (n_prob <= 0) return;
+  int64_t blocks = std::min<int64_t>((n_prob + 15) / 16, 256 * 32);
+  hipLaunchKernelGGL(k_fa_fill, dim3((unsigned)blocks), dim3(256), 0, st, A.ix.tx_ex, A.ix.seq_pool, F, n_prob);
+}
+
 static inline int grid_for(int64_t n, int per_block) { return (int)((n + per_block - 1) / per_block); }
 
 void launch_segment(hipStream_t st, int64_t n_aln, const int32_t *ref_id, const int32_t *ref_start,

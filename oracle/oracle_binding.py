@@ -154,10 +154,10 @@ class OracleIndex:
         L = lib()
         self.h = L.orc_index_new()
         seqs = annotation.get("ref_seqs") or {}
+        enc = {k: (v.encode() if isinstance(v, str) else v) for k, v in seqs.items()}   # once per reference, not per transcript
         for t in annotation["transcripts"]:
             ex = np.asarray(t["exons"], dtype=np.uint32).reshape(-1)
-            seq = seqs.get(t["ref_id"])
-            sb = seq.encode() if isinstance(seq, str) else seq
+            sb = enc.get(t["ref_id"])
             L.orc_index_add_transcript(self.h, t["ref_id"], t["strand"].encode(), t["id"].encode(),
                                        ex.ctypes.data, len(ex) // 2, sb, len(sb) if sb is not None else 0)
         L.orc_index_finish(self.h)
