@@ -5,8 +5,8 @@ T=${1:-ksw}
 O=gpurun_out/r02/$T
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-timeout -k 10 300 rocprofv3 --output-format csv --kernel-trace --stats -d $O/stats -o run -- python3 bench_extra.py c3 --reads 200000 --steps 2 --warmup 1 > $O/stats.log 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --output-format csv --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_VMEM_WR -d $O/pmc -o run -- python3 bench_extra.py c3 --reads 200000 --steps 1 --warmup 1 > $O/pmc.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --output-format csv --kernel-trace --stats -d $O/stats -o run -- python3 bench_extra.py c3 --reads ${READS:-200000} --steps 2 --warmup 1 > $O/stats.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --output-format csv --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_VMEM_WR -d $O/pmc -o run -- python3 bench_extra.py c3 --reads ${READS:-200000} --steps 1 --warmup 1 > $O/pmc.log 2>&1 || exit 1
 python3 profiles/kstats.py $O/stats/run_kernel_stats.csv | head -12
 python3 - $O <<'PY'
 import csv,sys,json
