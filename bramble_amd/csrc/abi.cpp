@@ -456,6 +456,7 @@ struct br_ctx {
   int ksw_fast = 1;            // 0: every problem through the general kernel k_ksw
   uint32_t ksw_groups[KSW_N_BINS] = {0};
   int64_t ksw_tape_mb = 49152; // HBM set aside for the direction tape; larger batches go through in pieces
+  int ksw_tape_pct = 100;      // test hook: the share of the computed tape the DP kernels may use (the rest of the problems goes to k_ksw)
   uint64_t ksw_diag[16] = {0};  // last call: pieces, problems per bin [4], leftovers before the DP, tape bytes (largest piece), spare, tape rows per bin [4]
   DevBuf n_rows, row_off, aln_group;
   // wide view of the rows (br_device_rows_expand): one array per field
@@ -550,6 +551,7 @@ extern "C" int br_ctx_set_param(br_ctx *c, const char *key, int64_t v) {
   if (!strcmp(key, "deflate_dynamic")) { c->deflate_dynamic = v != 0; return BR_OK; }
   if (!strcmp(key, "bam_lanes")) { if (v != 4 && v != 8 && v != 16 && v != 32 && v != 64) return BR_ERR_INVALID_ARG; c->bam_lanes = (int)v; return BR_OK; }
   if (!strcmp(key, "ksw_fast")) { c->ksw_fast = v != 0; return BR_OK; }
+  if (!strcmp(key, "ksw_tape_pct")) { if (v < 0 || v > 100) return BR_ERR_INVALID_ARG; c->ksw_tape_pct = (int)v; return BR_OK; }
   if (!strcmp(key, "ksw_tape_mb")) { if (v < 1) return BR_ERR_INVALID_ARG; c->ksw_tape_mb = v; return BR_OK; }
   if (!strcmp(key, "host_detail")) { c->host_detail = v != 0; return BR_OK; }
   if (!strcmp(key, "blocks_per_cu")) { if (v < 1 || v > 64) return BR_ERR_INVALID_ARG; c->blocks_per_cu = (int)v; return BR_OK; }
@@ -652,7 +654,7 @@ static int run_ksw(br_ctx *c, hipStream_t st, const KswRun &R) {
   if (!c->ksw_fast) return general(n_all, nullptr, nullptr);
 
   RC(c->ksw_raw.ensure((size_t)(R.seq_total + n_all + 1) * 4));
-  RC(c->ksw_cnt.ensure(64));
+  RC(c->ksw_cnt.ensure(128));
   uint32_t *h_cnt = (uint32_t *)(c->h_totals + 16);   // 16 words of the pinned totals
   const uint64_t tape_budget = (uint64_t)c->ksw_tape_mb << 20;
   // groups of a bin = what is resident at once (one wave of blocks: every group runs from the first cycle)
@@ -675,18 +677,21 @@ static int run_ksw(br_ctx *c, hipStream_t st, const KswRun &R) {
     for (int b = 0; b < KSW_N_BINS; b++) A.desc[b] = c->ksw_desc.as<KswDesc>() + (size_t)b * n;
     A.counters = c->ksw_cnt.as<uint32_t>(); A.leftover = c->ksw_left.as<uint32_t>(); A.dp = c->ksw_dp.as<KswDp>();
     A.stats = R.stats; A.raw_out = R.raw_out; A.raw_n = R.raw_n; A.max_out = R.max_out; A.raw_cap = R.raw_cap;
-    HIPCHK(hipMemsetAsync(c->ksw_cnt.p, 0, 64, st));
+    HIPCHK(hipMemsetAsync(c->ksw_cnt.p, 0, 128, st));
     launch_ksw_bin(st, A);
     HIPCHK(hipMemcpyAsync(h_cnt, c->ksw_cnt.p, 64, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     const uint64_t *h_rows = (const uint64_t *)(h_cnt + 8);
+    // tape: a row = one step of a wave (512 B); a bin's waves run (tape rows of its problems) / (groups per wave) steps when
+    // its groups stay equally busy (they share one queue), 15 % on top, and every wave rounds up to chunks and drains
     uint64_t tape_bytes = 0; uint32_t n_groups_total = 0;
     for (int b = 0; b < KSW_N_BINS; b++) {
       A.n_bin[b] = h_cnt[b];
-      A.n_groups[b] = std::min<uint32_t>(max_groups[b], h_cnt[b]);
-      A.group_base[b] = n_groups_total;
+      A.n_groups[b] = std::min<uint32_t>(max_groups[b], (h_cnt[b] + 7u) / 8u);   // a group takes its problems eight at a time
       n_groups_total += A.n_groups[b];
-      tape_bytes += (h_rows[b] + (uint64_t)A.n_groups[b] * (KSW_BIN_W(b) + KSW_TAIL_ROWS)) * (uint64_t)KSW_BIN_ROWBYTES(b);
+      const uint64_t gpw = 64u / (uint64_t)KSW_BIN_G(b), waves = (A.n_groups[b] + gpw - 1) / gpw;
+      const uint64_t rows = h_rows[b] / gpw + h_rows[b] / gpw / 7 + waves * (1ull * KSW_CHUNK_ROWS + KSW_BIN_W(b) + 64);
+      if (A.n_bin[b]) tape_bytes += rows * KSW_TAPE_ROWBYTES;
     }
     if (tape_bytes > tape_budget && n >= 2048) {
       uint64_t mid = p0 + n / 2;
@@ -699,11 +704,8 @@ static int run_ksw(br_ctx *c, hipStream_t st, const KswRun &R) {
     c->ksw_diag[5] += n_left; c->ksw_diag[6] = std::max<uint64_t>(c->ksw_diag[6], tape_bytes);
     for (int b = 0; b < KSW_N_BINS; b++) c->ksw_diag[8 + b] += h_rows[b];
     if (n_groups_total) {
-      RC(c->ksw_group.ensure((size_t)n_groups_total * 16));
       RC(c->ksw_tape.ensure((size_t)tape_bytes + 256));
-      A.group_rows = c->ksw_group.as<uint64_t>(); A.group_off = A.group_rows + n_groups_total;
-      A.tape = c->ksw_tape.as<uint8_t>();
-      launch_ksw_plan(st, A);
+      A.tape = c->ksw_tape.as<uint8_t>(); A.tape_cap = tape_bytes / 100 * (uint64_t)c->ksw_tape_pct;
       for (int b = 0; b < KSW_N_BINS; b++) launch_ksw_dp(st, A, b);
     }
     // what the arrays do not take: targets beyond the widest array, and (never seen outside tests) groups whose tape ran out

@@ -74,9 +74,9 @@ struct KswArgs {
   const uint32_t *list; const uint32_t *n_list;
 };
 
-// The streamed DP over one range of problems [p0, p0 + n): k_ksw_bin -> k_ksw_plan -> k_ksw_group_scan -> k_ksw_dp<G,K> per
-// bin -> k_ksw (the listed leftovers) -> k_ksw_trace.  counters: [0..3] problems per bin, [4] leftovers, [5] groups
-// (scan total, unused), u64 view [4..7] tape rows per bin.
+// The streamed DP over one range of problems [p0, p0 + n): k_ksw_bin -> k_ksw_dp<G,K> per bin -> k_ksw (the listed
+// leftovers) -> k_ksw_trace.  counters (u32[32]): [0..3] problems per bin, [4] leftovers, u64 view [4..7] = [8..15] tape
+// rows per bin, [16..19] the bins' problem queues, u64 at [24] tape bytes handed out.
 struct KswFastArgs {
   int64_t p0, n;
   const KswProb *probs;
@@ -87,9 +87,8 @@ struct KswFastArgs {
   uint32_t *counters;
   uint32_t *leftover;              // [n] problem indices for k_ksw
   KswDp *dp;                       // [n], indexed by p - p0
-  uint64_t *group_rows, *group_off;  // per group (all bins, bin b's groups from group_base[b]): tape rows / byte offset
-  uint8_t *tape;
-  uint32_t n_bin[KSW_N_BINS], n_groups[KSW_N_BINS], group_base[KSW_N_BINS];
+  uint8_t *tape; uint64_t tape_cap;
+  uint32_t n_bin[KSW_N_BINS], n_groups[KSW_N_BINS];
   uint64_t *stats;
   uint32_t *raw_out, *raw_n; int32_t *max_out; uint32_t raw_cap;
 };
@@ -295,7 +294,6 @@ void launch_project_fa(hipStream_t st, const ProjectArgs &A, const FaArgs &F, in
 void launch_fa_fill(hipStream_t st, const ProjectArgs &A, const FaArgs &F, int64_t n_prob);   // coded sequences of every problem
 void launch_ksw(hipStream_t st, const KswArgs &K, int n_blocks);
 void launch_ksw_bin(hipStream_t st, const KswFastArgs &A);
-void launch_ksw_plan(hipStream_t st, const KswFastArgs &A);       // group rows + the scan of their byte sizes
 void launch_ksw_dp(hipStream_t st, const KswFastArgs &A, int bin);
 void launch_ksw_trace(hipStream_t st, const KswFastArgs &A);
 uint32_t ksw_dp_resident_groups(int bin, int n_cu);

@@ -217,7 +217,7 @@ __global__ void __launch_bounds__(256) k_ksw(KswArgs K) {
 // the bin's tape rows.  Degenerate problems get their (empty) result here.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ int ksw_bin_of(uint32_t qlen, uint32_t tlen) {
-  if (qlen > 0xffffu) return KSW_N_BINS;
+  if (qlen > 0xffffu || qlen + tlen > (uint32_t)KSW_MAX_SPAN) return KSW_N_BINS;   // a problem spans at most two tape chunks
   if (tlen <= (uint32_t)KSW_BIN_W(0)) return 0;
   if (tlen <= (uint32_t)KSW_BIN_W(1)) return 1;
   if (tlen <= (uint32_t)KSW_BIN_W(2)) return 2;
@@ -228,77 +228,53 @@ __device__ __forceinline__ int ksw_bin_of(uint32_t qlen, uint32_t tlen) {
 // rows a problem occupies on its group's tape: its query bases, at least K steps between two first bases
 __device__ __forceinline__ uint32_t ksw_rows_of(uint32_t qlen, int K) { return (qlen > (uint32_t)K ? qlen : (uint32_t)K) + 1u; }
 
+#define KSW_BIN_PER_THREAD 16
 __global__ void __launch_bounds__(256) k_ksw_bin(KswFastArgs A) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int lane = threadIdx.x & 63;
-  int bin = -1; KswProb pr; pr.qlen = pr.tlen = pr.side = pr.t_has_n = 0; pr.seq_off = 0;
-  if (i < A.n) {
-    pr = A.probs[A.p0 + i];
+  // a block bins 256 x 16 consecutive problems: counts in LDS, one global atomic per bin and block for the bases (a
+  // wave-level version spent 2.3 ms per 1.6 M problems queueing on nine addresses)
+  __shared__ uint32_t sh_cnt[KSW_N_BINS + 1], sh_base[KSW_N_BINS + 1];
+  __shared__ unsigned long long sh_rows[KSW_N_BINS];
+  if (threadIdx.x <= KSW_N_BINS) sh_cnt[threadIdx.x] = 0;
+  if (threadIdx.x < KSW_N_BINS) sh_rows[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t first = (int64_t)blockIdx.x * (256 * KSW_BIN_PER_THREAD);
+  uint64_t bins = 0;            // 4 bits per problem: bin + 1 (0 = none)
+  uint32_t local[KSW_BIN_PER_THREAD];
+#pragma unroll
+  for (int k = 0; k < KSW_BIN_PER_THREAD; k++) {
+    const int64_t i = first + (int64_t)k * 256 + threadIdx.x;
+    local[k] = 0;
+    if (i >= A.n) continue;
+    const KswProb pr = A.probs[A.p0 + i];
     KswDp d; d.max = 0; d.max_t = d.max_q = -1; d.flags = 0; d.tape = 0;
     A.dp[i] = d;
     if (pr.qlen == 0 || pr.tlen == 0) {
       KswRes rs; rs.ok = 0; rs.score = 0; rs.refc = 0; rs.n_ops = 0;
       A.results[A.p0 + i] = rs;
       if (A.max_out) { A.max_out[A.p0 + i] = 0; A.raw_n[A.p0 + i] = 0; }
-    } else bin = pr.t_has_n ? KSW_N_BINS : ksw_bin_of(pr.qlen, pr.tlen);   // the arrays score a target base by t ^ q: no N
-  }
-#pragma unroll
-  for (int b = 0; b <= KSW_N_BINS; b++) {
-    uint64_t m = __ballot(bin == b);
-    if (!m) continue;
-    uint32_t base = 0;
-    const int leader = __ffsll((unsigned long long)m) - 1;
-    if (lane == leader) base = atomicAdd(&A.counters[b], (uint32_t)__popcll(m));
-    base = (uint32_t)__shfl((int)base, leader, 64);
-    if (bin == b) {
-      uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-      if (b < KSW_N_BINS) { KswDesc d; d.qt = pr.qlen | (pr.tlen << 16); d.prob = (uint32_t)(A.p0 + i); d.seq_off = pr.seq_off; A.desc[b][pos] = d; }
-      else A.leftover[pos] = (uint32_t)(A.p0 + i);
+      continue;
     }
+    const int b = pr.t_has_n ? KSW_N_BINS : ksw_bin_of(pr.qlen, pr.tlen);   // the arrays score a target base by t ^ q: no N
+    bins |= (uint64_t)(b + 1) << (4 * k);
+    local[k] = atomicAdd(&sh_cnt[b], 1u);
+    if (b < KSW_N_BINS) atomicAdd(&sh_rows[b], (unsigned long long)ksw_rows_of(pr.qlen, b == 0 ? KSW_BIN_K(0) : b == 1 ? KSW_BIN_K(1) : b == 2 ? KSW_BIN_K(2) : KSW_BIN_K(3)));
   }
-  // tape rows of every bin (the host sizes the tape from them)
-  unsigned long long *rows64 = (unsigned long long *)(A.counters + 8);
-#pragma unroll
-  for (int b = 0; b < KSW_N_BINS; b++) {
-    unsigned long long rws = bin == b ? (unsigned long long)ksw_rows_of(pr.qlen, KSW_BIN_K(b)) : 0ull;
-    for (int d = 32; d >= 1; d >>= 1) rws += (unsigned long long)__shfl_xor((long long)rws, d, 64);
-    if (lane == 0 && rws) atomicAdd(&rows64[b], rws);
-  }
-}
-
-// k_ksw_plan: one lane per group (all bins): the tape rows of the group's problems (group g of a bin with NG groups
-// takes problems g, g + NG, g + 2 NG, ...).
-__global__ void __launch_bounds__(256) k_ksw_plan(KswFastArgs A, uint32_t n_groups_total) {
-  const uint32_t gg = blockIdx.x * blockDim.x + threadIdx.x;
-  if (gg >= n_groups_total) return;
-  int b = 0;
-#pragma unroll
-  for (int k = 1; k < KSW_N_BINS; k++) if (gg >= A.group_base[k]) b = k;
-  const uint32_t g = gg - A.group_base[b], NG = A.n_groups[b], n = A.n_bin[b];
-  const int K = KSW_BIN_K(b);
-  uint64_t rows = 0;
-  for (uint32_t k = g; k < n; k += NG) rows += ksw_rows_of(A.desc[b][k].qt & 0xffffu, K);
-  rows += (uint64_t)KSW_BIN_W(b) + KSW_TAIL_ROWS;
-  A.group_rows[gg] = rows;
-  A.group_off[gg] = rows * (uint64_t)KSW_BIN_ROWBYTES(b);
-}
-
-// exclusive scan of group_off in place, one block
-__global__ void __launch_bounds__(1024) k_ksw_group_scan(uint64_t *v, uint32_t n) {
-  __shared__ uint64_t sh[1024];
-  const uint32_t per = (n + 1023u) / 1024u, lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
-  uint64_t s = 0;
-  for (uint32_t i = lo; i < hi; i++) s += v[i];
-  sh[threadIdx.x] = s;
   __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {
-    uint64_t y = threadIdx.x >= (uint32_t)d ? sh[threadIdx.x - d] : 0;
-    __syncthreads();
-    sh[threadIdx.x] += y;
-    __syncthreads();
+  if (threadIdx.x <= KSW_N_BINS) sh_base[threadIdx.x] = sh_cnt[threadIdx.x] ? atomicAdd(&A.counters[threadIdx.x], sh_cnt[threadIdx.x]) : 0u;
+  if (threadIdx.x < KSW_N_BINS && sh_rows[threadIdx.x]) atomicAdd((unsigned long long *)(A.counters + 8) + threadIdx.x, sh_rows[threadIdx.x]);
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < KSW_BIN_PER_THREAD; k++) {
+    const int bb = (int)((bins >> (4 * k)) & 15u) - 1;
+    if (bb < 0) continue;
+    const int64_t i = first + (int64_t)k * 256 + threadIdx.x;
+    const uint32_t pos = sh_base[bb] + local[k];
+    if (bb < KSW_N_BINS) {
+      const KswProb pr = A.probs[A.p0 + i];
+      KswDesc d; d.qt = pr.qlen | (pr.tlen << 16); d.prob = (uint32_t)(A.p0 + i); d.seq_off = pr.seq_off;
+      A.desc[bb][pos] = d;
+    } else A.leftover[pos] = (uint32_t)(A.p0 + i);
   }
-  uint64_t run = sh[threadIdx.x] - s;
-  for (uint32_t i = lo; i < hi; i++) { uint64_t x = v[i]; v[i] = run; run += x; }
 }
 
 // ---------------------------------------------------------------------------
@@ -326,36 +302,64 @@ __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SE
 
 struct KswDpArgs {
   const KswDesc *desc; uint32_t n, n_groups;
-  const uint64_t *group_rows, *group_off;   // already offset to the bin's first group
+  uint32_t *queue;                 // next problem of the bin's descriptor array
+  unsigned long long *tape_used;   // bytes of the tape handed out
+  uint64_t tape_cap;
   uint8_t *tape; const uint8_t *seq_arena;
   KswDp *dp; int64_t p0;
   uint32_t *leftover, *n_leftover;
   uint32_t bin;
 };
 
+#define KSW_NO_PROB 0xffffffffu
+
 template <int G, int K>
 __global__ void __launch_bounds__(256) k_ksw_dp(KswDpArgs A) {
-  constexpr int P = K / 2, W = G * K, GPW = 64 / G;
+  constexpr int P = K / 2, W = G * K, GPW = 64 / G, R = 2 * G;
   // column layout of a lane: pair j = columns c0 + j (low half) and c0 + j + P (high half), so that the left neighbours
   // of both halves of pair j are the two halves of pair j - 1: only pair 0 needs a shifted operand
   __shared__ uint32_t sh_pub[4][2][64 * P];     // [wave][v | u][lane * P + pair]: what the columns hold after the step
-  __shared__ uint32_t sh_mb[4][64];             // per bookkeeping lane: 0 = free, else first step of its problem + 1
-  __shared__ uint32_t sh_cx[4][GPW];            // per group: sequence number + 1 of a problem that z-dropped
+  __shared__ uint4 sh_mb[4][64];                // per bookkeeping lane: {first step + 1 (0 = free), qlen | tlen << 16, problem, 0}
+  __shared__ uint32_t sh_cx[4][GPW];            // per group: problem + 1 of a problem that z-dropped
+  __shared__ uint4 sh_ring[4][GPW][R];          // per group: descriptors of its problems n, n + 1, n + 2 (slot = sequence % R)
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int gl = lane & (G - 1), grp = lane / G;
   const uint32_t g = ((uint32_t)blockIdx.x * 4u + (uint32_t)w) * GPW + (uint32_t)grp;
-  const uint32_t NG = A.n_groups;
-  const uint32_t cnt = (g < NG && A.n > g) ? (A.n - g + NG - 1u) / NG : 0u;   // problems of this group: g, g + NG, ...
-  const uint32_t rows_alloc = g < NG ? (uint32_t)A.group_rows[g] : 0u;
-  const uint64_t tape_off_g = g < NG ? A.group_off[g] : 0ull;
-  uint8_t *tape_g = A.tape + tape_off_g + (size_t)gl * 8u;
+  const bool live = g < A.n_groups;
   const uint32_t c0 = (uint32_t)gl * K;
-  auto load_desc = [&](uint32_t k) { KswDesc d; d.qt = 0; d.prob = 0; d.seq_off = 0; if (k < cnt) d = A.desc[g + k * NG]; return d; };
   auto load8 = [&](uint64_t off) { uint2 v; __builtin_memcpy(&v, A.seq_arena + off, 8); return v; };
   auto load16 = [&](uint64_t off) { uint4 v; __builtin_memcpy(&v, A.seq_arena + off, 16); return v; };
+  auto ring_get = [&](uint32_t n) { return sh_ring[w][grp][n & (R - 1)]; };     // {qt, prob, seq_off lo, hi}
+  auto seq_off_of = [](uint4 d) { return (uint64_t)d.z | ((uint64_t)d.w << 32); };
+  const uint4 no_desc = make_uint4(0u, KSW_NO_PROB, 0u, 0u);
+  // feeder only: the next problem of the bin (the queue is shared by every group of the launch)
+  // (claimed eight at a time: one atomic per problem on a single address is ~15 ns of queueing each)
+  uint32_t cl_next = 0, cl_end = 0;
+  auto claim = [&]() {
+    if (cl_next == cl_end) { cl_next = atomicAdd(A.queue, 8u); cl_end = cl_next + 8u; }
+    const uint32_t k = cl_next++;
+    return k < A.n ? k : KSW_NO_PROB;
+  };
+  auto fetch = [&](uint32_t k) { uint4 d = no_desc; if (k != KSW_NO_PROB) { KswDesc e = A.desc[k]; d = make_uint4(e.qt, e.prob, (uint32_t)e.seq_off, (uint32_t)(e.seq_off >> 32)); } return d; };
 
-  sh_mb[w][lane] = 0;
+  sh_mb[w][lane] = make_uint4(0, 0, 0, 0);
   if (gl == 0) sh_cx[w][grp] = 0;
+  for (int k = gl; k < R; k += G) sh_ring[w][grp][k] = no_desc;
+  wave_sync();
+
+  // ---- feeder (lane 0 of the group): descriptors run three problems ahead of the one being fed
+  int32_t fk = -1; uint32_t fi = 0, fq = 0, fprob = KSW_NO_PROB, fgap = K;
+  uint64_t fbuf = 0, fnext = 0, fqn = 0, fqoff = 0;
+  uint4 fd_next = no_desc, fd_loaded = no_desc;   // descriptor of problem fk + 1; of fk + 3 (on its way to the ring)
+  uint32_t fi_pending = KSW_NO_PROB;              // queue index claimed for problem fk + 4
+  if (gl == 0 && live) {
+    const uint4 d0 = fetch(claim()), d1 = fetch(claim());
+    sh_ring[w][grp][0] = d0; sh_ring[w][grp][1] = d1;
+    fd_loaded = fetch(claim());      // problem 2: goes to the ring when problem 0 starts
+    fi_pending = claim();            // problem 3
+    fd_next = d0;
+    if (d0.y != KSW_NO_PROB) { uint2 v = load8(seq_off_of(d0)); fqn = (uint64_t)v.x | ((uint64_t)v.y << 32); }
+  }
   wave_sync();
 
   uint32_t U[P], Y[P], V[P], S[P], Q[P], T[P], TX[P];
@@ -374,55 +378,65 @@ __global__ void __launch_bounds__(256) k_ksw_dp(KswDpArgs A) {
       t[p] = __builtin_amdgcn_perm(hi, lo, sel) | 0x0c000c00u;
     }
   };
-  // the target bases of the problems to come: TX = next first base to arrive (problem kl), txx = the one after, dd = the
-  // descriptor after that (its target is fetched when txx moves up)
+  // the target bases of the problems to come: TX = next first base to arrive (problem kl), txx = the one after; the
+  // descriptor after that comes from the ring when txx moves up
   uint32_t kl = 0;
   uint4 txx = make_uint4(0, 0, 0, 0);
-  KswDesc dd;
   {
-    KswDesc d0 = load_desc(0), d1 = load_desc(1);
-    dd = load_desc(2);
-    if (cnt > 0) make_t(load16(d0.seq_off + (d0.qt & 0xffffu) + c0), TX);
-    if (cnt > 1) txx = load16(d1.seq_off + (d1.qt & 0xffffu) + c0);
+    const uint4 d0 = ring_get(0), d1 = ring_get(1);
+    if (d0.y != KSW_NO_PROB) make_t(load16(seq_off_of(d0) + (d0.x & 0xffffu) + c0), TX);
+    if (d1.y != KSW_NO_PROB) txx = load16(seq_off_of(d1) + (d1.x & 0xffffu) + c0);
   }
-  // ---- feeder (lane 0 of the group)
-  int32_t fk = -1; uint32_t fi = 0, fq = 0, fgap = K;
-  uint64_t fbuf = 0, fnext = 0, fqn = 0, fqoff = 0;
-  KswDesc fdn, fdn2;
-  fdn.qt = fdn2.qt = 0; fdn.prob = fdn2.prob = 0; fdn.seq_off = fdn2.seq_off = 0;
-  if (gl == 0) {
-    fdn = load_desc(0); fdn2 = load_desc(1);
-    if (cnt > 0) { uint2 v = load8(fdn.seq_off); fqn = (uint64_t)v.x | ((uint64_t)v.y << 32); }
-  }
-  // ---- bookkeeping lane: problems gl, gl + G, ... of the group
-  uint32_t tk = (uint32_t)gl; KswDesc td = load_desc(tk);
-  bool tr_on = false; int32_t tS = 0, tq = 0, tt = 0, H0 = 0, lastT = 0, emax = 0, emax_t = -1, emax_q = -1;
+  // ---- bookkeeping lane: one problem in flight
+  bool tr_on = false; int32_t tS = 0, tq = 0, tt = 0, H0 = 0, lastT = 0, emax = 0, emax_t = -1, emax_q = -1; uint32_t tprob = 0;
   const uint16_t *pubV = (const uint16_t *)&sh_pub[w][0][0] + grp * W, *pubU = (const uint16_t *)&sh_pub[w][1][0] + grp * W;
   // u16 index of group column t in a published array
   auto pub_idx = [&](int t) { const uint32_t ut = (uint32_t)t, ln = ut / K, jj = ut - ln * K, hf = jj >= (uint32_t)P ? 1u : 0u; return ln * K + 2u * (jj - hf * P) + hf; };
+  // ---- tape: the wave takes chunks of KSW_CHUNK_ROWS rows (one row = one step of the whole wave)
+  uint64_t chunk_cur = 0, chunk_prev = 0;   // byte offsets in the tape (wave-uniform)
+  bool dead = false;                         // the tape ran out: the wave gives its claimed problems back (k_ksw takes them)
 
   for (uint32_t s = 0;; s++) {
-    // the tape of a group holds rows_alloc steps; a group that would run past it (a queue of very short problems
-    // waiting for bookkeeping lanes) hands what it has not finished to k_ksw
-    if (s >= rows_alloc) {
-      if (tr_on) { A.leftover[atomicAdd(A.n_leftover, 1u)] = td.prob; tr_on = false; }
-      if (gl == 0) { for (uint32_t k = (uint32_t)(fk + 1); k < cnt; k++) A.leftover[atomicAdd(A.n_leftover, 1u)] = A.desc[g + k * NG].prob; fk = (int32_t)cnt; fi = fq = 0; }
-    }
-    bool busy = tr_on || (gl == 0 && (uint32_t)(fk + 1) < cnt);
+    bool busy = tr_on || (gl == 0 && fd_next.y != KSW_NO_PROB);
     if (!__any(busy)) break;
+    if ((s & (KSW_CHUNK_ROWS - 1)) == 0) {
+      unsigned long long off = 0;
+      if (lane == 0) off = atomicAdd(A.tape_used, (unsigned long long)KSW_CHUNK_ROWS * KSW_TAPE_ROWBYTES);
+      off = (unsigned long long)__shfl((long long)off, 0, 64);
+      chunk_prev = chunk_cur; chunk_cur = off;
+      if (off + (unsigned long long)KSW_CHUNK_ROWS * KSW_TAPE_ROWBYTES > A.tape_cap) dead = true;
+    }
+    if (dead) {
+      if (tr_on) { A.leftover[atomicAdd(A.n_leftover, 1u)] = tprob; tr_on = false; }
+      if (gl == 0) {
+        // claimed but not started: fk + 1, fk + 2 (ring), fk + 3 (fd_loaded), fk + 4 (fi_pending), the claimed batch's rest
+        if (fd_next.y != KSW_NO_PROB) A.leftover[atomicAdd(A.n_leftover, 1u)] = fd_next.y;
+        const uint4 d2 = ring_get((uint32_t)(fk + 2));
+        if (d2.y != KSW_NO_PROB) A.leftover[atomicAdd(A.n_leftover, 1u)] = d2.y;
+        if (fd_loaded.y != KSW_NO_PROB) A.leftover[atomicAdd(A.n_leftover, 1u)] = fd_loaded.y;
+        if (fi_pending != KSW_NO_PROB) A.leftover[atomicAdd(A.n_leftover, 1u)] = A.desc[fi_pending].prob;
+        for (; cl_next < cl_end && cl_next < A.n; cl_next++) A.leftover[atomicAdd(A.n_leftover, 1u)] = A.desc[cl_next].prob;   // the rest of the claimed batch
+        fd_next = no_desc; fd_loaded = no_desc; fi_pending = KSW_NO_PROB; fi = fq = 0;
+        sh_ring[w][grp][(uint32_t)(fk + 2) & (R - 1)] = no_desc;
+      }
+      continue;   // the next pass over the loop head leaves (nothing is busy any more)
+    }
 
     // ---- feeder: the base that enters column 0 now
     uint32_t qin = 0, vin = 0;
-    if (gl == 0 && s < rows_alloc) {
-      bool feeding = fk >= 0 && fi < fq && sh_cx[w][grp] != (uint32_t)(fk + 1);
-      if (!feeding && (uint32_t)(fk + 1) < cnt && fgap >= (uint32_t)K && sh_mb[w][grp * G + ((uint32_t)(fk + 1) & (G - 1))] == 0) {
+    if (gl == 0) {
+      bool feeding = fk >= 0 && fi < fq && sh_cx[w][grp] != fprob + 1u;
+      if (!feeding && fd_next.y != KSW_NO_PROB && fgap >= (uint32_t)K && sh_mb[w][grp * G + ((uint32_t)(fk + 1) & (G - 1))].x == 0) {
         fk++;
-        fq = fdn.qt & 0xffffu; fi = 0; fqoff = fdn.seq_off; fbuf = fqn;
+        fq = fd_next.x & 0xffffu; fi = 0; fqoff = seq_off_of(fd_next); fprob = fd_next.y; fbuf = fqn;
         { uint2 v = load8(fqoff + 8); fnext = (uint64_t)v.x | ((uint64_t)v.y << 32); }
-        fdn = fdn2;
-        if ((uint32_t)(fk + 1) < cnt) { uint2 v = load8(fdn.seq_off); fqn = (uint64_t)v.x | ((uint64_t)v.y << 32); }
-        fdn2 = load_desc((uint32_t)(fk + 2));
-        sh_mb[w][grp * G + ((uint32_t)fk & (G - 1))] = s + 1u;
+        sh_mb[w][grp * G + ((uint32_t)fk & (G - 1))] = make_uint4(s + 1u, fd_next.x, fd_next.y, 0u);
+        // the descriptor pipeline moves one problem: fk + 2 reaches the ring, fk + 3 is fetched, fk + 4 claimed
+        sh_ring[w][grp][(uint32_t)(fk + 2) & (R - 1)] = fd_loaded;
+        fd_loaded = fetch(fi_pending);
+        fi_pending = claim();
+        fd_next = ring_get((uint32_t)(fk + 1));
+        if (fd_next.y != KSW_NO_PROB) { uint2 v = load8(seq_off_of(fd_next)); fqn = (uint64_t)v.x | ((uint64_t)v.y << 32); }
         feeding = true; fgap = 0;
       }
       if (feeding) {
@@ -466,7 +480,7 @@ __global__ void __launch_bounds__(256) k_ksw_dp(KswDpArgs A) {
       D[p] = (pk_min_u(yn, 0x00040004u) << 1) | bfi32(m3, wv, pk_min_u(xt, 0x00050005u));
       Q[p] = qn;
     }
-    if (s < rows_alloc) {
+    {
       uint2 word;
       word.x = D[0];
 #pragma unroll
@@ -474,15 +488,15 @@ __global__ void __launch_bounds__(256) k_ksw_dp(KswDpArgs A) {
       word.y = P > 4 ? D[4] : 0u;
 #pragma unroll
       for (int p = 5; p < P; p++) word.y |= D[p] << (4 * (p - 4));
-      *(uint2 *)(tape_g + (size_t)s * (G * 8u)) = word;
+      *(uint2 *)(A.tape + chunk_cur + (size_t)(s & (KSW_CHUNK_ROWS - 1)) * KSW_TAPE_ROWBYTES + (size_t)lane * 8u) = word;
     }
 
     // ---- a first base leaves the lane: the next problem's target moves up
     if (leaving) {
       make_t(txx, TX);
       kl++;
-      if (kl + 1 < cnt) txx = load16(dd.seq_off + (dd.qt & 0xffffu) + c0);
-      dd = load_desc(kl + 2);
+      const uint4 dn = ring_get(kl + 1);
+      if (dn.y != KSW_NO_PROB) txx = load16(seq_off_of(dn) + (dn.x & 0xffffu) + c0);
     }
 
     // ---- publish v, u; approximate maximum and z-drop of the problems in flight
@@ -490,8 +504,8 @@ __global__ void __launch_bounds__(256) k_ksw_dp(KswDpArgs A) {
     for (int p = 0; p < P; p++) { sh_pub[w][0][lane * P + p] = V[p]; sh_pub[w][1][lane * P + p] = U[p]; }
     wave_sync();
     if (!tr_on) {
-      uint32_t mb = sh_mb[w][lane];
-      if (mb) { tr_on = true; tS = (int32_t)(mb - 1u); tq = (int32_t)(td.qt & 0xffffu); tt = (int32_t)(td.qt >> 16); H0 = 0; lastT = 0; emax = 0; emax_t = emax_q = -1; }
+      const uint4 mb = sh_mb[w][lane];
+      if (mb.x) { tr_on = true; tS = (int32_t)(mb.x - 1u); tq = (int32_t)(mb.y & 0xffffu); tt = (int32_t)(mb.y >> 16); tprob = mb.z; H0 = 0; lastT = 0; emax = 0; emax_t = emax_q = -1; }
     }
     if (tr_on) {
       const int r = (int32_t)s - tS;
@@ -516,15 +530,28 @@ __global__ void __launch_bounds__(256) k_ksw_dp(KswDpArgs A) {
       if (stop || last) {
         KswDp d; d.max = emax; d.max_t = emax_t; d.max_q = emax_q;
         d.flags = 1u | ((last && !stop) ? 2u : 0u) | (A.bin << 8);
-        d.tape = tape_off_g + (uint64_t)(uint32_t)tS * (G * 8u);
-        A.dp[(int64_t)td.prob - A.p0] = d;
-        if (stop) sh_cx[w][grp] = tk + 1u;
-        sh_mb[w][lane] = 0;
-        tr_on = false; tk += G; td = load_desc(tk);
+        // rows of the problem: tS .. s, in the current chunk or starting in the one before
+        const uint32_t srow = (uint32_t)tS & (KSW_CHUNK_ROWS - 1);
+        const bool same = ((uint32_t)tS / KSW_CHUNK_ROWS) == (s / KSW_CHUNK_ROWS);
+        d.tape = (same ? chunk_cur : chunk_prev) + (uint64_t)srow * KSW_TAPE_ROWBYTES + (uint64_t)(grp * G) * 8u;
+        d.tape2 = chunk_cur + (uint64_t)(grp * G) * 8u;
+        d.split = same ? 0xffffffffu : (uint32_t)KSW_CHUNK_ROWS - srow; d.pad = 0;
+        A.dp[(int64_t)tprob - A.p0] = d;
+        if (stop) sh_cx[w][grp] = tprob + 1u;
+        sh_mb[w][lane] = make_uint4(0, 0, 0, 0);
+        tr_on = false;
       }
     }
     wave_sync();
   }
+}
+
+// k_ksw_unclaimed: after a bin's k_ksw_dp: problems nobody took from the queue (every wave ran out of tape) go to the
+// general kernel's list.  Normally the queue is empty and this is a no-op.
+__global__ void __launch_bounds__(256) k_ksw_unclaimed(KswDpArgs A) {
+  const uint32_t q0 = *A.queue;
+  for (uint64_t k = (uint64_t)q0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < A.n; k += (uint64_t)gridDim.x * blockDim.x)
+    A.leftover[atomicAdd(A.n_leftover, 1u)] = A.desc[k].prob;
 }
 
 // ---------------------------------------------------------------------------
@@ -545,15 +572,16 @@ __global__ void __launch_bounds__(256) k_ksw_trace(KswFastArgs A) {
       if (d.max < 10 || !(d.flags & 2u) || d.max_t < 0 || d.max_q < 0) A.results[p] = rs;
       else {
         const int b = (int)(d.flags >> 8);
-        const uint32_t K = (uint32_t)KSW_BIN_K(b), P = K / 2, rb = (uint32_t)KSW_BIN_ROWBYTES(b);
-        const uint8_t *tp = A.tape + d.tape;
+        const uint32_t K = (uint32_t)KSW_BIN_K(b), P = K / 2;
+        const uint8_t *tp = A.tape + d.tape, *tp2 = A.tape + d.tape2;
         uint32_t *raw = A.raw_ops + (pr.seq_off + (uint64_t)p);
         int ci = d.max_t, cj = d.max_q, state = 0;
         RawSink sk{raw, 0};
         while (ci >= 0 && cj >= 0) {
           // column ci = lane ci / K, pair (ci % K) % P, half (ci % K) / P; pairs 0-3 sit in the lane's first dword
           const uint32_t r = (uint32_t)(ci + cj), ln = (uint32_t)ci / K, jj = (uint32_t)ci - ln * K, hf = jj >= P ? 1u : 0u, pj = jj - hf * P;
-          const uint32_t word = *(const uint32_t *)(tp + (size_t)r * rb + (size_t)ln * 8u + (pj >> 2) * 4u);
+          const uint8_t *rowp = r < d.split ? tp + (size_t)r * KSW_TAPE_ROWBYTES : tp2 + (size_t)(r - d.split) * KSW_TAPE_ROWBYTES;
+          const uint32_t word = *(const uint32_t *)(rowp + (size_t)ln * 8u + (pj >> 2) * 4u);
           const uint32_t nib = (word >> (hf * 16u + 4u * (pj & 3u))) & 0xfu;
           const uint32_t tmp = (2u - (nib & 3u)) | ((nib & 0xcu) << 1);
           if (state == 0) state = tmp & 7;
@@ -591,21 +619,15 @@ void launch_ksw(hipStream_t st, const KswArgs &K, int n_blocks) {
 
 void launch_ksw_bin(hipStream_t st, const KswFastArgs &A) {
   if (A.n <= 0) return;
-  hipLaunchKernelGGL(k_ksw_bin, dim3((unsigned)((A.n + 255) / 256)), dim3(256), 0, st, A);
-}
-
-void launch_ksw_plan(hipStream_t st, const KswFastArgs &A) {
-  uint32_t total = A.group_base[KSW_N_BINS - 1] + A.n_groups[KSW_N_BINS - 1];
-  if (!total) return;
-  hipLaunchKernelGGL(k_ksw_plan, dim3((total + 255) / 256), dim3(256), 0, st, A, total);
-  hipLaunchKernelGGL(k_ksw_group_scan, dim3(1), dim3(1024), 0, st, A.group_off, total);
+  const int64_t per_block = 256 * KSW_BIN_PER_THREAD;
+  hipLaunchKernelGGL(k_ksw_bin, dim3((unsigned)((A.n + per_block - 1) / per_block)), dim3(256), 0, st, A);
 }
 
 void launch_ksw_dp(hipStream_t st, const KswFastArgs &A, int bin) {
   if (!A.n_bin[bin] || !A.n_groups[bin]) return;
   KswDpArgs D{};
   D.desc = A.desc[bin]; D.n = A.n_bin[bin]; D.n_groups = A.n_groups[bin];
-  D.group_rows = A.group_rows + A.group_base[bin]; D.group_off = A.group_off + A.group_base[bin];
+  D.queue = A.counters + 16 + bin; D.tape_used = (unsigned long long *)(A.counters + 24); D.tape_cap = A.tape_cap;
   D.tape = A.tape; D.seq_arena = A.seq_arena; D.dp = A.dp; D.p0 = A.p0;
   D.leftover = A.leftover; D.n_leftover = A.counters + KSW_N_BINS; D.bin = (uint32_t)bin;
   const uint32_t gpw = 64u / (uint32_t)KSW_BIN_G(bin);
@@ -616,6 +638,7 @@ void launch_ksw_dp(hipStream_t st, const KswFastArgs &A, int bin) {
     case 2: hipLaunchKernelGGL((k_ksw_dp<KSW_BIN_G(2), KSW_BIN_K(2)>), dim3(blocks), dim3(256), 0, st, D); break;
     default: hipLaunchKernelGGL((k_ksw_dp<KSW_BIN_G(3), KSW_BIN_K(3)>), dim3(blocks), dim3(256), 0, st, D); break;
   }
+  hipLaunchKernelGGL(k_ksw_unclaimed, dim3(64), dim3(256), 0, st, D);
 }
 
 // groups of a bin that are resident at once (blocks per CU from the occupancy query x 4 waves x groups per wave)

@@ -15,15 +15,17 @@ struct KswRes { int32_t ok, score, refc; uint32_t n_ops; };                     
 struct KswDesc { uint32_t qt; uint32_t prob; uint64_t seq_off; };   // qlen | tlen << 16, problem index, first query code
 // What the DP leaves per problem for the traceback kernel.
 //   flags: bit 0 = handled by k_ksw_dp, bit 1 = the DP reached the last cell (score valid, no z-drop), bits 8.. = bin
-//   tape : byte offset of the problem's anti-diagonal 0 in the direction tape
-struct KswDp { int32_t max, max_t, max_q; uint32_t flags; uint64_t tape; };
+//   tape : byte offset (in the direction tape) of the group's first lane in the row of the problem's anti-diagonal 0;
+//   anti-diagonals >= split continue at tape2 (the wave's next tape chunk)
+struct KswDp { int32_t max, max_t, max_q; uint32_t flags; uint64_t tape, tape2; uint32_t split, pad; };
 
 #define KSW_N_BINS 4
 // lanes per group / target columns per lane of every bin (columns = product); a lane stores 8 tape bytes per step
 #define KSW_BIN_G(b) ((b) == 0 ? 8 : (b) == 1 ? 8 : (b) == 2 ? 16 : 32)
 #define KSW_BIN_K(b) ((b) == 0 ? 8 : (b) == 3 ? 12 : 16)
 #define KSW_BIN_W(b) (KSW_BIN_G(b) * KSW_BIN_K(b))      // 64, 128, 256, 384 target columns
-#define KSW_BIN_ROWBYTES(b) (KSW_BIN_G(b) * 8)
-#define KSW_TAIL_ROWS 64                                 // slack rows behind a group's last problem
+#define KSW_TAPE_ROWBYTES 512                            // a tape row = one step of a wave: 8 bytes per lane
+#define KSW_CHUNK_ROWS 1024                              // waves take tape in chunks; a problem spans at most two
+#define KSW_MAX_SPAN KSW_CHUNK_ROWS                      // qlen + tlen of a problem the arrays take
 
 }  // namespace br

@@ -517,7 +517,8 @@ int br_ctx_rescue_stats(br_ctx *, uint64_t out[4]);
 /* Diagnostic: routing of the last call's rescue DP problems: pieces, problems per register-array shape (64 / 128 / 256 /
  * 384 target columns), problems left to the general kernel before the DP, direction-tape bytes of the largest piece, 0,
  * leftovers of the last piece after the DP, tape rows (array steps) per shape [4], 0 x 4.  Keys of br_ctx_set_param: "ksw_fast" (0 = general kernel only),
- * "ksw_tape_mb" (tape budget; larger batches are processed in pieces). */
+ * "ksw_tape_mb" (tape budget; larger batches are processed in pieces), "ksw_tape_pct" (test hook: share of the tape the
+ * array kernels may use). */
 int br_ctx_ksw_diag(br_ctx *, uint64_t out[16]);
 
 /* Diagnostic: the -S rescue DP alone (k_ksw = ksw_extz2_sse as src/evaluate.cpp:296-313 calls it, on the device).

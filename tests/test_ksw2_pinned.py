@@ -176,6 +176,13 @@ def test_streamed_dp_every_array_shape_leftovers_and_pieces():
     ctx.set_param("ksw_tape_mb", 1)
     check(*ctx.ksw_pairs(pairs))
     assert ctx.ksw_diag()["pieces"] > 1
+    # a tape too small for the batch: waves that find no chunk hand their problems to the general kernel
+    ctx.set_param("ksw_tape_mb", 49152)
+    ctx.set_param("ksw_tape_pct", 20)
+    check(*ctx.ksw_pairs(pairs))
+    d = ctx.ksw_diag()
+    assert d["leftover_after"] > d["leftover_before"], d
+    ctx.set_param("ksw_tape_pct", 100)
     ctx.set_param("ksw_fast", 0)
     check(*ctx.ksw_pairs(pairs))
     assert ctx.ksw_diag()["pieces"] == 0
