@@ -635,23 +635,33 @@ static int run_ksw(br_ctx *c, hipStream_t st, const KswRun &R) {
   const uint64_t qmax = std::max<uint64_t>(R.qmax, 1), tmax = std::max<uint64_t>(R.tmax, 1);
   KswArgs K{};
   K.n_prob = R.n_prob; K.probs = R.probs; K.results = R.results; K.seq_arena = R.seq_arena; K.clip_ops = R.clip_ops;
-  K.tmax = (uint32_t)tmax; K.stats = R.stats;
+  K.stats = R.stats;
   K.raw_out = R.raw_out; K.raw_n = R.raw_n; K.max_out = R.max_out; K.raw_cap = R.raw_cap;
-  K.pmat_bytes = (size_t)(((qmax + tmax) * tmax + 15) & ~15ull);
-  K.raw_words = (size_t)((qmax + tmax + 4 + 3) & ~3ull);
-  K.scratch_per_wave = K.pmat_bytes + K.raw_words * 4 + ((4 * tmax + 15) & ~15ull);
-  const uint64_t budget = 16ull << 30;  // HBM set aside for the general kernel's direction matrices
-  auto general = [&](uint64_t n_work, const uint32_t *list, const uint32_t *n_list) -> int {
-    uint64_t waves = std::min<uint64_t>({(uint64_t)c->n_cu * 4 * 4, std::max<uint64_t>(budget / K.scratch_per_wave, 4), (n_work + 3) / 4 * 4});
-    int kb = (int)std::max<uint64_t>(waves / 4, 1);
-    RC(c->fa_scratch.ensure((size_t)kb * 4 * K.scratch_per_wave));
-    K.scratch = c->fa_scratch.as<uint8_t>(); K.list = list; K.n_list = n_list;
-    launch_ksw(st, K, kb);
+  // the general kernel: per-wave scratch = direction matrix + raw traceback ops + (large targets) u / v / x / y, sized by the
+  // longest query / target it will see.  16 GB are set aside; one outlier (a 100 kb soft clip) may take more: then a single
+  // wave runs, as long as its matrix fits in 60 % of the free HBM
+  auto general = [&](uint64_t n_work, uint64_t q_hi, uint64_t t_hi, const uint32_t *list, const uint32_t *n_list) -> int {
+    q_hi = std::max<uint64_t>(q_hi, 1); t_hi = std::max<uint64_t>(t_hi, 1);
+    K.tmax = (uint32_t)t_hi;
+    K.pmat_bytes = (size_t)(((q_hi + t_hi) * t_hi + 15) & ~15ull);
+    K.raw_words = (size_t)((q_hi + t_hi + 4 + 3) & ~3ull);
+    K.scratch_per_wave = K.pmat_bytes + K.raw_words * 4 + ((4 * t_hi + 15) & ~15ull);
+    const uint64_t budget = 16ull << 30;
+    uint64_t waves = std::min<uint64_t>({(uint64_t)c->n_cu * 16, budget / K.scratch_per_wave, n_work});
+    if (waves == 0) {
+      size_t free_b = 0, total_b = 0;
+      HIPCHK(hipMemGetInfo(&free_b, &total_b));
+      if ((double)K.scratch_per_wave > 0.6 * (double)(free_b + c->fa_scratch.cap)) return BR_ERR_CAPACITY;
+      waves = 1;
+    }
+    RC(c->fa_scratch.ensure((size_t)waves * K.scratch_per_wave));
+    K.scratch = c->fa_scratch.as<uint8_t>(); K.list = list; K.n_list = n_list; K.n_waves = (int64_t)waves;
+    launch_ksw(st, K, (int)((waves + 3) / 4));
     return BR_OK;
   };
   memset(c->ksw_diag, 0, sizeof(c->ksw_diag));
   c->h_totals[24] = 0;
-  if (!c->ksw_fast) return general(n_all, nullptr, nullptr);
+  if (!c->ksw_fast) return general(n_all, qmax, tmax, nullptr, nullptr);
 
   RC(c->ksw_raw.ensure((size_t)(R.seq_total + n_all + 1) * 4));
   RC(c->ksw_cnt.ensure(128));
@@ -709,7 +719,8 @@ static int run_ksw(br_ctx *c, hipStream_t st, const KswRun &R) {
       for (int b = 0; b < KSW_N_BINS; b++) launch_ksw_dp(st, A, b);
     }
     // what the arrays do not take: targets beyond the widest array, and (never seen outside tests) groups whose tape ran out
-    RC(general(n_left ? n_left : 64, A.leftover, A.counters + KSW_N_BINS));
+    // (problems a wave hands back when the tape runs out come from the arrays: at most KSW_MAX_SPAN bases)
+    RC(general(n_left ? n_left : 64, std::max<uint64_t>(h_cnt[5], KSW_MAX_SPAN), std::max<uint64_t>(h_cnt[6], KSW_BIN_W(KSW_N_BINS - 1)), A.leftover, A.counters + KSW_N_BINS));
     launch_ksw_trace(st, A);
     // leftovers after the DP (those of the last piece; read by br_ctx_ksw_diag once the stream has been synchronised)
     HIPCHK(hipMemcpyAsync((uint32_t *)(c->h_totals + 24), A.counters + KSW_N_BINS, 4, hipMemcpyDeviceToHost, st));

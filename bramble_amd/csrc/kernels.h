@@ -66,6 +66,7 @@ struct KswArgs {
   uint32_t *clip_ops;
   uint8_t *scratch;
   size_t scratch_per_wave, pmat_bytes, raw_words;
+  int64_t n_waves;   // waves that own a scratch slice
   uint32_t tmax;
   uint64_t *stats;  // [2] DP cells, accepted rescues (may be null)
   // diagnostic (br_ctx_ksw_pairs): the raw traceback CIGAR (forward order) and the maximum of every problem; null otherwise
@@ -75,7 +76,7 @@ struct KswArgs {
 };
 
 // The streamed DP over one range of problems [p0, p0 + n): k_ksw_bin -> k_ksw_dp<G,K> per bin -> k_ksw (the listed
-// leftovers) -> k_ksw_trace.  counters (u32[32]): [0..3] problems per bin, [4] leftovers, u64 view [4..7] = [8..15] tape
+// leftovers) -> k_ksw_trace.  counters (u32[32]): [0..3] problems per bin, [4] leftovers, [5] / [6] longest query / target among them, u64 view [4..7] = [8..15] tape
 // rows per bin, [16..19] the bins' problem queues, u64 at [24] tape bytes handed out.
 struct KswFastArgs {
   int64_t p0, n;

@@ -80,8 +80,9 @@ __device__ __forceinline__ KswRes clip_segment(const uint32_t *raw, uint32_t n, 
 __global__ void __launch_bounds__(256) k_ksw(KswArgs K) {
   __shared__ uint32_t sh_uvxy[4][KSW_LDS_T];   // u | v << 8 | x << 16 | y << 24 per target position: one LDS word per cell
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int64_t waves_total = (int64_t)gridDim.x * 4;
+  const int64_t waves_total = K.n_waves;   // waves that own scratch (the grid's last block may hold idle ones)
   const int64_t wid = (int64_t)blockIdx.x * 4 + w;
+  if (wid >= waves_total) return;
   uint8_t *pmat = K.scratch + (size_t)wid * K.scratch_per_wave;
   uint32_t *raw = (uint32_t *)(pmat + K.pmat_bytes);
   uint32_t *gl_uvxy = (uint32_t *)(raw + K.raw_words);
@@ -232,10 +233,11 @@ __device__ __forceinline__ uint32_t ksw_rows_of(uint32_t qlen, int K) { return (
 __global__ void __launch_bounds__(256) k_ksw_bin(KswFastArgs A) {
   // a block bins 256 x 16 consecutive problems: counts in LDS, one global atomic per bin and block for the bases (a
   // wave-level version spent 2.3 ms per 1.6 M problems queueing on nine addresses)
-  __shared__ uint32_t sh_cnt[KSW_N_BINS + 1], sh_base[KSW_N_BINS + 1];
+  __shared__ uint32_t sh_cnt[KSW_N_BINS + 1], sh_base[KSW_N_BINS + 1], sh_left[2];   // sh_left: longest query / target left to k_ksw
   __shared__ unsigned long long sh_rows[KSW_N_BINS];
   if (threadIdx.x <= KSW_N_BINS) sh_cnt[threadIdx.x] = 0;
   if (threadIdx.x < KSW_N_BINS) sh_rows[threadIdx.x] = 0;
+  if (threadIdx.x < 2) sh_left[threadIdx.x] = 0;
   __syncthreads();
   const int64_t first = (int64_t)blockIdx.x * (256 * KSW_BIN_PER_THREAD);
   uint64_t bins = 0;            // 4 bits per problem: bin + 1 (0 = none)
@@ -258,10 +260,12 @@ __global__ void __launch_bounds__(256) k_ksw_bin(KswFastArgs A) {
     bins |= (uint64_t)(b + 1) << (4 * k);
     local[k] = atomicAdd(&sh_cnt[b], 1u);
     if (b < KSW_N_BINS) atomicAdd(&sh_rows[b], (unsigned long long)ksw_rows_of(pr.qlen, b == 0 ? KSW_BIN_K(0) : b == 1 ? KSW_BIN_K(1) : b == 2 ? KSW_BIN_K(2) : KSW_BIN_K(3)));
+    else { atomicMax(&sh_left[0], pr.qlen); atomicMax(&sh_left[1], pr.tlen); }
   }
   __syncthreads();
   if (threadIdx.x <= KSW_N_BINS) sh_base[threadIdx.x] = sh_cnt[threadIdx.x] ? atomicAdd(&A.counters[threadIdx.x], sh_cnt[threadIdx.x]) : 0u;
   if (threadIdx.x < KSW_N_BINS && sh_rows[threadIdx.x]) atomicAdd((unsigned long long *)(A.counters + 8) + threadIdx.x, sh_rows[threadIdx.x]);
+  if (threadIdx.x < 2 && sh_left[threadIdx.x]) atomicMax(&A.counters[5 + threadIdx.x], sh_left[threadIdx.x]);
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < KSW_BIN_PER_THREAD; k++) {
@@ -613,7 +617,7 @@ size_t ksw_prob_bytes() { return sizeof(KswProb); }
 size_t ksw_res_bytes() { return sizeof(KswRes); }
 
 void launch_ksw(hipStream_t st, const KswArgs &K, int n_blocks) {
-  if (K.n_prob <= 0 || n_blocks <= 0) return;
+  if (K.n_prob <= 0 || n_blocks <= 0 || K.n_waves <= 0) return;
   hipLaunchKernelGGL(k_ksw, dim3(n_blocks), dim3(256), 0, st, K);
 }
 

@@ -15,7 +15,9 @@
 
 using namespace orc;
 
-struct orc_index { G2T g2t; };
+// ref_cache: test infrastructure convenience, not reference behaviour: a reference sequence handed over with every
+// transcript is copied once per reference, not once per transcript
+struct orc_index { G2T g2t; std::unordered_map<int32_t, std::string> ref_cache; };
 
 namespace {
 
@@ -286,9 +288,13 @@ int64_t orc_index_add_transcript(orc_index *ix, int32_t ref_id, char strand, con
   std::vector<GSeg> ex((size_t)n_exons);
   for (int i = 0; i < n_exons; i++) { ex[i].start = exons[2 * i]; ex[i].end = exons[2 * i + 1]; }
   std::stable_sort(ex.begin(), ex.end(), [](const GSeg &a, const GSeg &b) { return a.start < b.start; });
-  std::string seq;
-  if (ref_seq) seq.assign(ref_seq, ref_seq + ref_seq_len);
-  return (int64_t)ix->g2t.add_transcript(ref_id, strand, name ? name : "", ex, ref_seq ? &seq : nullptr);
+  const std::string *seq = nullptr;
+  if (ref_seq) {
+    auto it = ix->ref_cache.find(ref_id);
+    if (it == ix->ref_cache.end() || (int64_t)it->second.size() != ref_seq_len) it = ix->ref_cache.insert_or_assign(ref_id, std::string(ref_seq, ref_seq + ref_seq_len)).first;
+    seq = &it->second;
+  }
+  return (int64_t)ix->g2t.add_transcript(ref_id, strand, name ? name : "", ex, seq);
 }
 void orc_index_finish(orc_index *ix) { ix->g2t.finish(); }
 int64_t orc_index_num_transcripts(const orc_index *ix) { return (int64_t)ix->g2t.tid_names.size(); }

@@ -154,6 +154,7 @@ def test_streamed_dp_every_array_shape_leftovers_and_pieces():
     # very short problems in a row (first bases closer than a lane's column count), targets shorter than the query
     pairs += [("ACGTACGTAC"[:int(rng.randint(1, 11))], "ACGTTGCA"[:int(rng.randint(1, 9))]) for _ in range(300)]
     pairs += [(p[0][:int(rng.randint(1, 30))], p[1]) for p in (_long_pair(rng, int(rng.randint(60, 300))) for _ in range(300))]
+    pairs += [_long_pair(rng, 5000), _long_pair(rng, 2100)]   # targets beyond 2048: the general kernel keeps u / v / x / y in HBM
     order = rng.permutation(len(pairs))
     pairs = [pairs[k] for k in order]
     want = [ksw2_check.gotoh(t, q) for t, q in pairs]
