@@ -441,6 +441,7 @@ struct br_ctx {
   DevBuf pool, pool_sizes, pool_off, pk_ch;   // dense long-CIGAR pool + rewritten references for host downloads
   bool last_aux_cols = false;           // the last call's rows carry similarity / clip scores
   bool wide_valid = false;              // the wide view below matches the last call's rows
+  bool detail_valid = false;            // pk_x (br_row_x) has been derived for the last call's rows
   const int32_t *last_l_qseq = nullptr; // the last batch's l_qseq (device; insert sizes of the wide view / the encoder)
   int32_t last_long_reads = 0;
   int64_t last_n_pool = 0;
@@ -931,10 +932,10 @@ static int run_device_impl(br_ctx *c, const br_config *cfg, const br_device_batc
   if (c->rows_busy_set && (c->pk_a.cap < nr * sizeof(uint4) || (aux_cols && (c->pk_sim.cap < nr * 8 || c->pk_clip.cap < nr * 4))))
     HIPCHK(hipEventSynchronize(c->rows_busy));
   RC(c->r_rec.ensure(nr * sizeof(uint4)));
-  RC(c->pk_a.ensure(nr * sizeof(uint4))); RC(c->pk_c.ensure(nr * sizeof(uint2))); RC(c->pk_x.ensure(nr * sizeof(uint4)));
+  RC(c->pk_a.ensure(nr * sizeof(uint4))); RC(c->pk_c.ensure(nr * sizeof(uint2)));
   if (aux_cols) { RC(c->pk_sim.ensure(nr * 8)); RC(c->pk_clip.ensure(nr * 4)); }
   P.n_rows_total = (int64_t)n_rows; P.r_rec = c->r_rec.as<uint4>();
-  P.r_a = c->pk_a.as<uint4>(); P.r_c = c->pk_c.as<uint2>(); P.r_x = c->pk_x.as<uint4>();
+  P.r_a = c->pk_a.as<uint4>(); P.r_c = c->pk_c.as<uint2>(); P.r_x = nullptr;
   P.r_sim = aux_cols ? c->pk_sim.as<double>() : nullptr; P.r_clip = aux_cols ? c->pk_clip.as<int32_t>() : nullptr;
   if (n_rows) {
     RC(pf.begin(BR_K_PAIR_EMIT));
@@ -956,13 +957,36 @@ static int run_device_impl(br_ctx *c, const br_config *cfg, const br_device_batc
   out->total_complete = n_rows; out->total_unique = c->h_totals[5]; out->dropped_reads = c->h_totals[6];
   if (fa_mode && c->rescue_stats[0]) { c->rescue_stats[1] = c->h_totals[8]; c->rescue_stats[2] = c->h_totals[9]; }
 
-  out->a = (const br_row_a *)c->pk_a.p; out->cigar = (const uint64_t *)c->pk_c.p; out->x = (const br_row_x *)c->pk_x.p;
+  out->a = (const br_row_a *)c->pk_a.p; out->cigar = (const uint64_t *)c->pk_c.p; out->x = nullptr;   // br_device_rows_detail
   out->similarity_score = aux_cols ? c->pk_sim.as<double>() : nullptr;
   out->clip_score = aux_cols ? c->pk_clip.as<int32_t>() : nullptr;
   out->pool = c->cig_arena.as<uint32_t>(); out->row_off = c->row_off.as<uint64_t>();
   c->counters[6] = n_matches;
   c->last_n_rows = (int64_t)n_rows; c->last_n_aln = n; c->last_n_pool = (int64_t)n_cig_arena;
-  c->last_aux_cols = aux_cols; c->wide_valid = false; c->last_l_qseq = b->l_qseq; c->last_long_reads = dc.long_reads;
+  c->last_aux_cols = aux_cols; c->wide_valid = false; c->detail_valid = false; c->last_l_qseq = b->l_qseq; c->last_long_reads = dc.long_reads;
+  return BR_OK;
+}
+
+// br_row_x of the last call's rows, derived on first request (k_rows_detail)
+static int ensure_detail(br_ctx *c, hipStream_t st) {
+  if (c->detail_valid) return BR_OK;
+  const size_t nr = (size_t)std::max<int64_t>(c->last_n_rows, 1);
+  if (c->rows_busy_set && c->pk_x.cap < nr * sizeof(uint4)) HIPCHK(hipEventSynchronize(c->rows_busy));   // a download may still read it
+  RC(c->pk_x.ensure(nr * sizeof(uint4)));
+  if (c->last_n_rows > 0) {
+    PairArgs P{};
+    P.n_rows_total = c->last_n_rows; P.r_rec = c->r_rec.as<uint4>(); P.m_a = c->m_a.as<uint4>(); P.r_x = c->pk_x.as<uint4>();
+    launch_rows_detail(st, P);
+  }
+  c->detail_valid = true;
+  return BR_OK;
+}
+
+extern "C" int br_device_rows_detail(br_ctx *c, void *stream, const br_row_x **x) {
+  if (!c || !x) return BR_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(c->ix->device));
+  RC(ensure_detail(c, (hipStream_t)stream));
+  *x = (const br_row_x *)c->pk_x.p;
   return BR_OK;
 }
 
@@ -984,6 +1008,7 @@ static int expand_rows(br_ctx *c, hipStream_t st, br_device_wide_rows *out) {
   if (n_rows) {
     WideArgs W{};
     W.n_rows = (int64_t)n_rows; W.n_aln = c->last_n_aln; W.long_reads = c->last_long_reads;
+    RC(ensure_detail(c, st));
     W.r_a = c->pk_a.as<uint4>(); W.r_c = c->pk_c.as<uint2>(); W.r_x = c->pk_x.as<uint4>();
     W.r_sim = c->last_aux_cols ? c->pk_sim.as<double>() : nullptr; W.r_clip = c->last_aux_cols ? c->pk_clip.as<int32_t>() : nullptr;
     W.pool = c->cig_arena.as<uint32_t>(); W.aln_group = c->aln_group.as<uint32_t>(); W.l_qseq = c->last_l_qseq;
@@ -1072,7 +1097,7 @@ static int bam_encode_impl(br_ctx *c, const br_config *cfg, const br_device_reco
   RC(c->bam_aux.ensure(std::max<size_t>((size_t)n, 1) * sizeof(BamAux)));
   RC(c->bam_len.ensure(std::max<size_t>((size_t)nr, 1) * 4)); RC(c->bam_off.ensure(((size_t)nr + 1) * 8));
   B.aux = (BamAux *)c->bam_aux.p;
-  B.r_a = c->pk_a.as<uint4>(); B.r_c = c->pk_c.as<uint2>(); B.r_x = c->pk_x.as<uint4>();
+  B.r_a = c->pk_a.as<uint4>(); B.r_c = c->pk_c.as<uint2>(); B.r_rec = c->r_rec.as<uint4>();
   B.r_sim = c->last_aux_cols ? c->pk_sim.as<double>() : nullptr; B.r_clip = c->last_aux_cols ? c->pk_clip.as<int32_t>() : nullptr;
   B.pool = c->cig_arena.as<uint32_t>(); B.l_qseq = c->last_l_qseq;
   B.out_len = c->bam_len.as<uint32_t>(); B.out_off = c->bam_off.as<uint64_t>();
@@ -1527,6 +1552,7 @@ extern "C" int br_project_staged(br_ctx *c, const br_config *cfg, int slot, br_h
     PoolArgs Q{};
     Q.n_rows = (int64_t)nr; Q.r_a = c->pk_a.as<uint4>(); Q.r_c = c->pk_c.as<uint2>(); Q.arena = c->cig_arena.as<uint32_t>();
     Q.sizes = c->pool_sizes.as<uint32_t>(); Q.off = c->pool_off.as<uint64_t>(); Q.c_out = c->pk_ch.as<uint2>();
+    if (c->host_detail) RC(ensure_detail(c, st));
     launch_pool_sizes(st, Q);
     ScanArgs SP{}; SP.n = (int64_t)nr; SP.src32 = Q.sizes; SP.tile_sums = c->tile_sums.as<uint64_t>();
     launch_scan(st, SP, 2, c->pool_off.p, true, c->totals.as<uint64_t>() + 10);
@@ -1544,7 +1570,7 @@ extern "C" int br_project_staged(br_ctx *c, const br_config *cfg, int slot, br_h
   if (nn) HIPCHK(hipMemcpyAsync(S.h_row_off.data(), pr.row_off, (nn + 1) * 8, hipMemcpyDeviceToHost, ds));
   else S.h_row_off.p[0] = 0;
   RC(d2h(S.h_mate, db.mate_idx, nn, ds));
-  if (c->host_detail) RC(d2h(S.h_x, pr.x, nr, ds));
+  if (c->host_detail) RC(d2h(S.h_x, c->pk_x.p, nr, ds));
   if (pr.similarity_score) { RC(d2h(S.h_sim, pr.similarity_score, nr, ds)); RC(d2h(S.h_clip, pr.clip_score, nr, ds)); }
   HIPCHK(hipEventRecord(S.rows_home, ds));
   HIPCHK(hipEventRecord(c->rows_busy, ds));

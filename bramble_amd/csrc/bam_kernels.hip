@@ -132,7 +132,7 @@ __device__ __forceinline__ uint32_t row_out_len(const BamArgs &B, int64_t r, con
 __global__ void __launch_bounds__(256) k_bam_size(BamArgs B) {
   int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= B.n_rows) return;
-  int32_t a = (int32_t)((const uint32_t *)(B.r_x + r))[0];
+  int32_t a = (int32_t)((const uint32_t *)(B.r_rec + r))[1];
   const uint8_t *rec = B.blob + B.rec_off[a];
   B.out_len[r] = row_out_len(B, r, rec, B.aux[a]);
   if ((((const uint32_t *)(B.r_a + r))[2] & RM_NCIG) > 65535u) *B.too_long = 1;  // would need htslib's CG:B,I spill-over; refused by the host
@@ -193,9 +193,9 @@ __device__ __forceinline__ void encode_row(const BamArgs &B, int64_t r, int lane
   uint32_t n_cig_in = x.c_b & 0xffffu, flag = x.c_b >> 16;
   int32_t l_seq = (int32_t)x.c_c;
   uint32_t ls = l_seq > 0 ? (uint32_t)l_seq : 0;
-  // the packed row: {tid, pos, meta, NH}, {input, junc_hits, aligned_len, HI}; the pair's other record is the adjacent row
+  // the packed row {tid, pos, meta, NH} + the record {match, input, NH, HI | flags}; the pair's other record is the adjacent row
   const uint4 ra = B.r_a[r];
-  const uint32_t meta = ra.z, nh = ra.w, hi = ((const uint32_t *)(B.r_x + r))[3];
+  const uint32_t meta = ra.z, nh = ra.w, hi = ((const uint32_t *)(B.r_rec + r))[3] & RR_HI;
   uint32_t n_cig = meta & RM_NCIG;
   bool minus = meta & RM_MINUS;
   bool paired = meta & RM_PAIRED, same = meta & RM_SAME;
@@ -212,7 +212,7 @@ __device__ __forceinline__ void encode_row(const BamArgs &B, int64_t r, int lane
     mpos = (int32_t)rb.y;
     if (same) {
       flag |= 0x2u; mtid = (int32_t)ra.x;
-      const int32_t lq = B.l_qseq[((const uint32_t *)(B.r_x + r))[0]];
+      const int32_t lq = B.l_qseq[((const uint32_t *)(B.r_rec + r))[1]];
       tlen = (my_pos <= mpos) ? (mpos + lq) - my_pos : -((my_pos + lq) - mpos);
     } else { flag &= ~0x2u; mtid = (int32_t)rb.x; }
   }
@@ -305,7 +305,7 @@ __global__ void __launch_bounds__(256) k_bam_encode(BamArgs B) {
   const int lane = threadIdx.x & (G - 1);
   int64_t r = (int64_t)blockIdx.x * (256 / G) + (threadIdx.x / G);
   if (r >= B.n_rows) return;
-  int32_t a = (int32_t)((const uint32_t *)(B.r_x + r))[0];
+  int32_t a = (int32_t)((const uint32_t *)(B.r_rec + r))[1];
   encode_row<G>(B, r, lane, B.blob + B.rec_off[a], B.aux[a], B.out + B.out_off[r], (uint32_t)(B.out_off[r + 1] - B.out_off[r]));
 }
 

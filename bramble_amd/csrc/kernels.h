@@ -210,7 +210,7 @@ struct BamArgs {
   int8_t *xs_out, *ts_out;   // [n_aln] or null: tag_char1("XS") / tag_char1("ts") of every record
   BamAux *aux;               // [n_aln]
   uint32_t *cg_flag;         // set when a record's real CIGAR sits in a CG:B,I tag (null: not checked)
-  const uint4 *r_a; const uint2 *r_c; const uint4 *r_x;  // packed rows (PairArgs)
+  const uint4 *r_a; const uint2 *r_c; const uint4 *r_rec;  // packed rows + the records behind them (PairArgs)
   const double *r_sim; const int32_t *r_clip;              // null: all zero
   const uint32_t *pool;
   const int32_t *l_qseq;
@@ -314,7 +314,8 @@ void launch_scan3(hipStream_t st, ScanArgs S, uint32_t *match_off, uint64_t *cig
 void launch_pair(hipStream_t st, const PairArgs &P, bool emit);  // count pass: records per leader alignment; emit pass: r_rec
 // primary record per read name (RR_PRIMARY) + the per-group counters; names may be null (no primary flags)
 void launch_primary(hipStream_t st, const PairArgs &P, const uint32_t *name_off, const uint8_t *names, bool has_scores);
-void launch_rows(hipStream_t st, const PairArgs &P, bool aux);  // r_rec + match table -> packed rows
+void launch_rows(hipStream_t st, const PairArgs &P, bool aux);  // r_rec + match table -> packed rows (r_a, r_c, aux columns)
+void launch_rows_detail(hipStream_t st, const PairArgs &P);    // on request: r_x = {input, junc_hits, aligned_len, HI}
 void launch_pool_sizes(hipStream_t st, const PoolArgs &Q);
 void launch_pool_copy(hipStream_t st, const PoolArgs &Q, bool long_cigars);
 void launch_wide_fields(hipStream_t st, const WideArgs &W);

@@ -1523,7 +1523,8 @@ __global__ void __launch_bounds__(256) k_primary(PairArgs P, const uint32_t *__r
   }
 }
 
-// k_rows: one lane per emitted record: r_rec + its match's record -> the packed row (see PairArgs).  Rewritten
+// k_rows: one lane per emitted record: r_rec + its match's record -> the packed row (see PairArgs; the detail column
+// r_x is k_rows_detail's).  Rewritten
 // CIGARs of more than two ops stay in their arena slot; the row carries the slot's offset.
 template <bool AUX>
 __global__ void __launch_bounds__(256) k_rows(PairArgs P) {
@@ -1541,12 +1542,21 @@ __global__ void __launch_bounds__(256) k_rows(PairArgs P) {
                         ((f & RR_SAME) ? RM_SAME : 0u) | ((f & RR_FIRST) ? RM_FIRST : 0u) | ((f & RR_PRIMARY) ? RM_PRIMARY : 0u);
   P.r_a[r] = make_uint4(tid, ma.x, meta, rec.z);
   P.r_c[r] = make_uint2((uint32_t)cg, (uint32_t)(cg >> 32));
-  P.r_x[r] = make_uint4(rec.y, ma.z, ma.w, f & RR_HI);
   if (AUX) {
     const uint4 mb = P.m_b[x];
     P.r_clip[r] = (int32_t)mb.x;
     P.r_sim[r] = __longlong_as_double((long long)(((unsigned long long)mb.w << 32) | mb.z));
   }
+}
+
+// k_rows_detail: the detail column br_row_x of the packed rows, on request only (the wide view, host downloads with
+// host_detail): everything in it is in r_rec and the match table, which stay valid until the next projection call
+__global__ void __launch_bounds__(256) k_rows_detail(PairArgs P) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= P.n_rows_total) return;
+  const uint4 rec = P.r_rec[r];
+  const uint4 ma = P.m_a[rec.x];
+  P.r_x[r] = make_uint4(rec.y, ma.z, ma.w, rec.w & RR_HI);
 }
 
 // dense pool of the long rewritten CIGARs (host downloads only): sizes -> scan -> copy
@@ -1834,6 +1844,11 @@ void launch_rows(hipStream_t st, const PairArgs &P, bool aux) {
   dim3 g(grid_for(P.n_rows_total, 256)), b(256);
   if (aux) hipLaunchKernelGGL((k_rows<true>), g, b, 0, st, P);
   else hipLaunchKernelGGL((k_rows<false>), g, b, 0, st, P);
+}
+
+void launch_rows_detail(hipStream_t st, const PairArgs &P) {
+  if (P.n_rows_total <= 0) return;
+  hipLaunchKernelGGL(k_rows_detail, dim3(grid_for(P.n_rows_total, 256)), dim3(256), 0, st, P);
 }
 
 void launch_pool_sizes(hipStream_t st, const PoolArgs &Q) {

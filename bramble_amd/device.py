@@ -69,7 +69,7 @@ class _DevArray:
 _TYPESTR = {"int8": "|i1", "uint8": "|u1", "int32": "<i4", "int64": "<i8", "float64": "<f8"}
 
 
-def packed_as_tensors(rows, n_aln, device="cuda:0"):
+def packed_as_tensors(rows, n_aln, device="cuda:0", ctx=None, stream=0):
     """BrDeviceRows (packed) -> dict of torch tensors: a int32 [n, 4] = {tid, pos, meta, nh}, cigar int64 [n],
     x int32 [n, 4] = {input, junc_hits, aligned_len, hi}, pool int32, row_off int64 [n_aln + 1]."""
     n = int(rows.n_rows)
@@ -77,7 +77,8 @@ def packed_as_tensors(rows, n_aln, device="cuda:0"):
     if n == 0:
         return out
     out["a"] = torch.as_tensor(_DevArray(rows.a, 4 * n, "<i4"), device=device).view(n, 4)
-    out["x"] = torch.as_tensor(_DevArray(rows.x, 4 * n, "<i4"), device=device).view(n, 4)
+    if ctx is not None:   # the detail column is derived on request (br_device_rows_detail)
+        out["x"] = torch.as_tensor(_DevArray(ctx.rows_detail(stream), 4 * n, "<i4"), device=device).view(n, 4)
     out["cigar"] = torch.as_tensor(_DevArray(rows.cigar, n, "<i8"), device=device)
     if int(rows.n_pool_words):
         out["pool"] = torch.as_tensor(_DevArray(rows.pool, int(rows.n_pool_words), "<i4"), device=device)

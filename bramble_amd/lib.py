@@ -148,7 +148,7 @@ EXPORTS = ["br_index_build", "br_index_build_flat", "br_index_free", "br_index_n
            "br_pin_host", "br_unpin_host", "br_project_group", "br_bam_encode_device", "br_project_bam_device", "br_project_bam_bundle", "br_bam_bundle_stage", "br_project_bam_staged", "br_bam_split", "br_annotation_load", "br_annotation_free",
            "br_annotation_num_transcripts", "br_annotation_transcripts", "br_annotation_num_refs", "br_annotation_refnames", "br_cli_main", "br_bgzf_write_file", "br_bgzf_read_file",
            "br_free_buffer", "br_bgzf_codec", "br_bgzf_deflate_device", "br_ctx_set_profiling",
-           "br_ctx_set_param", "br_ctx_kernel_ms", "br_ctx_collect_counters", "br_ctx_last_counters", "br_ctx_rescue_stats", "br_ctx_ksw_diag", "br_ctx_ksw_pairs", "br_primary_pick", "br_row_mapq", "br_version", "br_strerror"]
+           "br_ctx_set_param", "br_ctx_kernel_ms", "br_ctx_collect_counters", "br_ctx_last_counters", "br_ctx_rescue_stats", "br_ctx_ksw_diag", "br_device_rows_detail", "br_ctx_ksw_pairs", "br_primary_pick", "br_row_mapq", "br_version", "br_strerror"]
 
 _LIB = None
 
@@ -233,6 +233,7 @@ def lib():
         L.br_ctx_last_counters.argtypes = [C.c_void_p, C.c_void_p]
         L.br_ctx_rescue_stats.argtypes = [C.c_void_p, C.c_void_p]
         L.br_ctx_ksw_diag.argtypes = [C.c_void_p, C.c_void_p]
+        L.br_device_rows_detail.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
         L.br_ctx_ksw_pairs.argtypes = [C.c_void_p, C.c_int64, _P(C.c_char_p), _P(C.c_char_p), C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_uint32]
         L.br_primary_pick.restype = C.c_uint32
@@ -623,6 +624,12 @@ class Context:
         out = (C.c_uint64 * 4)()
         check(lib().br_ctx_rescue_stats(self.h, out), "br_ctx_rescue_stats")
         return dict(zip(("problems", "dp_cells", "rescued", "seq_bytes"), [int(v) for v in out]))
+
+    def rows_detail(self, stream=0):
+        """Device pointer of the br_row_x array of the last call's rows (derived on first request)."""
+        x = C.c_void_p()
+        check(lib().br_device_rows_detail(self.h, C.c_void_p(stream), C.byref(x)), "br_device_rows_detail")
+        return x.value
 
     def ksw_diag(self):
         out = (C.c_uint64 * 16)()

@@ -250,13 +250,18 @@ typedef struct br_device_rows {
   int64_t n_rows, n_matches, n_pool_words;
   const br_row_a *a;
   const uint64_t *cigar;
-  const br_row_x *x;
+  const br_row_x *x;              /* NULL: the detail column is derived on request, br_device_rows_detail() */
   const double *similarity_score; /* NULL unless the preset filters by similarity (then every score is 0.0) */
   const int32_t *clip_score;      /* NULL likewise (0) */
   const uint32_t *pool;
   const uint64_t *row_off;        /* n_aln + 1 */
   uint64_t total_complete, total_unique, dropped_reads, total_processed;
 } br_device_rows;
+
+/* br_row_x of the rows of the context's last projection call (a device array of n_rows entries, valid until the next
+ * projection call): derived on the first request from what the call left in HBM -- the projection itself writes 24 bytes
+ * per record (br_row_a + the CIGAR reference). */
+int br_device_rows_detail(br_ctx *, void *stream, const br_row_x **x);
 
 /* The wide view: same field meaning as br_rows; is_primary is filled when the batch carries read names. */
 typedef struct br_device_wide_rows {
