@@ -435,7 +435,7 @@ struct br_ctx {
   int deflate_dynamic = 1;
   int emit_split = 1;
   int count_split = 1;   // count pass as two kernels: the main one without the exon walk, a second one for the alignments that need it
-  DevBuf walk_list, pmask;
+  DevBuf walk_list, pmask, pbit;
   // packed row table (the product of the row stage) and what its kernels need
   DevBuf r_rec, pk_a, pk_c, pk_x, pk_sim, pk_clip;
   DevBuf pool, pool_sizes, pool_off, pk_ch;   // dense long-CIGAR pool + rewritten references for host downloads
@@ -515,7 +515,7 @@ extern "C" void br_ctx_free(br_ctx *c) {
                     &c->r_ncig, &c->r_strand, &c->r_sim, &c->r_clip, &c->r_junc, &c->r_refc, &c->r_cigoff,
                     &c->cigar_out, &c->r_paired, &c->r_same, &c->r_first, &c->r_primary, &c->b_name_off, &c->b_names, &c->b_ref_id, &c->b_ref_start,
                     &c->b_flags, &c->b_xs, &c->b_ts, &c->b_cigar_off, &c->b_cigar, &c->b_mate_idx,
-                    &c->b_group_off, &c->b_lqseq, &c->walk_list, &c->pmask,
+                    &c->b_group_off, &c->b_lqseq, &c->walk_list, &c->pmask, &c->pbit,
                     &c->fa_srcs, &c->ksw_desc, &c->ksw_dp, &c->ksw_left, &c->ksw_cnt, &c->ksw_group, &c->ksw_tape, &c->ksw_raw};
   for (DevBuf *b : bufs) b->release();
   for (auto &e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -911,6 +911,7 @@ static int run_device_impl(br_ctx *c, const br_config *cfg, const br_device_batc
   P.n_rows = c->n_rows.as<uint32_t>();
   P.row_off = c->row_off.as<uint64_t>(); P.counters = c->counters_d.as<uint64_t>();
   RC(c->pmask.ensure((size_t)n * 8)); P.pmask = c->pmask.as<uint64_t>();
+  RC(c->pbit.ensure((size_t)n)); P.pbit = c->pbit.as<uint8_t>();
   RC(pf.begin(BR_K_PAIR_COUNT));
   launch_pair(st, P, false);
   RC(pf.end());

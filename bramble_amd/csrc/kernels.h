@@ -130,6 +130,7 @@ struct PairArgs {
   const uint4 *m_a, *m_b;
   const uint64_t *m_cigoff;
   uint32_t *n_rows;         // count pass: records per leader alignment
+  uint8_t *pbit;            // [n_aln] count pass: this leader emits pairs (k_primary counts its units without touching the records)
   uint64_t *pmask;          // [n_aln] count pass -> emit pass: list positions of a pair's common transcripts (lists <= 64)
   const uint64_t *row_off;  // [n_aln + 1] emit pass
   // per record {match, input alignment, NH, HI | RR_* bits}: written by k_pair_emit (one lane per alignment), flagged by

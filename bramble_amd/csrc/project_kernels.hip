@@ -1360,6 +1360,7 @@ __global__ void __launch_bounds__(256) k_pair(PairArgs P) {
   uint32_t mi0 = P.match_off[i], ni = P.n_matches[i];
   bool leader = !(m >= 0 && (uint32_t)m < i && (uint32_t)m >= a0);  // else: handled as the mate of an earlier leader
   uint32_t nh = 0, hi0 = 0;
+  bool unpaired = true;
   uint4 *__restrict__ rec = P.r_rec;
   if (EMIT) {
     const uint64_t gs = P.row_off[a0];
@@ -1370,6 +1371,7 @@ __global__ void __launch_bounds__(256) k_pair(PairArgs P) {
   if (leader && ni) {                          // a leader without matches drops the pair (mates.cpp:153)
     uint32_t nm = 0, mm0 = 0;
     if (m >= 0 && (uint32_t)m > i && (uint32_t)m < a1) { mm0 = P.match_off[m]; nm = P.n_matches[m]; }
+    unpaired = nm == 0;
     if (nm == 0) {
       // unpaired emission: one record per transcript, ascending tid (mates.cpp:157-176)
       if (EMIT)
@@ -1418,7 +1420,7 @@ __global__ void __launch_bounds__(256) k_pair(PairArgs P) {
       }
     }
   }
-  if (!EMIT) P.n_rows[i] = rows;
+  if (!EMIT) { P.n_rows[i] = rows; P.pbit[i] = (rows && !unpaired) ? 1 : 0; }
 }
 
 // k_primary: one lane per read name (grid-stride).  Primary = the emitted record (pair) with the
@@ -1453,7 +1455,7 @@ __global__ void __launch_bounds__(256) k_primary(PairArgs P, const uint32_t *__r
 #pragma unroll
           for (int k = 0; k < 5; k++) ro[k] = P.row_off[a0 + ((uint32_t)k < na ? (uint32_t)k : na)];
 #pragma unroll
-          for (int k = 0; k < 4; k++) fl[k] = flagw[4 * (ro[k + 1] > ro[k] ? ro[k] : rs)];   // spent slots re-read a valid record
+          for (int k = 0; k < 4; k++) fl[k] = P.pbit[a0 + ((uint32_t)k < na ? (uint32_t)k : 0u)] ? RR_PAIRED : 0u;   // the count pass's note, no record gather
           uint32_t units = 0;
 #pragma unroll
           for (int k = 0; k < 4; k++) { const uint32_t n = (uint32_t)(ro[k + 1] - ro[k]); un[k] = (fl[k] & RR_PAIRED) ? n / 2 : n; units += un[k]; }
@@ -1471,14 +1473,14 @@ __global__ void __launch_bounds__(256) k_primary(PairArgs P, const uint32_t *__r
           uint32_t units = 0;
           for (uint32_t i = a0; i < a1; i++) {
             const uint64_t b = P.row_off[i]; const uint32_t n = (uint32_t)(P.row_off[i + 1] - b);
-            if (n) units += (flagw[4 * b] & RR_PAIRED) ? n / 2 : n;
+            if (n) units += P.pbit[i] ? n / 2 : n;
           }
           if (units > 1) {
             uint32_t idx = primary_pick(names + name_off[a0], name_off[a0 + 1] - name_off[a0], units);
             for (uint32_t i = a0; i < a1; i++) {
               const uint64_t b = P.row_off[i]; const uint32_t n = (uint32_t)(P.row_off[i + 1] - b);
               if (!n) continue;
-              const bool paired = flagw[4 * b] & RR_PAIRED;
+              const bool paired = P.pbit[i] != 0;
               const uint32_t u = paired ? n / 2 : n;
               if (idx < u) { pick = b + (paired ? 2ull * idx : idx); break; }
               idx -= u;
