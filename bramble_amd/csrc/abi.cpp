@@ -693,7 +693,7 @@ static int run_ksw(br_ctx *c, hipStream_t st, const KswRun &R) {
     HIPCHK(hipMemcpyAsync(h_cnt, c->ksw_cnt.p, 64, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     const uint64_t *h_rows = (const uint64_t *)(h_cnt + 8);
-    // tape: a row = one step of a wave (512 B); a bin's waves run (tape rows of its problems) / (groups per wave) steps when
+    // tape: a row = one step of a wave (512 or 1024 B); a bin's waves run (tape rows of its problems) / (groups per wave) steps when
     // its groups stay equally busy (they share one queue), 15 % on top, and every wave rounds up to chunks and drains
     uint64_t tape_bytes = 0; uint32_t n_groups_total = 0;
     for (int b = 0; b < KSW_N_BINS; b++) {
@@ -702,7 +702,7 @@ static int run_ksw(br_ctx *c, hipStream_t st, const KswRun &R) {
       n_groups_total += A.n_groups[b];
       const uint64_t gpw = 64u / (uint64_t)KSW_BIN_G(b), waves = (A.n_groups[b] + gpw - 1) / gpw;
       const uint64_t rows = h_rows[b] / gpw + h_rows[b] / gpw / 7 + waves * (1ull * KSW_CHUNK_ROWS + KSW_BIN_W(b) + 64);
-      if (A.n_bin[b]) tape_bytes += rows * KSW_TAPE_ROWBYTES;
+      if (A.n_bin[b]) tape_bytes += rows * (uint64_t)KSW_BIN_ROWBYTES(b);
     }
     if (tape_bytes > tape_budget && n >= 2048) {
       uint64_t mid = p0 + n / 2;

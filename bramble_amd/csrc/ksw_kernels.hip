@@ -292,6 +292,10 @@ __device__ __forceinline__ uint32_t pk_max_i(uint32_t a, uint32_t b) { return __
 __device__ __forceinline__ uint32_t pk_min_u(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(ksw_u2, a), __builtin_bit_cast(ksw_u2, b))); }
 __device__ __forceinline__ uint32_t pk_sign(uint32_t a) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(ksw_s2, a) >> (ksw_s2)(15)); }
 __device__ __forceinline__ uint32_t bfi32(uint32_t m, uint32_t a, uint32_t b) { return (m & a) | (~m & b); }
+// single instructions the compiler takes apart when it sees literal masks / shifts (and + and + or, shift + or)
+__device__ __forceinline__ uint32_t v_bfi(uint32_t m, uint32_t a, uint32_t b) { uint32_t d; asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(m), "v"(a), "v"(b)); return d; }
+template <int SH>
+__device__ __forceinline__ uint32_t v_lshl_or(uint32_t a, uint32_t b) { uint32_t d; asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "n"(SH), "v"(b)); return d; }
 __device__ __forceinline__ uint32_t wave_shr1(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xf, 0xf, false); }
 
 // lanes of one wave exchange data through LDS: program order is enough for the hardware, the fence keeps the compiler from
@@ -319,7 +323,7 @@ struct KswDpArgs {
 
 template <int G, int K>
 __global__ void __launch_bounds__(256) k_ksw_dp(KswDpArgs A) {
-  constexpr int P = K / 2, W = G * K, GPW = 64 / G, R = 2 * G;
+  constexpr int P = K / 2, W = G * K, GPW = 64 / G, R = 2 * G, LB = K > 16 ? 16 : 8, RB = 64 * LB, TW = (K + 3) / 4;   // TW: dwords of target codes
   // column layout of a lane: pair j = columns c0 + j (low half) and c0 + j + P (high half), so that the left neighbours
   // of both halves of pair j are the two halves of pair j - 1: only pair 0 needs a shifted operand
   __shared__ uint32_t sh_pub[4][2][64 * P];     // [wave][v | u][lane * P + pair]: what the columns hold after the step
@@ -332,10 +336,19 @@ __global__ void __launch_bounds__(256) k_ksw_dp(KswDpArgs A) {
   const bool live = g < A.n_groups;
   const uint32_t c0 = (uint32_t)gl * K;
   auto load8 = [&](uint64_t off) { uint2 v; __builtin_memcpy(&v, A.seq_arena + off, 8); return v; };
-  auto load16 = [&](uint64_t off) { uint4 v; __builtin_memcpy(&v, A.seq_arena + off, 16); return v; };
+  struct Raw { uint32_t w[TW]; };
+  auto load_t = [&](uint64_t off) {   // K target codes (unaligned): 8, 16 or 16 + 8 bytes
+    Raw v;
+    const uint8_t *src = A.seq_arena + off;
+    if (TW == 2) { uint2 a; __builtin_memcpy(&a, src, 8); v.w[0] = a.x; v.w[1] = a.y; }
+    else {
+      uint4 a; __builtin_memcpy(&a, src, 16); v.w[0] = a.x; v.w[1] = a.y; v.w[2 < TW ? 2 : 0] = a.z; v.w[3 < TW ? 3 : 0] = a.w;
+      if (TW > 4) { uint2 b; __builtin_memcpy(&b, src + 16, 8); v.w[4 < TW ? 4 : 0] = b.x; v.w[5 < TW ? 5 : 0] = b.y; }
+    }
+    return v;
+  };
   auto ring_get = [&](uint32_t n) { return sh_ring[w][grp][n & (R - 1)]; };     // {qt, prob, seq_off lo, hi}
   auto seq_off_of = [](uint4 d) { return (uint64_t)d.z | ((uint64_t)d.w << 32); };
-  const uint4 no_desc = make_uint4(0u, KSW_NO_PROB, 0u, 0u);
   // feeder only: the next problem of the bin (the queue is shared by every group of the launch)
   // (claimed eight at a time: one atomic per problem on a single address is ~15 ns of queueing each)
   uint32_t cl_next = 0, cl_end = 0;
@@ -344,17 +357,17 @@ __global__ void __launch_bounds__(256) k_ksw_dp(KswDpArgs A) {
     const uint32_t k = cl_next++;
     return k < A.n ? k : KSW_NO_PROB;
   };
-  auto fetch = [&](uint32_t k) { uint4 d = no_desc; if (k != KSW_NO_PROB) { KswDesc e = A.desc[k]; d = make_uint4(e.qt, e.prob, (uint32_t)e.seq_off, (uint32_t)(e.seq_off >> 32)); } return d; };
+  auto fetch = [&](uint32_t k) { uint4 d = make_uint4(0u, KSW_NO_PROB, 0u, 0u); if (k != KSW_NO_PROB) { KswDesc e = A.desc[k]; d = make_uint4(e.qt, e.prob, (uint32_t)e.seq_off, (uint32_t)(e.seq_off >> 32)); } return d; };
 
   sh_mb[w][lane] = make_uint4(0, 0, 0, 0);
   if (gl == 0) sh_cx[w][grp] = 0;
-  for (int k = gl; k < R; k += G) sh_ring[w][grp][k] = no_desc;
+  for (int k = gl; k < R; k += G) sh_ring[w][grp][k] = make_uint4(0u, KSW_NO_PROB, 0u, 0u);
   wave_sync();
 
   // ---- feeder (lane 0 of the group): descriptors run three problems ahead of the one being fed
   int32_t fk = -1; uint32_t fi = 0, fq = 0, fprob = KSW_NO_PROB, fgap = K;
   uint64_t fbuf = 0, fnext = 0, fqn = 0, fqoff = 0;
-  uint4 fd_next = no_desc, fd_loaded = no_desc;   // descriptor of problem fk + 1; of fk + 3 (on its way to the ring)
+  uint4 fd_next = make_uint4(0u, KSW_NO_PROB, 0u, 0u), fd_loaded = make_uint4(0u, KSW_NO_PROB, 0u, 0u);   // descriptor of problem fk + 1; of fk + 3 (on its way to the ring)
   uint32_t fi_pending = KSW_NO_PROB;              // queue index claimed for problem fk + 4
   if (gl == 0 && live) {
     const uint4 d0 = fetch(claim()), d1 = fetch(claim());
@@ -371,8 +384,8 @@ __global__ void __launch_bounds__(256) k_ksw_dp(KswDpArgs A) {
 #pragma unroll
   for (int p = 0; p < P; p++) { U[p] = Y[p] = V[p] = Q[p] = 0; S[p] = 0x00010001u; T[p] = TX[p] = 0x0c000c00u; }
   // target codes of the lane's columns c0 .. c0 + K - 1 (16 raw bytes) -> per pair the perm selector halves 0x0c00 | code
-  auto make_t = [&](uint4 raw, uint32_t *t) {
-    const uint32_t wd[4] = {raw.x, raw.y, raw.z, raw.w};
+  auto make_t = [&](const Raw &raw, uint32_t *t) {
+    const uint32_t *wd = raw.w;
 #pragma unroll
     for (int p = 0; p < P; p++) {
       const int j0 = p, j1 = p + P;   // bytes j0 -> bits 0..7, j1 -> bits 16..23
@@ -385,11 +398,13 @@ __global__ void __launch_bounds__(256) k_ksw_dp(KswDpArgs A) {
   // the target bases of the problems to come: TX = next first base to arrive (problem kl), txx = the one after; the
   // descriptor after that comes from the ring when txx moves up
   uint32_t kl = 0;
-  uint4 txx = make_uint4(0, 0, 0, 0);
+  Raw txx;
+#pragma unroll
+  for (int k = 0; k < TW; k++) txx.w[k] = 0;
   {
     const uint4 d0 = ring_get(0), d1 = ring_get(1);
-    if (d0.y != KSW_NO_PROB) make_t(load16(seq_off_of(d0) + (d0.x & 0xffffu) + c0), TX);
-    if (d1.y != KSW_NO_PROB) txx = load16(seq_off_of(d1) + (d1.x & 0xffffu) + c0);
+    if (d0.y != KSW_NO_PROB) make_t(load_t(seq_off_of(d0) + (d0.x & 0xffffu) + c0), TX);
+    if (d1.y != KSW_NO_PROB) txx = load_t(seq_off_of(d1) + (d1.x & 0xffffu) + c0);
   }
   // ---- bookkeeping lane: one problem in flight
   bool tr_on = false; int32_t tS = 0, tq = 0, tt = 0, H0 = 0, lastT = 0, emax = 0, emax_t = -1, emax_q = -1; uint32_t tprob = 0;
@@ -405,10 +420,10 @@ __global__ void __launch_bounds__(256) k_ksw_dp(KswDpArgs A) {
     if (!__any(busy)) break;
     if ((s & (KSW_CHUNK_ROWS - 1)) == 0) {
       unsigned long long off = 0;
-      if (lane == 0) off = atomicAdd(A.tape_used, (unsigned long long)KSW_CHUNK_ROWS * KSW_TAPE_ROWBYTES);
+      if (lane == 0) off = atomicAdd(A.tape_used, (unsigned long long)KSW_CHUNK_ROWS * RB);
       off = (unsigned long long)__shfl((long long)off, 0, 64);
       chunk_prev = chunk_cur; chunk_cur = off;
-      if (off + (unsigned long long)KSW_CHUNK_ROWS * KSW_TAPE_ROWBYTES > A.tape_cap) dead = true;
+      if (off + (unsigned long long)KSW_CHUNK_ROWS * RB > A.tape_cap) dead = true;
     }
     if (dead) {
       if (tr_on) { A.leftover[atomicAdd(A.n_leftover, 1u)] = tprob; tr_on = false; }
@@ -420,8 +435,8 @@ __global__ void __launch_bounds__(256) k_ksw_dp(KswDpArgs A) {
         if (fd_loaded.y != KSW_NO_PROB) A.leftover[atomicAdd(A.n_leftover, 1u)] = fd_loaded.y;
         if (fi_pending != KSW_NO_PROB) A.leftover[atomicAdd(A.n_leftover, 1u)] = A.desc[fi_pending].prob;
         for (; cl_next < cl_end && cl_next < A.n; cl_next++) A.leftover[atomicAdd(A.n_leftover, 1u)] = A.desc[cl_next].prob;   // the rest of the claimed batch
-        fd_next = no_desc; fd_loaded = no_desc; fi_pending = KSW_NO_PROB; fi = fq = 0;
-        sh_ring[w][grp][(uint32_t)(fk + 2) & (R - 1)] = no_desc;
+        fd_next = make_uint4(0u, KSW_NO_PROB, 0u, 0u); fd_loaded = make_uint4(0u, KSW_NO_PROB, 0u, 0u); fi_pending = KSW_NO_PROB; fi = fq = 0;
+        sh_ring[w][grp][(uint32_t)(fk + 2) & (R - 1)] = make_uint4(0u, KSW_NO_PROB, 0u, 0u);
       }
       continue;   // the next pass over the loop head leaves (nothing is busy any more)
     }
@@ -461,8 +476,7 @@ __global__ void __launch_bounds__(256) k_ksw_dp(KswDpArgs A) {
     const bool leaving = (Q[P - 2 >= 0 ? P - 2 : 0] >> 31) != 0;   // a first base reaches the lane's last column in this step
     // ---- cells, pairs in descending order: pair j reads what pair j - 1 held after the step before
     uint32_t D[P];
-    uint32_t m3 = 0x00030003u;
-    asm("" : "+v"(m3));   // a register mask keeps the tag merge one v_bfi_b32 (a literal is taken apart into and / and / or)
+    const uint32_t m3 = 0x00030003u;
 #pragma unroll
     for (int p = P - 1; p >= 0; p--) {
       const uint32_t qn = p ? Q[p - 1] : qb, v1 = p ? V[p - 1] : vb, a = p ? S[p - 1] : sb;
@@ -481,18 +495,22 @@ __global__ void __launch_bounds__(256) k_ksw_dp(KswDpArgs A) {
       const uint32_t yn = pk_max_i(pk_sub(b, zq), 0u);
       V[p] = nv; Y[p] = yn; S[p] = pk_add(xt, nv);
       // direction nibble: winner tag | x continues << 2 | y continues << 3
-      D[p] = (pk_min_u(yn, 0x00040004u) << 1) | bfi32(m3, wv, pk_min_u(xt, 0x00050005u));
+      D[p] = v_lshl_or<1>(pk_min_u(yn, 0x00040004u), v_bfi(m3, wv, pk_min_u(xt, 0x00050005u)));
       Q[p] = qn;
     }
     {
-      uint2 word;
-      word.x = D[0];
+      // pairs 4k .. 4k + 3 share a dword: low halves in bits 0..15, high halves in bits 16..31
+      uint32_t word[LB / 4];
 #pragma unroll
-      for (int p = 1; p < 4 && p < P; p++) word.x |= D[p] << (4 * p);
-      word.y = P > 4 ? D[4] : 0u;
-#pragma unroll
-      for (int p = 5; p < P; p++) word.y |= D[p] << (4 * (p - 4));
-      *(uint2 *)(A.tape + chunk_cur + (size_t)(s & (KSW_CHUNK_ROWS - 1)) * KSW_TAPE_ROWBYTES + (size_t)lane * 8u) = word;
+      for (int k = 0; k < LB / 4; k++) {
+        word[k] = 4 * k < P ? D[4 * k < P ? 4 * k : 0] : 0u;
+        if (4 * k + 1 < P) word[k] = v_lshl_or<4>(D[4 * k + 1 < P ? 4 * k + 1 : 0], word[k]);
+        if (4 * k + 2 < P) word[k] = v_lshl_or<8>(D[4 * k + 2 < P ? 4 * k + 2 : 0], word[k]);
+        if (4 * k + 3 < P) word[k] = v_lshl_or<12>(D[4 * k + 3 < P ? 4 * k + 3 : 0], word[k]);
+      }
+      uint8_t *dst = A.tape + chunk_cur + (size_t)(s & (KSW_CHUNK_ROWS - 1)) * RB + (size_t)lane * LB;
+      if (LB == 8) *(uint2 *)dst = make_uint2(word[0], word[1]);
+      else *(uint4 *)dst = make_uint4(word[0], word[1], word[LB / 4 > 2 ? 2 : 0], word[LB / 4 > 3 ? 3 : 0]);
     }
 
     // ---- a first base leaves the lane: the next problem's target moves up
@@ -500,7 +518,7 @@ __global__ void __launch_bounds__(256) k_ksw_dp(KswDpArgs A) {
       make_t(txx, TX);
       kl++;
       const uint4 dn = ring_get(kl + 1);
-      if (dn.y != KSW_NO_PROB) txx = load16(seq_off_of(dn) + (dn.x & 0xffffu) + c0);
+      if (dn.y != KSW_NO_PROB) txx = load_t(seq_off_of(dn) + (dn.x & 0xffffu) + c0);
     }
 
     // ---- publish v, u; approximate maximum and z-drop of the problems in flight
@@ -537,8 +555,8 @@ __global__ void __launch_bounds__(256) k_ksw_dp(KswDpArgs A) {
         // rows of the problem: tS .. s, in the current chunk or starting in the one before
         const uint32_t srow = (uint32_t)tS & (KSW_CHUNK_ROWS - 1);
         const bool same = ((uint32_t)tS / KSW_CHUNK_ROWS) == (s / KSW_CHUNK_ROWS);
-        d.tape = (same ? chunk_cur : chunk_prev) + (uint64_t)srow * KSW_TAPE_ROWBYTES + (uint64_t)(grp * G) * 8u;
-        d.tape2 = chunk_cur + (uint64_t)(grp * G) * 8u;
+        d.tape = (same ? chunk_cur : chunk_prev) + (uint64_t)srow * RB + (uint64_t)(grp * G) * LB;
+        d.tape2 = chunk_cur + (uint64_t)(grp * G) * LB;
         d.split = same ? 0xffffffffu : (uint32_t)KSW_CHUNK_ROWS - srow; d.pad = 0;
         A.dp[(int64_t)tprob - A.p0] = d;
         if (stop) sh_cx[w][grp] = tprob + 1u;
@@ -576,7 +594,7 @@ __global__ void __launch_bounds__(256) k_ksw_trace(KswFastArgs A) {
       if (d.max < 10 || !(d.flags & 2u) || d.max_t < 0 || d.max_q < 0) A.results[p] = rs;
       else {
         const int b = (int)(d.flags >> 8);
-        const uint32_t K = (uint32_t)KSW_BIN_K(b), P = K / 2;
+        const uint32_t K = (uint32_t)KSW_BIN_K(b), P = K / 2, lb = (uint32_t)KSW_BIN_LANEBYTES(b), rb = 64u * lb;
         const uint8_t *tp = A.tape + d.tape, *tp2 = A.tape + d.tape2;
         uint32_t *raw = A.raw_ops + (pr.seq_off + (uint64_t)p);
         int ci = d.max_t, cj = d.max_q, state = 0;
@@ -584,8 +602,8 @@ __global__ void __launch_bounds__(256) k_ksw_trace(KswFastArgs A) {
         while (ci >= 0 && cj >= 0) {
           // column ci = lane ci / K, pair (ci % K) % P, half (ci % K) / P; pairs 0-3 sit in the lane's first dword
           const uint32_t r = (uint32_t)(ci + cj), ln = (uint32_t)ci / K, jj = (uint32_t)ci - ln * K, hf = jj >= P ? 1u : 0u, pj = jj - hf * P;
-          const uint8_t *rowp = r < d.split ? tp + (size_t)r * KSW_TAPE_ROWBYTES : tp2 + (size_t)(r - d.split) * KSW_TAPE_ROWBYTES;
-          const uint32_t word = *(const uint32_t *)(rowp + (size_t)ln * 8u + (pj >> 2) * 4u);
+          const uint8_t *rowp = r < d.split ? tp + (size_t)r * rb : tp2 + (size_t)(r - d.split) * rb;
+          const uint32_t word = *(const uint32_t *)(rowp + (size_t)ln * lb + (pj >> 2) * 4u);
           const uint32_t nib = (word >> (hf * 16u + 4u * (pj & 3u))) & 0xfu;
           const uint32_t tmp = (2u - (nib & 3u)) | ((nib & 0xcu) << 1);
           if (state == 0) state = tmp & 7;

@@ -20,11 +20,12 @@ struct KswDesc { uint32_t qt; uint32_t prob; uint64_t seq_off; };   // qlen | tl
 struct KswDp { int32_t max, max_t, max_q; uint32_t flags; uint64_t tape, tape2; uint32_t split, pad; };
 
 #define KSW_N_BINS 4
-// lanes per group / target columns per lane of every bin (columns = product); a lane stores 8 tape bytes per step
-#define KSW_BIN_G(b) ((b) == 0 ? 8 : (b) == 1 ? 8 : (b) == 2 ? 16 : 32)
-#define KSW_BIN_K(b) ((b) == 0 ? 8 : (b) == 3 ? 12 : 16)
+// lanes per group / target columns per lane of every bin (columns = product); a lane stores 8 or 16 tape bytes per step
+#define KSW_BIN_G(b) ((b) == 0 ? 8 : (b) == 1 ? 8 : (b) == 2 ? 16 : 16)
+#define KSW_BIN_K(b) ((b) == 0 ? 8 : (b) == 3 ? 24 : 16)
 #define KSW_BIN_W(b) (KSW_BIN_G(b) * KSW_BIN_K(b))      // 64, 128, 256, 384 target columns
-#define KSW_TAPE_ROWBYTES 512                            // a tape row = one step of a wave: 8 bytes per lane
+#define KSW_BIN_LANEBYTES(b) (KSW_BIN_K(b) > 16 ? 16 : 8)   // tape bytes of a lane and step (a nibble per column, rounded up)
+#define KSW_BIN_ROWBYTES(b) (64 * KSW_BIN_LANEBYTES(b))     // a tape row = one step of a wave
 #define KSW_CHUNK_ROWS 1024                              // waves take tape in chunks; a problem spans at most two
 #define KSW_MAX_SPAN KSW_CHUNK_ROWS                      // qlen + tlen of a problem the arrays take
 
