@@ -450,7 +450,7 @@ struct br_ctx {
   uint8_t *h_bam[2] = {nullptr, nullptr}; size_t h_bam_cap[2] = {0, 0}; int h_bam_next = 0;  // pinned download buffers of br_project_bam_bundle (alternating)
   int64_t last_n_rows = 0, last_n_aln = 0;
   DevBuf fa_stats, fa_n_prob, fa_seq_bytes, fa_prob_off, fa_seqarena_off, fa_probs, fa_results, fa_seq_arena, fa_clip_ops,
-      fa_ideal_cap, fa_scratch, fa_srcs, b_seq_off, b_seqs, b_seq_src;
+      fa_ideal_cap, fa_scratch, fa_srcs, fa_want, b_seq_off, b_seqs, b_seq_src;
   // the streamed -S DP (ksw_kernels.hip): per-bin descriptors, per-problem DP results, leftovers, counters, group
   // rows / offsets, the direction tape, raw traceback ops
   DevBuf ksw_desc, ksw_dp, ksw_left, ksw_cnt, ksw_group, ksw_tape, ksw_raw;
@@ -516,7 +516,7 @@ extern "C" void br_ctx_free(br_ctx *c) {
                     &c->cigar_out, &c->r_paired, &c->r_same, &c->r_first, &c->r_primary, &c->b_name_off, &c->b_names, &c->b_ref_id, &c->b_ref_start,
                     &c->b_flags, &c->b_xs, &c->b_ts, &c->b_cigar_off, &c->b_cigar, &c->b_mate_idx,
                     &c->b_group_off, &c->b_lqseq, &c->walk_list, &c->pmask, &c->pbit,
-                    &c->fa_srcs, &c->ksw_desc, &c->ksw_dp, &c->ksw_left, &c->ksw_cnt, &c->ksw_group, &c->ksw_tape, &c->ksw_raw};
+                    &c->fa_srcs, &c->fa_want, &c->ksw_desc, &c->ksw_dp, &c->ksw_left, &c->ksw_cnt, &c->ksw_group, &c->ksw_tape, &c->ksw_raw};
   for (DevBuf *b : bufs) b->release();
   for (auto &e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if (c->h_totals) (void)hipHostFree(c->h_totals);
@@ -804,11 +804,11 @@ static int run_device_impl(br_ctx *c, const br_config *cfg, const br_device_batc
     // rescue planning -> ksw2 DP -> count with the rescue results
     RC(c->fa_n_prob.ensure((size_t)n * 4)); RC(c->fa_seq_bytes.ensure((size_t)n * 4));
     RC(c->fa_prob_off.ensure((size_t)(n + 1) * 4)); RC(c->fa_seqarena_off.ensure((size_t)(n + 1) * 8));
-    RC(c->fa_ideal_cap.ensure((size_t)n * 4));
+    RC(c->fa_ideal_cap.ensure((size_t)n * 4)); RC(c->fa_want.ensure((size_t)n * 16));
     F.seq_src = b->seq_src; F.seq_off = b->seq_off; F.seqs = b->seqs;
     F.n_prob = c->fa_n_prob.as<uint32_t>(); F.seq_bytes = c->fa_seq_bytes.as<uint32_t>();
     F.prob_off = c->fa_prob_off.as<uint32_t>(); F.seqarena_off = c->fa_seqarena_off.as<uint64_t>();
-    F.ideal_cap = c->fa_ideal_cap.as<uint32_t>();
+    F.ideal_cap = c->fa_ideal_cap.as<uint32_t>(); F.want_l = c->fa_want.as<uint64_t>(); F.want_r = F.want_l + n;
     RC(pf.begin(BR_K_COUNT));
     launch_project_fa(st, A, F, 0, n_blocks);
     RC(pf.end());
@@ -870,8 +870,13 @@ static int run_device_impl(br_ctx *c, const br_config *cfg, const br_device_batc
   A.m_b = c->m_b.as<uint4>(); A.m_cigoff = c->m_cigoff.as<uint64_t>(); A.cig_arena = c->cig_arena.as<uint32_t>();
   if (n_matches) {
     if (fa_mode) {
+      // the work list + one lane per match for alignments with at most 64 candidate rows, k_project_fa<3> for the others
+      RC(pf.begin(BR_K_EXPAND));
+      launch_expand(st, A);
+      RC(pf.end());
       RC(pf.begin(BR_K_EMIT));
       launch_project_fa(st, A, F, 3, n_blocks);
+      launch_emit_dense_fa(st, A, F, (int64_t)n_matches);
       RC(pf.end());
     } else {
       RC(pf.begin(BR_K_EXPAND));

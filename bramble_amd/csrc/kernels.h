@@ -56,6 +56,7 @@ struct FaArgs {
   uint8_t *seq_arena;          // query / target codes of every problem
   uint32_t *clip_ops;          // clip-segment CIGARs: problem p at seq_off(p) + p
   uint32_t *ideal_cap;         // [n_aln] ideal-CIGAR capacity incl. clip ops
+  uint64_t *want_l, *want_r;   // [n_aln] k_project_fa<2>: candidates (by index, alignments with <= 64 candidate rows) that asked for a left / right rescue
 };
 
 struct KswArgs {
@@ -305,6 +306,7 @@ void launch_expand(hipStream_t st, const ProjectArgs &A);
 // n_simple: length of the work list's simple-class prefix (k_scan3's third total); part 0: one launch over
 // everything, 1: the simple prefix, 2: the rest
 void launch_emit_dense(hipStream_t st, const ProjectArgs &A, int64_t n_matches, int64_t n_simple, int part);
+void launch_emit_dense_fa(hipStream_t st, const ProjectArgs &A, const FaArgs &F, int64_t n_matches);
 int64_t scan_tiles_for(int64_t n);
 // mode 0: src32 as is; 1: n_matches * CIGAR slot capacity; 2: src32 as is (alias of 0);
 // 3: n_matches * CIGAR slot capacity with the per-alignment ideal_cap[] of the -S path

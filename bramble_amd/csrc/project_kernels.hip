@@ -987,8 +987,10 @@ __global__ void __launch_bounds__(256) k_expand(ProjectArgs A) {
 // match record at match_off[a] + rank.
 // CLS: 0 = the whole work list, 1 = its simple prefix only (no walk, no merge loop, no LDS: a much lighter kernel),
 // 2 = the rest; the list is partitioned by class (k_expand), `first` is where this launch starts
-template <bool SIMF, int CLS>
-__global__ void __launch_bounds__(256, CLS == 1 ? 8 : 6) k_emit_dense(ProjectArgs A, int64_t first, int64_t n_matches) {
+// FA: the -S rescue's emit pass (long reads): the survivor mask and the candidates' rescue wishes come from
+// k_project_fa<2>, the clip segments from the DP's results; no fast class.
+template <bool SIMF, int CLS, bool FA = false>
+__global__ void __launch_bounds__(256, CLS == 1 ? 8 : 6) k_emit_dense(ProjectArgs A, int64_t first, int64_t n_matches, FaArgs F) {
   __shared__ uint32_t sh_cig[CLS == 1 ? 1 : 256 * LDS_SLOT];
   __shared__ uint16_t sh_mops[CLS == 1 ? 1 : 256];
   if (CLS != 1) {
@@ -1005,7 +1007,8 @@ __global__ void __launch_bounds__(256, CLS == 1 ? 8 : 6) k_emit_dense(ProjectArg
   uint4 hd2 = A.head2[a];
   uint4 rg = A.ranges[a];
   uint64_t mask = A.mask[a];
-  const uint32_t is_fast = CLS == 1 ? 1u : CLS == 2 ? 0u : (A.fast_flag[a] >> 31);
+  const uint32_t part_fast = CLS == 1 ? 1u : CLS == 2 ? 0u : (A.fast_flag[a] >> 31);   // which part of the work list the entry is in
+  const uint32_t is_fast = FA ? 0u : part_fast;
   uint32_t moff = A.match_off[a];
   uint64_t cbase = A.cig_base[a];
   uint32_t c0 = A.cigar_off[a], c1 = A.cigar_off[a + 1];
@@ -1018,7 +1021,7 @@ __global__ void __launch_bounds__(256, CLS == 1 ? 8 : 6) k_emit_dense(ProjectArg
   // k-th survivor in candidate-row order
   // which survivor: the entry's distance from the alignment's first entry in the class-partitioned list (k_expand)
   const uint32_t fpre = A.fast_pre[a];
-  uint32_t k = (uint32_t)mi64 - (is_fast ? fpre : A.fast_pre[A.n_aln] + (moff - fpre));
+  uint32_t k = (uint32_t)mi64 - (part_fast ? fpre : A.fast_pre[A.n_aln] + (moff - fpre));
   uint64_t mm = mask;
   for (uint32_t j = 0; j < k; j++) mm &= mm - 1;
   uint32_t item = (uint32_t)(__ffsll((long long)mm) - 1);
@@ -1075,7 +1078,7 @@ __global__ void __launch_bounds__(256, CLS == 1 ? 8 : 6) k_emit_dense(ProjectArg
   bool plain = false;
   uint32_t sb = ix.slab_off[2 * rid + s], se = ix.slab_off[2 * rid + s + 1];
   if (n_seg == 1) { p1.alive = true; p1.fwpos = h0.pos; p1.rcpos = h0.pos; p1.n_seg = 1; p1.n_gex = 1; p1.i_lastm = i0; p1.last_right_ins = h0.right_ins; p1.last_right_gap = h0.right_gap; }
-  else if (!cfg.long_reads && !cfg.ignore_small_exons) {
+  else if (!FA && !cfg.long_reads && !cfg.ignore_small_exons) {
     // short-read presets without --max-error-exon: a survivor's every read exon is one plain hit on the next guide exon
     // (no skipped-exon or inserted-exon segments), so pass 1's counts are the read's exon count and its walk is not
     // needed; rcpos comes out of pass 2 (the last hit's position)
@@ -1084,7 +1087,23 @@ __global__ void __launch_bounds__(256, CLS == 1 ? 8 : 6) k_emit_dense(ProjectArg
     p1.last_right_ins = 0; p1.last_right_gap = 0;
   }
   else p1 = walk_pass1(ix, cfg, rd, E, s == 1, sb, se, i0, make_uint4(gs, gend, pay.z, 0), make_uint2(r_a.z, r_b.w), q0, h0);
-  uint32_t ideal_cap = 4u * n_seg + 2u;
+  // -S: the candidate's rescue problems are numbered in candidate order, left before right (k_project_fa<0 / 1>)
+  ClipSide L = no_clip(), R = no_clip();
+  if (FA) {
+    const uint64_t wl = F.want_l[a], wr = F.want_r[a], lower = (1ull << item) - 1ull;
+    const uint32_t pL = F.prob_off[a] + (uint32_t)__popcll(wl & lower) + (uint32_t)__popcll(wr & lower);
+    const uint32_t pR = pL + (uint32_t)((wl >> item) & 1ull);
+    if ((wl >> item) & 1ull) {
+      const KswRes rs = F.results[pL];
+      if (rs.ok) { L.ok = true; L.ops = F.clip_ops + (F.probs[pL].seq_off + pL); L.n_ops = rs.n_ops; L.score = rs.score; L.refc = (uint32_t)rs.refc; }
+    }
+    if ((wr >> item) & 1ull) {
+      const KswRes rs = F.results[pR];
+      if (rs.ok) { R.ok = true; R.ops = F.clip_ops + (F.probs[pR].seq_off + pR); R.n_ops = rs.n_ops; R.score = rs.score; R.refc = (uint32_t)rs.refc; }
+    }
+    apply_clips(p1, s == 1, pay.z, E[p1.i_lastm].z, L, R);
+  }
+  uint32_t ideal_cap = FA ? F.ideal_cap[a] : 4u * n_seg + 2u;
   uint32_t cap = rd.n_real + 2u * ideal_cap;
   uint32_t *slot = A.cig_arena + cbase + (uint64_t)rank * cap;
   uint32_t *lds = &sh_cig[threadIdx.x * LDS_SLOT];
@@ -1092,7 +1111,7 @@ __global__ void __launch_bounds__(256, CLS == 1 ? 8 : 6) k_emit_dense(ProjectArg
   uint32_t *ideal = ideal_lds ? lds : slot + rd.n_real + ideal_cap;
   Acc acc; IdealSink sk; double score = 0.0;
   sk.init(ideal);
-  walk_pass2(ix, cfg, rd, E, s == 1, sb, se, i0, q0, make_uint4(gs, gend, pay.z, 0), make_uint2(r_a.z, r_b.w), h0, p1, acc, sk, no_clip(), no_clip());
+  walk_pass2(ix, cfg, rd, E, s == 1, sb, se, i0, q0, make_uint4(gs, gend, pay.z, 0), make_uint2(r_a.z, r_b.w), h0, p1, acc, sk, L, R);
   uint32_t n_ideal = sk.finish();
   if (SIMF) similarity(cfg, acc, score);
   bool out_lds = ideal_lds && (rd.n_real + n_ideal <= LDS_SLOT - LDS_IDEAL);
@@ -1776,11 +1795,18 @@ void launch_expand(hipStream_t st, const ProjectArgs &A) {
 
 void launch_emit_dense(hipStream_t st, const ProjectArgs &A, int64_t n_matches, int64_t n_simple, int part) {
   if (A.n_aln <= 0 || n_matches <= 0) return;
-  if (A.cfg.filter_by_similarity) { hipLaunchKernelGGL((k_emit_dense<true, 0>), dim3(grid_for(n_matches, 256)), dim3(256), 0, st, A, (int64_t)0, n_matches); return; }
-  if (part == 0 || n_simple < 0) { hipLaunchKernelGGL((k_emit_dense<false, 0>), dim3(grid_for(n_matches, 256)), dim3(256), 0, st, A, (int64_t)0, n_matches); return; }
+  const FaArgs F{};
+  if (A.cfg.filter_by_similarity) { hipLaunchKernelGGL((k_emit_dense<true, 0>), dim3(grid_for(n_matches, 256)), dim3(256), 0, st, A, (int64_t)0, n_matches, F); return; }
+  if (part == 0 || n_simple < 0) { hipLaunchKernelGGL((k_emit_dense<false, 0>), dim3(grid_for(n_matches, 256)), dim3(256), 0, st, A, (int64_t)0, n_matches, F); return; }
   // the simple prefix of the work list and the rest as two launches: the first needs a third of the registers and no LDS
-  if (part == 1) { if (n_simple > 0) hipLaunchKernelGGL((k_emit_dense<false, 1>), dim3(grid_for(n_simple, 256)), dim3(256), 0, st, A, (int64_t)0, n_simple); }
-  else if (n_matches > n_simple) hipLaunchKernelGGL((k_emit_dense<false, 2>), dim3(grid_for(n_matches - n_simple, 256)), dim3(256), 0, st, A, n_simple, n_matches);
+  if (part == 1) { if (n_simple > 0) hipLaunchKernelGGL((k_emit_dense<false, 1>), dim3(grid_for(n_simple, 256)), dim3(256), 0, st, A, (int64_t)0, n_simple, F); }
+  else if (n_matches > n_simple) hipLaunchKernelGGL((k_emit_dense<false, 2>), dim3(grid_for(n_matches - n_simple, 256)), dim3(256), 0, st, A, n_simple, n_matches, F);
+}
+
+// the -S rescue's emit pass over the work list (alignments with at most 64 candidate rows; the others: k_project_fa<3>)
+void launch_emit_dense_fa(hipStream_t st, const ProjectArgs &A, const FaArgs &F, int64_t n_matches) {
+  if (A.n_aln <= 0 || n_matches <= 0) return;
+  hipLaunchKernelGGL((k_emit_dense<true, 0, true>), dim3(grid_for(n_matches, 256)), dim3(256), 0, st, A, (int64_t)0, n_matches, F);
 }
 
 int64_t scan_tiles_for(int64_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE; }
