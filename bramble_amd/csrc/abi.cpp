@@ -455,6 +455,7 @@ struct br_ctx {
   // rows / offsets, the direction tape, raw traceback ops
   DevBuf ksw_desc, ksw_dp, ksw_left, ksw_cnt, ksw_group, ksw_tape, ksw_raw;
   int ksw_fast = 1;            // 0: every problem through the general kernel k_ksw
+  hipStream_t ksw_stream = nullptr; hipEvent_t ksw_ev[KSW_N_BINS + 1] = {};
   uint32_t ksw_groups[KSW_N_BINS] = {0};
   int64_t ksw_tape_mb = 49152; // HBM set aside for the direction tape; larger batches go through in pieces
   int ksw_tape_pct = 100;      // test hook: the share of the computed tape the DP kernels may use (the rest of the problems goes to k_ksw)
@@ -533,6 +534,7 @@ extern "C" void br_ctx_free(br_ctx *c) {
     S.h_clip.release(); S.h_sim.release();
   }
   if (c->rows_busy) (void)hipEventDestroy(c->rows_busy);
+  if (c->ksw_stream) { (void)hipStreamDestroy(c->ksw_stream); for (auto &e : c->ksw_ev) if (e) (void)hipEventDestroy(e); }
   if (c->run_stream) (void)hipStreamDestroy(c->run_stream);
   if (c->d2h_stream) (void)hipStreamDestroy(c->d2h_stream);
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
@@ -717,12 +719,25 @@ static int run_ksw(br_ctx *c, hipStream_t st, const KswRun &R) {
     if (n_groups_total) {
       RC(c->ksw_tape.ensure((size_t)tape_bytes + 256));
       A.tape = c->ksw_tape.as<uint8_t>(); A.tape_cap = tape_bytes / 100 * (uint64_t)c->ksw_tape_pct;
-      for (int b = 0; b < KSW_N_BINS; b++) launch_ksw_dp(st, A, b);
+      // a shape's tracebacks (one lane per problem, waiting on tape lines) run on a second stream beside the next shape's
+      // DP kernel (issue-bound, one wave of registers to spare per SIMD)
+      if (!c->ksw_stream) {
+        HIPCHK(hipStreamCreateWithFlags(&c->ksw_stream, hipStreamNonBlocking));
+        for (auto &e : c->ksw_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      }
+      for (int b = KSW_N_BINS - 1; b >= 0; b--) {     // widest shape first: the exposed last traceback is the smallest shape's
+        if (!A.n_bin[b]) continue;
+        launch_ksw_dp(st, A, b);
+        HIPCHK(hipEventRecord(c->ksw_ev[b], st));
+        HIPCHK(hipStreamWaitEvent(c->ksw_stream, c->ksw_ev[b], 0));
+        launch_ksw_trace(c->ksw_stream, A, b);
+      }
+      HIPCHK(hipEventRecord(c->ksw_ev[KSW_N_BINS], c->ksw_stream));
     }
     // what the arrays do not take: targets beyond the widest array, and (never seen outside tests) groups whose tape ran out
     // (problems a wave hands back when the tape runs out come from the arrays: at most KSW_MAX_SPAN bases)
     RC(general(n_left ? n_left : 64, std::max<uint64_t>(h_cnt[5], KSW_MAX_SPAN), std::max<uint64_t>(h_cnt[6], KSW_BIN_W(KSW_N_BINS - 1)), A.leftover, A.counters + KSW_N_BINS));
-    launch_ksw_trace(st, A);
+    if (n_groups_total) HIPCHK(hipStreamWaitEvent(st, c->ksw_ev[KSW_N_BINS], 0));   // the tape and the result arrays are free again
     // leftovers after the DP (those of the last piece; read by br_ctx_ksw_diag once the stream has been synchronised)
     HIPCHK(hipMemcpyAsync((uint32_t *)(c->h_totals + 24), A.counters + KSW_N_BINS, 4, hipMemcpyDeviceToHost, st));
   }

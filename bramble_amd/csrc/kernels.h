@@ -298,7 +298,7 @@ void launch_fa_fill(hipStream_t st, const ProjectArgs &A, const FaArgs &F, int64
 void launch_ksw(hipStream_t st, const KswArgs &K, int n_blocks);
 void launch_ksw_bin(hipStream_t st, const KswFastArgs &A);
 void launch_ksw_dp(hipStream_t st, const KswFastArgs &A, int bin);
-void launch_ksw_trace(hipStream_t st, const KswFastArgs &A);
+void launch_ksw_trace(hipStream_t st, const KswFastArgs &A, int bin);   // bin < 0: every problem of the piece
 uint32_t ksw_dp_resident_groups(int bin, int n_cu);
 size_t ksw_prob_bytes();
 size_t ksw_res_bytes();

@@ -579,11 +579,15 @@ __global__ void __launch_bounds__(256) k_ksw_unclaimed(KswDpArgs A) {
 // ---------------------------------------------------------------------------
 // k_ksw_trace: one lane per problem: acceptance (src/evaluate.cpp:484,643), ksw_backtrack over the tape, clip segment
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_ksw_trace(KswFastArgs A) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// list / n_list: the problems of one array shape (its descriptor array), so that a shape's tracebacks can run beside the
+// next shape's DP kernel; null: every problem of the piece
+__global__ void __launch_bounds__(256) k_ksw_trace(KswFastArgs A, const KswDesc *list, uint32_t n_list) {
+  const int64_t li = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
   unsigned long long rescued = 0, cells = 0;
-  if (i < A.n) {
+  const bool have = list ? li < (int64_t)n_list : li < A.n;
+  const int64_t i = !have ? 0 : list ? (int64_t)list[li].prob - A.p0 : li;
+  if (have) {
     const KswDp d = A.dp[i];
     if (d.flags & 1u) {
       const int64_t p = A.p0 + i;
@@ -677,9 +681,10 @@ uint32_t ksw_dp_resident_groups(int bin, int n_cu) {
   return (uint32_t)blocks * (uint32_t)n_cu * 4u * (64u / (uint32_t)KSW_BIN_G(bin));
 }
 
-void launch_ksw_trace(hipStream_t st, const KswFastArgs &A) {
-  if (A.n <= 0) return;
-  hipLaunchKernelGGL(k_ksw_trace, dim3((unsigned)((A.n + 255) / 256)), dim3(256), 0, st, A);
+void launch_ksw_trace(hipStream_t st, const KswFastArgs &A, int bin) {
+  const int64_t n = bin < 0 ? A.n : (int64_t)A.n_bin[bin];
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_ksw_trace, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, A, bin < 0 ? (const KswDesc *)nullptr : A.desc[bin], (uint32_t)n);
 }
 
 }  // namespace br
