@@ -1086,7 +1086,7 @@ extern "C" int br_ctx_collect_counters(br_ctx *c, const br_device_batch *b, void
   HIPCHK(hipMemsetAsync(stats.p, 0, 8 * 8, st));
   StatsArgs T{};
   T.ix = c->ix->dev; T.n_aln = b->n_aln; T.ref_id = b->ref_id; T.cigar_off = b->cigar_off;
-  T.seg = c->seg.as<uint2>(); T.meta = c->meta.as<AlnMeta>(); T.out = stats.as<uint64_t>();
+  T.seg = c->seg.as<uint2>(); T.head = c->head.as<uint4>(); T.out = stats.as<uint64_t>();
   int64_t nm = (int64_t)c->counters[6];
   launch_stats(st, T, c->m_a.as<uint4>(), nm);
   uint64_t h[8];

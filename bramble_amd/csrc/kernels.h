@@ -188,7 +188,7 @@ struct StatsArgs {
   const int32_t *ref_id;
   const uint32_t *cigar_off;
   const uint2 *seg;
-  const AlnMeta *meta;
+  const uint4 *head;
   uint64_t *out;  // [8]
 };
 void launch_stats(hipStream_t st, const StatsArgs &T, const uint4 *m_a, int64_t n_matches);

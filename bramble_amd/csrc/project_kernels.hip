@@ -120,8 +120,8 @@ __global__ void __launch_bounds__(256) k_segment(int64_t n_aln, const int32_t *_
       else if (CIG_OP(wl) == OP_S) rclip = CIG_LEN(wl);
     }
   }
-  AlnMeta m; m.n_seg = n; m.smode = smode; m.n_left_clip = lclip; m.n_right_clip = rclip;
-  meta[a] = m;
+  // clip lengths, for the -S rescue kernels only (long reads): short-read presets do not write the 16 bytes
+  if (cfg.long_reads) { AlnMeta m; m.n_seg = n; m.smode = smode; m.n_left_clip = lclip; m.n_right_clip = rclip; meta[a] = m; }
   // everything k_project needs for read exon 0 in one 16-byte record
   uint2 q0 = n ? out[0] : make_uint2(0, 0);
   head[a] = make_uint4(q0.x, q0.y, n, n ? (((uint32_t)rid << 2) | smode) : 0u);
@@ -1665,7 +1665,8 @@ __global__ void __launch_bounds__(256) k_stats(StatsArgs T) {
   int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long b_idx = 0, hits = 0, exons = 0, ncig = 0;
   if (a < T.n_aln) {
-    AlnMeta mt = T.meta[a];
+    const uint4 hd = T.head[a];   // {exon 0, n_seg, refid << 2 | strands to try}
+    AlnMeta mt; mt.n_seg = hd.z; mt.smode = hd.w & 3u; mt.n_left_clip = mt.n_right_clip = 0;
     uint32_t c0 = T.cigar_off[a];
     ncig = T.cigar_off[a + 1] - c0;
     if (mt.n_seg) {
