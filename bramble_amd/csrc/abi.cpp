@@ -40,11 +40,12 @@ struct br_index {
   uint32_t n_refs = 0;
   bool has_seq = false;
   // host copies of the flattened tables
-  std::vector<uint32_t> slab_off, s_start, s_pmax, s_tid, tx_first, bin_off, t_hi, t_lo;
+  std::vector<uint32_t> slab_off, s_start, s_pmax, s_tid, tx_first, bin_off;
+  std::vector<uint4> t_bin;
   std::vector<uint4> s_row, tx_ex;
   std::vector<uint8_t> seq_pool;
   // device copies
-  void *d_slab_off = nullptr, *d_s_start = nullptr, *d_s_pmax = nullptr, *d_bin_off = nullptr, *d_t_hi = nullptr, *d_t_lo = nullptr, *d_s_tid = nullptr,
+  void *d_slab_off = nullptr, *d_s_start = nullptr, *d_s_pmax = nullptr, *d_bin_off = nullptr, *d_t_bin = nullptr, *d_s_tid = nullptr,
        *d_s_row = nullptr, *d_tx_ex = nullptr, *d_tx_first = nullptr, *d_seq_pool = nullptr;
   size_t device_bytes = 0;
   DevIndex dev{};
@@ -150,21 +151,29 @@ static int build_index_flat(size_t n_tx, const int32_t *tx_ref, const int8_t *tx
   // bucket tables (replace the per-read binary search of the slab)
   const uint32_t SHIFT = 10;
   ix->bin_off.push_back(0);
-  for (size_t sl = 0; sl + 1 < ix->slab_off.size(); sl++) {
-    uint32_t sb = ix->slab_off[sl], se = ix->slab_off[sl + 1];
-    uint32_t maxc = 0;
-    if (se > sb) maxc = std::max(ix->s_start[se - 1], ix->s_pmax[se - 1]);
-    uint64_t nb = ((uint64_t)maxc >> SHIFT) + 2;
-    uint32_t rh = sb, rl = sb;
-    for (uint64_t b = 0; b < nb; b++) {
-      uint64_t edge = b << SHIFT;
-      while (rh < se && (uint64_t)ix->s_start[rh] < edge) rh++;
-      while (rl < se && (uint64_t)ix->s_pmax[rl] <= edge) rl++;
-      ix->t_hi.push_back(rh); ix->t_lo.push_back(rl);
+  for (uint32_t r = 0; r < ix->n_refs; r++) {
+    uint64_t nb = 2;
+    for (int s = 0; s < 2; s++) {
+      uint32_t sb = ix->slab_off[2 * r + s], se = ix->slab_off[2 * r + s + 1];
+      if (se > sb) nb = std::max<uint64_t>(nb, ((uint64_t)std::max(ix->s_start[se - 1], ix->s_pmax[se - 1]) >> SHIFT) + 2);
     }
-    ix->t_hi.push_back(se); ix->t_lo.push_back(se);
-    if (ix->t_hi.size() >= 0xfffffff0ull) { delete ix; return BR_ERR_CAPACITY; }
-    ix->bin_off.push_back((uint32_t)ix->t_hi.size());
+    const size_t first = ix->t_bin.size();
+    ix->t_bin.resize(first + nb + 1);
+    for (int s = 0; s < 2; s++) {
+      uint32_t sb = ix->slab_off[2 * r + s], se = ix->slab_off[2 * r + s + 1];
+      uint32_t rh = sb, rl = sb;
+      for (uint64_t b = 0; b <= nb; b++) {
+        if (b < nb) {
+          uint64_t edge = b << SHIFT;
+          while (rh < se && (uint64_t)ix->s_start[rh] < edge) rh++;
+          while (rl < se && (uint64_t)ix->s_pmax[rl] <= edge) rl++;
+        } else rh = rl = se;
+        uint4 &e = ix->t_bin[first + b];
+        if (s == 0) { e.x = rl; e.y = rh; } else { e.z = rl; e.w = rh; }
+      }
+    }
+    if (ix->t_bin.size() >= 0xfffffff0ull) { delete ix; return BR_ERR_CAPACITY; }
+    ix->bin_off.push_back((uint32_t)ix->t_bin.size());
   }
   ix->device = device;
   if (device >= 0) {
@@ -174,7 +183,7 @@ static int build_index_flat(size_t n_tx, const int32_t *tx_ref, const int8_t *tx
     size_t acc = 0;
     if ((rc = upload(&ix->d_slab_off, ix->slab_off, acc)) || (rc = upload(&ix->d_s_start, ix->s_start, acc)) ||
         (rc = upload(&ix->d_s_pmax, ix->s_pmax, acc)) || (rc = upload(&ix->d_bin_off, ix->bin_off, acc)) ||
-        (rc = upload(&ix->d_t_hi, ix->t_hi, acc)) || (rc = upload(&ix->d_t_lo, ix->t_lo, acc)) ||
+        (rc = upload(&ix->d_t_bin, ix->t_bin, acc)) ||
         (rc = upload(&ix->d_s_tid, ix->s_tid, acc)) ||
         (rc = upload(&ix->d_s_row, ix->s_row, acc)) || (rc = upload(&ix->d_tx_ex, ix->tx_ex, acc)) ||
         (rc = upload(&ix->d_tx_first, ix->tx_first, acc)) || (rc = upload(&ix->d_seq_pool, ix->seq_pool, acc))) {
@@ -186,7 +195,7 @@ static int build_index_flat(size_t n_tx, const int32_t *tx_ref, const int8_t *tx
     d.slab_off = (const uint32_t *)ix->d_slab_off; d.s_start = (const uint32_t *)ix->d_s_start;
     d.s_pmax = (const uint32_t *)ix->d_s_pmax;
     d.bin_shift = SHIFT; d.bin_off = (const uint32_t *)ix->d_bin_off;
-    d.t_hi = (const uint32_t *)ix->d_t_hi; d.t_lo = (const uint32_t *)ix->d_t_lo;
+    d.t_bin = (const uint4 *)ix->d_t_bin;
     d.s_tid = (const uint32_t *)ix->d_s_tid;
     d.s_row = (const uint4 *)ix->d_s_row; d.tx_ex = (const uint4 *)ix->d_tx_ex;
     d.tx_first = (const uint32_t *)ix->d_tx_first; d.seq_pool = (const uint8_t *)ix->d_seq_pool;
@@ -241,7 +250,7 @@ extern "C" void br_index_free(br_index *ix) {
   if (!ix) return;
   if (ix->device >= 0) {
     (void)hipSetDevice(ix->device);
-    void *ptrs[] = {ix->d_slab_off, ix->d_s_start, ix->d_s_pmax, ix->d_bin_off, ix->d_t_hi, ix->d_t_lo, ix->d_s_tid, ix->d_s_row, ix->d_tx_ex,
+    void *ptrs[] = {ix->d_slab_off, ix->d_s_start, ix->d_s_pmax, ix->d_bin_off, ix->d_t_bin, ix->d_s_tid, ix->d_s_row, ix->d_tx_ex,
                     ix->d_tx_first, ix->d_seq_pool};
     for (void *p : ptrs) if (p) (void)hipFree(p);
   }

@@ -21,12 +21,13 @@ struct DevIndex {
                                // closed by a sentinel {~0u, ~0u, 0, 0}
   const uint32_t *tx_first;    // [n_tx + 1] first tx_ex row of each transcript (incl. sentinels)
   const uint8_t *seq_pool;     // exon sequences (only with -S)
-  // bucket tables over genomic coordinate (bin = coord >> bin_shift), per slab:
-  // t_hi[b] = first row with start >= b<<shift; t_lo[b] = first row whose running
-  // max end exceeds b<<shift.  Slab s owns entries [bin_off[s], bin_off[s+1]).
+  // bucket tables over genomic coordinate (bin = coord >> bin_shift), per reference, both strands' slabs in one
+  // 16-byte entry {lo+, hi+, lo-, hi-}: hi = first row of the slab with start >= b<<shift, lo = first row whose running
+  // max end exceeds b<<shift (a read's two table words per strand come with two loads, usually from one line).
+  // Reference r owns entries [bin_off[r], bin_off[r+1]).
   uint32_t bin_shift;
-  const uint32_t *bin_off;     // [2*n_refs + 1]
-  const uint32_t *t_hi, *t_lo;
+  const uint32_t *bin_off;     // [n_refs + 1]
+  const uint4 *t_bin;
 };
 
 // Resolved evaluator thresholds (ReadEvaluationConfig, include/evaluate.h:275-285)

@@ -681,7 +681,7 @@ __global__ void __launch_bounds__(256, EMIT ? 4 : 8) k_project(ProjectArgs A) {
   if (slab_in_lds) {
     for (uint32_t i = threadIdx.x; i < n_slab_off; i += blockDim.x) {
       sh_slab[i] = ix.slab_off[i];
-      if (!EMIT) sh_bin[i] = ix.bin_off[i];
+      if (!EMIT && i <= ix.n_refs) sh_bin[i] = ix.bin_off[i];
     }
     __syncthreads();
   }
@@ -717,13 +717,14 @@ __global__ void __launch_bounds__(256, EMIT ? 4 : 8) k_project(ProjectArgs A) {
       // edge above qend.  A superset (x1.5 rows on GENCODE-shaped data) of the exact [lo, hi) a search inside the bins
       // would give -- every row is tested for overlap anyway -- that costs one dependent round trip less.
       uint32_t tw[4];
-#pragma unroll
-      for (int s = 0; s < 2; s++) {  // every slab owns >= 3 table entries: unconditional loads
-        uint32_t bo = slab_in_lds ? sh_bin[2 * rid + s] : ix.bin_off[2 * rid + s];
-        uint32_t nb = (slab_in_lds ? sh_bin[2 * rid + s + 1] : ix.bin_off[2 * rid + s + 1]) - bo - 1;
-        uint32_t bh = q0.y >> ix.bin_shift, bl = q0.x >> ix.bin_shift;
-        bh = bh < nb - 1 ? bh : nb - 1; bl = bl < nb - 1 ? bl : nb - 1;
-        tw[2 * s] = ix.t_lo[bo + bl]; tw[2 * s + 1] = ix.t_hi[bo + bh + 1];
+      // every reference owns >= 3 table entries: unconditional loads, both strands' words in each
+      const uint32_t bo = slab_in_lds ? sh_bin[rid] : ix.bin_off[rid];
+      const uint32_t nb = (slab_in_lds ? sh_bin[rid + 1] : ix.bin_off[rid + 1]) - bo - 1;
+      uint32_t bh = q0.y >> ix.bin_shift, bl = q0.x >> ix.bin_shift;
+      bh = bh < nb - 1 ? bh : nb - 1; bl = bl < nb - 1 ? bl : nb - 1;
+      {
+        const uint4 tl = ix.t_bin[bo + bl], th = ix.t_bin[bo + bh + 1];
+        tw[0] = tl.x; tw[1] = th.y; tw[2] = tl.z; tw[3] = th.w;
       }
 #pragma unroll
       for (int s = 0; s < 2; s++) {
@@ -736,16 +737,13 @@ __global__ void __launch_bounds__(256, EMIT ? 4 : 8) k_project(ProjectArgs A) {
         // start >= qend, lo = first row whose running max end exceeds qstart) with a G-wide count inside the two bins,
         // so that only alignments with > 64 overlapping-range rows go to the wave-per-alignment emit kernel.
         uint32_t ra[4], rb[4];  // 0/1: hi/lo on '+', 2/3: hi/lo on '-'
+        const uint4 th0 = ix.t_bin[bo + bh], tl1 = ix.t_bin[bo + bl + 1];
 #pragma unroll
         for (int s = 0; s < 2; s++) {
           ra[2 * s] = rb[2 * s] = ra[2 * s + 1] = rb[2 * s + 1] = sb[s];
           if (!((smode >> s) & 1u) || sb[s] == se[s]) continue;
-          uint32_t bo = slab_in_lds ? sh_bin[2 * rid + s] : ix.bin_off[2 * rid + s];
-          uint32_t nb = (slab_in_lds ? sh_bin[2 * rid + s + 1] : ix.bin_off[2 * rid + s + 1]) - bo - 1;
-          uint32_t bh = q0.y >> ix.bin_shift, bl = q0.x >> ix.bin_shift;
-          bh = bh < nb - 1 ? bh : nb - 1; bl = bl < nb - 1 ? bl : nb - 1;
-          ra[2 * s] = ix.t_hi[bo + bh]; rb[2 * s] = hi[s];
-          ra[2 * s + 1] = tw[2 * s]; rb[2 * s + 1] = ix.t_lo[bo + bl + 1];
+          ra[2 * s] = s ? th0.w : th0.y; rb[2 * s] = hi[s];
+          ra[2 * s + 1] = tw[2 * s]; rb[2 * s + 1] = s ? tl1.z : tl1.x;
         }
         uint32_t res[4] = {ra[0], ra[1], ra[2], ra[3]};
         for (uint32_t it = 0;; it += G) {
