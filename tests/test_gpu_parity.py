@@ -194,6 +194,63 @@ def test_dense_locus_more_than_64_candidates():
         assert_rows_equal(prod, orc)
 
 
+def test_dense_locus_with_clip_rescue():
+    """-S at a locus where 150 isoforms share exons: long reads with soft clips there have > 64 candidate rows (the
+    rescue's emit pass for them is k_project_fa<3>) next to reads with few candidates (work list + k_emit_dense<.., FA>);
+    clips that are the neighbouring exon's bases, foreign clips, both sides."""
+    rng = np.random.RandomState(19)
+    genome = "".join("ACGT"[k] for k in rng.randint(0, 4, 12000))
+    txs = []
+    for t in range(150):
+        strand = "+" if t % 3 else "-"
+        ex = [[1000, 1200 + (t % 4)], [2000 + 5 * (t % 7), 2300], [3000, 3100 + t]]
+        if t % 5 == 0:
+            ex = ex[:2]
+        txs.append({"id": "iso%d" % t, "ref_id": 0, "strand": strand, "exons": ex})
+    txs.append({"id": "duo", "ref_id": 0, "strand": "+", "exons": [[9000, 9400], [10000, 10500]]})
+    ann = {"refnames": ["chr1"], "transcripts": txs, "ref_seqs": {0: genome}}
+
+    def sub(a, b_):     # 1-based half-open genome slice
+        return genome[a - 1:b_ - 1]
+
+    def foreign(n):
+        return "".join("ACGT"[k] for k in rng.randint(0, 4, n))
+
+    recs = []
+    for i in range(240):
+        kind = i % 6
+        if kind == 0:      # second exon of the dense locus, left clip = the end of the first exon (rescuable for many isoforms)
+            st, cl = 2000 + 5 * int(rng.randint(0, 7)), int(rng.randint(8, 60))
+            seq = sub(1200 - cl, 1200) + sub(st, st + 90)
+            recs.append({"name": "r%d" % i, "ref_id": 0, "ref_start": st, "cigar": "%dS90M" % cl, "seq": seq})
+        elif kind == 1:    # first exon, right clip = the start of the second exon
+            cl = int(rng.randint(8, 60))
+            st = 1100 + int(rng.randint(0, 40))
+            seq = sub(st, 1200) + sub(2000, 2000 + cl)
+            recs.append({"name": "r%d" % i, "ref_id": 0, "ref_start": st, "cigar": "%dM%dS" % (1200 - st, cl), "seq": seq})
+        elif kind == 2:    # foreign clip at the dense locus
+            cl = int(rng.randint(8, 40))
+            seq = foreign(cl) + sub(2035, 2035 + 80)
+            recs.append({"name": "r%d" % i, "ref_id": 0, "ref_start": 2035, "cigar": "%dS80M" % cl, "seq": seq})
+        elif kind == 3:    # spliced through the dense locus with a clip on either side
+            cl, cr = int(rng.randint(5, 30)), int(rng.randint(5, 30))
+            seq = foreign(cl) + sub(1150, 1200) + sub(2000, 2300) + sub(3000, 3040) + foreign(cr)
+            recs.append({"name": "r%d" % i, "ref_id": 0, "ref_start": 1150, "cigar": "%dS50M800N300M700N40M%dS" % (cl, cr), "seq": seq})
+        elif kind == 4:    # the two-exon transcript: few candidates, rescuable left clip
+            cl = int(rng.randint(8, 80))
+            seq = sub(9400 - cl, 9400) + sub(10000, 10100)
+            recs.append({"name": "r%d" % i, "ref_id": 0, "ref_start": 10000, "cigar": "%dS100M" % cl, "seq": seq})
+        else:              # ... and a rescuable right clip
+            cl = int(rng.randint(8, 80))
+            seq = sub(9300, 9400) + sub(10000, 10000 + cl)
+            recs.append({"name": "r%d" % i, "ref_id": 0, "ref_start": 9300, "cigar": "100M%dS" % cl, "seq": seq})
+    b = make_batch(recs)
+    for flags in ({"lr": 1, "use_fasta": 1}, {"lr_hq": 1, "use_fasta": 1}):
+        prod, orc = run_both(ann, b, group_lanes=8, **flags)
+        assert orc["nh"].max() > 64 and (orc["clip_score"] != 0).sum() > 100
+        assert_rows_equal(prod, orc)
+
+
 def test_empty_and_degenerate_inputs():
     ann = synth.Annotation("S").as_dict()
     idx = lib.Index(ann, device=0)
