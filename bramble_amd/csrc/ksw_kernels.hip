@@ -5,18 +5,20 @@
 //   Scores as src/evaluate.cpp:296-313: match 1, mismatch -4, N -1, gap open 4, extend 1, z-drop 40, full band,
 //   EXTZ_ONLY | APPROX_MAX | APPROX_DROP.
 //
-// k_ksw_dp<G,K>: a systolic array in registers.  A group of G lanes owns G*K target columns (K consecutive columns per
-// lane, two 16-bit cells per VGPR, packed-16 arithmetic); the query streams through the columns one column per step, so
-// that column c holds cell (r, c) of anti-diagonal r with query base r - c.  A cell needs x, v of column c-1 from the
-// step before (one wave_shr DPP move per stream and lane, v_alignbit inside the lane) and its own u, y: no LDS, no
-// loads in the recurrence.  Problems follow each other through the array back to back: while problem A's band leaves
-// the low columns, problem B's first anti-diagonals already use them, which removes the two idle triangles of an
-// anti-diagonal sweep.  The first base of a problem carries a flag; a column that sees it resets its u / y and takes
-// the next problem's target base.  Values are kept x4 with a 2-bit tag in the low bits (match 2 > deletion 1 >
-// insertion 0), so that one packed max gives the winner and ksw2's tie order at once.  Per step every lane stores the
-// 4-bit directions of its K columns as one dword of a per-group tape (row = step); k_ksw_trace walks the tape with one
-// lane per problem.  The approximate-maximum / z-drop bookkeeping (one scalar chain per problem in ksw2) runs in the
-// lanes of the group, one problem per lane, on the u / v values the columns publish to LDS.
+// k_ksw_dp<G,K>: a systolic array in registers.  A group of G lanes owns G*K target columns (K columns per lane, two
+// 16-bit cells per VGPR, packed-16 arithmetic; pair j of a lane = columns c0 + j and c0 + j + K/2, so that only pair 0
+// needs a shifted operand); the query streams through the columns one column per step, so that column c holds cell
+// (r, c) of anti-diagonal r with query base r - c.  A cell needs x, v of column c-1 from the step before (one wave_shr
+// DPP move per stream and lane) and its own u, y: no LDS, no loads in the recurrence.  Problems follow each other
+// through the array back to back: while problem A's band leaves the low columns, problem B's first anti-diagonals
+// already use them, which removes the two idle triangles of an anti-diagonal sweep.  The first base of a problem
+// carries a flag; a column that sees it resets its u / y and takes the next problem's target base.  Values are kept
+// x4 with a 2-bit tag in the low bits (match 2 > deletion 1 > insertion 0), so that one packed max gives the winner and
+// ksw2's tie order at once.  Per step every lane stores the 4-bit directions of its K columns (8 or 16 bytes) in the
+// wave's tape row (row = step; chunks of 1024 rows from a pool); k_ksw_trace walks the tape with one lane per problem.
+// The groups of a launch share one queue of problems per array shape (descriptors three problems ahead, through an LDS
+// ring).  The approximate-maximum / z-drop bookkeeping (one scalar chain per problem in ksw2) runs in the lanes of the
+// group, one problem per lane, on the u / v values the columns publish to LDS.
 // k_ksw: the general kernel (any size; one wave per problem, state in LDS / HBM) for what does not fit the arrays.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
