@@ -133,3 +133,28 @@ def test_two_batches_in_flight_through_the_staging_slots():
             assert np.array_equal(g[key], w[key]), key
     ctx.close()
     idx.close()
+
+
+def test_device_detail_column_on_request():
+    """br_device_rows.x is NULL after a projection call; br_device_rows_detail derives the br_row_x array from what the
+    call left in HBM, and it agrees with the wide view (which is compared with the oracle everywhere else)."""
+    import torch
+    from bramble_amd import device as brdev
+    ann = synth.Annotation("G", n_genes=800, n_refs=2)
+    b = ann.reads(5000, "pe", p_multimap=0.2)
+    idx = lib.Index(ann.as_dict(), device=0)
+    ctx = lib.Context(idx)
+    cfg = lib.make_config()
+    db = brdev.upload_batch(b, "cuda:0")
+    rows = ctx.project_batch_device(cfg, db, 0)
+    assert not rows.x and rows.n_rows > 1000
+    p = brdev.packed_as_tensors(rows, int(b["n_aln"]), ctx=ctx)
+    w = brdev.rows_as_tensors(ctx)
+    x = p["x"].cpu().numpy()
+    assert np.array_equal(x[:, 0], w["input_index"].cpu().numpy())
+    assert np.array_equal(x[:, 1], w["junc_hits"].cpu().numpy())
+    assert np.array_equal(x[:, 2], w["aligned_len"].cpu().numpy())
+    assert np.array_equal(x[:, 3], w["hi"].cpu().numpy())
+    torch.cuda.synchronize()
+    ctx.close()
+    idx.close()
