@@ -1810,7 +1810,7 @@ extern "C" uint32_t br_row_mapq(uint32_t nh, int long_reads) {  // src/core.cpp:
   return nh > 1 ? 0u : 3u;
 }
 
-extern "C" const char *br_version(void) { return "bramble_amd 0.2.0 (gfx950, ABI 2)"; }
+extern "C" const char *br_version(void) { return "bramble_amd 0.3.0 (gfx950, ABI 3)"; }
 extern "C" const char *br_strerror(int code) {
   switch (code) {
     case BR_OK: return "ok";

@@ -210,8 +210,10 @@ typedef struct br_device_batch {
 /* ABI version 2: the rows of the device-resident entry points are PACKED (24 bytes + 16 bytes of detail per emitted
  * record instead of 22 separate arrays): the row stage of the pipeline is bound by the bytes it writes, and a host
  * that downloads rows pays for them a second time over PCIe.  The wide one-array-per-field view (ABI version 1's
- * br_device_rows, now br_device_wide_rows) is derived from the packed table on request. */
-#define BR_ABI_VERSION 2
+ * br_device_rows, now br_device_wide_rows) is derived from the packed table on request.
+ * ABI version 3: the projection writes the 24 bytes only; the 16 bytes of detail (br_row_x) are derived on request as
+ * well (br_device_rows.x is NULL: br_device_rows_detail(); host rows carry it with "host_detail" = 1 as before). */
+#define BR_ABI_VERSION 3
 
 /* One emitted BAM record (ProjectedAlignment, bramble-rs/src/api.rs:135-176; the fields write_to_bam sets,
  * src/core.cpp:96-212).  Rows of one read name are contiguous and a pair's two records are adjacent (the leader's own
