@@ -464,7 +464,7 @@ struct br_ctx {
   // rows / offsets, the direction tape, raw traceback ops
   DevBuf ksw_desc, ksw_dp, ksw_left, ksw_cnt, ksw_group, ksw_tape, ksw_raw;
   int ksw_fast = 1;            // 0: every problem through the general kernel k_ksw
-  hipStream_t ksw_stream = nullptr; hipEvent_t ksw_ev[KSW_N_BINS + 1] = {};
+  hipStream_t ksw_stream = nullptr; hipEvent_t ksw_ev[KSW_N_BINS + 1] = {}; hipEvent_t aux_ev[2] = {};   // the second stream
   uint32_t ksw_groups[KSW_N_BINS] = {0};
   int64_t ksw_tape_mb = 49152; // HBM set aside for the direction tape; larger batches go through in pieces
   int ksw_tape_pct = 100;      // test hook: the share of the computed tape the DP kernels may use (the rest of the problems goes to k_ksw)
@@ -543,7 +543,7 @@ extern "C" void br_ctx_free(br_ctx *c) {
     S.h_clip.release(); S.h_sim.release();
   }
   if (c->rows_busy) (void)hipEventDestroy(c->rows_busy);
-  if (c->ksw_stream) { (void)hipStreamDestroy(c->ksw_stream); for (auto &e : c->ksw_ev) if (e) (void)hipEventDestroy(e); }
+  if (c->ksw_stream) { (void)hipStreamDestroy(c->ksw_stream); for (auto &e : c->ksw_ev) if (e) (void)hipEventDestroy(e); for (auto &e : c->aux_ev) if (e) (void)hipEventDestroy(e); }
   if (c->run_stream) (void)hipStreamDestroy(c->run_stream);
   if (c->d2h_stream) (void)hipStreamDestroy(c->d2h_stream);
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
@@ -599,7 +599,9 @@ namespace {
 
 struct Prof {
   br_ctx *c; hipStream_t st;
-  int begin(int which) {
+  hipStream_t cur = nullptr;   // stream of the open begin / end pair
+  int begin(int which, hipStream_t on = nullptr) {
+    cur = on ? on : st;
     if (!c->profiling) return BR_OK;
     if (c->events_used == c->events.size()) {
       KEvent e; e.which = which;
@@ -607,12 +609,12 @@ struct Prof {
       c->events.push_back(e);
     }
     c->events[c->events_used].which = which;
-    HIPCHK(hipEventRecord(c->events[c->events_used].a, st));
+    HIPCHK(hipEventRecord(c->events[c->events_used].a, cur));
     return BR_OK;
   }
   int end() {
     if (!c->profiling) return BR_OK;
-    HIPCHK(hipEventRecord(c->events[c->events_used].b, st));
+    HIPCHK(hipEventRecord(c->events[c->events_used].b, cur));
     c->events_used++;
     return BR_OK;
   }
@@ -631,6 +633,16 @@ struct Prof {
 };
 
 #define RC(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+
+// a second stream for kernels that can run beside the main one (a shape's tracebacks beside the next shape's DP; the
+// few-block emit kernel of the > 64-candidate alignments beside the work-list kernels)
+static int ensure_aux_stream(br_ctx *c) {
+  if (c->ksw_stream) return BR_OK;
+  HIPCHK(hipStreamCreateWithFlags(&c->ksw_stream, hipStreamNonBlocking));
+  for (auto &e : c->ksw_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  for (auto &e : c->aux_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  return BR_OK;
+}
 
 // The -S rescue DP over n_prob problems.  Problems whose target fits a register array go
 // through the streamed kernels piece by piece (a piece = a range of problems whose direction tape fits the budget):
@@ -730,10 +742,7 @@ static int run_ksw(br_ctx *c, hipStream_t st, const KswRun &R) {
       A.tape = c->ksw_tape.as<uint8_t>(); A.tape_cap = tape_bytes / 100 * (uint64_t)c->ksw_tape_pct;
       // a shape's tracebacks (one lane per problem, waiting on tape lines) run on a second stream beside the next shape's
       // DP kernel (issue-bound, one wave of registers to spare per SIMD)
-      if (!c->ksw_stream) {
-        HIPCHK(hipStreamCreateWithFlags(&c->ksw_stream, hipStreamNonBlocking));
-        for (auto &e : c->ksw_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-      }
+      RC(ensure_aux_stream(c));
       for (int b = KSW_N_BINS - 1; b >= 0; b--) {     // widest shape first: the exposed last traceback is the smallest shape's
         if (!A.n_bin[b]) continue;
         launch_ksw_dp(st, A, b);
@@ -903,11 +912,16 @@ static int run_device_impl(br_ctx *c, const br_config *cfg, const br_device_batc
       launch_emit_dense_fa(st, A, F, (int64_t)n_matches);
       RC(pf.end());
     } else {
+      // alignments with > 64 candidate rows only: a few long-running blocks, on the second stream beside the work list
+      RC(ensure_aux_stream(c));
+      HIPCHK(hipEventRecord(c->aux_ev[0], st));
+      HIPCHK(hipStreamWaitEvent(c->ksw_stream, c->aux_ev[0], 0));
+      RC(pf.begin(BR_K_EMIT_AUX, c->ksw_stream));
+      launch_project(c->ksw_stream, A, true, 64, c->n_cu);
+      RC(pf.end());
+      HIPCHK(hipEventRecord(c->aux_ev[1], c->ksw_stream));
       RC(pf.begin(BR_K_EXPAND));
       launch_expand(st, A);
-      RC(pf.end());
-      RC(pf.begin(BR_K_EMIT_AUX));
-      launch_project(st, A, true, 64, c->n_cu);  // alignments with > 64 candidate rows only
       RC(pf.end());
       if (c->emit_split && n_simple >= 0 && !dc.filter_by_similarity) {
         RC(pf.begin(BR_K_EMIT_SIMPLE));
@@ -921,6 +935,7 @@ static int run_device_impl(br_ctx *c, const br_config *cfg, const br_device_batc
         launch_emit_dense(st, A, (int64_t)n_matches, -1, 0);
         RC(pf.end());
       }
+      HIPCHK(hipStreamWaitEvent(st, c->aux_ev[1], 0));
     }
   }
 
