@@ -444,7 +444,7 @@ struct br_ctx {
   int deflate_dynamic = 1;
   int emit_split = 1;
   int count_split = 1;   // count pass as two kernels: the main one without the exon walk, a second one for the alignments that need it
-  DevBuf walk_list, pmask, pbit;
+  DevBuf walk_list, pmask, pbit, pick;
   // packed row table (the product of the row stage) and what its kernels need
   DevBuf r_rec, pk_a, pk_c, pk_x, pk_sim, pk_clip;
   DevBuf pool, pool_sizes, pool_off, pk_ch;   // dense long-CIGAR pool + rewritten references for host downloads
@@ -525,7 +525,7 @@ extern "C" void br_ctx_free(br_ctx *c) {
                     &c->r_ncig, &c->r_strand, &c->r_sim, &c->r_clip, &c->r_junc, &c->r_refc, &c->r_cigoff,
                     &c->cigar_out, &c->r_paired, &c->r_same, &c->r_first, &c->r_primary, &c->b_name_off, &c->b_names, &c->b_ref_id, &c->b_ref_start,
                     &c->b_flags, &c->b_xs, &c->b_ts, &c->b_cigar_off, &c->b_cigar, &c->b_mate_idx,
-                    &c->b_group_off, &c->b_lqseq, &c->walk_list, &c->pmask, &c->pbit,
+                    &c->b_group_off, &c->b_lqseq, &c->walk_list, &c->pmask, &c->pbit, &c->pick,
                     &c->fa_srcs, &c->fa_want, &c->ksw_desc, &c->ksw_dp, &c->ksw_left, &c->ksw_cnt, &c->ksw_group, &c->ksw_tape, &c->ksw_raw};
   for (DevBuf *b : bufs) b->release();
   for (auto &e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -982,14 +982,30 @@ static int run_device_impl(br_ctx *c, const br_config *cfg, const br_device_batc
   P.n_rows_total = (int64_t)n_rows; P.r_rec = c->r_rec.as<uint4>();
   P.r_a = c->pk_a.as<uint4>(); P.r_c = c->pk_c.as<uint2>(); P.r_x = nullptr;
   P.r_sim = aux_cols ? c->pk_sim.as<double>() : nullptr; P.r_clip = aux_cols ? c->pk_clip.as<int32_t>() : nullptr;
+  // presets without scores: the primary choice (ALU: the mt19937_64 seeding chain) needs row_off and the pair bits only,
+  // so it runs on the second stream beside the emit pass of k_pair and leaves its choice for k_rows
+  const bool split_primary = !aux_cols;
+  if (split_primary) {
+    RC(ensure_aux_stream(c));
+    RC(c->pick.ensure((size_t)std::max<int64_t>(ng, 1) * 8)); P.pick = c->pick.as<uint64_t>();
+    HIPCHK(hipEventRecord(c->aux_ev[0], st));
+    HIPCHK(hipStreamWaitEvent(c->ksw_stream, c->aux_ev[0], 0));
+    RC(pf.begin(BR_K_PRIMARY, c->ksw_stream));
+    launch_primary(c->ksw_stream, P, b->name_off, (b->names && b->name_off) ? b->names : nullptr, false);  // + per-group counters
+    RC(pf.end());
+    HIPCHK(hipEventRecord(c->aux_ev[1], c->ksw_stream));
+  }
   if (n_rows) {
     RC(pf.begin(BR_K_PAIR_EMIT));
     launch_pair(st, P, true);
     RC(pf.end());
   }
-  RC(pf.begin(BR_K_PRIMARY));
-  launch_primary(st, P, b->name_off, (b->names && b->name_off) ? b->names : nullptr, aux_cols);  // + per-group counters
-  RC(pf.end());
+  if (split_primary) HIPCHK(hipStreamWaitEvent(st, c->aux_ev[1], 0));
+  else {
+    RC(pf.begin(BR_K_PRIMARY));
+    launch_primary(st, P, b->name_off, (b->names && b->name_off) ? b->names : nullptr, aux_cols);  // + per-group counters
+    RC(pf.end());
+  }
   if (n_rows) {
     RC(pf.begin(BR_K_ROWS));
     launch_rows(st, P, aux_cols);

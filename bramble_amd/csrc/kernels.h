@@ -131,6 +131,7 @@ struct PairArgs {
   const uint4 *m_a, *m_b;
   const uint64_t *m_cigoff;
   uint32_t *n_rows;         // count pass: records per leader alignment
+  uint64_t *pick;           // [n_groups] or null: k_primary<false> leaves the primary record's row here (~0: none) and k_rows sets the bit
   uint8_t *pbit;            // [n_aln] count pass: this leader emits pairs (k_primary counts its units without touching the records)
   uint64_t *pmask;          // [n_aln] count pass -> emit pass: list positions of a pair's common transcripts (lists <= 64)
   const uint64_t *row_off;  // [n_aln + 1] emit pass

@@ -1459,6 +1459,7 @@ __global__ void __launch_bounds__(256) k_primary(PairArgs P, const uint32_t *__r
     uint32_t any = 0;
     for (uint32_t i = a0; i < a1; i++) any |= P.n_matches[i];
     dropped += any ? 0 : 1;
+    if (!SCORES && P.pick) P.pick[g] = ~0ull;     // no primary record (no names / no records): rewritten below otherwise
     if (!names || re == rs) continue;
     uint64_t pick = rs;
     if (!SCORES) {
@@ -1530,6 +1531,8 @@ __global__ void __launch_bounds__(256) k_primary(PairArgs P, const uint32_t *__r
         }
       }
     }
+    if (!SCORES && P.pick) { P.pick[g] = pick; continue; }   // k_rows sets the bit: no record is touched here (the kernel
+                                                              // runs beside the emit pass of k_pair)
     const uint32_t fw = flagw[4 * pick];
     flagw[4 * pick] = fw | RR_PRIMARY;
     if (fw & RR_PAIRED) flagw[4 * (pick + 1)] |= RR_PRIMARY;
@@ -1557,8 +1560,13 @@ __global__ void __launch_bounds__(256) k_rows(PairArgs P) {
   const uint32_t n = ma.y & 0x7fffffffu;
   if (n > RM_NCIG) P.counters[3] = 1;
   const uint32_t f = rec.w;
+  bool primary = (f & RR_PRIMARY) != 0;
+  if (P.pick) {   // the read name's primary record (pair: the leader's record and the one after it) from k_primary's choice
+    const uint64_t pk = P.pick[P.aln_group[rec.y]];
+    primary = (uint64_t)r == pk || ((f & RR_PAIRED) && !(f & RR_FIRST) && (uint64_t)r == pk + 1ull);
+  }
   const uint32_t meta = (n & RM_NCIG) | ((ma.y >> 31) ? RM_MINUS : 0u) | ((f & RR_PAIRED) ? RM_PAIRED : 0u) |
-                        ((f & RR_SAME) ? RM_SAME : 0u) | ((f & RR_FIRST) ? RM_FIRST : 0u) | ((f & RR_PRIMARY) ? RM_PRIMARY : 0u);
+                        ((f & RR_SAME) ? RM_SAME : 0u) | ((f & RR_FIRST) ? RM_FIRST : 0u) | (primary ? RM_PRIMARY : 0u);
   P.r_a[r] = make_uint4(tid, ma.x, meta, rec.z);
   P.r_c[r] = make_uint2((uint32_t)cg, (uint32_t)(cg >> 32));
   if (AUX) {
