@@ -410,7 +410,7 @@ struct KEvent { int which; hipEvent_t a, b; };
 struct br_ctx {
   const br_index *ix = nullptr;
   int group_lanes = 8;
-  int bam_lanes = 8;
+  int bam_lanes = 0;   // 0: k_bam_rows (a wave per 32 rows); 4..64: k_bam_encode<G>, G lanes per row
   int blocks_per_cu = 8;
   int n_cu = 256;
   bool profiling = false;
@@ -421,7 +421,7 @@ struct br_ctx {
   // device scratch
   DevBuf seg, meta, head, head2, fast_flag, fast_pre, n_matches, ranges, mask, match_off, cig_base, tile_sums, totals, counters_d;
   DevBuf m_tid, m_aux, m_a, m_b, m_cigoff, cig_arena, big_list, n_big, m_aln;
-  DevBuf bam_aux, bam_len, bam_off, bam_out;
+  DevBuf bam_aux, bam_len, bam_off, bam_out, bam_end;
   struct StageSlot { DevBuf blob, off, len; hipEvent_t ready = nullptr; std::vector<uint64_t> h_off; int64_t n = 0; };
   StageSlot stage[3];              // br_bam_bundle_stage: uploads of the next bundles overlap the current projection
   hipStream_t copy_stream = nullptr;
@@ -504,7 +504,7 @@ extern "C" int br_ctx_new(const br_index *ix, br_ctx **out) {
   c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   HIPCHK(hipHostMalloc((void **)&c->h_totals, 32 * sizeof(uint64_t), hipHostMallocDefault));
   const char *bl = getenv("BRAMBLE_AMD_BAM_LANES");
-  if (bl) { int v = atoi(bl); if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) c->bam_lanes = v; }
+  if (bl) { int v = atoi(bl); if (v == 0 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) c->bam_lanes = v; }
   const char *g = getenv("BRAMBLE_AMD_GROUP_LANES");
   if (g) { int v = atoi(g); if (v == 8 || v == 16 || v == 32 || v == 64) c->group_lanes = v; }
   *out = c;
@@ -517,7 +517,7 @@ extern "C" void br_ctx_free(br_ctx *c) {
   DevBuf *bufs[] = {&c->seg, &c->meta, &c->head, &c->head2, &c->fast_flag, &c->fast_pre, &c->n_matches, &c->ranges, &c->mask, &c->match_off, &c->cig_base,
                     &c->tile_sums, &c->totals, &c->counters_d, &c->m_tid, &c->m_aux, &c->m_a, &c->m_b,
                     &c->m_cigoff, &c->cig_arena, &c->big_list, &c->n_big, &c->m_aln,
-                    &c->bam_aux, &c->bam_len, &c->bam_off, &c->bam_out, &c->z_slots, &c->z_sizes, &c->z_off, &c->z_dense, &c->z_tabs, &c->z_tokens, &c->p_ncig, &c->p_name_len, &c->p_isnew, &c->p_group_pre, &c->p_small, &c->p_big, &c->p_seq_len, &c->p_ref_map, &c->fa_stats, &c->fa_n_prob, &c->fa_seq_bytes, &c->fa_prob_off, &c->fa_seqarena_off, &c->fa_probs, &c->fa_results,
+                    &c->bam_aux, &c->bam_len, &c->bam_off, &c->bam_out, &c->bam_end, &c->z_slots, &c->z_sizes, &c->z_off, &c->z_dense, &c->z_tabs, &c->z_tokens, &c->p_ncig, &c->p_name_len, &c->p_isnew, &c->p_group_pre, &c->p_small, &c->p_big, &c->p_seq_len, &c->p_ref_map, &c->fa_stats, &c->fa_n_prob, &c->fa_seq_bytes, &c->fa_prob_off, &c->fa_seqarena_off, &c->fa_probs, &c->fa_results,
                     &c->fa_seq_arena, &c->fa_clip_ops, &c->fa_ideal_cap, &c->fa_scratch, &c->b_seq_off, &c->b_seqs, &c->b_seq_src,
                     &c->r_rec, &c->pk_a, &c->pk_c, &c->pk_x, &c->pk_sim, &c->pk_clip, &c->pool, &c->pool_sizes, &c->pool_off, &c->pk_ch,
                     &c->n_rows, &c->row_off, &c->aln_group, &c->r_input, &c->r_nh, &c->r_hi, &c->r_mapq,
@@ -561,7 +561,7 @@ extern "C" int br_ctx_set_param(br_ctx *c, const char *key, int64_t v) {
   if (!strcmp(key, "emit_split")) { c->emit_split = v != 0; return BR_OK; }
   if (!strcmp(key, "count_split")) { c->count_split = v != 0; return BR_OK; }
   if (!strcmp(key, "deflate_dynamic")) { c->deflate_dynamic = v != 0; return BR_OK; }
-  if (!strcmp(key, "bam_lanes")) { if (v != 4 && v != 8 && v != 16 && v != 32 && v != 64) return BR_ERR_INVALID_ARG; c->bam_lanes = (int)v; return BR_OK; }
+  if (!strcmp(key, "bam_lanes")) { if (v != 0 && v != 4 && v != 8 && v != 16 && v != 32 && v != 64) return BR_ERR_INVALID_ARG; c->bam_lanes = (int)v; return BR_OK; }
   if (!strcmp(key, "ksw_fast")) { c->ksw_fast = v != 0; return BR_OK; }
   if (!strcmp(key, "ksw_tape_pct")) { if (v < 0 || v > 100) return BR_ERR_INVALID_ARG; c->ksw_tape_pct = (int)v; return BR_OK; }
   if (!strcmp(key, "ksw_tape_mb")) { if (v < 1) return BR_ERR_INVALID_ARG; c->ksw_tape_mb = v; return BR_OK; }
@@ -1158,6 +1158,7 @@ static int bam_encode_impl(br_ctx *c, const br_config *cfg, const br_device_reco
   RC(c->bam_aux.ensure(std::max<size_t>((size_t)n, 1) * sizeof(BamAux)));
   RC(c->bam_len.ensure(std::max<size_t>((size_t)nr, 1) * 4)); RC(c->bam_off.ensure(((size_t)nr + 1) * 8));
   B.aux = (BamAux *)c->bam_aux.p;
+  RC(c->bam_end.ensure(8)); B.blob_end = c->bam_end.as<uint64_t>();
   B.r_a = c->pk_a.as<uint4>(); B.r_c = c->pk_c.as<uint2>(); B.r_rec = c->r_rec.as<uint4>();
   B.r_sim = c->last_aux_cols ? c->pk_sim.as<double>() : nullptr; B.r_clip = c->last_aux_cols ? c->pk_clip.as<int32_t>() : nullptr;
   B.pool = c->cig_arena.as<uint32_t>(); B.l_qseq = c->last_l_qseq;
@@ -1167,7 +1168,7 @@ static int bam_encode_impl(br_ctx *c, const br_config *cfg, const br_device_reco
   B.too_long = c->totals.as<uint64_t>() + 6;
   HIPCHK(hipMemsetAsync(B.too_long, 0, 8, st));
   RC(pf.begin(BR_K_BAM));
-  if (!aux_done) launch_bam_scan(st, B);
+  if (!aux_done) { HIPCHK(hipMemsetAsync(B.blob_end, 0, 8, st)); launch_bam_scan(st, B); }
   launch_bam_size(st, B);
   RC(pf.end());
   ScanArgs S{}; S.n = nr; S.src32 = B.out_len; S.tile_sums = c->tile_sums.as<uint64_t>();
@@ -1246,6 +1247,8 @@ extern "C" int br_project_bam_device(br_ctx *c, const br_config *cfg, const br_d
   B.n_aln = n; B.long_reads = dc.long_reads ? 1 : 0; B.blob = recs->blob; B.rec_off = recs->rec_off; B.rec_len = recs->rec_len;
   B.aux = (BamAux *)c->bam_aux.p; B.xs_out = c->b_xs.as<int8_t>(); B.ts_out = c->b_ts.as<int8_t>();
   B.cg_flag = c->p_small.as<uint32_t>() + 3;
+  RC(c->bam_end.ensure(8)); B.blob_end = c->bam_end.as<uint64_t>();
+  HIPCHK(hipMemsetAsync(B.blob_end, 0, 8, st));
 
   RC(pf.begin(BR_K_PARSE));
   launch_rec_fields(st, P);

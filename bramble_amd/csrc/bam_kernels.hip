@@ -22,9 +22,19 @@
 
 namespace br {
 
+// Unaligned wide accesses: gfx950 global loads / stores need no alignment.
+struct __attribute__((packed, aligned(1))) W4 { uint32_t a, b, c, d; };
+typedef uint32_t u32u __attribute__((aligned(1)));
 __device__ __forceinline__ uint32_t ld_u16(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
 __device__ __forceinline__ uint32_t ld_u32(const uint8_t *p) {
   return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+
+__device__ __forceinline__ uint32_t fix_nib(uint32_t x) {   // nibbles that are not one of 1, 2, 4, 8 become 15 (comp_table, src/bam.cpp:658-667)
+  uint32_t pop = (x & 0x11111111u) + ((x >> 1) & 0x11111111u) + ((x >> 2) & 0x11111111u) + ((x >> 3) & 0x11111111u);
+  uint32_t y = pop ^ 0x11111111u;
+  uint32_t bad = (y | (y >> 1) | (y >> 2) | (y >> 3)) & 0x11111111u;
+  return x | (bad * 15u);
 }
 
 // htslib skip_aux: size of the value of a tag of `type` at p (p = first value byte), or -1
@@ -46,9 +56,7 @@ __device__ int64_t aux_value_len(uint8_t type, const uint8_t *p, const uint8_t *
   }
 }
 
-__global__ void __launch_bounds__(256) k_bam_scan(BamArgs B) {
-  int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (a >= B.n_aln) return;
+__device__ __forceinline__ void bam_scan_one(const BamArgs &B, int64_t a) {
   const uint8_t *rec = B.blob + B.rec_off[a];
   uint64_t rlen = B.rec_len ? (uint64_t)B.rec_len[a] : B.rec_off[a + 1] - B.rec_off[a];
   BamAux x;
@@ -64,6 +72,18 @@ __global__ void __launch_bounds__(256) k_bam_scan(BamArgs B) {
     x.c_a = ld_u32(rec + 8); x.c_b = ld_u32(rec + 12); x.c_c = (uint32_t)l_seq;
     if (start <= rlen) {
       if (ls > 0) x.qual_present = rec[32 + (uint64_t)l_qname + 4ull * n_cig + (ls + 1) / 2] != 0xff;
+      {
+        // bit 1: every base code is one of 1, 2, 4, 8, 15 (A C G T N) -- then the reverse complement of the record is a
+        // plain bit reversal and k_bam_rows skips the per-nibble repair of the other codes
+        const uint8_t *sq = rec + 32 + (uint64_t)l_qname + 4ull * n_cig;
+        const uint64_t sb = (ls + 1) / 2, full = ls / 2;   // bytes with two bases
+        uint32_t dirty = 0;
+        uint64_t i = 0;
+        for (; i + 4 <= full; i += 4) { uint32_t v = *(const u32u *)(sq + i); dirty |= fix_nib(v) ^ v; }
+        for (; i < full; i++) { uint32_t v = sq[i] | 0x11111100u; dirty |= fix_nib(v) ^ v; }
+        if (sb > full) { uint32_t v = (sq[full] >> 4) | 0x11111110u; dirty |= fix_nib(v) ^ v; }
+        if (!dirty) x.qual_present |= 2u;
+      }
       x.aux_start = (uint32_t)start; x.aux_len = (uint32_t)(rlen - start);
       const uint8_t *s = rec + start, *end = rec + rlen;
       // slots: 0 NH, 1 XS (short) / ts (long), 2 HI, 3 AS (long reads only)
@@ -120,6 +140,22 @@ __global__ void __launch_bounds__(256) k_bam_scan(BamArgs B) {
   if (B.xs_out) { B.xs_out[a] = xs_c; B.ts_out[a] = ts_c; }
 }
 
+__global__ void __launch_bounds__(256) k_bam_scan(BamArgs B) {
+  __shared__ unsigned long long sh_end[4];
+  int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // end of the last record byte of the blob: k_bam_rows reads 16 bytes at a time and must not read past it
+  unsigned long long e = 0;
+  if (a < B.n_aln) e = B.rec_off[a] + (B.rec_len ? (uint64_t)B.rec_len[a] : B.rec_off[a + 1] - B.rec_off[a]);
+  for (int o = 32; o; o >>= 1) { unsigned long long t = __shfl_xor(e, o); e = t > e ? t : e; }
+  if ((threadIdx.x & 63) == 0) sh_end[threadIdx.x >> 6] = e;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; w++) e = sh_end[w] > e ? sh_end[w] : e;
+    atomicMax((unsigned long long *)B.blob_end, e);
+  }
+  if (a < B.n_aln) bam_scan_one(B, a);
+}
+
 __device__ __forceinline__ uint32_t row_out_len(const BamArgs &B, int64_t r, const uint8_t *rec, const BamAux &x) {
   uint32_t l_qname = x.c_a & 0xffu;
   int32_t l_seq = (int32_t)x.c_c;
@@ -143,8 +179,6 @@ __device__ __forceinline__ uint8_t comp4(uint8_t nt) { return nt == 1 ? 8 : nt =
 
 // Unaligned wide accesses: gfx950 global loads / stores need no alignment, so byte
 // regions are moved 16 bytes per lane-instruction.
-struct __attribute__((packed, aligned(1))) W4 { uint32_t a, b, c, d; };
-typedef uint32_t u32u __attribute__((aligned(1)));
 
 template <int G>
 __device__ __forceinline__ void copy_fwd(uint8_t *dst, const uint8_t *src, uint32_t n, int lane) {
@@ -267,7 +301,7 @@ __device__ __forceinline__ void encode_row(const BamArgs &B, int64_t r, int lane
   o += sb;
   // qualities: reversed on '-' unless absent (0xff) (bam.cpp:680-686)
   const uint8_t *qual = seq + sb;
-  bool rev_q = minus && ls > 0 && x.qual_present;
+  bool rev_q = minus && ls > 0 && (x.qual_present & 1u);
   if (rev_q) copy_rev<G>(out + o, qual, ls, lane); else copy_fwd<G>(out + o, qual, ls, lane);
   o += ls;
   // aux: original minus the first NH, XS|ts, HI (and AS for long reads): up to five kept pieces ...
@@ -309,6 +343,300 @@ __global__ void __launch_bounds__(256) k_bam_encode(BamArgs B) {
   encode_row<G>(B, r, lane, B.blob + B.rec_off[a], B.aux[a], B.out + B.out_off[r], (uint32_t)(B.out_off[r + 1] - B.out_off[r]));
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// k_bam_rows<R>: one wave encodes R consecutive rows = one contiguous span of the output.
+//
+// k_bam_encode<G> gives a row G lanes and walks its regions one after the other: ~43 vector-memory instructions per
+// wave of 8 rows, most of them with 2-7 of a row's 8 lanes at work -- the kernel is bound by the address / L1 path
+// (24 cycles per instruction and CU, profiles/r02/pmc_bam.txt), not by bytes.  Here the work is cut the other way:
+//   1. lane i < R describes row i (what encode_row computes per row, once instead of G times) and leaves the row's
+//      segment table in LDS: output offset of every non-empty segment, where its bytes come from and how
+//      (skip = written in step 3, copy, byte-reversed QUAL, reverse-complemented SEQ of even / odd length);
+//   2. every lane owns one 16-byte chunk of the span per iteration: it finds its row and segment (two binary searches
+//      in LDS), then walks the 1-4 segments the chunk touches: one unaligned 16-byte load per segment, placed so that
+//      source byte j lands on chunk byte j, merged under a "bytes >= c" mask; one 16-byte store per chunk.  The span's
+//      last chunk ends at the span's end (it overlaps its predecessor, same bytes) instead of a byte tail;
+//   3. after the chunk stores have completed (release fence), lane i writes row i's fixed fields, <= 2-op CIGAR and
+//      tags over the skipped bytes; CIGARs of more than two ops are copied from the arena by the whole wave.
+#define BSEG_MAX 12   // hdr, name, cigar, seq, qual, 5 aux pieces, tags (+ the end mark)
+enum { BM_SKIP = 0, BM_COPY = 1, BM_REV = 2, BM_REVC_CLEAN = 3, BM_REVC = 4, BM_REVC_ODD = 5 };
+#define BM_MODE_SHIFT 60             // src: mode in bits 60..62, bit 63 = the row's last segment
+#define BM_LAST (1ull << 63)
+#define BM_OFF ((1ull << 48) - 1)    // src: offset in the blob of the segment's first source byte
+struct __attribute__((aligned(16))) BamRowDesc {
+  uint32_t start[16];                // row-relative output offset of segment s; start[n_seg] = row length, then ~0
+  uint64_t src[BSEG_MAX];
+  uint32_t cig_at, cig_n;            // > 2-op CIGAR: span-relative output offset, n_cigar | minus << 31
+  uint64_t cig_src;                  // ... and its word offset in the arena
+};
+template <int R> struct __attribute__((aligned(16))) BamWaveLds { BamRowDesc d[R]; uint32_t row_start[R + 4]; };
+
+// 16 source bytes at p; bytes at or after `end` read as 0 (only the chunk at the very end of the blob takes the byte path)
+__device__ __forceinline__ uint4 load16_end(const uint8_t *p, const uint8_t *end) {
+  if (p + 16 <= end) { W4 w = *(const W4 *)p; return make_uint4(w.a, w.b, w.c, w.d); }
+  uint32_t v[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < 16; j++) if (p + j < end) v[j >> 2] |= (uint32_t)p[j] << (8 * (j & 3));
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
+template <int R>
+__global__ void __launch_bounds__(256) k_bam_rows(BamArgs B) {
+  __shared__ BamWaveLds<R> sh_w[4];
+  __shared__ uint4 sh_from[17];      // sh_from[c]: mask of the chunk bytes >= c
+  if (threadIdx.x < 17) {
+    uint32_t m[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { int kk = (int)threadIdx.x - 4 * k; m[k] = kk <= 0 ? 0xffffffffu : kk >= 4 ? 0u : ~((1u << (8 * kk)) - 1u); }
+    sh_from[threadIdx.x] = make_uint4(m[0], m[1], m[2], m[3]);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  BamWaveLds<R> &L = sh_w[wv];
+  const int64_t r0 = ((int64_t)blockIdx.x * 4 + wv) * R;
+  if (r0 >= B.n_rows) return;
+  const int nr = (int)(B.n_rows - r0 < R ? B.n_rows - r0 : R);
+  const uint64_t span0 = B.out_off[r0];
+  const uint32_t span = (uint32_t)(B.out_off[r0 + nr] - span0);
+  const uint64_t blob_len = *B.blob_end;
+  const uint8_t *blob_end = B.blob + blob_len;
+
+  // ---- 1. one lane per row ----
+  uint32_t h0 = 0, h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0, h6 = 0, h7 = 0, h8 = 0;   // block_size + the 32 fixed bytes
+  uint32_t row_at = 0xffffffffu, o_cig = 0, o_tags = 0, n_cig = 0, c_x = 0, c_y = 0;
+  uint32_t tag_nh = 0, tag_hi = 0, tag_as = 0;
+  bool minus = false;
+  if (lane < nr) {
+    const int64_t r = r0 + lane;
+    const uint4 rr = B.r_rec[r];
+    const uint4 ra = B.r_a[r];
+    const uint2 c = B.r_c[r];
+    const uint64_t oo = B.out_off[r];
+    const uint32_t total = (uint32_t)(B.out_off[r + 1] - oo);
+    const int32_t a = (int32_t)rr.y;
+    const BamAux x = B.aux[a];
+    const uint64_t ro = B.rec_off[a];
+    row_at = (uint32_t)(oo - span0);
+    const uint32_t l_qname = x.c_a & 0xffu, bin = x.c_a >> 16, n_cig_in = x.c_b & 0xffffu;
+    uint32_t flag = x.c_b >> 16;
+    const int32_t l_seq = (int32_t)x.c_c;
+    const uint32_t ls = l_seq > 0 ? (uint32_t)l_seq : 0, sb = (ls + 1) / 2;
+    const uint32_t meta = ra.z, nh = ra.w;
+    n_cig = meta & RM_NCIG; minus = meta & RM_MINUS; c_x = c.x; c_y = c.y;
+    const bool paired = meta & RM_PAIRED, same = meta & RM_SAME;
+    // flags: secondary (src/core.cpp:142-143), reverse (bam.cpp:698), mate bits (bam.cpp:531-588)
+    if (meta & RM_PRIMARY) flag &= ~0x100u; else flag |= 0x100u;
+    if (minus) flag ^= 0x10u;
+    int32_t mtid = -1, mpos = -1, tlen = 0;
+    if (!paired) flag &= ~(0x1u | 0x2u | 0x20u);
+    else {
+      flag |= 0x1u;
+      if (minus) flag |= 0x20u;
+      const uint4 rb = B.r_a[(meta & RM_FIRST) ? r + 1 : r - 1];
+      const int32_t my_pos = (int32_t)ra.y;
+      mpos = (int32_t)rb.y;
+      if (same) {
+        flag |= 0x2u; mtid = (int32_t)ra.x;
+        const int32_t lq = B.l_qseq[a];
+        tlen = (my_pos <= mpos) ? (mpos + lq) - my_pos : -((my_pos + lq) - mpos);
+      } else { flag &= ~0x2u; mtid = (int32_t)rb.x; }
+    }
+    const uint32_t mapq = B.long_reads ? (nh > 1 ? 0u : 3u) : (nh == 1 ? 255u : nh == 2 ? 3u : (nh == 3 || nh == 4) ? 1u : 0u);  // get_mapq (src/core.cpp:46-58)
+    h0 = total - 4u; h1 = ra.x; h2 = ra.y; h3 = l_qname | (mapq << 8) | (bin << 16);
+    h4 = (n_cig & 0xffffu) | (flag << 16); h5 = (uint32_t)l_seq; h6 = (uint32_t)mtid; h7 = (uint32_t)mpos; h8 = (uint32_t)tlen;
+    tag_nh = nh; tag_hi = rr.w & RR_HI;
+    if (B.long_reads) tag_as = (uint32_t)(int32_t)(((double)x.as_val + (double)(B.r_clip ? B.r_clip[r] : 0)) * (B.r_sim ? B.r_sim[r] : 0.0));  // set_as_tag
+    // the segment table: non-empty segments only, in output order; a copy that continues its predecessor's source joins it
+    BamRowDesc &D = L.d[lane];
+    int ns = 0;
+    uint32_t o = 0, prev_mode = 0xffu, prev_end = 0;
+    auto seg = [&](uint32_t len, uint32_t mode, uint32_t src) {
+      if (len == 0) return;
+      if (mode == BM_COPY && prev_mode == BM_COPY && prev_end == src) { o += len; prev_end += len; return; }
+      D.start[ns] = o; D.src[ns] = (ro + src) | ((uint64_t)mode << BM_MODE_SHIFT); ns++; o += len;
+      prev_mode = mode; prev_end = src + len;
+    };
+    seg(36u, BM_SKIP, 0);
+    seg(l_qname, BM_COPY, 32u);
+    o_cig = o;
+    seg(4u * n_cig, BM_SKIP, 0);
+    const uint32_t seq_at = 32u + l_qname + 4u * n_cig_in;
+    seg(sb, !minus ? BM_COPY : (ls & 1u) ? BM_REVC_ODD : (x.qual_present & 2u) ? BM_REVC_CLEAN : BM_REVC, seq_at);
+    seg(ls, (minus && (x.qual_present & 1u)) ? BM_REV : BM_COPY, seq_at + sb);
+    uint32_t src = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (x.off[k] == 0xffffffffu) break;
+      seg(x.off[k] - src, BM_COPY, x.aux_start + src);
+      src = x.off[k] + x.len[k];
+    }
+    seg(x.aux_len - src, BM_COPY, x.aux_start + src);
+    o_tags = o;
+    seg(B.long_reads ? 21u : 14u, BM_SKIP, 0);
+    D.src[ns - 1] |= BM_LAST;
+    D.start[ns] = o;
+    for (int k = ns + 1; k < 16; k++) D.start[k] = 0xffffffffu;
+    D.cig_at = row_at + o_cig; D.cig_n = n_cig | (minus ? 0x80000000u : 0u);
+    D.cig_src = ((uint64_t)c.y << 32) | c.x;
+  }
+  static_assert(R + 4 <= 64 && (R & (R - 1)) == 0, "rows per wave");
+  if (lane < R + 4) L.row_start[lane] = row_at;   // ~0 behind the last row
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+  // ---- 2. one lane per 16-byte chunk of the span ----
+  uint8_t *const out = B.out + span0;
+  const uint32_t n_chunks = (span + 15u) >> 4;
+  // a chunk's store is issued behind the loads of the next chunk: the wait for those loads then does not include the
+  // store's way to L2 (gfx9 counts loads and stores in one in-order counter)
+  uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0, o_at = 0;
+  bool pending = false;
+  for (uint32_t k = lane; k < n_chunks; k += 64) {
+    uint32_t p0 = k << 4;
+    if (p0 + 16u > span) p0 = span - 16u;
+    int i = 0;
+#pragma unroll
+    for (int st = R / 2; st; st >>= 1) if (L.row_start[i + st] <= p0) i += st;
+    uint32_t q = p0 - L.row_start[i];
+    int s = 0;
+#pragma unroll
+    for (int st = 8; st; st >>= 1) if (L.d[i].start[s + st] <= q) s += st;
+    uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    uint32_t c = 0;
+    auto round = [&](const bool with_store) __attribute__((always_inline)) {
+      // up to four segments per round.  First every segment's load, branch-free, so that the four are in flight together
+      // (a lane without a segment, a skipped one or one at the very end of the blob loads the blob's first bytes instead),
+      // then the rare repairs, then the merges.
+      uint4 w[4];
+      uint32_t cm[4];     // chunk byte the segment starts at | mode << 8 (0: nothing to merge) | 1 << 12: load again, carefully
+      uint64_t at[4];     // blob offset the 16 bytes come from
+      uint32_t padb[4];   // odd-length SEQ: chunk byte that holds the pad nibble
+#pragma unroll
+      for (int T = 0; T < 4; T++) {
+        const bool on = c < 16u;
+        const BamRowDesc &D = L.d[on ? i : 0];
+        const int s_ = on ? s : 0;
+        const uint32_t ss = D.start[s_], se = D.start[s_ + 1];
+        const uint64_t sd = D.src[s_];
+        const uint32_t left = se - q, room = 16u - c;
+        const uint32_t n = on ? (left < room ? left : room) : 0u;
+        const uint32_t mode = on ? (uint32_t)(sd >> BM_MODE_SHIFT) & 7u : (uint32_t)BM_SKIP;
+        const uint32_t t = q - ss;     // first byte of this visit inside the segment
+        // copy: chunk byte b <- source byte t - c + b.  The other modes read backwards: chunk byte b <- source byte
+        // (len - 1 - t + c) - b, so they load the 16 bytes that end there and turn them around
+        const uint32_t back = se - ss - 1u - t + c;
+        const int32_t off = mode == BM_COPY ? (int32_t)(t - c) : (int32_t)back - 15;
+        const uint64_t src = (sd & BM_OFF) + (int64_t)off;
+        const bool careful = mode != BM_SKIP && (src + 16u > blob_len || mode == BM_REVC_ODD);
+        const uint64_t from = (mode == BM_SKIP || src + 16u > blob_len) ? 0ull : src;
+        const W4 ld = *(const W4 *)(B.blob + from);
+        w[T] = make_uint4(ld.a, ld.b, ld.c, ld.d);
+        at[T] = src; padb[T] = c + (se - ss - 1u - t);
+        cm[T] = mode == BM_SKIP ? 0u : (c | (mode << 8) | (careful ? 0x1000u : 0u) | (n << 16));
+        c += n; q += n;
+        const bool done = on && q == se, last = done && (sd & BM_LAST);
+        s = last ? 0 : done ? s + 1 : s;
+        i += last ? 1 : 0;
+        q = last ? 0u : q;
+      }
+      if (with_store) { W4 o4; o4.a = o0; o4.b = o1; o4.c = o2; o4.d = o3; *(W4 *)(out + (pending ? o_at : p0)) = o4; }   // (a lane's first chunk: zeros, written over below)
+      // the merges, in segment order: a segment writes the chunk bytes from its first one on, its successor the rest
+#pragma unroll
+      for (int T = 0; T < 4; T++) {
+        const uint32_t mode = (cm[T] & 0x1000u) ? 0u : (cm[T] >> 8) & 7u;
+        if (mode) {
+          uint4 v = w[T];
+          if (mode != BM_COPY) {
+            // qualities: bytes reversed; bases: all 128 bits reversed = base order, and A<->T, C<->G inside every nibble (bam.cpp:671-686)
+            const bool bits = mode != BM_REV;
+            const uint4 u = v;
+            v.x = bits ? __builtin_bitreverse32(u.w) : __builtin_bswap32(u.w); v.y = bits ? __builtin_bitreverse32(u.z) : __builtin_bswap32(u.z);
+            v.z = bits ? __builtin_bitreverse32(u.y) : __builtin_bswap32(u.y); v.w = bits ? __builtin_bitreverse32(u.x) : __builtin_bswap32(u.x);
+            if (mode == BM_REVC) { v.x = fix_nib(v.x); v.y = fix_nib(v.y); v.z = fix_nib(v.z); v.w = fix_nib(v.w); }   // a base code other than A C G T N in the record: rare
+          }
+          const uint4 m = sh_from[cm[T] & 0x1fu];
+          a0 = (a0 & ~m.x) | (v.x & m.x); a1 = (a1 & ~m.y) | (v.y & m.y); a2 = (a2 & ~m.z) | (v.z & m.z); a3 = (a3 & ~m.w) | (v.w & m.w);
+        }
+      }
+      // the careful ones afterwards, each under the mask of exactly its bytes
+      if (__any((cm[0] | cm[1] | cm[2] | cm[3]) & 0x1000u)) {
+#pragma unroll
+        for (int T = 0; T < 4; T++) {
+          if (cm[T] & 0x1000u) {
+            const uint32_t mode = (cm[T] >> 8) & 7u;
+            const uint8_t *p = B.blob + at[T];
+            uint4 v = load16_end(p, blob_end);
+            if (mode == BM_REVC_ODD) {
+              // odd length: the stream moves up by one nibble, the low nibble of output byte u is the high nibble of the next
+              const uint4 v2 = load16_end(p - 1, blob_end);
+              const uint32_t x0 = __builtin_bitreverse32(v.w), x1 = __builtin_bitreverse32(v.z), x2 = __builtin_bitreverse32(v.y), x3 = __builtin_bitreverse32(v.x);
+              const uint32_t y0 = __builtin_bitreverse32(v2.w), y1 = __builtin_bitreverse32(v2.z), y2 = __builtin_bitreverse32(v2.y), y3 = __builtin_bitreverse32(v2.x);
+              v.x = fix_nib(((x0 & 0x0f0f0f0fu) << 4) | ((y0 >> 4) & 0x0f0f0f0fu)); v.y = fix_nib(((x1 & 0x0f0f0f0fu) << 4) | ((y1 >> 4) & 0x0f0f0f0fu));
+              v.z = fix_nib(((x2 & 0x0f0f0f0fu) << 4) | ((y2 >> 4) & 0x0f0f0f0fu)); v.w = fix_nib(((x3 & 0x0f0f0f0fu) << 4) | ((y3 >> 4) & 0x0f0f0f0fu));
+              // the pad nibble of the last byte stays 0 (when that byte is inside this chunk)
+              const uint32_t bp = padb[T];
+              if (bp < 16u) {
+                const uint32_t clr = ~(0xfu << (8u * (bp & 3u)));
+                if ((bp >> 2) == 0) v.x &= clr; else if ((bp >> 2) == 1) v.y &= clr; else if ((bp >> 2) == 2) v.z &= clr; else v.w &= clr;
+              }
+            } else if (mode != BM_COPY) {
+              const bool bits = mode != BM_REV;
+              const uint4 u = v;
+              v.x = bits ? __builtin_bitreverse32(u.w) : __builtin_bswap32(u.w); v.y = bits ? __builtin_bitreverse32(u.z) : __builtin_bswap32(u.z);
+              v.z = bits ? __builtin_bitreverse32(u.y) : __builtin_bswap32(u.y); v.w = bits ? __builtin_bitreverse32(u.x) : __builtin_bswap32(u.x);
+              if (mode == BM_REVC) { v.x = fix_nib(v.x); v.y = fix_nib(v.y); v.z = fix_nib(v.z); v.w = fix_nib(v.w); }
+            }
+            const uint32_t c0 = cm[T] & 0x1fu, c1 = c0 + ((cm[T] >> 16) & 0x1fu);
+            const uint4 m0 = sh_from[c0], m1 = sh_from[c1];
+            const uint4 m = make_uint4(m0.x & ~m1.x, m0.y & ~m1.y, m0.z & ~m1.z, m0.w & ~m1.w);
+            a0 = (a0 & ~m.x) | (v.x & m.x); a1 = (a1 & ~m.y) | (v.y & m.y); a2 = (a2 & ~m.z) | (v.z & m.z); a3 = (a3 & ~m.w) | (v.w & m.w);
+          }
+        }
+      }
+    };
+    round(true);
+    while (c < 16u) round(false);
+    o0 = a0; o1 = a1; o2 = a2; o3 = a3; o_at = p0; pending = true;
+  }
+  if (pending) { W4 o4; o4.a = o0; o4.b = o1; o4.c = o2; o4.d = o3; *(W4 *)(out + o_at) = o4; }
+
+  // ---- 3. the synthesized bytes, after the chunk stores ----
+  // the chunk stores have reached L2 before the stores below are issued (an agent-scope release fence would also write
+  // L2 back: buffer_wbl2 per wave, 6x the kernel's time)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane < nr) {
+    uint8_t *w = out + row_at;
+    W4 x0; x0.a = h0; x0.b = h1; x0.c = h2; x0.d = h3; *(W4 *)w = x0;
+    W4 x1; x1.a = h4; x1.b = h5; x1.c = h6; x1.d = h7; *(W4 *)(w + 16) = x1;
+    *(u32u *)(w + 32) = h8;
+    // rewritten CIGAR (op order reversed on '-', bam.cpp:688-695)
+    if (n_cig == 1u) *(u32u *)(w + o_cig) = c_x;
+    else if (n_cig == 2u) { *(u32u *)(w + o_cig) = minus ? c_y : c_x; *(u32u *)(w + o_cig + 4) = minus ? c_x : c_y; }
+    // NH:i, (AS:i,) HI:i appended in that order (bam.cpp:590-634, core.cpp:118-161): seven bytes [t0 t1 'i' v0 v1 v2 v3] each
+    uint8_t *t = w + o_tags;
+    *(u32u *)t = (uint32_t)'N' | ((uint32_t)'H' << 8) | ((uint32_t)'i' << 16) | (tag_nh << 24);
+    *(u32u *)(t + 3) = tag_nh;
+    if (B.long_reads) {
+      *(u32u *)(t + 7) = (uint32_t)'A' | ((uint32_t)'S' << 8) | ((uint32_t)'i' << 16) | (tag_as << 24);
+      *(u32u *)(t + 10) = tag_as;
+      t += 7;
+    }
+    *(u32u *)(t + 7) = (uint32_t)'H' | ((uint32_t)'I' << 8) | ((uint32_t)'i' << 16) | (tag_hi << 24);
+    *(u32u *)(t + 10) = tag_hi;
+  }
+  // CIGARs of more than two ops: the whole wave, row by row
+  uint64_t big = __ballot(lane < nr && n_cig > 2u);
+  while (big) {
+    const int i = __builtin_ctzll(big);
+    big &= big - 1;
+    const uint32_t at = L.d[i].cig_at, cn = L.d[i].cig_n, n = cn & 0x7fffffffu;
+    const uint32_t *cg = B.pool + L.d[i].cig_src;
+    for (uint32_t k2 = lane; k2 < n; k2 += 64) *(u32u *)(out + at + 4u * k2) = cg[(cn >> 31) ? n - 1u - k2 : k2];
+  }
+}
+
 void launch_bam_scan(hipStream_t st, const BamArgs &B) {
   if (B.n_aln > 0) hipLaunchKernelGGL(k_bam_scan, dim3((unsigned)((B.n_aln + 255) / 256)), dim3(256), 0, st, B);
 }
@@ -317,6 +645,7 @@ void launch_bam_size(hipStream_t st, const BamArgs &B) {
 }
 void launch_bam_encode(hipStream_t st, const BamArgs &B, int lanes) {
   if (B.n_rows <= 0) return;
+  if (lanes == 0) { hipLaunchKernelGGL((k_bam_rows<32>), dim3((unsigned)((B.n_rows + 127) / 128)), dim3(256), 0, st, B); return; }
   if (lanes == 4) hipLaunchKernelGGL((k_bam_encode<4>), dim3((unsigned)((B.n_rows + 63) / 64)), dim3(256), 0, st, B);
   else if (lanes == 8) hipLaunchKernelGGL((k_bam_encode<8>), dim3((unsigned)((B.n_rows + 31) / 32)), dim3(256), 0, st, B);
   else if (lanes == 32) hipLaunchKernelGGL((k_bam_encode<32>), dim3((unsigned)((B.n_rows + 7) / 8)), dim3(256), 0, st, B);

@@ -273,3 +273,63 @@ def test_staged_bundles_equal_one_shot_calls():
         assert_streams_equal(got, expect[k])
     ctx.close()
     idx.close()
+
+
+@pytest.mark.parametrize("seed,flags", [(11, {}), (12, {"lr": 1}), (13, {"strict": 1})])
+def test_bam_rows_random_records(seed, flags):
+    """k_bam_rows (a wave per 32 rows, 16-byte chunks of the output span) on records built to hit every segment kind:
+    odd and even SEQ lengths on both strands, records whose bases are only A C G T N and records with '=' / IUPAC codes,
+    absent qualities, one-byte to 40-byte names, CIGARs that stay above two ops after the rewrite (soft clips on both
+    sides, insertions: the arena path, reversed on '-'), aux areas with the removed tags first, last, in the middle,
+    repeated or missing, and several isoforms per locus so that a wave holds rows of few records.  Both encoders
+    (bam_lanes 0 = k_bam_rows, 8 = k_bam_encode<8>) against the oracle, byte for byte."""
+    rng = np.random.RandomState(seed)
+    txs = []
+    for g in range(12):
+        base = 1000 + 6000 * g
+        strand = "+" if g % 2 == 0 else "-"
+        for iso in range(1 + g % 4):
+            txs.append({"id": "g%d.%d" % (g, iso), "ref_id": 0, "strand": strand,
+                        "exons": [[base, base + 900 + 10 * iso], [base + 2000, base + 2700], [base + 4000 - 3 * iso, base + 4800]]})
+    ann = {"refnames": ["chr1"], "transcripts": txs}
+    i32 = lambda v: int(v).to_bytes(4, "little", signed=True)
+    clean, dirty = "ACGTN", "=ACMGRSVTWYHKDBN"
+    tags = [b"NHC\x02", b"HIi" + i32(3), b"XSA+", b"XSA-", b"tsA-", b"ASs\x30\x00", b"ASC\x07", b"NMC\x01", b"MDZ10A5\x00",
+            b"RGZgrp1\x00", b"XXBs\x02\x00\x00\x00\x01\x00\x02\x00", b"ffff\x00\x00\x80?"]
+    recs = []
+    for k in range(2500):
+        g = int(rng.randint(0, 12))
+        base = 1000 + 6000 * g
+        ls = int(rng.randint(1, 181))
+        form = int(rng.randint(0, 5))
+        alphabet = clean if rng.rand() < 0.5 else dirty
+        seq = "".join(alphabet[int(x)] for x in rng.randint(0, len(alphabet), size=ls))
+        qual = None if rng.rand() < 0.2 else rng.randint(0, 42, ls).astype(np.uint8).tobytes()
+        if form == 0 or ls < 8:
+            cig = "%dM" % ls
+        elif form == 1:
+            a = int(rng.randint(1, ls // 2)); cig = "%dS%dM" % (a, ls - a)
+        elif form == 2:
+            a = int(rng.randint(1, ls // 3 + 1)); c = int(rng.randint(1, ls // 3 + 1)); cig = "%dS%dM%dS" % (a, ls - a - c, c)
+        elif form == 3:
+            a = int(rng.randint(1, ls - 3)); cig = "%dM2I%dM" % (a, ls - a - 2) if ls - a - 2 > 0 else "%dM" % ls
+        else:
+            a = int(rng.randint(1, ls // 2)); cig = "%dM1D%dM" % (a, ls - a)
+        pos0 = base + int(rng.randint(0, 600))
+        flag = (16 if rng.rand() < 0.5 else 0) | (256 if rng.rand() < 0.1 else 0)
+        n_tags = int(rng.randint(0, 7))
+        aux = b"".join(tags[int(t)] for t in rng.randint(0, len(tags), size=n_tags))
+        name = "r%d" % k + "x" * int(rng.randint(0, 36))
+        recs.append(_rec_full(name, 0, pos0, flag, cig, -1, -1, seq, qual, aux))
+    stream = np.frombuffer(b"".join(recs), dtype=np.uint8)
+    roff, rlen, n_un, used = lib.bam_split(stream)
+    idx = lib.Index(ann, device=0)
+    orc, _, _, parsed = ob.run_bam(ob.OracleIndex(ann), ob.make_flags(**flags), stream, roff, rlen, np.array([0], dtype=np.int32))
+    assert orc["n_rows"] > 2000
+    for lanes in (0, 8):
+        ctx = lib.Context(idx)
+        ctx.set_param("bam_lanes", lanes)
+        got, counters = ctx.project_bam_bundle(lib.make_config(**flags), stream, roff, rlen, np.array([0], dtype=np.int32))
+        ctx.close()
+        assert_streams_equal(got, orc["bam_stream"])
+    idx.close()
