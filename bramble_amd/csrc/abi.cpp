@@ -410,7 +410,7 @@ struct KEvent { int which; hipEvent_t a, b; };
 struct br_ctx {
   const br_index *ix = nullptr;
   int group_lanes = 8;
-  int bam_lanes = 0;   // 0: k_bam_rows (a wave per 32 rows); 4..64: k_bam_encode<G>, G lanes per row
+  int bam_lanes = 0;   // 0: k_bam_tasks (a wave per 32 rows); 4..64: k_bam_encode<G>, G lanes per row
   int blocks_per_cu = 8;
   int n_cu = 256;
   bool profiling = false;

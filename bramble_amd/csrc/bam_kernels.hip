@@ -13,7 +13,8 @@
 //                 XS|ts and (long reads) AS live, plus the AS value (bam_aux2i) and the
 //                 tag_char1 value of XS / ts for the reader side (parse_kernels.hip).
 //   k_bam_size    one lane per row: output length -> scanned into offsets.
-//   k_bam_encode  G lanes (default 8) per row: 16-byte unaligned copies of name / SEQ / QUAL / kept aux pieces,
+//   k_bam_tasks   (default) a wave per 32 rows: the rows' byte regions as 16-byte copy tasks over all 64 lanes.
+//   k_bam_encode  G lanes per row (bam_lanes = 4..64): 16-byte unaligned copies of name / SEQ / QUAL / kept aux pieces,
 //                 bit-reverse reverse complement, the fixed fields and the appended tags.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -74,11 +75,15 @@ __device__ __forceinline__ void bam_scan_one(const BamArgs &B, int64_t a) {
       if (ls > 0) x.qual_present = rec[32 + (uint64_t)l_qname + 4ull * n_cig + (ls + 1) / 2] != 0xff;
       {
         // bit 1: every base code is one of 1, 2, 4, 8, 15 (A C G T N) -- then the reverse complement of the record is a
-        // plain bit reversal and k_bam_rows skips the per-nibble repair of the other codes
+        // plain bit reversal and k_bam_tasks skips the per-nibble repair of the other codes
         const uint8_t *sq = rec + 32 + (uint64_t)l_qname + 4ull * n_cig;
         const uint64_t sb = (ls + 1) / 2, full = ls / 2;   // bytes with two bases
         uint32_t dirty = 0;
         uint64_t i = 0;
+        for (; i + 16 <= full; i += 16) {
+          const W4 v = *(const W4 *)(sq + i);
+          dirty |= (fix_nib(v.a) ^ v.a) | (fix_nib(v.b) ^ v.b) | (fix_nib(v.c) ^ v.c) | (fix_nib(v.d) ^ v.d);
+        }
         for (; i + 4 <= full; i += 4) { uint32_t v = *(const u32u *)(sq + i); dirty |= fix_nib(v) ^ v; }
         for (; i < full; i++) { uint32_t v = sq[i] | 0x11111100u; dirty |= fix_nib(v) ^ v; }
         if (sb > full) { uint32_t v = (sq[full] >> 4) | 0x11111110u; dirty |= fix_nib(v) ^ v; }
@@ -143,7 +148,7 @@ __device__ __forceinline__ void bam_scan_one(const BamArgs &B, int64_t a) {
 __global__ void __launch_bounds__(256) k_bam_scan(BamArgs B) {
   __shared__ unsigned long long sh_end[4];
   int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  // end of the last record byte of the blob: k_bam_rows reads 16 bytes at a time and must not read past it
+  // end of the last record byte of the blob: a k_bam_tasks copy of fewer than 16 bytes loads 16 and must not read past it
   unsigned long long e = 0;
   if (a < B.n_aln) e = B.rec_off[a] + (B.rec_len ? (uint64_t)B.rec_len[a] : B.rec_off[a + 1] - B.rec_off[a]);
   for (int o = 32; o; o >>= 1) { unsigned long long t = __shfl_xor(e, o); e = t > e ? t : e; }
@@ -343,35 +348,11 @@ __global__ void __launch_bounds__(256) k_bam_encode(BamArgs B) {
   encode_row<G>(B, r, lane, B.blob + B.rec_off[a], B.aux[a], B.out + B.out_off[r], (uint32_t)(B.out_off[r + 1] - B.out_off[r]));
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// k_bam_rows<R>: one wave encodes R consecutive rows = one contiguous span of the output.
-//
-// k_bam_encode<G> gives a row G lanes and walks its regions one after the other: ~43 vector-memory instructions per
-// wave of 8 rows, most of them with 2-7 of a row's 8 lanes at work -- the kernel is bound by the address / L1 path
-// (24 cycles per instruction and CU, profiles/r02/pmc_bam.txt), not by bytes.  Here the work is cut the other way:
-//   1. lane i < R describes row i (what encode_row computes per row, once instead of G times) and leaves the row's
-//      segment table in LDS: output offset of every non-empty segment, where its bytes come from and how
-//      (skip = written in step 3, copy, byte-reversed QUAL, reverse-complemented SEQ of even / odd length);
-//   2. every lane owns one 16-byte chunk of the span per iteration: it finds its row and segment (two binary searches
-//      in LDS), then walks the 1-4 segments the chunk touches: one unaligned 16-byte load per segment, placed so that
-//      source byte j lands on chunk byte j, merged under a "bytes >= c" mask; one 16-byte store per chunk.  The span's
-//      last chunk ends at the span's end (it overlaps its predecessor, same bytes) instead of a byte tail;
-//   3. after the chunk stores have completed (release fence), lane i writes row i's fixed fields, <= 2-op CIGAR and
-//      tags over the skipped bytes; CIGARs of more than two ops are copied from the arena by the whole wave.
-#define BSEG_MAX 12   // hdr, name, cigar, seq, qual, 5 aux pieces, tags (+ the end mark)
 enum { BM_SKIP = 0, BM_COPY = 1, BM_REV = 2, BM_REVC_CLEAN = 3, BM_REVC = 4, BM_REVC_ODD = 5 };
-#define BM_MODE_SHIFT 60             // src: mode in bits 60..62, bit 63 = the row's last segment
-#define BM_LAST (1ull << 63)
+#define BM_MODE_SHIFT 60             // src: mode in bits 60..62
 #define BM_OFF ((1ull << 48) - 1)    // src: offset in the blob of the segment's first source byte
-struct __attribute__((aligned(16))) BamRowDesc {
-  uint32_t start[16];                // row-relative output offset of segment s; start[n_seg] = row length, then ~0
-  uint64_t src[BSEG_MAX];
-  uint32_t cig_at, cig_n;            // > 2-op CIGAR: span-relative output offset, n_cigar | minus << 31
-  uint64_t cig_src;                  // ... and its word offset in the arena
-};
-template <int R> struct __attribute__((aligned(16))) BamWaveLds { BamRowDesc d[R]; uint32_t row_start[R + 4]; };
 
-// 16 source bytes at p; bytes at or after `end` read as 0 (only the chunk at the very end of the blob takes the byte path)
+// 16 source bytes at p; bytes at or after `end` read as 0 (only a task at the very end of the blob takes the byte path)
 __device__ __forceinline__ uint4 load16_end(const uint8_t *p, const uint8_t *end) {
   if (p + 16 <= end) { W4 w = *(const W4 *)p; return make_uint4(w.a, w.b, w.c, w.d); }
   uint32_t v[4] = {0, 0, 0, 0};
@@ -380,32 +361,45 @@ __device__ __forceinline__ uint4 load16_end(const uint8_t *p, const uint8_t *end
   return make_uint4(v[0], v[1], v[2], v[3]);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// k_bam_tasks<R>: one wave encodes R consecutive rows; the byte regions of all of them are cut into 16-byte copy
+// tasks that fill the wave's lanes densely.  (k_bam_encode<G> gives a row G lanes and walks its regions one after the
+// other: ~43 vector-memory instructions per wave of 8 rows, most with 2-7 of a row's 8 lanes at work, every region's
+// loads waiting for its predecessor's stores.)
+//   1. lane i < R describes row i (what encode_row computes per row, once instead of G times) and lists the row's copy segments -- read name, SEQ, QUAL, kept aux
+//      pieces; a copy that continues its predecessor's source and destination joins it -- with where the bytes go, where
+//      they come from, how (copy, byte-reversed, reverse-complemented) and how many tasks that is: ceil(len / 16), the
+//      last one ending at the segment's end (it overlaps its predecessor) instead of a byte tail; one task for a segment
+//      under 16 bytes.  A wave-wide scan of the rows' task counts numbers the tasks.
+//   2. task t -> row (binary search over the rows' first tasks) -> segment (over the segments' first tasks) -> chunk:
+//      one 16-byte load, the turn-around if any, one 16-byte store; no masks, no chunk is shared between segments.
+//   3. lane i writes row i's fixed fields, <= 2-op CIGAR and tags; longer CIGARs are copied from the arena by the wave.
+#define BT_SEGS 8   // name, seq, qual, 5 aux pieces
+struct __attribute__((aligned(16))) BamTaskRow {
+  uint32_t tp[12];                   // first task of segment s (row-relative); tp[n_seg] = the row's tasks, then ~0
+  uint32_t dst[BT_SEGS], len[BT_SEGS];
+  uint64_t src[BT_SEGS];             // BM_OFF | mode << BM_MODE_SHIFT
+  uint32_t cig_at, cig_n;            // > 2-op CIGAR: span-relative output offset, n_cigar | minus << 31
+  uint64_t cig_src;                  // ... and its word offset in the arena
+};
+template <int R> struct __attribute__((aligned(16))) BamTaskLds { BamTaskRow d[R]; uint32_t row_tp[R + 4], row_at[R + 4]; };
+
 template <int R>
-__global__ void __launch_bounds__(256) k_bam_rows(BamArgs B) {
-  __shared__ BamWaveLds<R> sh_w[4];
-  __shared__ uint4 sh_from[17];      // sh_from[c]: mask of the chunk bytes >= c
-  if (threadIdx.x < 17) {
-    uint32_t m[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) { int kk = (int)threadIdx.x - 4 * k; m[k] = kk <= 0 ? 0xffffffffu : kk >= 4 ? 0u : ~((1u << (8 * kk)) - 1u); }
-    sh_from[threadIdx.x] = make_uint4(m[0], m[1], m[2], m[3]);
-  }
-  __syncthreads();
+__global__ void __launch_bounds__(256) k_bam_tasks(BamArgs B) {
+  __shared__ BamTaskLds<R> sh_w[4];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  BamWaveLds<R> &L = sh_w[wv];
+  BamTaskLds<R> &L = sh_w[wv];
   const int64_t r0 = ((int64_t)blockIdx.x * 4 + wv) * R;
   if (r0 >= B.n_rows) return;
   const int nr = (int)(B.n_rows - r0 < R ? B.n_rows - r0 : R);
   const uint64_t span0 = B.out_off[r0];
-  const uint32_t span = (uint32_t)(B.out_off[r0 + nr] - span0);
-  const uint64_t blob_len = *B.blob_end;
-  const uint8_t *blob_end = B.blob + blob_len;
+  const uint8_t *blob_end = B.blob + *B.blob_end;
 
   // ---- 1. one lane per row ----
   uint32_t h0 = 0, h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0, h6 = 0, h7 = 0, h8 = 0;   // block_size + the 32 fixed bytes
-  uint32_t row_at = 0xffffffffu, o_cig = 0, o_tags = 0, n_cig = 0, c_x = 0, c_y = 0;
-  uint32_t tag_nh = 0, tag_hi = 0, tag_as = 0;
+  uint32_t row_at = 0, o_cig = 0, o_tags = 0, n_cig = 0, c_x = 0, c_y = 0;
+  uint32_t tag_nh = 0, tag_hi = 0, tag_as = 0, row_tasks = 0;
   bool minus = false;
   if (lane < nr) {
     const int64_t r = r0 + lane;
@@ -447,165 +441,162 @@ __global__ void __launch_bounds__(256) k_bam_rows(BamArgs B) {
     h4 = (n_cig & 0xffffu) | (flag << 16); h5 = (uint32_t)l_seq; h6 = (uint32_t)mtid; h7 = (uint32_t)mpos; h8 = (uint32_t)tlen;
     tag_nh = nh; tag_hi = rr.w & RR_HI;
     if (B.long_reads) tag_as = (uint32_t)(int32_t)(((double)x.as_val + (double)(B.r_clip ? B.r_clip[r] : 0)) * (B.r_sim ? B.r_sim[r] : 0.0));  // set_as_tag
-    // the segment table: non-empty segments only, in output order; a copy that continues its predecessor's source joins it
-    BamRowDesc &D = L.d[lane];
+    BamTaskRow &D = L.d[lane];
     int ns = 0;
-    uint32_t o = 0, prev_mode = 0xffu, prev_end = 0;
-    auto seg = [&](uint32_t len, uint32_t mode, uint32_t src) {
-      if (len == 0) return;
-      if (mode == BM_COPY && prev_mode == BM_COPY && prev_end == src) { o += len; prev_end += len; return; }
-      D.start[ns] = o; D.src[ns] = (ro + src) | ((uint64_t)mode << BM_MODE_SHIFT); ns++; o += len;
-      prev_mode = mode; prev_end = src + len;
-    };
-    seg(36u, BM_SKIP, 0);
-    seg(l_qname, BM_COPY, 32u);
+    uint32_t o = 36u, prev_mode = 0xffu, prev_end = 0, prev_len = 0, prev_o = 0;
+#define BT_TASKS(n) ((n) >= 16u ? ((n) + 15u) >> 4 : 1u)
+#define BT_SEG(len_, mode_, src_) do {                                                                                  \
+      const uint32_t sl = (len_), sm = (mode_), ss = (src_);                                                            \
+      if (sl != 0u) {                                                                                                   \
+        if (sm == BM_COPY && prev_mode == BM_COPY && prev_end == ss && prev_o == o) {                                   \
+          prev_len += sl; prev_end += sl; prev_o += sl; o += sl;                                                        \
+          D.len[ns - 1] = prev_len;                                                                                     \
+          row_tasks = prev_tp + BT_TASKS(prev_len);                                                                     \
+        } else {                                                                                                        \
+          D.tp[ns] = row_tasks; D.dst[ns] = o; D.len[ns] = sl; D.src[ns] = (ro + ss) | ((uint64_t)sm << BM_MODE_SHIFT); \
+          prev_tp = row_tasks; row_tasks += BT_TASKS(sl); ns++; o += sl;                                                \
+          prev_mode = sm; prev_end = ss + sl; prev_len = sl; prev_o = o;                                                \
+        }                                                                                                               \
+      }                                                                                                                 \
+    } while (0)
+    uint32_t prev_tp = 0;
+    BT_SEG(l_qname, BM_COPY, 32u);
     o_cig = o;
-    seg(4u * n_cig, BM_SKIP, 0);
+    o += 4u * n_cig;
     const uint32_t seq_at = 32u + l_qname + 4u * n_cig_in;
-    seg(sb, !minus ? BM_COPY : (ls & 1u) ? BM_REVC_ODD : (x.qual_present & 2u) ? BM_REVC_CLEAN : BM_REVC, seq_at);
-    seg(ls, (minus && (x.qual_present & 1u)) ? BM_REV : BM_COPY, seq_at + sb);
+    BT_SEG(sb, !minus ? BM_COPY : (ls & 1u) ? BM_REVC_ODD : (x.qual_present & 2u) ? BM_REVC_CLEAN : BM_REVC, seq_at);
+    BT_SEG(ls, (minus && (x.qual_present & 1u)) ? BM_REV : BM_COPY, seq_at + sb);
     uint32_t src = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       if (x.off[k] == 0xffffffffu) break;
-      seg(x.off[k] - src, BM_COPY, x.aux_start + src);
+      BT_SEG(x.off[k] - src, BM_COPY, x.aux_start + src);
       src = x.off[k] + x.len[k];
     }
-    seg(x.aux_len - src, BM_COPY, x.aux_start + src);
+    BT_SEG(x.aux_len - src, BM_COPY, x.aux_start + src);
     o_tags = o;
-    seg(B.long_reads ? 21u : 14u, BM_SKIP, 0);
-    D.src[ns - 1] |= BM_LAST;
-    D.start[ns] = o;
-    for (int k = ns + 1; k < 16; k++) D.start[k] = 0xffffffffu;
+    D.tp[ns] = row_tasks;
+    for (int k = ns + 1; k < 12; k++) D.tp[k] = 0xffffffffu;
     D.cig_at = row_at + o_cig; D.cig_n = n_cig | (minus ? 0x80000000u : 0u);
     D.cig_src = ((uint64_t)c.y << 32) | c.x;
   }
   static_assert(R + 4 <= 64 && (R & (R - 1)) == 0, "rows per wave");
-  if (lane < R + 4) L.row_start[lane] = row_at;   // ~0 behind the last row
+  // first task of every row: a scan over the wave
+  uint32_t incl = row_tasks;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const uint32_t up = __shfl_up(incl, d); if (lane >= d) incl += up; }
+  const uint32_t n_tasks = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl(incl, 63));
+  if (lane < R + 4) { L.row_tp[lane] = lane < nr ? incl - row_tasks : 0xffffffffu; L.row_at[lane] = row_at; }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
-  // ---- 2. one lane per 16-byte chunk of the span ----
+  // ---- 2. one lane per copy task, two tasks in flight: the next task is looked up and its load issued before the
+  //         current one is finished, so that neither the look-up (two chains of LDS reads) nor the store sit between a
+  //         load and the wait for it ----
   uint8_t *const out = B.out + span0;
-  const uint32_t n_chunks = (span + 15u) >> 4;
-  // a chunk's store is issued behind the loads of the next chunk: the wait for those loads then does not include the
-  // store's way to L2 (gfx9 counts loads and stores in one in-order counter)
-  uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0, o_at = 0;
-  bool pending = false;
-  for (uint32_t k = lane; k < n_chunks; k += 64) {
-    uint32_t p0 = k << 4;
-    if (p0 + 16u > span) p0 = span - 16u;
+  struct Task { const uint8_t *p; uint8_t *d; uint32_t len, at, mode; bool on; };
+  auto find = [&](uint32_t t) __attribute__((always_inline)) {
+    Task S;
+    S.on = t < n_tasks;
+    const uint32_t tt = S.on ? t : 0u;
     int i = 0;
 #pragma unroll
-    for (int st = R / 2; st; st >>= 1) if (L.row_start[i + st] <= p0) i += st;
-    uint32_t q = p0 - L.row_start[i];
+    for (int st = R / 2; st; st >>= 1) if (L.row_tp[i + st] <= tt) i += st;
+    const BamTaskRow &D = L.d[i];
+    const uint32_t t1 = tt - L.row_tp[i];
     int s = 0;
 #pragma unroll
-    for (int st = 8; st; st >>= 1) if (L.d[i].start[s + st] <= q) s += st;
-    uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    uint32_t c = 0;
-    auto round = [&](const bool with_store) __attribute__((always_inline)) {
-      // up to four segments per round.  First every segment's load, branch-free, so that the four are in flight together
-      // (a lane without a segment, a skipped one or one at the very end of the blob loads the blob's first bytes instead),
-      // then the rare repairs, then the merges.
-      uint4 w[4];
-      uint32_t cm[4];     // chunk byte the segment starts at | mode << 8 (0: nothing to merge) | 1 << 12: load again, carefully
-      uint64_t at[4];     // blob offset the 16 bytes come from
-      uint32_t padb[4];   // odd-length SEQ: chunk byte that holds the pad nibble
-#pragma unroll
-      for (int T = 0; T < 4; T++) {
-        const bool on = c < 16u;
-        const BamRowDesc &D = L.d[on ? i : 0];
-        const int s_ = on ? s : 0;
-        const uint32_t ss = D.start[s_], se = D.start[s_ + 1];
-        const uint64_t sd = D.src[s_];
-        const uint32_t left = se - q, room = 16u - c;
-        const uint32_t n = on ? (left < room ? left : room) : 0u;
-        const uint32_t mode = on ? (uint32_t)(sd >> BM_MODE_SHIFT) & 7u : (uint32_t)BM_SKIP;
-        const uint32_t t = q - ss;     // first byte of this visit inside the segment
-        // copy: chunk byte b <- source byte t - c + b.  The other modes read backwards: chunk byte b <- source byte
-        // (len - 1 - t + c) - b, so they load the 16 bytes that end there and turn them around
-        const uint32_t back = se - ss - 1u - t + c;
-        const int32_t off = mode == BM_COPY ? (int32_t)(t - c) : (int32_t)back - 15;
-        const uint64_t src = (sd & BM_OFF) + (int64_t)off;
-        const bool careful = mode != BM_SKIP && (src + 16u > blob_len || mode == BM_REVC_ODD);
-        const uint64_t from = (mode == BM_SKIP || src + 16u > blob_len) ? 0ull : src;
-        const W4 ld = *(const W4 *)(B.blob + from);
-        w[T] = make_uint4(ld.a, ld.b, ld.c, ld.d);
-        at[T] = src; padb[T] = c + (se - ss - 1u - t);
-        cm[T] = mode == BM_SKIP ? 0u : (c | (mode << 8) | (careful ? 0x1000u : 0u) | (n << 16));
-        c += n; q += n;
-        const bool done = on && q == se, last = done && (sd & BM_LAST);
-        s = last ? 0 : done ? s + 1 : s;
-        i += last ? 1 : 0;
-        q = last ? 0u : q;
+    for (int st = 4; st; st >>= 1) if (D.tp[s + st] <= t1) s += st;
+    const uint32_t j = t1 - D.tp[s];
+    const uint64_t sd = D.src[s];
+    S.len = D.len[s];
+    S.mode = (uint32_t)(sd >> BM_MODE_SHIFT) & 7u;
+    // a segment of 16 bytes or more: chunk j, the last one ending at the segment's end.  A shorter one: the 16 bytes that
+    // start (copy) or end (the modes that read backwards) with it, of which the first len are stored.
+    S.at = S.len < 16u ? 0u : 16u * j + 16u <= S.len ? 16u * j : S.len - 16u;
+    // copy: bytes [at, at + 16).  The others read backwards: output byte u <- source byte len - 1 - u
+    S.p = B.blob + (sd & BM_OFF) + (int32_t)(S.mode == BM_COPY ? S.at : S.len - 16u - S.at);
+    S.d = out + L.row_at[i] + D.dst[s];
+    return S;
+  };
+  // (a copy of fewer than 16 bytes may reach past the blob's last record: that one is loaded again, byte by byte, in finish)
+  auto past_end = [&](const Task &S) __attribute__((always_inline)) { return S.len < 16u && S.mode == BM_COPY && S.p + 16 > blob_end; };
+  auto fetch = [&](const Task &S) __attribute__((always_inline)) {
+    const W4 ld = *(const W4 *)(past_end(S) ? B.blob : S.p);
+    return make_uint4(ld.a, ld.b, ld.c, ld.d);
+  };
+  // "the data of the current task is needed here": placed right behind the next task's load, in straight-line code, where
+  // the compiler counts exactly one younger operation (s_waitcnt vmcnt(1)); left to the first real use, behind the branches
+  // of finish, its count ends in "wait for everything", the next task's load included
+  auto landed = [&](uint4 v) __attribute__((always_inline)) {
+    asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+    return v;
+  };
+  auto finish = [&](const Task &S, uint4 v) __attribute__((always_inline)) {
+    if (!S.on) return;
+    const uint32_t mode = S.mode, len = S.len;
+    if (past_end(S)) v = load16_end(S.p, blob_end);
+    if (len < 16u && mode == BM_REVC_ODD) {   // fewer than 31 bases, odd: byte by byte
+      const uint8_t *src = S.p + 16 - len;
+      const uint32_t ls = 2u * len - 1u;
+      for (uint32_t b = 0; b < len; b++) {
+        const uint32_t s0 = ls - 1u - 2u * b;
+        uint8_t q = (uint8_t)(comp4((src[s0 >> 1] >> ((~s0 & 1u) << 2)) & 0xf) << 4);
+        if (2u * b + 1u < ls) { const uint32_t s1 = s0 - 1u; q |= comp4((src[s1 >> 1] >> ((~s1 & 1u) << 2)) & 0xf); }
+        S.d[b] = q;
       }
-      if (with_store) { W4 o4; o4.a = o0; o4.b = o1; o4.c = o2; o4.d = o3; *(W4 *)(out + (pending ? o_at : p0)) = o4; }   // (a lane's first chunk: zeros, written over below)
-      // the merges, in segment order: a segment writes the chunk bytes from its first one on, its successor the rest
-#pragma unroll
-      for (int T = 0; T < 4; T++) {
-        const uint32_t mode = (cm[T] & 0x1000u) ? 0u : (cm[T] >> 8) & 7u;
-        if (mode) {
-          uint4 v = w[T];
-          if (mode != BM_COPY) {
-            // qualities: bytes reversed; bases: all 128 bits reversed = base order, and A<->T, C<->G inside every nibble (bam.cpp:671-686)
-            const bool bits = mode != BM_REV;
-            const uint4 u = v;
-            v.x = bits ? __builtin_bitreverse32(u.w) : __builtin_bswap32(u.w); v.y = bits ? __builtin_bitreverse32(u.z) : __builtin_bswap32(u.z);
-            v.z = bits ? __builtin_bitreverse32(u.y) : __builtin_bswap32(u.y); v.w = bits ? __builtin_bitreverse32(u.x) : __builtin_bswap32(u.x);
-            if (mode == BM_REVC) { v.x = fix_nib(v.x); v.y = fix_nib(v.y); v.z = fix_nib(v.z); v.w = fix_nib(v.w); }   // a base code other than A C G T N in the record: rare
-          }
-          const uint4 m = sh_from[cm[T] & 0x1fu];
-          a0 = (a0 & ~m.x) | (v.x & m.x); a1 = (a1 & ~m.y) | (v.y & m.y); a2 = (a2 & ~m.z) | (v.z & m.z); a3 = (a3 & ~m.w) | (v.w & m.w);
+      return;
+    }
+    if (mode != BM_COPY) {
+      // qualities: bytes reversed; bases: all 128 bits reversed = base order, and A<->T, C<->G inside every nibble (bam.cpp:671-686)
+      const bool bits = mode != BM_REV;
+      const uint4 u = v;
+      v.x = bits ? __builtin_bitreverse32(u.w) : __builtin_bswap32(u.w); v.y = bits ? __builtin_bitreverse32(u.z) : __builtin_bswap32(u.z);
+      v.z = bits ? __builtin_bitreverse32(u.y) : __builtin_bswap32(u.y); v.w = bits ? __builtin_bitreverse32(u.x) : __builtin_bswap32(u.x);
+      if (mode >= BM_REVC) {   // a base code other than A C G T N in the record, or an odd length
+        if (mode == BM_REVC_ODD) {
+          // odd length: the stream moves up by one nibble; the low nibble of output byte u is the high nibble of the next
+          const W4 l2 = *(const W4 *)(S.p - 1);
+          const uint32_t y0 = __builtin_bitreverse32(l2.d), y1 = __builtin_bitreverse32(l2.c), y2 = __builtin_bitreverse32(l2.b), y3 = __builtin_bitreverse32(l2.a);
+          v.x = ((v.x & 0x0f0f0f0fu) << 4) | ((y0 >> 4) & 0x0f0f0f0fu); v.y = ((v.y & 0x0f0f0f0fu) << 4) | ((y1 >> 4) & 0x0f0f0f0fu);
+          v.z = ((v.z & 0x0f0f0f0fu) << 4) | ((y2 >> 4) & 0x0f0f0f0fu); v.w = ((v.w & 0x0f0f0f0fu) << 4) | ((y3 >> 4) & 0x0f0f0f0fu);
         }
+        v.x = fix_nib(v.x); v.y = fix_nib(v.y); v.z = fix_nib(v.z); v.w = fix_nib(v.w);
+        if (mode == BM_REVC_ODD && S.at + 16u == len) v.w &= 0xf0ffffffu;   // the pad nibble of the last byte stays 0
       }
-      // the careful ones afterwards, each under the mask of exactly its bytes
-      if (__any((cm[0] | cm[1] | cm[2] | cm[3]) & 0x1000u)) {
-#pragma unroll
-        for (int T = 0; T < 4; T++) {
-          if (cm[T] & 0x1000u) {
-            const uint32_t mode = (cm[T] >> 8) & 7u;
-            const uint8_t *p = B.blob + at[T];
-            uint4 v = load16_end(p, blob_end);
-            if (mode == BM_REVC_ODD) {
-              // odd length: the stream moves up by one nibble, the low nibble of output byte u is the high nibble of the next
-              const uint4 v2 = load16_end(p - 1, blob_end);
-              const uint32_t x0 = __builtin_bitreverse32(v.w), x1 = __builtin_bitreverse32(v.z), x2 = __builtin_bitreverse32(v.y), x3 = __builtin_bitreverse32(v.x);
-              const uint32_t y0 = __builtin_bitreverse32(v2.w), y1 = __builtin_bitreverse32(v2.z), y2 = __builtin_bitreverse32(v2.y), y3 = __builtin_bitreverse32(v2.x);
-              v.x = fix_nib(((x0 & 0x0f0f0f0fu) << 4) | ((y0 >> 4) & 0x0f0f0f0fu)); v.y = fix_nib(((x1 & 0x0f0f0f0fu) << 4) | ((y1 >> 4) & 0x0f0f0f0fu));
-              v.z = fix_nib(((x2 & 0x0f0f0f0fu) << 4) | ((y2 >> 4) & 0x0f0f0f0fu)); v.w = fix_nib(((x3 & 0x0f0f0f0fu) << 4) | ((y3 >> 4) & 0x0f0f0f0fu));
-              // the pad nibble of the last byte stays 0 (when that byte is inside this chunk)
-              const uint32_t bp = padb[T];
-              if (bp < 16u) {
-                const uint32_t clr = ~(0xfu << (8u * (bp & 3u)));
-                if ((bp >> 2) == 0) v.x &= clr; else if ((bp >> 2) == 1) v.y &= clr; else if ((bp >> 2) == 2) v.z &= clr; else v.w &= clr;
-              }
-            } else if (mode != BM_COPY) {
-              const bool bits = mode != BM_REV;
-              const uint4 u = v;
-              v.x = bits ? __builtin_bitreverse32(u.w) : __builtin_bswap32(u.w); v.y = bits ? __builtin_bitreverse32(u.z) : __builtin_bswap32(u.z);
-              v.z = bits ? __builtin_bitreverse32(u.y) : __builtin_bswap32(u.y); v.w = bits ? __builtin_bitreverse32(u.x) : __builtin_bswap32(u.x);
-              if (mode == BM_REVC) { v.x = fix_nib(v.x); v.y = fix_nib(v.y); v.z = fix_nib(v.z); v.w = fix_nib(v.w); }
-            }
-            const uint32_t c0 = cm[T] & 0x1fu, c1 = c0 + ((cm[T] >> 16) & 0x1fu);
-            const uint4 m0 = sh_from[c0], m1 = sh_from[c1];
-            const uint4 m = make_uint4(m0.x & ~m1.x, m0.y & ~m1.y, m0.z & ~m1.z, m0.w & ~m1.w);
-            a0 = (a0 & ~m.x) | (v.x & m.x); a1 = (a1 & ~m.y) | (v.y & m.y); a2 = (a2 & ~m.z) | (v.z & m.z); a3 = (a3 & ~m.w) | (v.w & m.w);
-          }
-        }
-      }
-    };
-    round(true);
-    while (c < 16u) round(false);
-    o0 = a0; o1 = a1; o2 = a2; o3 = a3; o_at = p0; pending = true;
+    }
+    if (len >= 16u) {
+      W4 o4; o4.a = v.x; o4.b = v.y; o4.c = v.z; o4.d = v.w;
+      *(W4 *)(S.d + S.at) = o4;
+    } else {
+      typedef uint16_t u16u __attribute__((aligned(1)));
+      struct __attribute__((packed, aligned(1))) W2 { uint32_t a, b; };
+      uint8_t *d = S.d;
+      if (len & 8u) { W2 o2; o2.a = v.x; o2.b = v.y; *(W2 *)d = o2; v.x = v.z; v.y = v.w; d += 8; }
+      if (len & 4u) { *(u32u *)d = v.x; v.x = v.y; d += 4; }
+      if (len & 2u) { *(u16u *)d = (uint16_t)v.x; v.x >>= 16; d += 2; }
+      if (len & 1u) *d = (uint8_t)v.x;
+    }
+  };
+  if (n_tasks) {
+    // (two copies of the loop body, the tasks alternating between two sets of registers: a register copy of the next
+    // task's data at the end of a round would wait for its load)
+    // (two copies of the loop body, the tasks alternating between two sets of registers; no branch between a task's load
+    // and the "landed" of the task before it)
+    Task S0 = find(lane), S1;
+    uint4 v0 = fetch(S0), v1;
+    for (uint32_t base = 0;; base += 128) {
+      if (base + 64u >= n_tasks) { finish(S0, v0); break; }   // the same for every lane
+      S1 = find(base + 64u + lane); v1 = fetch(S1);
+      finish(S0, landed(v0));
+      if (base + 128u >= n_tasks) { finish(S1, v1); break; }
+      S0 = find(base + 128u + lane); v0 = fetch(S0);
+      finish(S1, landed(v1));
+    }
   }
-  if (pending) { W4 o4; o4.a = o0; o4.b = o1; o4.c = o2; o4.d = o3; *(W4 *)(out + o_at) = o4; }
 
-  // ---- 3. the synthesized bytes, after the chunk stores ----
-  // the chunk stores have reached L2 before the stores below are issued (an agent-scope release fence would also write
-  // L2 back: buffer_wbl2 per wave, 6x the kernel's time)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // ---- 3. the synthesized bytes ----
   if (lane < nr) {
     uint8_t *w = out + row_at;
     W4 x0; x0.a = h0; x0.b = h1; x0.c = h2; x0.d = h3; *(W4 *)w = x0;
@@ -645,7 +636,7 @@ void launch_bam_size(hipStream_t st, const BamArgs &B) {
 }
 void launch_bam_encode(hipStream_t st, const BamArgs &B, int lanes) {
   if (B.n_rows <= 0) return;
-  if (lanes == 0) { hipLaunchKernelGGL((k_bam_rows<32>), dim3((unsigned)((B.n_rows + 127) / 128)), dim3(256), 0, st, B); return; }
+  if (lanes == 0) { hipLaunchKernelGGL((k_bam_tasks<32>), dim3((unsigned)((B.n_rows + 127) / 128)), dim3(256), 0, st, B); return; }
   if (lanes == 4) hipLaunchKernelGGL((k_bam_encode<4>), dim3((unsigned)((B.n_rows + 63) / 64)), dim3(256), 0, st, B);
   else if (lanes == 8) hipLaunchKernelGGL((k_bam_encode<8>), dim3((unsigned)((B.n_rows + 31) / 32)), dim3(256), 0, st, B);
   else if (lanes == 32) hipLaunchKernelGGL((k_bam_encode<32>), dim3((unsigned)((B.n_rows + 7) / 8)), dim3(256), 0, st, B);

@@ -221,7 +221,7 @@ struct BamArgs {
   const uint64_t *out_off;   // [n_rows + 1]
   uint8_t *out;
   uint64_t *too_long;        // set when a row's CIGAR exceeds the 16-bit n_cigar_op field
-  uint64_t *blob_end;        // k_bam_scan: end (byte offset in blob) of the record that ends last; k_bam_rows never loads past it
+  uint64_t *blob_end;        // k_bam_scan: end (byte offset in blob) of the record that ends last; k_bam_tasks never loads past it
 };
 void launch_bam_scan(hipStream_t st, const BamArgs &B);
 

@@ -502,8 +502,8 @@ const char *br_bgzf_codec(void); /* "libdeflate" (bound at run time when present
 /* When enabled, every launch is bracketed by hipEvents on the launch stream. */
 int br_ctx_set_profiling(br_ctx *, int enabled);
 /* Launch tuning: "group_lanes" (8|16|32|64 lanes cooperating on one alignment),
- * "blocks_per_cu" (grid size of the grid-stride projection kernels), "bam_lanes" (4..64 lanes per
- * re-encoded record), "deflate_dynamic" (1: per-block Huffman codes, 0: the fixed code), "emit_split" (1: the emit
+ * "blocks_per_cu" (grid size of the grid-stride projection kernels), "bam_lanes" (0, the default: a wave per 32
+ * re-encoded records, their byte regions as 16-byte copy tasks; 4..64: that many lanes per record), "deflate_dynamic" (1: per-block Huffman codes, 0: the fixed code), "emit_split" (1: the emit
  * work list is launched per class, 0: one launch), "count_split" (1: short-read presets run the count pass as a main
  * kernel without the exon walk plus a second one for the alignments that need it, 0: one kernel). */
 int br_ctx_set_param(br_ctx *, const char *key, int64_t value);

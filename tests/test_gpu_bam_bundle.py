@@ -276,13 +276,13 @@ def test_staged_bundles_equal_one_shot_calls():
 
 
 @pytest.mark.parametrize("seed,flags", [(11, {}), (12, {"lr": 1}), (13, {"strict": 1})])
-def test_bam_rows_random_records(seed, flags):
-    """k_bam_rows (a wave per 32 rows, 16-byte chunks of the output span) on records built to hit every segment kind:
+def test_bam_tasks_random_records(seed, flags):
+    """k_bam_tasks (a wave per 32 rows, their byte regions as 16-byte copy tasks) on records built to hit every segment kind:
     odd and even SEQ lengths on both strands, records whose bases are only A C G T N and records with '=' / IUPAC codes,
     absent qualities, one-byte to 40-byte names, CIGARs that stay above two ops after the rewrite (soft clips on both
     sides, insertions: the arena path, reversed on '-'), aux areas with the removed tags first, last, in the middle,
     repeated or missing, and several isoforms per locus so that a wave holds rows of few records.  Both encoders
-    (bam_lanes 0 = k_bam_rows, 8 = k_bam_encode<8>) against the oracle, byte for byte."""
+    (bam_lanes 0 = k_bam_tasks, 8 = k_bam_encode<8>) against the oracle, byte for byte."""
     rng = np.random.RandomState(seed)
     txs = []
     for g in range(12):
