@@ -26,10 +26,9 @@ namespace br {
 // Unaligned wide accesses: gfx950 global loads / stores need no alignment.
 struct __attribute__((packed, aligned(1))) W4 { uint32_t a, b, c, d; };
 typedef uint32_t u32u __attribute__((aligned(1)));
-__device__ __forceinline__ uint32_t ld_u16(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
-__device__ __forceinline__ uint32_t ld_u32(const uint8_t *p) {
-  return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
-}
+typedef uint16_t u16u __attribute__((aligned(1)));
+__device__ __forceinline__ uint32_t ld_u16(const uint8_t *p) { return *(const u16u *)p; }
+__device__ __forceinline__ uint32_t ld_u32(const uint8_t *p) { return *(const u32u *)p; }
 
 __device__ __forceinline__ uint32_t fix_nib(uint32_t x) {   // nibbles that are not one of 1, 2, 4, 8 become 15 (comp_table, src/bam.cpp:658-667)
   uint32_t pop = (x & 0x11111111u) + ((x >> 1) & 0x11111111u) + ((x >> 2) & 0x11111111u) + ((x >> 3) & 0x11111111u);
@@ -66,11 +65,12 @@ __device__ __forceinline__ void bam_scan_one(const BamArgs &B, int64_t a) {
   for (int k = 0; k < 4; k++) { x.off[k] = 0xffffffffu; x.len[k] = 0; }
   x.as_val = 0; x.aux_start = 0; x.aux_len = 0; x.c_a = x.c_b = x.c_c = 0; x.qual_present = 0;
   if (rlen >= 32) {
-    uint32_t l_qname = rec[8], n_cig = ld_u16(rec + 12);
+    x.c_a = ld_u32(rec + 8); x.c_b = ld_u32(rec + 12);
+    uint32_t l_qname = x.c_a & 0xffu, n_cig = x.c_b & 0xffffu;
     int32_t l_seq = (int32_t)ld_u32(rec + 16);
     uint64_t ls = l_seq > 0 ? (uint64_t)l_seq : 0;
     uint64_t start = 32 + (uint64_t)l_qname + 4ull * n_cig + (ls + 1) / 2 + ls;
-    x.c_a = ld_u32(rec + 8); x.c_b = ld_u32(rec + 12); x.c_c = (uint32_t)l_seq;
+    x.c_c = (uint32_t)l_seq;
     if (start <= rlen) {
       if (ls > 0) x.qual_present = rec[32 + (uint64_t)l_qname + 4ull * n_cig + (ls + 1) / 2] != 0xff;
       {
@@ -95,13 +95,15 @@ __device__ __forceinline__ void bam_scan_one(const BamArgs &B, int64_t a) {
       bool have[4] = {false, false, false, false};
       bool have_cg = false;
       while (end - s >= 3) {
-        uint8_t t0 = s[0], t1 = s[1], ty = s[2];
+        // tag, type and the first value byte in one load (a tag without room for a value ends the walk below)
+        const uint32_t tw = end - s >= 4 ? ld_u32(s) : (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16);
+        const uint8_t t0 = (uint8_t)tw, t1 = (uint8_t)(tw >> 8), ty = (uint8_t)(tw >> 16), b3 = (uint8_t)(tw >> 24);
         int64_t vl = aux_value_len(ty, s + 3, end);
         if (vl < 0 || s + 3 + vl > end) break;  // malformed: htslib stops here too
-        if (t0 == 'C' && t1 == 'G' && ty == 'B' && s[3] == 'I') have_cg = true;
+        if (t0 == 'C' && t1 == 'G' && ty == 'B' && b3 == 'I') have_cg = true;
         // tag_char1 (gclib/GSam.cpp:310-318): first value byte of the first XS / ts tag when A or Z
-        if (t0 == 'X' && t1 == 'S' && !have_xs) { have_xs = true; if (ty == 'A' || ty == 'Z') xs_c = (int8_t)s[3]; }
-        if (t0 == 't' && t1 == 's' && !have_ts) { have_ts = true; if (ty == 'A' || ty == 'Z') ts_c = (int8_t)s[3]; }
+        if (t0 == 'X' && t1 == 'S' && !have_xs) { have_xs = true; if (ty == 'A' || ty == 'Z') xs_c = (int8_t)b3; }
+        if (t0 == 't' && t1 == 's' && !have_ts) { have_ts = true; if (ty == 'A' || ty == 'Z') ts_c = (int8_t)b3; }
         int slot = -1;
         if (t0 == 'N' && t1 == 'H') slot = 0;
         else if (!B.long_reads && t0 == 'X' && t1 == 'S') slot = 1;
