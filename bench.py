@@ -273,8 +273,10 @@ def main():
                 "per_kernel": table,
                 "note": "achieved = the SURVEY 8d algorithmic bytes of one step over the whole step (every launch of the path); "
                         "per_kernel charges each stage only the formula terms it must move itself (DESIGN.md section 4) over its "
-                        "own hipEvent time; traffic = corrected rocprofv3 FETCH_SIZE + WRITE_SIZE per launch "
-                        "(profiles/pmc_traffic.json) when collected for this workload",
+                        "own hipEvent time (k_project<64,true> and k_primary run on the context's second stream beside "
+                        "k_emit_dense / k_pair<true>: overlapped kernels stretch each other, so the stage times sum to more "
+                        "than ms_per_step and the emit / rows fractions are lower bounds); traffic = corrected rocprofv3 "
+                        "FETCH_SIZE + WRITE_SIZE per launch (profiles/pmc_traffic.json) when collected for this workload",
             },
         }
         if not args.no_cpu_baseline:

@@ -44,7 +44,16 @@ __device__ int64_t aux_value_len(uint8_t type, const uint8_t *p, const uint8_t *
     case 's': case 'S': return 2;
     case 'i': case 'I': case 'f': return 4;
     case 'd': return 8;
-    case 'Z': case 'H': { const uint8_t *q = p; while (q < end && *q) q++; return q < end ? (q - p) + 1 : -1; }
+    case 'Z': case 'H': {   // up to and including the NUL: four bytes per load while four are left
+      const uint8_t *q = p;
+      while (end - q >= 4) {
+        const uint32_t w = ld_u32(q), z = (w - 0x01010101u) & ~w & 0x80808080u;
+        if (z) return (q - p) + (__builtin_ctz(z) >> 3) + 1;
+        q += 4;
+      }
+      while (q < end && *q) q++;
+      return q < end ? (q - p) + 1 : -1;
+    }
     case 'B': {
       if (end - p < 5) return -1;
       uint8_t st = p[0]; uint32_t n = ld_u32(p + 1);

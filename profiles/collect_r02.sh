@@ -25,6 +25,12 @@ echo "c3 stats + issue counters done"
 python3 bench_extra.py c5 > $O/bench_extra_c5.json.log 2> $O/c5.err || exit 1
 rocprofv3 --output-format csv --kernel-trace --stats -d $O/stats_c5 -o run -- python3 bench_extra.py c5 > $O/c5_stats.log 2>&1 || exit 1
 echo "c5 done"
+python3 bench_extra.py bam > $O/bench_extra_bam.json.log 2> $O/bam.err || exit 1
+BAM_LANES=8 python3 bench_extra.py bam > $O/bench_extra_bam_lanes8.json.log 2> $O/bam8.err || exit 1
+bash profiles/pmc_bam.sh 4000000 k_bam_ 0 > $O/pmc_bam_tasks_4m.txt 2>&1 || exit 1
+bash profiles/pmc_bam.sh 4000000 k_bam_encode 8 > $O/pmc_bam_encode8_4m.txt 2>&1 || exit 1
+profiles/bin/calib_store > $O/calib_store.txt 2>&1 || exit 1
+echo "bam stage done"
 python3 bench_extra.py bundle > $O/bench_extra_bundle.json.log 2> $O/bundle.err || exit 1
 rocprofv3 --output-format csv --kernel-trace --stats -d $O/stats_bundle -o run -- python3 bench_extra.py bundle > $O/bundle_stats.log 2>&1 || exit 1
 echo "bundle done"
