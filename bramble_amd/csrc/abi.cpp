@@ -1250,11 +1250,17 @@ extern "C" int br_project_bam_device(br_ctx *c, const br_config *cfg, const br_d
   RC(c->bam_end.ensure(8)); B.blob_end = c->bam_end.as<uint64_t>();
   HIPCHK(hipMemsetAsync(B.blob_end, 0, 8, st));
 
+  // the aux walk of the records (one lane per record, latency-bound) on the second stream beside the reader side
+  // (k_rec_fields .. k_mates, the same kind of kernel over the same records): joined below, in front of the projection
+  RC(ensure_aux_stream(c));
+  HIPCHK(hipEventRecord(c->aux_ev[0], st));
+  HIPCHK(hipStreamWaitEvent(c->ksw_stream, c->aux_ev[0], 0));
+  RC(pf.begin(BR_K_BAM, c->ksw_stream));
+  launch_bam_scan(c->ksw_stream, B);
+  RC(pf.end());
+  HIPCHK(hipEventRecord(c->aux_ev[1], c->ksw_stream));
   RC(pf.begin(BR_K_PARSE));
   launch_rec_fields(st, P);
-  RC(pf.end());
-  RC(pf.begin(BR_K_BAM));
-  launch_bam_scan(st, B);
   RC(pf.end());
   uint64_t *d_tot = c->totals.as<uint64_t>();
   ScanArgs S{}; S.n = n; S.tile_sums = c->tile_sums.as<uint64_t>();
@@ -1264,12 +1270,11 @@ extern "C" int br_project_bam_device(br_ctx *c, const br_config *cfg, const br_d
   S.src32 = P.isnew;    launch_scan(st, S, 2, c->p_group_pre.p, false, d_tot + 2);
   RC(pf.end());
   HIPCHK(hipMemcpyAsync(c->h_totals + 16, d_tot, 3 * 8, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipMemcpyAsync(c->h_totals + 20, c->p_small.p, 16, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(c->h_totals + 20, c->p_small.p, 8, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
-  if (c->h_totals[21] >> 32) { pf.collect(); return BR_ERR_UNSUPPORTED; }  // a CIGAR spilled into a CG:B,I tag (> 65535 ops)
   uint64_t n_words = c->h_totals[16], name_bytes = c->h_totals[17], ng = c->h_totals[18];
   uint32_t max_nc = (uint32_t)(c->h_totals[20] & 0xffffffffu), max_clip = (uint32_t)(c->h_totals[20] >> 32);
-  if (n_words >= 0xffffffffull - (uint64_t)n || name_bytes >= 0xfffffff0ull) { pf.collect(); return BR_ERR_CAPACITY; }
+  if (n_words >= 0xffffffffull - (uint64_t)n || name_bytes >= 0xfffffff0ull) { (void)hipStreamSynchronize(c->ksw_stream); pf.collect(); return BR_ERR_CAPACITY; }
   RC(c->b_cigar.ensure(std::max<size_t>((size_t)n_words, 1) * 4)); RC(c->b_names.ensure(std::max<size_t>((size_t)name_bytes, 1)));
   RC(c->b_group_off.ensure(((size_t)ng + 1) * 4));
   P.n_groups = (int64_t)ng; P.group_off = c->b_group_off.as<uint32_t>();
@@ -1279,6 +1284,10 @@ extern "C" int br_project_bam_device(br_ctx *c, const br_config *cfg, const br_d
   launch_rec_copy(st, P);
   launch_mates(st, P);
   RC(pf.end());
+  HIPCHK(hipStreamWaitEvent(st, c->aux_ev[1], 0));   // k_bam_scan: XS / ts characters, the aux table, the CG flag
+  HIPCHK(hipMemcpyAsync(c->h_totals + 21, c->p_small.as<uint32_t>() + 2, 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (c->h_totals[21] >> 32) { pf.collect(); return BR_ERR_UNSUPPORTED; }  // a CIGAR spilled into a CG:B,I tag (> 65535 ops)
 
   br_device_batch db{};
   if (fa_mode) {
