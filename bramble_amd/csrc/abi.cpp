@@ -421,7 +421,7 @@ struct br_ctx {
   // device scratch
   DevBuf seg, meta, head, head2, fast_flag, fast_pre, n_matches, ranges, mask, match_off, cig_base, tile_sums, totals, counters_d;
   DevBuf m_tid, m_aux, m_a, m_b, m_cigoff, cig_arena, big_list, n_big, m_aln;
-  DevBuf bam_aux, bam_len, bam_off, bam_out, bam_end;
+  DevBuf bam_aux, bam_base, bam_len, bam_off, bam_out, bam_end;
   struct StageSlot { DevBuf blob, off, len; hipEvent_t ready = nullptr; std::vector<uint64_t> h_off; int64_t n = 0; };
   StageSlot stage[3];              // br_bam_bundle_stage: uploads of the next bundles overlap the current projection
   hipStream_t copy_stream = nullptr;
@@ -517,7 +517,7 @@ extern "C" void br_ctx_free(br_ctx *c) {
   DevBuf *bufs[] = {&c->seg, &c->meta, &c->head, &c->head2, &c->fast_flag, &c->fast_pre, &c->n_matches, &c->ranges, &c->mask, &c->match_off, &c->cig_base,
                     &c->tile_sums, &c->totals, &c->counters_d, &c->m_tid, &c->m_aux, &c->m_a, &c->m_b,
                     &c->m_cigoff, &c->cig_arena, &c->big_list, &c->n_big, &c->m_aln,
-                    &c->bam_aux, &c->bam_len, &c->bam_off, &c->bam_out, &c->bam_end, &c->z_slots, &c->z_sizes, &c->z_off, &c->z_dense, &c->z_tabs, &c->z_tokens, &c->p_ncig, &c->p_name_len, &c->p_isnew, &c->p_group_pre, &c->p_small, &c->p_big, &c->p_seq_len, &c->p_ref_map, &c->fa_stats, &c->fa_n_prob, &c->fa_seq_bytes, &c->fa_prob_off, &c->fa_seqarena_off, &c->fa_probs, &c->fa_results,
+                    &c->bam_aux, &c->bam_base, &c->bam_len, &c->bam_off, &c->bam_out, &c->bam_end, &c->z_slots, &c->z_sizes, &c->z_off, &c->z_dense, &c->z_tabs, &c->z_tokens, &c->p_ncig, &c->p_name_len, &c->p_isnew, &c->p_group_pre, &c->p_small, &c->p_big, &c->p_seq_len, &c->p_ref_map, &c->fa_stats, &c->fa_n_prob, &c->fa_seq_bytes, &c->fa_prob_off, &c->fa_seqarena_off, &c->fa_probs, &c->fa_results,
                     &c->fa_seq_arena, &c->fa_clip_ops, &c->fa_ideal_cap, &c->fa_scratch, &c->b_seq_off, &c->b_seqs, &c->b_seq_src,
                     &c->r_rec, &c->pk_a, &c->pk_c, &c->pk_x, &c->pk_sim, &c->pk_clip, &c->pool, &c->pool_sizes, &c->pool_off, &c->pk_ch,
                     &c->n_rows, &c->row_off, &c->aln_group, &c->r_input, &c->r_nh, &c->r_hi, &c->r_mapq,
@@ -1156,8 +1156,9 @@ static int bam_encode_impl(br_ctx *c, const br_config *cfg, const br_device_reco
   B.n_aln = n; B.n_rows = nr; B.long_reads = (cfg->lr || cfg->lr_hq) ? 1 : 0;
   B.blob = recs->blob; B.rec_off = recs->rec_off; B.rec_len = recs->rec_len;
   RC(c->bam_aux.ensure(std::max<size_t>((size_t)n, 1) * sizeof(BamAux)));
+  RC(c->bam_base.ensure(std::max<size_t>((size_t)n, 1) * 4));
   RC(c->bam_len.ensure(std::max<size_t>((size_t)nr, 1) * 4)); RC(c->bam_off.ensure(((size_t)nr + 1) * 8));
-  B.aux = (BamAux *)c->bam_aux.p;
+  B.aux = (BamAux *)c->bam_aux.p; B.base_len = c->bam_base.as<uint32_t>();
   RC(c->bam_end.ensure(8)); B.blob_end = c->bam_end.as<uint64_t>();
   B.r_a = c->pk_a.as<uint4>(); B.r_c = c->pk_c.as<uint2>(); B.r_rec = c->r_rec.as<uint4>();
   B.r_sim = c->last_aux_cols ? c->pk_sim.as<double>() : nullptr; B.r_clip = c->last_aux_cols ? c->pk_clip.as<int32_t>() : nullptr;
@@ -1229,6 +1230,7 @@ extern "C" int br_project_bam_device(br_ctx *c, const br_config *cfg, const br_d
   RC(c->p_group_pre.ensure((nn + 1) * 4)); RC(c->p_small.ensure(64)); RC(c->p_big.ensure((nn / 96 + 2) * 4));
   RC(c->p_ref_map.ensure(std::max<size_t>((size_t)n_ref_map, 1) * 4));
   RC(c->bam_aux.ensure(nn * sizeof(BamAux)));
+  RC(c->bam_base.ensure(nn * 4));
   RC(c->tile_sums.ensure((size_t)std::max<int64_t>(scan_tiles_for(n + 1), 1) * 8 * 3));
   RC(c->totals.ensure(16 * 8));
   if (n_ref_map) HIPCHK(hipMemcpyAsync(c->p_ref_map.p, ref_map, (size_t)n_ref_map * 4, hipMemcpyHostToDevice, st));
@@ -1245,7 +1247,7 @@ extern "C" int br_project_bam_device(br_ctx *c, const br_config *cfg, const br_d
 
   BamArgs B{};
   B.n_aln = n; B.long_reads = dc.long_reads ? 1 : 0; B.blob = recs->blob; B.rec_off = recs->rec_off; B.rec_len = recs->rec_len;
-  B.aux = (BamAux *)c->bam_aux.p; B.xs_out = c->b_xs.as<int8_t>(); B.ts_out = c->b_ts.as<int8_t>();
+  B.aux = (BamAux *)c->bam_aux.p; B.base_len = c->bam_base.as<uint32_t>(); B.xs_out = c->b_xs.as<int8_t>(); B.ts_out = c->b_ts.as<int8_t>();
   B.cg_flag = c->p_small.as<uint32_t>() + 3;
   RC(c->bam_end.ensure(8)); B.blob_end = c->bam_end.as<uint64_t>();
   HIPCHK(hipMemsetAsync(B.blob_end, 0, 8, st));

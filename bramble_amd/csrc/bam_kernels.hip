@@ -65,6 +65,7 @@ __device__ int64_t aux_value_len(uint8_t type, const uint8_t *p, const uint8_t *
   }
 }
 
+__device__ __forceinline__ uint32_t row_base_len(const BamArgs &B, const BamAux &x);
 __device__ __forceinline__ void bam_scan_one(const BamArgs &B, int64_t a) {
   const uint8_t *rec = B.blob + B.rec_off[a];
   uint64_t rlen = B.rec_len ? (uint64_t)B.rec_len[a] : B.rec_off[a + 1] - B.rec_off[a];
@@ -153,6 +154,7 @@ __device__ __forceinline__ void bam_scan_one(const BamArgs &B, int64_t a) {
     }
   }
   B.aux[a] = x;
+  B.base_len[a] = row_base_len(B, x);
   if (B.xs_out) { B.xs_out[a] = xs_c; B.ts_out[a] = ts_c; }
 }
 
@@ -172,22 +174,24 @@ __global__ void __launch_bounds__(256) k_bam_scan(BamArgs B) {
   if (a < B.n_aln) bam_scan_one(B, a);
 }
 
-__device__ __forceinline__ uint32_t row_out_len(const BamArgs &B, int64_t r, const uint8_t *rec, const BamAux &x) {
+// what a record contributes to the length of each of its output rows, whatever their CIGAR (k_bam_scan leaves it per
+// record, so that k_bam_size reads four bytes per row instead of the aux table's 64)
+__device__ __forceinline__ uint32_t row_base_len(const BamArgs &B, const BamAux &x) {
   uint32_t l_qname = x.c_a & 0xffu;
   int32_t l_seq = (int32_t)x.c_c;
   uint32_t ls = l_seq > 0 ? (uint32_t)l_seq : 0;
   uint32_t removed = x.len[0] + x.len[1] + x.len[2] + x.len[3];
   uint32_t added = 7u + 7u + (B.long_reads ? 7u : 0u);  // NH:i, HI:i, AS:i
-  return 4u + 32u + l_qname + 4u * (((const uint32_t *)(B.r_a + r))[2] & RM_NCIG) + (ls + 1) / 2 + ls + (x.aux_len - removed) + added;
+  return 4u + 32u + l_qname + (ls + 1) / 2 + ls + (x.aux_len - removed) + added;
 }
 
 __global__ void __launch_bounds__(256) k_bam_size(BamArgs B) {
   int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= B.n_rows) return;
   int32_t a = (int32_t)((const uint32_t *)(B.r_rec + r))[1];
-  const uint8_t *rec = B.blob + B.rec_off[a];
-  B.out_len[r] = row_out_len(B, r, rec, B.aux[a]);
-  if ((((const uint32_t *)(B.r_a + r))[2] & RM_NCIG) > 65535u) *B.too_long = 1;  // would need htslib's CG:B,I spill-over; refused by the host
+  const uint32_t n_cig = ((const uint32_t *)(B.r_a + r))[2] & RM_NCIG;
+  B.out_len[r] = B.base_len[a] + 4u * n_cig;
+  if (n_cig > 65535u) *B.too_long = 1;  // would need htslib's CG:B,I spill-over; refused by the host
 }
 
 // 4-bit base complement of reverse_complement_bam (src/bam.cpp:658-667)

@@ -212,6 +212,7 @@ struct BamArgs {
   const uint32_t *rec_len;   // [n_aln] or null: rec_off[i + 1] - rec_off[i]
   int8_t *xs_out, *ts_out;   // [n_aln] or null: tag_char1("XS") / tag_char1("ts") of every record
   BamAux *aux;               // [n_aln]
+  uint32_t *base_len;        // [n_aln] bytes of an output row of this record without its CIGAR (k_bam_scan -> k_bam_size)
   uint32_t *cg_flag;         // set when a record's real CIGAR sits in a CG:B,I tag (null: not checked)
   const uint4 *r_a; const uint2 *r_c; const uint4 *r_rec;  // packed rows + the records behind them (PairArgs)
   const double *r_sim; const int32_t *r_clip;              // null: all zero
