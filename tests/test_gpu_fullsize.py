@@ -113,6 +113,7 @@ def test_full_size_bam_bundle_stream_properties():
       * the output is a well-formed chain: every record's block_size equals the distance to the next row offset;
       * the fixed fields written into the stream equal the row table (refID = transcript id, pos, mapq, flag bits);
       * l_seq of every output record equals its input record's, and the rewritten n_cigar_op equals the row's;
+      * the bytes of the first and of the last 3000 read names' records equal the oracle's (the tail lies beyond 20 GB);
       * the rows equal those of the flat-batch path on the same alignments (checksums);
       * BGZF deflate on the device: the first and the last blocks and a sample in between inflate (zlib) to the
         stream bytes they cover, with correct CRC32 / ISIZE, and all block sizes chain up to the compressed length."""
@@ -156,6 +157,21 @@ def test_full_size_bam_bundle_stream_properties():
     assert bool((u32_at(starts, 20) == lq_in[t["input_index"].to(torch.int64)]).all())
     cs_bundle = _checksums(t)
     del w3, w4, flag
+
+    # bytes: the records of the first and of the last 3000 read names equal the oracle's stream of those records (read
+    # names are independent of each other; the tail of the stream lies beyond 20 GB: 64-bit offsets everywhere)
+    from oracle import oracle_binding as ob
+    gs = _name_group_starts(batch)
+    oi = ob.OracleIndex(ann.as_dict())
+    ref_map = np.arange(ann.flat["n_refs"], dtype=np.int32)
+    n_aln = int(batch["n_aln"])
+    for a0, a1 in ((0, int(gs[3000])), (int(gs[-3001]), n_aln)):
+        orc = ob.run_bam(oi, ob.make_flags(), stream_h, roff[a0:a1], rlen[a0:a1], ref_map)[0]
+        exp = orc["bam_stream"]
+        assert orc["n_rows"] > 10000
+        got = (out[:len(exp)] if a0 == 0 else out[int(bam.n_bytes) - len(exp):]).cpu().numpy()
+        assert np.array_equal(got, exp), "BAM stream differs from the oracle's in the %s" % ("head" if a0 == 0 else "tail")
+    assert int(bam.n_bytes) > 20 * 1000 ** 3
 
     # the flat-batch path on the same alignments gives the same rows
     db = brdev.upload_batch(batch, "cuda:0")
