@@ -489,7 +489,7 @@ const char *br_bgzf_codec(void); /* "libdeflate" (bound at run time when present
 #define BR_K_SCAN 6       /* k_scan_* */
 #define BR_K_EMIT_AUX 7   /* k_project<64,true> (alignments with > 64 candidate rows) */
 #define BR_K_KSW 8        /* k_ksw (-S clip rescue DP) */
-#define BR_K_BAM 9        /* k_bam_scan + k_bam_size + k_bam_encode */
+#define BR_K_BAM 9        /* k_bam_scan + k_bam_size + k_bam_tasks (or k_bam_encode<G>) */
 #define BR_K_PARSE 10     /* k_rec_fields + k_group_off + k_rec_copy + k_mates* + k_seq_* */
 #define BR_K_CODEC 11     /* k_deflate_dynamic | k_deflate_fixed, k_bgzf_compact */
 #define BR_K_EMIT_SIMPLE 12 /* k_emit_dense, simple class (one read exon from a single M op) */

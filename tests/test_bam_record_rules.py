@@ -1,5 +1,5 @@
 """An independent, literal reading of write_to_bam's record rules (src/core.cpp:96-212; src/bam.cpp:474-702) on two tiny
-records, assembled byte by byte here and compared with the oracle (CPU) and, in the GPU run, with k_bam_encode.  This is
+records, assembled byte by byte here and compared with the oracle (CPU) and, in the GPU run, with the device encoders (k_bam_tasks).  This is
 the cross-check for the part of the oracle that restates htslib primitives (declared "parity unpinned")."""
 import struct
 

@@ -133,7 +133,7 @@ def test_fasta_flag_is_inert_for_short_reads():
 @pytest.mark.parametrize("mode,flags,kw", [("pe", {}, {"xs_tag": True}), ("pe", {}, {}), ("se", {"strict": 1}, {}),
                                            ("hifi", {"lr_hq": 1}, {}), ("ont", {"lr": 1}, {})])
 def test_bam_reencode_matches_oracle(mode, flags, kw):
-    """k_bam_scan / k_bam_size / k_bam_encode against the oracle's restatement of write_to_bam
+    """k_bam_scan / k_bam_size / k_bam_tasks against the oracle's restatement of write_to_bam
     (update_cigar, NH/HI/AS tags, XS/ts deletion, reverse_complement_bam, set_mate_info): the whole
     uncompressed BAM record stream must be byte-identical."""
     import torch
