@@ -420,7 +420,7 @@ struct br_ctx {
   uint64_t rescue_stats[4] = {0};  // problems, DP cells, accepted rescues, coded sequence bytes
   // device scratch
   DevBuf seg, meta, head, head2, fast_flag, fast_pre, n_matches, ranges, mask, match_off, cig_base, tile_sums, totals, counters_d;
-  DevBuf m_tid, m_aux, m_a, m_b, m_cigoff, cig_arena, big_list, n_big, m_aln;
+  DevBuf m_tid, m_aux, m_p, m_x, m_b, m_cigoff, cig_arena, big_list, n_big, m_aln;
   DevBuf bam_aux, bam_base, bam_len, bam_off, bam_out, bam_end;
   struct StageSlot { DevBuf blob, off, len; hipEvent_t ready = nullptr; std::vector<uint64_t> h_off; int64_t n = 0; };
   StageSlot stage[3];              // br_bam_bundle_stage: uploads of the next bundles overlap the current projection
@@ -515,7 +515,7 @@ extern "C" void br_ctx_free(br_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->ix->device);
   DevBuf *bufs[] = {&c->seg, &c->meta, &c->head, &c->head2, &c->fast_flag, &c->fast_pre, &c->n_matches, &c->ranges, &c->mask, &c->match_off, &c->cig_base,
-                    &c->tile_sums, &c->totals, &c->counters_d, &c->m_tid, &c->m_aux, &c->m_a, &c->m_b,
+                    &c->tile_sums, &c->totals, &c->counters_d, &c->m_tid, &c->m_aux, &c->m_p, &c->m_x, &c->m_b,
                     &c->m_cigoff, &c->cig_arena, &c->big_list, &c->n_big, &c->m_aln,
                     &c->bam_aux, &c->bam_base, &c->bam_len, &c->bam_off, &c->bam_out, &c->bam_end, &c->z_slots, &c->z_sizes, &c->z_off, &c->z_dense, &c->z_tabs, &c->z_tokens, &c->p_ncig, &c->p_name_len, &c->p_isnew, &c->p_group_pre, &c->p_small, &c->p_big, &c->p_seq_len, &c->p_ref_map, &c->fa_stats, &c->fa_n_prob, &c->fa_seq_bytes, &c->fa_prob_off, &c->fa_seqarena_off, &c->fa_probs, &c->fa_results,
                     &c->fa_seq_arena, &c->fa_clip_ops, &c->fa_ideal_cap, &c->fa_scratch, &c->b_seq_off, &c->b_seqs, &c->b_seq_src,
@@ -895,11 +895,11 @@ static int run_device_impl(br_ctx *c, const br_config *cfg, const br_device_batc
   out->n_matches = (int64_t)n_matches;
 
   size_t nm = (size_t)std::max<uint64_t>(n_matches, 1);
-  RC(c->m_tid.ensure(nm * 4)); RC(c->m_aux.ensure(nm * 4)); RC(c->m_a.ensure(nm * sizeof(uint4)));
+  RC(c->m_tid.ensure(nm * 4)); RC(c->m_aux.ensure(nm * 4)); RC(c->m_p.ensure(nm * sizeof(uint2))); RC(c->m_x.ensure(nm * sizeof(uint2)));
   RC(c->m_b.ensure(nm * sizeof(uint4))); RC(c->m_cigoff.ensure(nm * 8)); RC(c->m_aln.ensure(nm * 4));
   A.m_aln = c->m_aln.as<uint32_t>();
   RC(c->cig_arena.ensure((size_t)std::max<uint64_t>(n_cig_arena, 1) * 4));
-  A.m_tid = c->m_tid.as<uint32_t>(); A.m_aux = c->m_aux.as<uint32_t>(); A.m_a = c->m_a.as<uint4>();
+  A.m_tid = c->m_tid.as<uint32_t>(); A.m_aux = c->m_aux.as<uint32_t>(); A.m_p = c->m_p.as<uint2>(); A.m_x = c->m_x.as<uint2>();
   A.m_b = c->m_b.as<uint4>(); A.m_cigoff = c->m_cigoff.as<uint64_t>(); A.cig_arena = c->cig_arena.as<uint32_t>();
   if (n_matches) {
     if (fa_mode) {
@@ -950,7 +950,7 @@ static int run_device_impl(br_ctx *c, const br_config *cfg, const br_device_batc
   PairArgs P{};
   P.n_groups = ng; P.n_aln = n; P.long_reads = dc.long_reads; P.group_off = b->group_off; P.mate_idx = b->mate_idx;
   P.aln_group = c->aln_group.as<uint32_t>();
-  P.match_off = c->match_off.as<uint32_t>(); P.n_matches = c->n_matches.as<uint32_t>(); P.m_tid = A.m_tid; P.m_a = A.m_a; P.m_b = A.m_b;
+  P.match_off = c->match_off.as<uint32_t>(); P.n_matches = c->n_matches.as<uint32_t>(); P.m_tid = A.m_tid; P.m_p = A.m_p; P.m_x = A.m_x; P.m_b = A.m_b;
   P.m_cigoff = A.m_cigoff;
   P.n_rows = c->n_rows.as<uint32_t>();
   P.row_off = c->row_off.as<uint64_t>(); P.counters = c->counters_d.as<uint64_t>();
@@ -1036,7 +1036,7 @@ static int ensure_detail(br_ctx *c, hipStream_t st) {
   RC(c->pk_x.ensure(nr * sizeof(uint4)));
   if (c->last_n_rows > 0) {
     PairArgs P{};
-    P.n_rows_total = c->last_n_rows; P.r_rec = c->r_rec.as<uint4>(); P.m_a = c->m_a.as<uint4>(); P.r_x = c->pk_x.as<uint4>();
+    P.n_rows_total = c->last_n_rows; P.r_rec = c->r_rec.as<uint4>(); P.m_x = c->m_x.as<uint2>(); P.r_x = c->pk_x.as<uint4>();
     launch_rows_detail(st, P);
   }
   c->detail_valid = true;
@@ -1128,7 +1128,7 @@ extern "C" int br_ctx_collect_counters(br_ctx *c, const br_device_batch *b, void
   T.ix = c->ix->dev; T.n_aln = b->n_aln; T.ref_id = b->ref_id; T.cigar_off = b->cigar_off;
   T.seg = c->seg.as<uint2>(); T.head = c->head.as<uint4>(); T.out = stats.as<uint64_t>();
   int64_t nm = (int64_t)c->counters[6];
-  launch_stats(st, T, c->m_a.as<uint4>(), nm);
+  launch_stats(st, T, c->m_p.as<uint2>(), nm);
   uint64_t h[8];
   HIPCHK(hipMemcpyAsync(h, stats.p, 8 * 8, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));

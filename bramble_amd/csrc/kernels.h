@@ -34,7 +34,8 @@ struct ProjectArgs {
   const uint64_t *cig_base;   // [n_aln + 1]
   // match table (emit)
   uint32_t *m_tid, *m_aux;
-  uint4 *m_a;            // {pos, n_cigar | minus<<31, junc_hits, ref_consumed}
+  uint2 *m_p;            // {pos, n_cigar | minus<<31}: what the packed row needs
+  uint2 *m_x;            // {junc_hits, ref_consumed}: the detail column only
   uint4 *m_b;            // {clip_score, 0, similarity lo, similarity hi}
   uint64_t *m_cigoff;
   uint32_t *cig_arena;
@@ -128,7 +129,8 @@ struct PairArgs {
   const uint32_t *match_off;
   const uint32_t *n_matches;
   const uint32_t *m_tid;
-  const uint4 *m_a, *m_b;
+  const uint2 *m_p, *m_x;
+  const uint4 *m_b;
   const uint64_t *m_cigoff;
   uint32_t *n_rows;         // count pass: records per leader alignment
   uint64_t *pick;           // [n_groups] or null: k_primary<false> leaves the primary record's row here (~0: none) and k_rows sets the bit
@@ -192,7 +194,7 @@ struct StatsArgs {
   const uint4 *head;
   uint64_t *out;  // [8]
 };
-void launch_stats(hipStream_t st, const StatsArgs &T, const uint4 *m_a, int64_t n_matches);
+void launch_stats(hipStream_t st, const StatsArgs &T, const uint2 *m_p, int64_t n_matches);
 
 // BAM re-encoding (bam_kernels.hip)
 struct BamAux {

@@ -928,8 +928,8 @@ __global__ void __launch_bounds__(256, EMIT ? 4 : 8) k_project(ProjectArgs A) {
           else if (out_lds) for (uint32_t k = 0; k < n_out; k++) slot[k] = outp[k];
           uint32_t mi = moff + rank;
           A.m_tid[mi] = pay.x;
-          A.m_a[mi] = make_uint4((s == 0) ? p1.fwpos : p1.rcpos, n_out | ((uint32_t)s << 31), (uint32_t)acc.junc_hits,
-                                 (uint32_t)acc.ref_consumed);
+          A.m_p[mi] = make_uint2((s == 0) ? p1.fwpos : p1.rcpos, n_out | ((uint32_t)s << 31));
+          A.m_x[mi] = make_uint2((uint32_t)acc.junc_hits, (uint32_t)acc.ref_consumed);
           if (SIMF) {
             unsigned long long sb64 = (unsigned long long)__double_as_longlong(score);
             A.m_b[mi] = make_uint4((uint32_t)acc.clip_score, 0u, (uint32_t)sb64, (uint32_t)(sb64 >> 32));
@@ -1062,7 +1062,8 @@ __global__ void __launch_bounds__(256, CLS == 1 ? 8 : 6) k_emit_dense(ProjectArg
     }
     uint32_t mo = moff + rank;
     A.m_tid[mo] = pay.x;
-    A.m_a[mo] = make_uint4(h0.pos, n_out | ((uint32_t)s << 31), junc, ml);
+    A.m_p[mo] = make_uint2(h0.pos, n_out | ((uint32_t)s << 31));
+    A.m_x[mo] = make_uint2(junc, ml);
     if (SIMF) A.m_b[mo] = make_uint4(0u, 0u, 0u, 0u);
     A.m_cigoff[mo] = cref;
     return;
@@ -1122,8 +1123,8 @@ __global__ void __launch_bounds__(256, CLS == 1 ? 8 : 6) k_emit_dense(ProjectArg
   else if (out_lds) for (uint32_t q = 0; q < n_out; q++) slot[q] = outp[q];
   uint32_t mo = moff + rank;
   A.m_tid[mo] = pay.x;
-  A.m_a[mo] = make_uint4((s == 0) ? p1.fwpos : (plain ? acc.last_pos : p1.rcpos), n_out | ((uint32_t)s << 31), (uint32_t)acc.junc_hits,
-                         (uint32_t)acc.ref_consumed);
+  A.m_p[mo] = make_uint2((s == 0) ? p1.fwpos : (plain ? acc.last_pos : p1.rcpos), n_out | ((uint32_t)s << 31));
+  A.m_x[mo] = make_uint2((uint32_t)acc.junc_hits, (uint32_t)acc.ref_consumed);
   // without the similarity filter the score is 0.0 and (no -S rescue in this kernel) the clip score is 0: the row
   // kernel then neither reads m_b nor rewrites the two all-zero row columns
   if (SIMF) {
@@ -1555,7 +1556,7 @@ __global__ void __launch_bounds__(256) k_rows(PairArgs P) {
   const uint4 rec = P.r_rec[r];
   const uint32_t x = rec.x;
   const uint32_t tid = P.m_tid[x];
-  const uint4 ma = P.m_a[x];
+  const uint2 ma = P.m_p[x];   // {pos, n_cigar | minus << 31}; junc_hits / aligned_len sit in m_x, which only the detail column reads
   const uint64_t cg = P.m_cigoff[x];
   const uint32_t n = ma.y & 0x7fffffffu;
   if (n > RM_NCIG) P.counters[3] = 1;
@@ -1582,8 +1583,8 @@ __global__ void __launch_bounds__(256) k_rows_detail(PairArgs P) {
   int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= P.n_rows_total) return;
   const uint4 rec = P.r_rec[r];
-  const uint4 ma = P.m_a[rec.x];
-  P.r_x[r] = make_uint4(rec.y, ma.z, ma.w, rec.w & RR_HI);
+  const uint2 mx = P.m_x[rec.x];
+  P.r_x[r] = make_uint4(rec.y, mx.x, mx.y, rec.w & RR_HI);
 }
 
 // dense pool of the long rewritten CIGARs (host downloads only): sizes -> scan -> copy
@@ -1708,9 +1709,9 @@ __global__ void __launch_bounds__(256) k_stats(StatsArgs T) {
   }
 }
 
-__global__ void __launch_bounds__(256) k_sum_ncig(const uint4 *m_a, int64_t n, uint64_t *out) {
+__global__ void __launch_bounds__(256) k_sum_ncig(const uint2 *m_p, int64_t n, uint64_t *out) {
   unsigned long long acc = 0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) acc += m_a[i].y & 0x7fffffffu;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) acc += m_p[i].y & 0x7fffffffu;
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) acc += __shfl_down(acc, d, 64);
   if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long *)out, acc);
@@ -1851,9 +1852,9 @@ void launch_scan3(hipStream_t st, ScanArgs S, uint32_t *match_off, uint64_t *cig
   hipLaunchKernelGGL(k_scan3_apply, g, b, 0, st, S, match_off, cig_base, fast_pre);
 }
 
-void launch_stats(hipStream_t st, const StatsArgs &T, const uint4 *m_a, int64_t n_matches) {
+void launch_stats(hipStream_t st, const StatsArgs &T, const uint2 *m_p, int64_t n_matches) {
   if (T.n_aln > 0) hipLaunchKernelGGL(k_stats, dim3(grid_for(T.n_aln, 256)), dim3(256), 0, st, T);
-  if (n_matches > 0) hipLaunchKernelGGL(k_sum_ncig, dim3(1024), dim3(256), 0, st, m_a, n_matches, T.out + 7);
+  if (n_matches > 0) hipLaunchKernelGGL(k_sum_ncig, dim3(1024), dim3(256), 0, st, m_p, n_matches, T.out + 7);
 }
 
 void launch_group_ids(hipStream_t st, int64_t n_groups, const uint32_t *group_off, uint32_t *aln_group) {
