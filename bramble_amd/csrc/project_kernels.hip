@@ -961,21 +961,50 @@ __global__ void __launch_bounds__(256, EMIT ? 4 : 8) k_project(ProjectArgs A) {
   }
 }
 
-// k_expand: one lane per alignment appends its matches to the emit work list:
+// k_expand: the emit work list, one entry per match:
 // (alignment, k-th survivor) pairs, simple alignments first so that whole waves of
 // k_emit_dense take the short path.  Alignments with > 64 candidate rows are left
 // to the group kernel (~0u entries).
 __global__ void __launch_bounds__(256) k_expand(ProjectArgs A) {
-  int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (a >= A.n_aln) return;
-  uint32_t nm = A.n_matches[a];
-  if (nm == 0) return;
-  uint32_t fp = A.fast_pre[a];
-  uint32_t pos = (A.fast_flag[a] >> 31) ? fp : A.fast_pre[A.n_aln] + (A.match_off[a] - fp);
-  uint4 rg = A.ranges[a];
-  uint32_t n_items = (rg.y - rg.x) + (rg.w - rg.z);
-  uint32_t v = n_items <= 64 ? (uint32_t)a : 0xffffffffu;
-  for (uint32_t k = 0; k < nm; k++) A.m_aln[pos + k] = v;
+  // A wave takes 64 alignments.  Their entries of one class are one contiguous run of the list (the class offsets are
+  // prefix sums over the alignments), so the wave writes the run with all its lanes -- entry e belongs to the alignment
+  // whose exclusive count prefix is the last one <= e -- instead of every lane writing its own n_matches entries one by one.
+  __shared__ uint32_t sh_pre[4][64], sh_v[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t nm = 0, pos = 0, v = 0;
+  bool fast = false;
+  if (a < A.n_aln) nm = A.n_matches[a];
+  if (nm) {
+    const uint32_t fp = A.fast_pre[a];
+    fast = A.fast_flag[a] >> 31;
+    pos = fast ? fp : A.fast_pre[A.n_aln] + (A.match_off[a] - fp);
+    const uint4 rg = A.ranges[a];
+    const uint32_t n_items = (rg.y - rg.x) + (rg.w - rg.z);
+    v = n_items <= 64 ? (uint32_t)a : 0xffffffffu;
+  }
+  sh_v[wv][lane] = v;
+#pragma unroll
+  for (int c = 0; c < 2; c++) {
+    const uint32_t mine = (nm && fast == (c == 0)) ? nm : 0u;
+    const uint64_t have = __ballot(mine != 0u);
+    if (!have) continue;                       // the same for the whole wave
+    uint32_t inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t up = __shfl_up(inc, d); if (lane >= d) inc += up; }
+    const uint32_t total = __shfl(inc, 63), first = __shfl(pos, (int)__builtin_ctzll(have));
+    __builtin_amdgcn_wave_barrier();           // (the previous class's reads of sh_pre are done)
+    sh_pre[wv][lane] = inc - mine;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    for (uint32_t e = lane; e < total; e += 64) {
+      int l = 0;
+#pragma unroll
+      for (int st = 32; st; st >>= 1) if (sh_pre[wv][l + st] <= e) l += st;
+      A.m_aln[first + e] = sh_v[wv][l];
+    }
+  }
 }
 
 // k_emit_dense: one lane per match.  Match mi of alignment a is the k-th set bit
