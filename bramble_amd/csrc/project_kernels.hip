@@ -1470,6 +1470,99 @@ __global__ void __launch_bounds__(256) k_pair(PairArgs P) {
   if (!EMIT) { P.n_rows[i] = rows; P.pbit[i] = (rows && !unpaired) ? 1 : 0; }
 }
 
+// k_pair_emit: the emit pass of k_pair with the records written by the whole wave.  A wave takes 64 alignments; the
+// records of its leaders are one contiguous run of the row order (row_off is a prefix sum over the alignments), so
+//   1. lane i describes leader i (case, first match of either mate, NH, first HI, the two sets of common list positions
+//      the count pass left) in LDS,
+//   2. every lane takes one record of the run per round: record e -> leader (search over the wave's count prefixes) ->
+//      the k-th record of that leader, computed from the description (the c-th common pair = the c-th set bits of the two
+//      position sets), one 16-byte store, coalesced,
+// instead of every leader lane writing its 1..2 x 64 records one after the other.  Leaders whose lists exceed the 64-bit
+// position sets (rare) write their records themselves with the merge loop, as k_pair<true> does.
+struct PairLead { uint32_t pre, kind, mi0, mm0, m, nh, hi0, pad; uint64_t pa, pb; };   // kind: 0 none, 1 unpaired, 2 common pairs, 3 one pair of different transcripts, 4 merge loop
+__global__ void __launch_bounds__(256) k_pair_emit(PairArgs P) {
+  __shared__ PairLead sh_l[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t i64 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t i = (uint32_t)i64;
+  uint4 *__restrict__ rec = P.r_rec;
+  uint32_t rows = 0, kind = 0, mi0 = 0, mm0 = 0, ni = 0, nm = 0, nh = 0, hi0 = 0;
+  int32_t m = -1;
+  uint64_t r0 = 0, pa = 0, pb = 0;
+  if (i64 < P.n_aln) {
+    r0 = P.row_off[i];
+    rows = (uint32_t)(P.row_off[i + 1] - r0);
+  }
+  if (rows) {   // a leader with records (the count pass: leader && ni, src/mates.cpp:153)
+    m = P.mate_idx[i];
+    const uint32_t g = P.aln_group[i];
+    const uint32_t a0 = P.group_off[g], a1 = P.group_off[g + 1];
+    mi0 = P.match_off[i]; ni = P.n_matches[i];
+    const uint64_t gs = P.row_off[a0], gn = P.row_off[a1] - gs;
+    nh = (uint32_t)gn; hi0 = (uint32_t)(r0 - gs) + 1u;
+    if (gn > (uint64_t)RR_HI) P.counters[3] = 1;   // HI does not fit its 28 bits
+    if (m >= 0 && (uint32_t)m > i && (uint32_t)m < a1) { mm0 = P.match_off[m]; nm = P.n_matches[m]; }
+    if (nm == 0) kind = 1;
+    else if (ni <= 64u && nm <= 64u) { pa = P.pmask[i]; pb = P.pmask[m]; kind = pa ? 2u : 3u; }
+    else kind = 4;
+  }
+  // the wave's record run
+  uint32_t inc = rows;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const uint32_t up = __shfl_up(inc, d); if (lane >= d) inc += up; }
+  const uint32_t total = __shfl(inc, 63);
+  const uint64_t have = __ballot(rows != 0u);
+  if (!have) return;   // the same for the whole wave
+  const int first_lane = (int)__builtin_ctzll(have);
+  const uint64_t run0 = ((uint64_t)__shfl((uint32_t)(r0 >> 32), first_lane) << 32) | __shfl((uint32_t)r0, first_lane);
+  PairLead &L = sh_l[wv][lane];
+  L.pre = inc - rows; L.kind = kind; L.mi0 = mi0; L.mm0 = mm0; L.m = (uint32_t)m; L.nh = nh; L.hi0 = hi0; L.pa = pa; L.pb = pb;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  const uint32_t i_base = i - (uint32_t)lane;
+  for (uint32_t e = lane; e < total; e += 64) {
+    int l = 0;
+#pragma unroll
+    for (int st = 32; st; st >>= 1) if (sh_l[wv][l + st].pre <= e) l += st;
+    const PairLead &D = sh_l[wv][l];
+    const uint32_t k = e - D.pre, kd = D.kind;
+    if (kd == 4u) continue;   // written by its leader below
+    uint4 v;
+    if (kd == 1u) {
+      // unpaired emission: one record per transcript, ascending tid (mates.cpp:157-176)
+      v = make_uint4(D.mi0 + k, i_base + (uint32_t)l, D.nh, (D.hi0 + k) | RR_FIRST);
+    } else if (kd == 2u) {
+      // both mates matched, the c-th common transcript (mates.cpp:204-231): the c-th set bit of either position set
+      const uint32_t c = k >> 1, second = k & 1u;
+      uint64_t bits = second ? D.pb : D.pa;
+      for (uint32_t j = 0; j < c; j++) bits &= bits - 1;
+      const uint32_t p = (uint32_t)__builtin_ctzll(bits);
+      v = second ? make_uint4(D.mm0 + p, D.m, D.nh, (D.hi0 + k) | RR_PAIRED | RR_SAME)
+                 : make_uint4(D.mi0 + p, i_base + (uint32_t)l, D.nh, (D.hi0 + k) | RR_FIRST | RR_PAIRED | RR_SAME);
+    } else {
+      // one transcript each, different ones
+      v = k ? make_uint4(D.mm0, D.m, D.nh, (D.hi0 + 1u) | RR_PAIRED)
+            : make_uint4(D.mi0, i_base + (uint32_t)l, D.nh, D.hi0 | RR_FIRST | RR_PAIRED);
+    }
+    rec[run0 + e] = v;
+  }
+  if (kind == 4u) {   // lists beyond the 64-bit position sets: the merge itself
+    uint32_t x = 0, y = 0, common = 0;
+    while (x < ni && y < nm) {
+      const uint32_t tx = P.m_tid[mi0 + x], ty = P.m_tid[mm0 + y];
+      if (tx < ty) x++;
+      else if (ty < tx) y++;
+      else {
+        const uint64_t r = r0 + 2ull * common;
+        rec[r] = make_uint4(mi0 + x, i, nh, (hi0 + 2u * common) | RR_FIRST | RR_PAIRED | RR_SAME);
+        rec[r + 1] = make_uint4(mm0 + y, (uint32_t)m, nh, (hi0 + 2u * common + 1u) | RR_PAIRED | RR_SAME);
+        common++; x++; y++;
+      }
+    }
+  }
+}
+
 // k_primary: one lane per read name (grid-stride).  Primary = the emitted record (pair) with the
 // best similarity score; ties are broken by get_rand(n_tied, std::hash(name))
 // (src/core.cpp:243-307), restated in primary_pick.h.  A leader's records are all paired or all
@@ -1893,7 +1986,7 @@ void launch_group_ids(hipStream_t st, int64_t n_groups, const uint32_t *group_of
 
 void launch_pair(hipStream_t st, const PairArgs &P, bool emit) {
   if (P.n_aln <= 0) return;
-  if (emit) hipLaunchKernelGGL((k_pair<true>), dim3(grid_for(P.n_aln, 256)), dim3(256), 0, st, P);
+  if (emit) hipLaunchKernelGGL(k_pair_emit, dim3(grid_for(P.n_aln, 256)), dim3(256), 0, st, P);
   else hipLaunchKernelGGL((k_pair<false>), dim3(grid_for(P.n_aln, 256)), dim3(256), 0, st, P);
 }
 
