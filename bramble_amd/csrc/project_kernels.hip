@@ -1393,9 +1393,31 @@ __global__ void __launch_bounds__(256) k_group_ids(int64_t n_groups, const uint3
 // EMIT=true writes {match, input, NH, HI | flags} per record at the scanned
 // offset: NH = records of the read name (flush, src/core.cpp:250-258), HI = 1-based rank among them (:309-325).
 // k_rows turns those into the packed rows, one lane per record.
+#define PAIR_TIDS 1024   // transcript ids of a wave's 64 alignments staged in LDS (count pass)
 template <bool EMIT>
 __global__ void __launch_bounds__(256) k_pair(PairArgs P) {
   int64_t i64 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // count pass: the merge of two mates' tid lists is a chain of dependent loads, two per step.  The lists of a wave's 64
+  // alignments are one contiguous piece of m_tid (match_off is a prefix sum) and mates sit next to each other, so the wave
+  // copies that piece to LDS first (coalesced) and the chains run on LDS latency; lists outside the piece, or a piece that
+  // does not fit, are read from memory as before.
+  __shared__ uint32_t sh_tid[EMIT ? 1 : 4][EMIT ? 1 : PAIR_TIDS];
+  uint32_t t0 = 0, t_n = 0;
+  const int wv_ = EMIT ? 0 : (int)(threadIdx.x >> 6);
+  if (!EMIT) {
+    const int lane = threadIdx.x & 63;
+    const int64_t w0 = i64 - lane;
+    if (w0 < P.n_aln) {
+      const int64_t w1 = w0 + 64 < P.n_aln ? w0 + 64 : P.n_aln;
+      t0 = P.match_off[w0];
+      const uint32_t n = P.match_off[w1] - t0;
+      if (n <= PAIR_TIDS) { t_n = n; for (uint32_t k = lane; k < n; k += 64) sh_tid[wv_][k] = P.m_tid[t0 + k]; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+  auto tid_at = [&](uint32_t idx) -> uint32_t { return (!EMIT && idx - t0 < t_n) ? sh_tid[wv_][idx - t0] : P.m_tid[idx]; };
   if (i64 >= P.n_aln) return;
   uint32_t i = (uint32_t)i64;
   uint32_t rows = 0;
@@ -1444,7 +1466,7 @@ __global__ void __launch_bounds__(256) k_pair(PairArgs P) {
       }
       uint64_t bits_a = 0, bits_b = 0;
       while (x < ni && y < nm) {
-        uint32_t tx = P.m_tid[mi0 + x], ty = P.m_tid[mm0 + y];
+        uint32_t tx = tid_at(mi0 + x), ty = tid_at(mm0 + y);
         if (tx < ty) x++;
         else if (ty < tx) y++;
         else {
