@@ -59,6 +59,8 @@ __global__ void __launch_bounds__(256) k_segment(int64_t n_aln, const int32_t *_
   bool exon_started = false, intron = false, ins = false;
   uint32_t n = 0;
   uint32_t ex_start = 0, ex_end = 0;  // GSeg exon (zero-initialised)
+  uint2 e0 = make_uint2(0, 0), e1 = e0, e2 = e0;   // the first three read exons stay in registers for head / head2 (reading them
+                                                   // back from seg[] would wait for the stores above and then for the loads)
   for (uint32_t i = 0; i < n_cigar; ++i) {
     uint32_t w = cg[i], op = CIG_OP(w), len = CIG_LEN(w);
     switch (op) {
@@ -70,7 +72,9 @@ __global__ void __launch_bounds__(256) k_segment(int64_t n_aln, const int32_t *_
         if (!exon_started) break;
         if (!ins || !intron) {
           ex_end = (uint32_t)(pos0 + l); ex_start = (uint32_t)(exstart + 1);
-          out[n++] = make_uint2(ex_start, ex_end + 1);
+          const uint2 v = make_uint2(ex_start, ex_end + 1);
+          if (n == 0) e0 = v; else if (n == 1) e1 = v; else if (n == 2) e2 = v;
+          out[n++] = v;
         }
         l += (int)len; exstart = pos0 + l; intron = true;
         break;
@@ -80,7 +84,9 @@ __global__ void __launch_bounds__(256) k_segment(int64_t n_aln, const int32_t *_
   }
   if (!intron) {
     ex_start = (uint32_t)(exstart + 1); ex_end = (uint32_t)(pos0 + l);
-    out[n++] = make_uint2(ex_start, ex_end + 1);
+    const uint2 v = make_uint2(ex_start, ex_end + 1);
+    if (n == 0) e0 = v; else if (n == 1) e1 = v; else if (n == 2) e2 = v;
+    out[n++] = v;
   }
   if (ex_end == 0) n = 0;  // the reference aborts here (GSam.cpp:290); we project nothing
   int32_t rid = ref_id[a];
@@ -123,9 +129,9 @@ __global__ void __launch_bounds__(256) k_segment(int64_t n_aln, const int32_t *_
   // clip lengths, for the -S rescue kernels only (long reads): short-read presets do not write the 16 bytes
   if (cfg.long_reads) { AlnMeta m; m.n_seg = n; m.smode = smode; m.n_left_clip = lclip; m.n_right_clip = rclip; meta[a] = m; }
   // everything k_project needs for read exon 0 in one 16-byte record
-  uint2 q0 = n ? out[0] : make_uint2(0, 0);
+  uint2 q0 = n ? e0 : make_uint2(0, 0);
   head[a] = make_uint4(q0.x, q0.y, n, n ? (((uint32_t)rid << 2) | smode) : 0u);
-  uint2 q1 = n > 1 ? out[1] : make_uint2(0, 0), q2 = n > 2 ? out[2] : make_uint2(0, 0);
+  uint2 q1 = n > 1 ? e1 : make_uint2(0, 0), q2 = n > 2 ? e2 : make_uint2(0, 0);
   head2[a] = make_uint4(q1.x, q1.y, q2.x, q2.y);
   // "simple" alignments: one read exon from a single M op, short-read presets.  They
   // are processed first (k_perm) so that whole waves take the short code paths.
