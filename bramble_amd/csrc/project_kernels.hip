@@ -61,8 +61,13 @@ __global__ void __launch_bounds__(256) k_segment(int64_t n_aln, const int32_t *_
   uint32_t ex_start = 0, ex_end = 0;  // GSeg exon (zero-initialised)
   uint2 e0 = make_uint2(0, 0), e1 = e0, e2 = e0;   // the first three read exons stay in registers for head / head2 (reading them
                                                    // back from seg[] would wait for the stores above and then for the loads)
+  // the first four CIGAR words with one load (nearly every short read has no more): the loop below then waits once, not
+  // once per word.  Not for the last words of the array: the load would read past it.
+  uint32_t w4[4] = {0, 0, 0, 0};
+  const bool pre4 = (uint64_t)c0 + 4u <= (uint64_t)cigar_off[n_aln];
+  if (pre4) { struct __attribute__((packed, aligned(4))) Q4 { uint32_t a, b, c, d; }; const Q4 q = *(const Q4 *)cg; w4[0] = q.a; w4[1] = q.b; w4[2] = q.c; w4[3] = q.d; }
   for (uint32_t i = 0; i < n_cigar; ++i) {
-    uint32_t w = cg[i], op = CIG_OP(w), len = CIG_LEN(w);
+    uint32_t w = (pre4 && i < 4u) ? (i == 0 ? w4[0] : i == 1 ? w4[1] : i == 2 ? w4[2] : w4[3]) : cg[i], op = CIG_OP(w), len = CIG_LEN(w);
     switch (op) {
       case OP_EQ: case OP_X: case OP_M:
         exon_started = true; l += (int)len; intron = false; ins = false; break;
