@@ -67,6 +67,11 @@ def main():
             return "k_scan_*"
         if re.match(r"k_(rows|primary)<", k):
             return re.sub(r"<.*>$", "", k)
+        m = re.match(r"k_emit_dense<(true|false),(\d),(true|false)>", k)
+        if m:
+            return "k_emit_dense<%s,%s>" % (m.group(1), m.group(2))   # the timer's name (the third parameter is the -S variant)
+        if k == "k_pair_emit":
+            return "k_pair<true>"                                      # the emit pass keeps its timer's name
         return k
     kern = {}
     for k, v in full.items():
