@@ -61,6 +61,12 @@ def main():
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive leg")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # One command, N ranks: like the reference's one reader feeding N workers from a single process
+        # (src/threads.cpp:114-162, src/bramble.cpp:675-690), `python bench.py --gpus N` starts its own ranks.  This
+        # process has not touched HIP (torch is not even imported yet): the ranks are fresh children, one per GPU.
+        raise SystemExit(spawn_ranks(args.gpus))
+
     import ctypes as C
     import numpy as np
     import torch
@@ -69,8 +75,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d, or without a launcher" % (args.gpus, world, args.gpus))
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
@@ -124,6 +129,16 @@ def main():
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         return float(t.item()), float(cnt.item())
 
+    def gather_all(x):
+        """every rank's value of x (rank order): what the max above hides"""
+        if dist is None:
+            return [float(x)]
+        rdev = dev if dist.get_backend() == "nccl" else "cpu"
+        mine = torch.tensor([x], dtype=torch.float64, device=rdev)
+        parts = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        return [float(p.item()) for p in parts]
+
     # ---- leg 1 (value): device-resident ----
     rows = None
     for _ in range(args.warmup):
@@ -141,6 +156,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t_start
     ctx.set_profiling(False)
+    per_rank_ms = [1e3 * e / args.steps for e in gather_all(elapsed)]
+    per_rank_aln = gather_all(n_aln)
     elapsed, total_aln = reduce_max_sum(elapsed, n_aln)
     n_rows, n_matches = int(rows.n_rows), int(rows.n_matches)
     counters = ctx.collect_counters(dbatch, stream) if rank == 0 else None
@@ -232,6 +249,10 @@ def main():
             "value": total_aln * args.steps / elapsed,
             "unit": "alignments/s",
             "n_gpus": world,
+            "n_ranks_seen": dist.get_world_size() if dist is not None else 1,
+            "dist_backend": (dist.get_backend() if dist is not None else None),
+            "per_rank_ms_per_step": [round(x, 4) for x in per_rank_ms],
+            "per_rank_alignments_per_step": [int(x) for x in per_rank_aln],
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * step_s,
@@ -279,12 +300,44 @@ def main():
                         "FETCH_SIZE + WRITE_SIZE per launch (profiles/pmc_traffic.json) when collected for this workload",
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed at N=1 only (the other ranks would wait for it)
             out["cpu_baseline"] = cpu_baseline(ann, batch, args.cpu_sample)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py <same
+    arguments>` as a child (fresh processes: nothing here has initialised the GPU), pass the ranks' output through, and
+    return the launcher's exit code -- non-zero when any rank failed, in which case no JSON line counts."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "2")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout:
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln.strip()          # rank 0's single JSON line: printed last, once the launcher has ended cleanly
+        else:
+            sys.stdout.write(ln)
+            sys.stdout.flush()
+    rc = proc.wait()
+    if rc == 0 and line is None:
+        print("bench.py: the ranks ended without a result line", file=sys.stderr)
+        return 1
+    if rc == 0:
+        print(line, flush=True)
+    return rc
 
 
 def cpu_baseline(ann, batch, sample_aln):

@@ -93,3 +93,44 @@ def test_shards_never_split_a_name_group():
             assert lo == prev and lo in starts and hi in starts
             prev = hi
         assert prev == batch["n_aln"]
+
+
+def _run_bench(extra, env_extra=None, timeout=600):
+    import subprocess
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    env.pop("LOCAL_RANK", None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=env, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, text=True, timeout=timeout)
+
+
+def test_bench_without_launcher_fails_loudly_when_a_rank_fails():
+    """`python bench.py --gpus 2` starts its own ranks (no external torchrun); on a box without a GPU every rank
+    fails, and the command must end non-zero without a result line instead of hanging or printing a number."""
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    r = _run_bench(["--gpus", "2", "--pairs", "1000", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-pcie"],
+                   {"BENCH_DIST_BACKEND": "gloo"})
+    assert r.returncode != 0
+    assert '"metric"' not in r.stdout
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks():
+    """one command, N ranks.  Two ranks share the one card of the test box (gloo for the barrier and
+    the reductions); the line must say n_gpus 2 = n_ranks_seen 2, carry both ranks' times, and value = both ranks'
+    alignments over the slowest rank's time."""
+    import json
+    r = _run_bench(["--gpus", "2", "--pairs", "20000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                   {"BENCH_DIST_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and len(d["per_rank_ms_per_step"]) == 2
+    assert d["scaling"] == "weak" and d["pcie_inclusive"] is not None
+    total = sum(d["per_rank_alignments_per_step"])
+    assert abs(d["value"] - total / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert abs(d["ms_per_step"] - max(d["per_rank_ms_per_step"])) <= 1e-3 * d["ms_per_step"] + 1e-3
