@@ -346,6 +346,7 @@ def cpu_baseline(ann, batch, sample_aln):
     read-name boundary: -p 1 and -p nproc, bundle-per-thread like src/threads.cpp."""
     import numpy as np
     from oracle import oracle_binding as ob
+    native = ob.use_native()   # -O3 -march=native -ffp-contract=off, compiled on this machine (BASELINE.md)
     n = int(batch["n_aln"])
     noff = batch["name_off"]
     names = batch["names"]
@@ -386,21 +387,21 @@ def cpu_baseline(ann, batch, sample_aln):
     except AttributeError:
         avail = os.cpu_count() or 1
     cores = max(1, min(avail, int(os.environ.get("BENCH_CPU_THREADS", 16))))
-    sub1 = head(sample_aln)
-    # the reference cuts bundles of >= 100000 alignments (src/bramble.cpp:362): give every worker two
+    # the reference cuts bundles of >= 100000 alignments (src/bramble.cpp:362): give every worker two.  Both legs run the
+    # SAME sample (about 13 s on one thread, 1 s on sixteen)
     subn = head(max(sample_aln, 2 * 100000 * cores))
-    _, _, s1 = ob.run(oi, ob.make_flags(), sub1, n_threads=1, want_matches=False)
+    _, _, s1 = ob.run(oi, ob.make_flags(), subn, n_threads=1, want_matches=False)
     _, _, sn = ob.run(oi, ob.make_flags(), subn, n_threads=cores, want_matches=False)
     return {
         "value": subn["n_aln"] / sn,
         "unit": "alignments/s",
         "cores": cores,
         "kind": "port",
-        "sample": "first %d alignments of the same batch (cut at a read-name boundary) on %d threads, bundles of "
-                  ">=100000 alignments per worker like src/threads.cpp; CPU oracle = restatement of the reference "
-                  "algorithm (not the bramble binary); 1-thread figure on the first %d alignments"
-                  % (subn["n_aln"], cores, sub1["n_aln"]),
-        "value_1_thread": sub1["n_aln"] / s1,
+        "build": "g++ -O3 -march=native -ffp-contract=off on this host" if native else "g++ -O3 -ffp-contract=off (portable build: the native rebuild failed)",
+        "sample": "first %d alignments of the same batch (cut at a read-name boundary) on %d threads and on 1 thread, "
+                  "bundles of >=100000 alignments per worker like src/threads.cpp; CPU oracle = restatement of the "
+                  "reference algorithm (not the bramble binary)" % (subn["n_aln"], cores),
+        "value_1_thread": subn["n_aln"] / s1,
         "cores_1_thread": 1,
     }
 

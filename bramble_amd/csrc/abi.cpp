@@ -1730,38 +1730,53 @@ extern "C" int br_project_batch(br_ctx *c, const br_config *cfg, const br_batch 
   return BR_OK;
 }
 
-// project_group_with (bramble-rs/src/api.rs:285-290): one query name, AoS in/out
-extern "C" int br_project_group(br_ctx *c, const br_config *cfg, const br_alignment *alns, size_t n,
-                                const br_projected **out, size_t *n_out) {
+// project_group_with (bramble-rs/src/api.rs:285-464), AoS in/out.  Shape and field meanings are the Rust library's;
+// the values are the C++ path's: mates pair up by the C++ rule (name + position hash, src/bramble.cpp:272-311
+// = k_mates), not by find_mate_pairs' mutual pointers (groups.rs:126-190), and hit_index is carried for layout parity
+// only -- neither the C++ reader nor find_mate_pairs reads it.
+// single_name: one call = one query name (br_project_group); else any number of name-collated groups (br_project_groups).
+static int project_groups_impl(br_ctx *c, const br_config *cfg, const br_alignment *alns, size_t n, bool single_name,
+                               const br_projected **out, size_t *n_out) {
   if (!c || !cfg || (!alns && n) || !out || !n_out) return BR_ERR_INVALID_ARG;
   *out = nullptr; *n_out = 0;
-  std::vector<int32_t> ref_id(n), ref_start(n), mate_ref(n), mate_start(n), lq(n);
-  std::vector<uint16_t> flags(n); std::vector<int8_t> xs(n), ts(n);
-  std::vector<uint64_t> coff(n + 1, 0), noff(n + 1, 0), soff(n + 1, 0);
+  std::vector<int32_t> ref_id, ref_start, mate_ref, mate_start, lq;
+  std::vector<uint16_t> flags; std::vector<int8_t> xs, ts;
+  std::vector<uint64_t> coff(1, 0), noff(1, 0), soff(1, 0);
   std::vector<uint32_t> cig; std::string names, seqs;
+  std::vector<uint64_t> kept;          // batch position -> caller's index (alignments with ref_id < 0 are skipped, api.rs:316-318)
+  std::vector<char> read_strand;       // infer_strand (api.rs:470-489) per kept alignment
   const char *name0 = n ? (alns[0].query_name ? alns[0].query_name : "") : "";
   bool any_seq = false;
   for (size_t i = 0; i < n; i++) {
     const br_alignment &a = alns[i];
+    const char *nm = a.query_name ? a.query_name : "";
     // one call = one query name (GenomicAlignment::query_name: "shared by all alignments in the group", api.rs:74-75)
-    if (strcmp(a.query_name ? a.query_name : "", name0) != 0) return BR_ERR_INVALID_ARG;
+    if (single_name && strcmp(nm, name0) != 0) return BR_ERR_INVALID_ARG;
     if (a.ref_start < 0 || a.ref_start > 0x7fffffffll || a.mate_ref_start < 0 || a.mate_ref_start > 0x7fffffffll) return BR_ERR_INVALID_ARG;
     if ((a.n_cigar && !a.cigar) || (a.sequence_len && !a.sequence)) return BR_ERR_INVALID_ARG;
-    ref_id[i] = a.ref_id; ref_start[i] = (int32_t)a.ref_start;
+    if (a.ref_id < 0) continue;        // api.rs:316-318
+    kept.push_back(i);
+    ref_id.push_back(a.ref_id); ref_start.push_back((int32_t)a.ref_start);
     uint16_t f = 0;
     if (a.is_paired) { f |= 0x1; if (a.mate_is_unmapped) f |= 0x8; f |= a.is_first_in_pair ? 0x40 : 0x80; }
     if (a.is_reverse) f |= 0x10;
-    flags[i] = f; xs[i] = (int8_t)a.xs_strand; ts[i] = (int8_t)a.ts_strand;
-    mate_ref[i] = a.mate_ref_id; mate_start[i] = (int32_t)a.mate_ref_start;
-    cig.insert(cig.end(), a.cigar, a.cigar + a.n_cigar); coff[i + 1] = cig.size();
-    names += name0; noff[i + 1] = names.size();
+    flags.push_back(f); xs.push_back((int8_t)a.xs_strand); ts.push_back((int8_t)a.ts_strand);
+    char rs = '.';
+    if (a.xs_strand == '+' || a.xs_strand == '-') rs = a.xs_strand;
+    else if (a.ts_strand == '+' || a.ts_strand == '-') rs = a.is_reverse ? (a.ts_strand == '+' ? '-' : '+') : a.ts_strand;
+    read_strand.push_back(rs);
+    mate_ref.push_back(a.mate_ref_id); mate_start.push_back((int32_t)a.mate_ref_start);
+    cig.insert(cig.end(), a.cigar, a.cigar + a.n_cigar); coff.push_back(cig.size());
+    names += nm; noff.push_back(names.size());
     // sequence: Option<Vec<u8>> (api.rs:91-95); the clip rescue shares the first one of the group (api.rs:308-312, src/core.cpp:353-378)
     if (a.sequence && a.sequence_len) { seqs.append(a.sequence, a.sequence_len); any_seq = true; }
-    soff[i + 1] = seqs.size();
-    lq[i] = (int32_t)(a.read_len ? a.read_len : a.sequence_len);   // api.rs:345-349
+    soff.push_back(seqs.size());
+    lq.push_back((int32_t)(a.read_len ? a.read_len : a.sequence_len));   // api.rs:345-349
   }
+  const size_t nk = kept.size();
+  if (nk == 0) { c->h_proj.clear(); *out = c->h_proj.data(); return BR_OK; }   // api.rs:392-394
   br_batch b{};
-  b.n_aln = (int64_t)n; b.ref_id = ref_id.data(); b.ref_start = ref_start.data(); b.flags = flags.data();
+  b.n_aln = (int64_t)nk; b.ref_id = ref_id.data(); b.ref_start = ref_start.data(); b.flags = flags.data();
   b.xs = xs.data(); b.ts = ts.data(); b.cigar_off = coff.data(); b.cigar = cig.data();
   b.mate_ref_id = mate_ref.data(); b.mate_start = mate_start.data(); b.name_off = noff.data();
   b.names = names.data(); b.l_qseq = lq.data();
@@ -1786,15 +1801,33 @@ extern "C" int br_project_group(br_ctx *c, const br_config *cfg, const br_alignm
       if (op == OP_M || op == OP_EQ || op == OP_X || op == OP_I || op == OP_MATCH_OVR || op == OP_INS_OVR) qa += cg[k] >> 4;
     }
     p.query_aligned_len = qa;
-    p.is_reverse = rows.strand[r] == '-';
+    const size_t bi = (size_t)rows.input_index[r];
+    // api.rs:453 <- evaluate.rs:1062: the transcript's strand differs from the read's INFERRED strand ('.' for a read
+    // without XS / ts: then true on either strand).  The C++ AlignInfo::is_reverse is never assigned (include/evaluate.h:157);
+    // what the C++ path acts on is the transcript strand (src/bam.cpp:549-553): transcript_strand below.
+    p.transcript_strand = (char)rows.strand[r];
+    p.is_reverse = p.transcript_strand != read_strand[bi];
     p.similarity_score = rows.similarity_score[r];
     p.nh = rows.nh[r]; p.hi = rows.hi[r]; p.is_primary = rows.is_primary[r];
     p.same_transcript_as_mate = rows.same_transcript_as_mate[r]; p.is_paired_out = rows.is_paired[r];
-    p.insert_size = rows.insert_size[r]; p.input_index = (uint64_t)rows.input_index[r];
+    p.insert_size = rows.insert_size[r]; p.input_index = kept[bi];
     p.mapq = rows.mapq[r]; p.cigar = cg; p.n_cigar = nc;
   }
   *out = c->h_proj.data(); *n_out = c->h_proj.size();
   return BR_OK;
+}
+
+extern "C" int br_project_group(br_ctx *c, const br_config *cfg, const br_alignment *alns, size_t n,
+                                const br_projected **out, size_t *n_out) {
+  return project_groups_impl(c, cfg, alns, n, true, out, n_out);
+}
+
+// Many read-name groups per call (name-collated: each query name one contiguous run of `alns`): what a caller that holds
+// batches of groups (bramble-cli batches 64, bramble-cli/src/pipeline.rs:29) should use -- one trip through the device
+// pipeline instead of one per group.  NH / HI / primary are per query name, as in the per-group call.
+extern "C" int br_project_groups(br_ctx *c, const br_config *cfg, const br_alignment *alns, size_t n,
+                                 const br_projected **out, size_t *n_out) {
+  return project_groups_impl(c, cfg, alns, n, false, out, n_out);
 }
 
 extern "C" uint32_t br_primary_pick(const char *name, size_t len, uint32_t n_tied) {

@@ -431,6 +431,15 @@ extern "C" int br_cli_main(int argc, char **argv) {
   if (!o.quiet) printf("[bramble] processing alignments :-)\n");
   double t_setup = since();
 
+  // One failure anywhere stops every runner.  The flag flips under each worker's done_m before its condition variable is
+  // notified: a runner that has just evaluated the wait predicate as false holds that mutex until it blocks, so the
+  // notification cannot fall between its check and its wait (a lost wakeup would leave it -- and the join below -- hanging).
+  std::atomic<int> fail{0};
+  auto raise_fail = [&]() {
+    for (auto &x : workers) { std::lock_guard<std::mutex> l(x->done_m); fail = 1; }
+    for (auto &x : workers) x->done_cv.notify_all();
+  };
+
   // ordered writer: chunks arrive tagged with their bundle's sequence number
   std::mutex out_m; std::condition_variable out_cv; std::map<uint64_t, OutChunk> out_map; uint64_t out_next = 0; bool out_done = false;
   std::thread writer([&]() {
@@ -444,7 +453,10 @@ extern "C" int br_cli_main(int argc, char **argv) {
         c = it->second; out_map.erase(it); out_next++;
       }
       auto td0 = now();
-      if (writer_err.empty() && c.n && !(o.device_deflate ? wr.write_raw(c.data, (size_t)c.n) : wr.write(c.data, (size_t)c.n))) writer_err = wr.error();
+      if (writer_err.empty() && c.n && !(o.device_deflate ? wr.write_raw(c.data, (size_t)c.n) : wr.write(c.data, (size_t)c.n))) {
+        writer_err = wr.error();
+        raise_fail();                      // nothing projected from here on could be written: the runners drain
+      }
       t_deflate += secs(td0, now());
       Worker *w = workers[(size_t)c.worker].get();
       { std::lock_guard<std::mutex> l(w->done_m); w->written++; }
@@ -452,7 +464,6 @@ extern "C" int br_cli_main(int argc, char **argv) {
     }
   });
 
-  std::atomic<int> fail{0};
   for (auto &wp : workers) {
     Worker *w = wp.get();
     // uploader: stages bundle k of this worker into device slot k % 3 on the context's copy stream while the runner
@@ -481,7 +492,7 @@ extern "C" int br_cli_main(int argc, char **argv) {
         w->t_wait_in += secs(tw0, now());
         if (!st) break;
         auto &b = st->b;
-        if (!fail && st->rc) { fprintf(stderr, "error: upload failed on device %d: %s\n", w->device, br_strerror(st->rc)); fail = 1; }
+        if (!fail && st->rc) { fprintf(stderr, "error: upload failed on device %d: %s\n", w->device, br_strerror(st->rc)); raise_fail(); }
         br_host_bam hb;
         memset(&hb, 0, sizeof(hb));
         if (!fail) {
@@ -491,13 +502,13 @@ extern "C" int br_cli_main(int argc, char **argv) {
           auto t0 = now();
           int prc2 = fail ? 0 : br_project_bam_staged(w->ctx, &o.cfg, &bb, st->slot, &hb);
           w->gpu_seconds += secs(t0, now());
-          if (prc2) { fprintf(stderr, "error: projection failed on device %d: %s\n", w->device, br_strerror(prc2)); fail = 1; }
+          if (prc2) { fprintf(stderr, "error: projection failed on device %d: %s\n", w->device, br_strerror(prc2)); raise_fail(); }
         }
         const uint64_t seq = b->seq;
         { auto spare = std::make_unique<brio::ByteBuf>(); spare->swap(b->blob); std::lock_guard<std::mutex> l(pool_m); pool.push_back(std::move(spare)); }
         { std::lock_guard<std::mutex> l(w->permit_m); w->permits++; }
         w->permit_cv.notify_all();
-        if (fail) { for (auto &x : workers) x->done_cv.notify_all(); continue; }  // drain
+        if (fail) continue;  // drain
         w->total_complete += hb.total_complete; w->total_unique += hb.total_unique; w->dropped += hb.dropped_reads; w->n_bundles++;
         { std::lock_guard<std::mutex> l(w->done_m); w->produced++; }
         { std::lock_guard<std::mutex> l(out_m); out_map[seq] = OutChunk{hb.data, hb.n_bytes, w->id}; }

@@ -108,7 +108,7 @@ class BrAlignment(C.Structure):  # br_alignment = GenomicAlignment (bramble-rs/s
 class BrProjected(C.Structure):  # br_projected = ProjectedAlignment (api.rs:135-176) + mapq + rewritten CIGAR
     _fields_ = [("transcript_id", C.c_uint32), ("transcript_start", C.c_uint32), ("transcript_end", C.c_uint32),
                 ("aligned_len", C.c_uint32), ("query_aligned_len", C.c_uint32), ("is_reverse", C.c_uint8),
-                ("similarity_score", C.c_double), ("nh", C.c_uint32), ("hi", C.c_uint32), ("is_primary", C.c_uint8),
+                ("transcript_strand", C.c_char), ("similarity_score", C.c_double), ("nh", C.c_uint32), ("hi", C.c_uint32), ("is_primary", C.c_uint8),
                 ("same_transcript_as_mate", C.c_uint8), ("is_paired_out", C.c_uint8), ("insert_size", C.c_int32),
                 ("input_index", C.c_uint64), ("mapq", C.c_uint32), ("cigar", _P(C.c_uint32)), ("n_cigar", C.c_uint32)]
 
@@ -145,7 +145,7 @@ EXPORTS = ["br_index_build", "br_index_build_flat", "br_index_free", "br_index_n
            "br_index_transcript_len", "br_index_num_refs", "br_index_num_intervals", "br_index_device_bytes", "br_config_short_read",
            "br_config_long_read", "br_config_resolve", "br_batch_prepare", "br_batch_seq_source", "br_ctx_new", "br_ctx_free",
            "br_project_batch", "br_project_batch_device", "br_device_rows_expand", "br_batch_stage", "br_project_staged", "br_host_rows_wait", "br_project_batch_packed",
-           "br_pin_host", "br_unpin_host", "br_project_group", "br_bam_encode_device", "br_project_bam_device", "br_project_bam_bundle", "br_bam_bundle_stage", "br_project_bam_staged", "br_bam_split", "br_annotation_load", "br_annotation_free",
+           "br_pin_host", "br_unpin_host", "br_project_group", "br_project_groups", "br_bam_encode_device", "br_project_bam_device", "br_project_bam_bundle", "br_bam_bundle_stage", "br_project_bam_staged", "br_bam_split", "br_annotation_load", "br_annotation_free",
            "br_annotation_num_transcripts", "br_annotation_transcripts", "br_annotation_num_refs", "br_annotation_refnames", "br_cli_main", "br_bgzf_write_file", "br_bgzf_read_file",
            "br_free_buffer", "br_bgzf_codec", "br_bgzf_deflate_device", "br_ctx_set_profiling",
            "br_ctx_set_param", "br_ctx_kernel_ms", "br_ctx_collect_counters", "br_ctx_last_counters", "br_ctx_rescue_stats", "br_ctx_ksw_diag", "br_device_rows_detail", "br_ctx_ksw_pairs", "br_primary_pick", "br_row_mapq", "br_version", "br_strerror"]
@@ -208,6 +208,7 @@ def lib():
                                               _P(BrDeviceRows)]
         L.br_project_group.argtypes = [C.c_void_p, _P(BrConfig), _P(BrAlignment), C.c_size_t, _P(_P(BrProjected)),
                                        _P(C.c_size_t)]
+        L.br_project_groups.argtypes = L.br_project_group.argtypes
         L.br_batch_stage.argtypes = [C.c_void_p, _P(BrBatch), C.c_int]
         L.br_project_staged.argtypes = [C.c_void_p, _P(BrConfig), C.c_int, _P(BrHostRows)]
         L.br_host_rows_wait.argtypes = [C.c_void_p, C.c_int]
@@ -646,7 +647,11 @@ class Context:
         check(lib().br_project_batch_packed(self.h, C.byref(cfg), C.byref(b), C.byref(r)), "br_project_batch_packed")
         return host_rows_to_numpy(r)
 
-    def project_group(self, cfg, alns):
+    def project_groups(self, cfg, alns):
+        """br_project_groups: any number of name-collated groups in one call (same dicts as project_group)."""
+        return self.project_group(cfg, alns, _many=True)
+
+    def project_group(self, cfg, alns, _many=False):
         """project_group_with (bramble-rs/src/api.rs:285-290): alns = list of dicts with the GenomicAlignment fields
         (query_name, ref_id, ref_start, cigar [uint32 BAM-packed] and optional is_reverse, is_paired, is_first_in_pair,
         mate_is_unmapped, xs_strand, ts_strand, hit_index, mate_ref_id, mate_ref_start, sequence, read_len) -> list of
@@ -680,11 +685,13 @@ class Context:
                 x.sequence_len = len(sb)
             x.read_len = int(a.get("read_len", 0))
         out, n_out = _P(BrProjected)(), C.c_size_t()
-        check(lib().br_project_group(self.h, C.byref(cfg), arr, n, C.byref(out), C.byref(n_out)), "br_project_group")
+        fn = lib().br_project_groups if _many else lib().br_project_group
+        check(fn(self.h, C.byref(cfg), arr, n, C.byref(out), C.byref(n_out)), "br_project_groups" if _many else "br_project_group")
         res = []
         for k in range(n_out.value):
             p = out[k]
             d = {f: getattr(p, f) for f, _ in BrProjected._fields_ if f != "cigar"}
+            d["transcript_strand"] = p.transcript_strand.decode()
             d["cigar"] = np.array([p.cigar[j] for j in range(p.n_cigar)], dtype=np.uint32)
             res.append(d)
         return res

@@ -326,9 +326,15 @@ int br_project_batch_packed(br_ctx *, const br_config *, const br_batch *, br_ho
 int br_pin_host(void *p, size_t bytes);
 int br_unpin_host(void *p);
 
-/* AoS convenience mirroring project_group_with (bramble-rs/src/api.rs:285-290):
+/* AoS convenience mirroring project_group_with (bramble-rs/src/api.rs:285-464):
  * all alignments of ONE query name in, one br_projected per emitted record out
- * (array owned by the context). */
+ * (array owned by the context; alignments with ref_id < 0 are skipped, api.rs:316-318).
+ * The shape is the Rust library's, the values are the C++ path's: mates
+ * pair up by the C++ rule (name + position, src/bramble.cpp:272-311), not by the mutual
+ * mate pointers of groups.rs:126-190; hit_index is carried for layout parity only (neither
+ * rule reads it).  br_project_groups takes any number of name-collated groups in one call
+ * (the Rust CLI hands over 64 at a time, bramble-cli/src/pipeline.rs:29): one trip through
+ * the device pipeline instead of one per group. */
 typedef struct br_alignment { /* GenomicAlignment, api.rs:73-126 */
   const char *query_name;
   int32_t ref_id;
@@ -347,10 +353,13 @@ typedef struct br_alignment { /* GenomicAlignment, api.rs:73-126 */
 
 typedef struct br_projected { /* ProjectedAlignment, api.rs:135-176 */
   uint32_t transcript_id;
-  uint32_t transcript_start; /* align_pos (groups.rs:362-368): fwpos / rcpos */
+  uint32_t transcript_start; /* align_pos (groups.rs:362-368): fwpos / rcpos, 0-BASED like the Rust code and the BAM
+                              * POS field (the doc comment at api.rs:141-142 says 1-based; the code does not add 1) */
   uint32_t transcript_end;   /* transcript_start + aligned_len - 1, saturating */
   uint32_t aligned_len, query_aligned_len;
-  uint8_t is_reverse;        /* transcript strand '-' */
+  uint8_t is_reverse;        /* api.rs:453 <- evaluate.rs:1062: transcript strand != the read's inferred strand
+                              * (infer_strand, api.rs:470-489: XS, else ts flipped on a reverse read, else '.': then 1) */
+  char transcript_strand;    /* '+' / '-': AlignInfo::strand of the C++ path (what src/bam.cpp:549-553 acts on) */
   double similarity_score;
   uint32_t nh, hi;
   uint8_t is_primary, same_transcript_as_mate, is_paired_out;
@@ -363,6 +372,8 @@ typedef struct br_projected { /* ProjectedAlignment, api.rs:135-176 */
 
 int br_project_group(br_ctx *, const br_config *, const br_alignment *alns, size_t n,
                      const br_projected **out, size_t *n_out);
+int br_project_groups(br_ctx *, const br_config *, const br_alignment *alns, size_t n,
+                      const br_projected **out, size_t *n_out);
 
 /* ---- BAM record re-encoding (next row of the scope table: the data format after the path) -- */
 

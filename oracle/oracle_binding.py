@@ -89,10 +89,28 @@ def build():
     subprocess.check_call(["make", "-s", "-C", _HERE])
 
 
+_NATIVE = False
+
+
+def use_native():
+    """bench.py's cpu_baseline leg only: rebuild the oracle ON THIS MACHINE with -march=native (the CPU
+    figure is a host-tuned build; -ffp-contract=off stays) into oracle/_native/ and load that copy from now on.  The
+    parity tests keep the portable liboracle.so, which is built in the container and travels to the GPU box -- a
+    -march=native object from another machine could fault there.  Returns True when the native copy is in use."""
+    global _LIB, _NATIVE
+    try:
+        subprocess.check_call(["make", "-s", "-C", _HERE, "native"], timeout=600)
+    except Exception:
+        return False
+    _LIB = None
+    _NATIVE = True
+    return True
+
+
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "liboracle.so")
+        path = os.path.join(_HERE, "_native", "liboracle.so") if _NATIVE else os.path.join(_HERE, "liboracle.so")
         if not os.path.exists(path):
             build()
         L = C.CDLL(path)

@@ -41,7 +41,7 @@ int main(void) {
     for (size_t r = 0; r < n; r++) {
       printf("%s %s %u %u %u %u %c nh=%u hi=%u mapq=%u primary=%u cigar=", reads[k].query_name,
              br_index_transcript_name(ix, out[r].transcript_id), out[r].transcript_start, out[r].transcript_end,
-             out[r].aligned_len, out[r].query_aligned_len, out[r].is_reverse ? '-' : '+', out[r].nh, out[r].hi, out[r].mapq,
+             out[r].aligned_len, out[r].query_aligned_len, out[r].transcript_strand, out[r].nh, out[r].hi, out[r].mapq,
              (unsigned)out[r].is_primary);
       for (uint32_t j = 0; j < out[r].n_cigar; j++) printf("%u%c", out[r].cigar[j] >> 4, "MIDNSHP=XB"[out[r].cigar[j] & 15u]);
       printf("\n");

@@ -28,7 +28,10 @@ def test_reference_fixture_through_project_group(golden):
         assert len(res) == len(rd["expect"]), rd["id"]
         for p, exp in zip(res, rd["expect"]):
             assert idx.transcript_name(p["transcript_id"]) == exp["transcript"]
-            assert p["transcript_start"] == exp["pos"] and p["is_reverse"] == (exp["strand"] == "-")
+            assert p["transcript_start"] == exp["pos"] and p["transcript_strand"] == exp["strand"]
+            # api.rs:453 <- evaluate.rs:1062: an untagged read's inferred strand is '.', which differs from either
+            # transcript strand -- the Rust API returns true for K9 / K10; an XS tag that agrees gives false
+            assert p["is_reverse"] == 1
             assert (p["nh"], p["hi"], p["mapq"]) == (exp["nh"], exp["hi"], exp["mapq"])
             assert format_cigar(p["cigar"]) == exp["out"]
             assert p["aligned_len"] == 100 and p["query_aligned_len"] == 100
@@ -72,13 +75,18 @@ def _check_groups(ann, b, flags, max_groups):
     order = np.argsort(-sizes, kind="stable")[:max_groups // 2].tolist() + list(range(0, len(sizes), max(1, len(sizes) // (max_groups // 2))))
     for g in order:
         lo, hi = int(goff[g]), int(goff[g + 1])
-        res = ctx.project_group(cfg, _group_alignments(b, lo, hi))
+        alns = _group_alignments(b, lo, hi)
+        res = ctx.project_group(cfg, alns)
         sel = np.nonzero(ogroup == g)[0]
         assert len(res) == len(sel), (g, len(res), len(sel))
         for p, r in zip(res, sel):
             c0, c1 = int(orc["cigar_off"][r]), int(orc["cigar_off"][r + 1])
             assert p["transcript_id"] == orc["tid"][r] and p["transcript_start"] == orc["pos"][r]
-            assert p["is_reverse"] == (orc["strand"][r] == ord("-"))
+            assert p["transcript_strand"] == chr(orc["strand"][r])
+            a_in = alns[p["input_index"]]
+            rs = a_in["xs_strand"] or ((a_in["ts_strand"] if not a_in["is_reverse"] else {"+": "-", "-": "+"}[a_in["ts_strand"]])
+                                       if a_in["ts_strand"] else ".")
+            assert p["is_reverse"] == int(p["transcript_strand"] != rs)
             assert p["aligned_len"] == max(int(orc["ref_consumed"][r]), 0)
             assert np.array_equal(p["cigar"], orc["cigar"][c0:c1])
             assert (p["nh"], p["hi"], p["mapq"]) == (orc["nh"][r], orc["hi"][r], orc["mapq"][r])
@@ -134,6 +142,63 @@ def test_project_group_passes_the_sequence_to_the_clip_rescue():
         if rescued >= 40:
             break
     assert rescued >= 10
+    ctx.close()
+    idx.close()
+
+
+def test_project_groups_many_names_in_one_call_equal_the_per_group_calls():
+    """br_project_groups: a run of name-collated groups in one call = the concatenation of the per-group calls (input_index
+    counted over the whole call); alignments with ref_id < 0 are skipped (api.rs:316-318) without shifting input_index."""
+    ann = synth.Annotation("G", n_genes=900, n_refs=2)
+    b = ann.reads(600, "pe", p_multimap=0.3)
+    idx = lib.Index(ann.as_dict(), device=0)
+    ctx = lib.Context(idx)
+    cfg = lib.make_config()
+    _, goff = lib.prepare_batch(b)
+    n_groups = min(len(goff) - 1, 200)
+    many, per_group = [], []
+    for g in range(n_groups):
+        lo, hi = int(goff[g]), int(goff[g + 1])
+        alns = _group_alignments(b, lo, hi)
+        base = len(many)
+        # an unplaced record in front of every third group
+        if g % 3 == 0:
+            many.append(dict(alns[0], ref_id=-1))
+            base += 1
+        many.extend(alns)
+        for p in ctx.project_group(cfg, alns):
+            q = dict(p)
+            q["input_index"] += base
+            per_group.append(q)
+    res = ctx.project_groups(cfg, many)
+    assert len(res) == len(per_group) and len(res) > 200
+    for p, q in zip(res, per_group):
+        for k in ("transcript_id", "transcript_start", "transcript_end", "aligned_len", "query_aligned_len", "is_reverse",
+                  "transcript_strand", "nh", "hi", "is_primary", "same_transcript_as_mate", "is_paired_out", "insert_size",
+                  "input_index", "mapq"):
+            assert p[k] == q[k], k
+        assert np.array_equal(p["cigar"], q["cigar"])
+    # a call that holds only unplaced records returns nothing (api.rs:392-394)
+    assert ctx.project_groups(cfg, [dict(many[1], ref_id=-1)]) == []
+    ctx.close()
+    idx.close()
+
+
+def test_project_group_strand_tags_decide_is_reverse(golden):
+    """is_reverse = transcript strand != inferred read strand (evaluate.rs:1062 with infer_strand, api.rs:470-489)."""
+    fx = golden["projection"]
+    ann = annotation_from_gtf_like(fx["refnames"], fx["transcripts"])
+    idx = lib.Index(ann, device=0)
+    ctx = lib.Context(idx)
+    rd = fx["reads"][0]   # K9: tx1 on '+'
+    base = {"query_name": rd["name"], "ref_id": rd["ref_id"], "ref_start": rd["ref_start"], "cigar": parse_cigar(rd["cigar"]),
+            "read_len": rd["read_len"]}
+    for extra, want_n, want_rev in (({}, 1, 1), ({"xs_strand": "+"}, 1, 0), ({"ts_strand": "+"}, 1, 0),
+                                    ({"ts_strand": "-", "is_reverse": True}, 1, 0), ({"xs_strand": "-"}, 0, None)):
+        res = ctx.project_group(lib.make_config(), [dict(base, **extra)])
+        assert len(res) == want_n, extra
+        if want_n:
+            assert res[0]["transcript_strand"] == "+" and res[0]["is_reverse"] == want_rev, extra
     ctx.close()
     idx.close()
 
