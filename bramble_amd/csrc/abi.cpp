@@ -444,6 +444,11 @@ struct br_ctx {
   int deflate_dynamic = 1;
   int emit_split = 1;
   int count_split = 1;   // count pass as two kernels: the main one without the exon walk, a second one for the alignments that need it
+  int single_pass = 0;   // short-read presets: count and emit in one sweep (k_project1 + k_emit_wl) instead of count / scan / expand / emit.
+                         // Built for VERDICT r02 item 2, bit-exact, and SLOWER (11.3-12.3 ms against 9.2-9.8 ms per 10 M pairs,
+                         // DESIGN section 10): off unless asked for ("single_pass" / BRAMBLE_AMD_SINGLE_PASS=1, the A/B switch)
+  DevBuf wl, p1;         // the single pass's work list and counters
+  uint64_t p1_hw[3] = {0, 0, 0};   // high-water marks of its three allocators (match slots, work-list entries, arena words): next call's capacities
   DevBuf walk_list, pmask, pbit, pick;
   // packed row table (the product of the row stage) and what its kernels need
   DevBuf r_rec, pk_a, pk_c, pk_x, pk_sim, pk_clip;
@@ -477,7 +482,7 @@ struct br_ctx {
   DevBuf b_name_off, b_names;
   // device staging of host batches (br_project_batch)
   DevBuf b_ref_id, b_ref_start, b_flags, b_xs, b_ts, b_cigar_off, b_cigar, b_mate_idx, b_group_off, b_lqseq;
-  uint64_t *h_totals = nullptr;  // pinned, 8 words
+  uint64_t *h_totals = nullptr;  // pinned, 192 words
   // host result storage (br_project_batch / br_project_group)
   // pinned: the row download runs at PCIe speed instead of through the pageable bounce path
   PinnedVec<int32_t> h_input, h_clip, h_junc, h_refc, h_mate_tid, h_mate_pos, h_isize;
@@ -502,9 +507,11 @@ extern "C" int br_ctx_new(const br_index *ix, br_ctx **out) {
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, ix->device));
   c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  HIPCHK(hipHostMalloc((void **)&c->h_totals, 32 * sizeof(uint64_t), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void **)&c->h_totals, 192 * sizeof(uint64_t), hipHostMallocDefault));   // [0..31] scan totals and counters, [96..] the single pass's counters
   const char *bl = getenv("BRAMBLE_AMD_BAM_LANES");
   if (bl) { int v = atoi(bl); if (v == 0 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) c->bam_lanes = v; }
+  const char *sp = getenv("BRAMBLE_AMD_SINGLE_PASS");   // A/B: 0 = the two-pass count / scan / expand / emit path
+  if (sp) c->single_pass = atoi(sp) != 0;
   const char *g = getenv("BRAMBLE_AMD_GROUP_LANES");
   if (g) { int v = atoi(g); if (v == 8 || v == 16 || v == 32 || v == 64) c->group_lanes = v; }
   *out = c;
@@ -525,7 +532,7 @@ extern "C" void br_ctx_free(br_ctx *c) {
                     &c->r_ncig, &c->r_strand, &c->r_sim, &c->r_clip, &c->r_junc, &c->r_refc, &c->r_cigoff,
                     &c->cigar_out, &c->r_paired, &c->r_same, &c->r_first, &c->r_primary, &c->b_name_off, &c->b_names, &c->b_ref_id, &c->b_ref_start,
                     &c->b_flags, &c->b_xs, &c->b_ts, &c->b_cigar_off, &c->b_cigar, &c->b_mate_idx,
-                    &c->b_group_off, &c->b_lqseq, &c->walk_list, &c->pmask, &c->pbit, &c->pick,
+                    &c->b_group_off, &c->b_lqseq, &c->walk_list, &c->pmask, &c->pbit, &c->pick, &c->wl, &c->p1,
                     &c->fa_srcs, &c->fa_want, &c->ksw_desc, &c->ksw_dp, &c->ksw_left, &c->ksw_cnt, &c->ksw_group, &c->ksw_tape, &c->ksw_raw};
   for (DevBuf *b : bufs) b->release();
   for (auto &e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -560,6 +567,7 @@ extern "C" int br_ctx_set_param(br_ctx *c, const char *key, int64_t v) {
   if (!strcmp(key, "group_lanes")) { if (v != 8 && v != 16 && v != 32 && v != 64) return BR_ERR_INVALID_ARG; c->group_lanes = (int)v; return BR_OK; }
   if (!strcmp(key, "emit_split")) { c->emit_split = v != 0; return BR_OK; }
   if (!strcmp(key, "count_split")) { c->count_split = v != 0; return BR_OK; }
+  if (!strcmp(key, "single_pass")) { c->single_pass = v != 0; return BR_OK; }
   if (!strcmp(key, "deflate_dynamic")) { c->deflate_dynamic = v != 0; return BR_OK; }
   if (!strcmp(key, "bam_lanes")) { if (v != 0 && v != 4 && v != 8 && v != 16 && v != 32 && v != 64) return BR_ERR_INVALID_ARG; c->bam_lanes = (int)v; return BR_OK; }
   if (!strcmp(key, "ksw_fast")) { c->ksw_fast = v != 0; return BR_OK; }
@@ -820,7 +828,52 @@ static int run_device_impl(br_ctx *c, const br_config *cfg, const br_device_batc
   S.n = n; S.src32 = c->n_matches.as<uint32_t>(); S.cigar_off = b->cigar_off; S.head = c->head.as<uint4>();
   S.tile_sums = c->tile_sums.as<uint64_t>(); S.fast_flag = c->fast_flag.as<uint32_t>();
   FaArgs F{};
-  if (!fa_mode) {
+  // Short-read presets (no similarity filter, no -S): count and emit in one sweep.  The match table, the general class's
+  // work list and the CIGAR arena are sized from the last call's high-water marks (first call: a guess); a pass that runs
+  // out of room says so, and is run again with what its counters ask for.
+  bool one_pass = !fa_mode && !dc.filter_by_similarity && c->single_pass && c->count_split && ix->dev.n_rows < 0x7fffffffu &&
+                  (c->group_lanes == 8 || c->group_lanes == 16);
+  uint64_t p1_matches = 0, p1_entries = 0, p1_words = 0;
+  if (one_pass) {
+    RC(c->p1.ensure(P1_WORDS * 8));
+    RC(c->walk_list.ensure((size_t)n * 4)); A.walk_list = c->walk_list.as<uint32_t>(); A.n_walk = c->n_big.as<uint32_t>() + 1;
+    int nb1 = n_blocks;
+    { const int64_t need = (n + 127) / 128 / 4 + 1; if (need < nb1) nb1 = (int)need; }
+    const uint64_t n_waves = (uint64_t)nb1 * 4;
+    uint64_t cap_m = std::max<uint64_t>(c->p1_hw[0] + c->p1_hw[0] / 4, 8ull * (uint64_t)n) + n_waves * P1_PAGE_M + 4096;
+    uint64_t cap_w = std::max<uint64_t>(c->p1_hw[1] + c->p1_hw[1] / 4, 4ull * (uint64_t)n) + n_waves * P1_PAGE_W + 4096;
+    uint64_t cap_c = std::max<uint64_t>(c->p1_hw[2] + c->p1_hw[2] / 4, 48ull * (uint64_t)n) + n_waves * P1_PAGE_C + 4096;
+    for (int attempt = 0;; attempt++) {
+      if (cap_m >= 0xffffffffull || cap_w >= 0xffffffffull) { one_pass = false; break; }   // slots are 32-bit: the two-pass path reports the capacity error
+      RC(c->m_tid.ensure(cap_m * 4)); RC(c->m_aux.ensure(cap_m * 4)); RC(c->m_p.ensure(cap_m * sizeof(uint2))); RC(c->m_x.ensure(cap_m * sizeof(uint2)));
+      RC(c->m_cigoff.ensure(cap_m * 8)); RC(c->wl.ensure(cap_w * sizeof(uint4))); RC(c->cig_arena.ensure(cap_c * 4));
+      A.m_tid = c->m_tid.as<uint32_t>(); A.m_aux = c->m_aux.as<uint32_t>(); A.m_p = c->m_p.as<uint2>(); A.m_x = c->m_x.as<uint2>();
+      A.m_b = nullptr; A.m_cigoff = c->m_cigoff.as<uint64_t>(); A.cig_arena = c->cig_arena.as<uint32_t>();
+      A.match_off_w = c->match_off.as<uint32_t>(); A.cig_base_w = c->cig_base.as<uint64_t>(); A.wl = c->wl.as<uint4>();
+      A.p1 = c->p1.as<uint64_t>(); A.cap_m = cap_m; A.cap_w = cap_w; A.cap_c = cap_c;
+      HIPCHK(hipMemsetAsync(c->p1.p, 0, P1_WORDS * 8, st));
+      HIPCHK(hipMemsetAsync(c->n_big.p, 0, 8, st));
+      RC(pf.begin(BR_K_P1));
+      launch_project1(st, A, c->group_lanes, n_blocks, 1);
+      RC(pf.end());
+      RC(pf.begin(BR_K_P1_WALK));
+      launch_project1(st, A, c->group_lanes, n_blocks, 2);
+      RC(pf.end());
+      HIPCHK(hipMemcpyAsync(c->h_totals + 96, c->p1.p, P1_WORDS * 8, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      const uint64_t *h = c->h_totals + 96;
+      if (!h[P1_OVF]) { p1_matches = h[P1_NM]; p1_entries = h[P1_W]; p1_words = h[P1_C]; c->p1_hw[0] = h[P1_M]; c->p1_hw[1] = h[P1_W]; c->p1_hw[2] = h[P1_C]; break; }
+      if (attempt >= 4) return BR_ERR_CAPACITY;
+      // what the counters reached (waves that ran out stopped placing, but kept counting their requests) + a margin
+      cap_m = std::max(cap_m, h[P1_M]) + std::max(cap_m, h[P1_M]) / 4 + n_waves * P1_PAGE_M;
+      cap_w = std::max(cap_w, h[P1_W]) + std::max(cap_w, h[P1_W]) / 4 + n_waves * P1_PAGE_W;
+      cap_c = std::max(cap_c, h[P1_C]) + std::max(cap_c, h[P1_C]) / 4 + n_waves * P1_PAGE_C;
+    }
+    if (!one_pass) { A.p1 = nullptr; A.wl = nullptr; HIPCHK(hipMemsetAsync(c->n_big.p, 0, 8, st)); }
+  }
+  if (one_pass) {
+    // nothing: counted and placed above
+  } else if (!fa_mode) {
     const bool split = A.walk_list && !dc.filter_by_similarity;
     RC(pf.begin(BR_K_COUNT));
     launch_project(st, A, false, c->group_lanes, n_blocks, split ? 1 : 0);
@@ -887,21 +940,42 @@ static int run_device_impl(br_ctx *c, const br_config *cfg, const br_device_batc
     launch_scan3(st, S, c->match_off.as<uint32_t>(), c->cig_base.as<uint64_t>(), c->fast_pre.as<uint32_t>(), d_tot + 0);
     RC(pf.end());
   }
-  HIPCHK(hipMemcpyAsync(c->h_totals, d_tot, 3 * 8, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
-  uint64_t n_matches = c->h_totals[0], n_cig_arena = c->h_totals[1];
-  const int64_t n_simple = fa_mode ? -1 : (int64_t)c->h_totals[2];  // matches of the single-M class (first in the emit list)
+  uint64_t n_matches = 0, n_cig_arena = 0;
+  int64_t n_simple = -1;
+  if (one_pass) { n_matches = p1_matches; n_cig_arena = p1_words; }
+  else {
+    HIPCHK(hipMemcpyAsync(c->h_totals, d_tot, 3 * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    n_matches = c->h_totals[0]; n_cig_arena = c->h_totals[1];
+    n_simple = fa_mode ? -1 : (int64_t)c->h_totals[2];  // matches of the single-M class (first in the emit list)
+  }
   if (n_matches >= 0xffffffffull) return BR_ERR_CAPACITY;
   out->n_matches = (int64_t)n_matches;
 
-  size_t nm = (size_t)std::max<uint64_t>(n_matches, 1);
-  RC(c->m_tid.ensure(nm * 4)); RC(c->m_aux.ensure(nm * 4)); RC(c->m_p.ensure(nm * sizeof(uint2))); RC(c->m_x.ensure(nm * sizeof(uint2)));
-  RC(c->m_b.ensure(nm * sizeof(uint4))); RC(c->m_cigoff.ensure(nm * 8)); RC(c->m_aln.ensure(nm * 4));
-  A.m_aln = c->m_aln.as<uint32_t>();
-  RC(c->cig_arena.ensure((size_t)std::max<uint64_t>(n_cig_arena, 1) * 4));
-  A.m_tid = c->m_tid.as<uint32_t>(); A.m_aux = c->m_aux.as<uint32_t>(); A.m_p = c->m_p.as<uint2>(); A.m_x = c->m_x.as<uint2>();
-  A.m_b = c->m_b.as<uint4>(); A.m_cigoff = c->m_cigoff.as<uint64_t>(); A.cig_arena = c->cig_arena.as<uint32_t>();
-  if (n_matches) {
+  if (!one_pass) {
+    size_t nm = (size_t)std::max<uint64_t>(n_matches, 1);
+    RC(c->m_tid.ensure(nm * 4)); RC(c->m_aux.ensure(nm * 4)); RC(c->m_p.ensure(nm * sizeof(uint2))); RC(c->m_x.ensure(nm * sizeof(uint2)));
+    RC(c->m_b.ensure(nm * sizeof(uint4))); RC(c->m_cigoff.ensure(nm * 8)); RC(c->m_aln.ensure(nm * 4));
+    A.m_aln = c->m_aln.as<uint32_t>();
+    RC(c->cig_arena.ensure((size_t)std::max<uint64_t>(n_cig_arena, 1) * 4));
+    A.m_tid = c->m_tid.as<uint32_t>(); A.m_aux = c->m_aux.as<uint32_t>(); A.m_p = c->m_p.as<uint2>(); A.m_x = c->m_x.as<uint2>();
+    A.m_b = c->m_b.as<uint4>(); A.m_cigoff = c->m_cigoff.as<uint64_t>(); A.cig_arena = c->cig_arena.as<uint32_t>();
+  }
+  if (n_matches && one_pass) {
+    // alignments with > 64 candidate rows (or more survivors than the stash holds): a few long-running blocks on the second
+    // stream beside the work-list kernel
+    RC(ensure_aux_stream(c));
+    HIPCHK(hipEventRecord(c->aux_ev[0], st));
+    HIPCHK(hipStreamWaitEvent(c->ksw_stream, c->aux_ev[0], 0));
+    RC(pf.begin(BR_K_EMIT_AUX, c->ksw_stream));
+    launch_project(c->ksw_stream, A, true, 64, c->n_cu);
+    RC(pf.end());
+    HIPCHK(hipEventRecord(c->aux_ev[1], c->ksw_stream));
+    RC(pf.begin(BR_K_EMIT_WL));
+    launch_emit_wl(st, A, (int64_t)p1_entries);
+    RC(pf.end());
+    HIPCHK(hipStreamWaitEvent(st, c->aux_ev[1], 0));
+  } else if (n_matches) {
     if (fa_mode) {
       // the work list + one lane per match for alignments with at most 64 candidate rows, k_project_fa<3> for the others
       RC(pf.begin(BR_K_EXPAND));
@@ -1128,7 +1202,7 @@ extern "C" int br_ctx_collect_counters(br_ctx *c, const br_device_batch *b, void
   T.ix = c->ix->dev; T.n_aln = b->n_aln; T.ref_id = b->ref_id; T.cigar_off = b->cigar_off;
   T.seg = c->seg.as<uint2>(); T.head = c->head.as<uint4>(); T.out = stats.as<uint64_t>();
   int64_t nm = (int64_t)c->counters[6];
-  launch_stats(st, T, c->m_p.as<uint2>(), nm);
+  launch_stats(st, T, nm ? c->m_p.as<uint2>() : nullptr, c->match_off.as<uint32_t>(), c->n_matches.as<uint32_t>());
   uint64_t h[8];
   HIPCHK(hipMemcpyAsync(h, stats.p, 8 * 8, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));

@@ -39,7 +39,22 @@ struct ProjectArgs {
   uint4 *m_b;            // {clip_score, 0, similarity lo, similarity hi}
   uint64_t *m_cigoff;
   uint32_t *cig_arena;
+  // single-pass count + emit (k_project1 / k_emit_wl; null p1: the two-pass path): the kernel that finds an alignment's
+  // survivors takes its slice of the match table, of the general-class work list and of the CIGAR arena from pages its
+  // wave owns, and writes match_off / cig_base itself
+  uint32_t *match_off_w;
+  uint64_t *cig_base_w;
+  uint4 *wl;             // work list of the general class: {alignment, slab row | strand << 31, match slot, rank}; ~0u in .x: hole
+  uint64_t *p1;          // device counters, see P1_* below
+  uint64_t cap_m, cap_w, cap_c;   // capacities of the match table (slots), the work list (entries) and the arena (words)
 };
+// k_project1's counters (u64 each): the three allocators' high-water marks, "a capacity was exceeded", matches found,
+// work-list entries written
+// (the three allocators sit in different 128-byte lines: same-line atomics serialise in one L2 channel)
+enum { P1_M = 0, P1_W = 16, P1_C = 32, P1_OVF = 48, P1_NM = 49, P1_NW = 50, P1_WORDS = 64 };
+#define P1_PAGE_M 16384u   // match slots a wave takes from the global counter at a time
+#define P1_PAGE_W 4096u    // work-list entries per page (unused entries are filled with hole markers)
+#define P1_PAGE_C 262144u  // arena words per page
 
 
 // -S clip rescue (rescue_kernels.inc)
@@ -194,7 +209,7 @@ struct StatsArgs {
   const uint4 *head;
   uint64_t *out;  // [8]
 };
-void launch_stats(hipStream_t st, const StatsArgs &T, const uint2 *m_p, int64_t n_matches);
+void launch_stats(hipStream_t st, const StatsArgs &T, const uint2 *m_p, const uint32_t *match_off, const uint32_t *n_matches);
 
 // BAM re-encoding (bam_kernels.hip)
 struct BamAux {
@@ -307,6 +322,9 @@ void launch_ksw_trace(hipStream_t st, const KswFastArgs &A, int bin);   // bin <
 uint32_t ksw_dp_resident_groups(int bin, int n_cu);
 size_t ksw_prob_bytes();
 size_t ksw_res_bytes();
+// single pass: part 1 = the main kernel (alignments that need the exon walk go to walk_list), 2 = the listed ones
+void launch_project1(hipStream_t st, const ProjectArgs &A, int group_lanes, int n_blocks, int part);
+void launch_emit_wl(hipStream_t st, const ProjectArgs &A, int64_t n_entries);
 void launch_expand(hipStream_t st, const ProjectArgs &A);
 // n_simple: length of the work list's simple-class prefix (k_scan3's third total); part 0: one launch over
 // everything, 1: the simple prefix, 2: the rest

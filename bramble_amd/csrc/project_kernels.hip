@@ -793,8 +793,8 @@ __global__ void __launch_bounds__(256, EMIT ? 4 : 8) k_project(ProjectArgs A) {
       moff = A.match_off[a]; cbase = A.cig_base[a];
       ideal_cap = 4u * n_seg + 2u;
       cap = rd.n_real + 2u * ideal_cap;
-      have_mask = n_items <= 64;
-      mask_in = A.mask[a];
+      have_mask = n_items <= 64 && !A.p1;   // the single-pass count kernel stores no masks (and sends alignments with > P1_STASH survivors here too)
+      mask_in = have_mask ? A.mask[a] : 0;
     }
     uint32_t total = 0;
     uint64_t mask_all = 0;
@@ -1175,6 +1175,435 @@ __global__ void __launch_bounds__(256, CLS == 1 ? 8 : 6) k_emit_dense(ProjectArg
 }
 
 // ---------------------------------------------------------------------------
+// Single pass (short-read presets, no similarity filter, no -S): count and emit in one sweep.
+//
+// The two-pass path re-fetches, re-classifies and re-ranks in the emit pass what the count pass had in registers, and
+// needs a scan, a work-list expansion and per-alignment ranges / masks to connect the two.  Here the G-lane group that
+// finds an alignment's survivors also places them: survivors (slab row, tid) go to a small LDS stash while the rows are
+// tested; afterwards the wave takes the slices its eight alignments need -- match slots, work-list entries, CIGAR arena
+// words -- from PAGES THE WAVE OWNS (one global atomic per page, not per alignment: same-address atomics serialise at
+// ~9 ns each), each survivor ranks itself by tid against the stash, and
+//   * the simple class (one read exon from a single M op) writes its match record right away,
+//   * the general class writes a 16-byte work item {alignment, row, match slot, rank} for k_emit_wl, which then starts
+//     from the item instead of from masks, ranges, scanned offsets and eight rank keys.
+// A wave walks CHUNKS of consecutive alignments (P1_CHUNK at a time), so the matches of neighbouring alignments stay
+// neighbours in the match table (k_pair / k_rows read it in alignment order).  Rows are still addressed by alignment
+// (match_off[a], n_matches[a]): the result does not depend on which wave got which page.
+// Capacities are the host's guess; a wave that would exceed one sets the overflow flag and stops writing, the host
+// grows the buffers to what the counters say and runs the pass again.
+// ---------------------------------------------------------------------------
+#define P1_STASH 32       // survivors of one alignment kept in LDS; more (or > 64 candidate rows): the dense-locus kernel
+#define P1_CHUNK 128      // consecutive alignments a wave takes at a time
+#define WALK1_LDS 1024
+#define P1_SLAB 513
+
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t rfl64(uint64_t v) { return ((uint64_t)rfl((uint32_t)(v >> 32)) << 32) | rfl((uint32_t)v); }
+// Wave-uniform (all arguments are the same in every lane; the state lives in scalar registers): `need` units from the
+// wave's page [cur, end); a new page (or, for a request beyond a page, exactly the request) comes from the global counter
+// with one atomic.  Returns the first unit; ovf is set past the capacity.
+__device__ __forceinline__ uint32_t page_take32(uint32_t &cur, uint32_t &end, uint32_t need, uint64_t *ctr, uint32_t page,
+                                                uint64_t cap, bool &ovf, int lane) {
+  if (need != 0 && (uint64_t)cur + need > (uint64_t)end) {
+    const uint32_t take = need > page ? need : page;
+    unsigned long long b = 0;
+    if (lane == 0) b = atomicAdd((unsigned long long *)ctr, (unsigned long long)take);
+    b = rfl64(b);
+    if (b + take > cap) ovf = true;
+    cur = (uint32_t)b; end = cur + take;
+  }
+  const uint32_t r = cur;
+  cur = rfl(cur + need);
+  return r;
+}
+__device__ __forceinline__ uint64_t page_take64(uint64_t &cur, uint64_t &end, uint64_t need, uint64_t *ctr, uint64_t page,
+                                                uint64_t cap, bool &ovf, int lane) {
+  if (need != 0 && cur + need > end) {
+    const uint64_t take = need > page ? need : page;
+    unsigned long long b = 0;
+    if (lane == 0) b = atomicAdd((unsigned long long *)ctr, (unsigned long long)take);
+    b = rfl64(b);
+    cur = b; end = b + take;
+    if (end > cap) ovf = true;
+  }
+  const uint64_t r = cur;
+  cur = rfl64(cur + need);
+  return r;
+}
+// inclusive sum over the groups of a wave (every lane of a group holds the group's value)
+template <int G, typename T>
+__device__ __forceinline__ T wave_group_scan(T v, int lane) {
+  T x = v;
+#pragma unroll
+  for (int d = G; d < 64; d <<= 1) { const T y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
+  return x;
+}
+
+template <int G, int MODE>
+__global__ void __launch_bounds__(256, 8) k_project1(ProjectArgs A) {
+  __shared__ uint32_t sh_slab[P1_SLAB];   // (<= 256 references; more: the offsets come from memory)
+  __shared__ uint32_t sh_bin[P1_SLAB];
+  __shared__ uint32_t sh_wl[MODE == 1 ? WALK1_LDS : 1];
+  __shared__ uint32_t sh_wn, sh_wbase;
+  __shared__ uint64_t sh_st[256 / G][P1_STASH];   // survivor stash: tid << 32 | strand << 31 | slab row
+  if (MODE == 1 && threadIdx.x == 0) sh_wn = 0;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int gl = threadIdx.x & (G - 1);
+  const int gbase = lane & ~(G - 1);
+  const int grp = threadIdx.x / G;
+  const uint64_t gmask = (G == 64) ? ~0ull : ((1ull << G) - 1);
+  constexpr int GPW = 64 / G;
+  const DevIndex &ix = A.ix;
+  const DevCfg &cfg = A.cfg;
+  const uint32_t n_slab_off = 2 * ix.n_refs + 1;
+  const bool slab_in_lds = n_slab_off <= P1_SLAB;
+  if (slab_in_lds) {
+    for (uint32_t i = threadIdx.x; i < n_slab_off; i += blockDim.x) {
+      sh_slab[i] = ix.slab_off[i];
+      if (i <= ix.n_refs) sh_bin[i] = ix.bin_off[i];
+    }
+  }
+  __syncthreads();
+  const uint32_t n_work = MODE == 2 ? *A.n_walk : (uint32_t)A.n_aln;   // (n_aln < 2^31, checked by the host)
+  const uint32_t n_waves = gridDim.x * 4;
+  // the wave's pages (wave-uniform, scalar registers) and what it found
+  uint32_t m_cur = 0, m_end = 0, w_cur = 0, w_end = 0;
+  uint64_t c_cur = 0, c_end = 0;
+  bool ovf = false;
+  uint32_t found_m = 0, found_w = 0;
+  for (uint32_t w_first = rfl((blockIdx.x * 4 + wv) * P1_CHUNK); w_first < n_work; w_first += n_waves * P1_CHUNK) {
+   for (uint32_t it = 0; it < P1_CHUNK / GPW && w_first + it * GPW < n_work; it++) {
+    const uint32_t w = w_first + it * GPW + (uint32_t)(lane / G);
+    const bool valid = w < n_work;
+    const uint32_t a = valid ? (MODE == 2 ? A.walk_list[w] : w) : 0u;
+    uint4 hd = make_uint4(0, 0, 0, 0), hd2 = hd;
+    uint32_t ff = 0;
+    if (valid) { hd = A.head[a]; hd2 = A.head2[a]; ff = A.fast_flag[a]; }
+    const uint32_t n_seg = hd.z;
+    const uint2 q0 = make_uint2(hd.x, hd.y);
+    const uint32_t smode = hd.w & 3u, rid = hd.w >> 2;
+    const int st0 = (n_seg == 1) ? ST_ONLY : ST_FIRST;
+    uint32_t sb[2], se[2];
+    if (slab_in_lds) { sb[0] = sh_slab[2 * rid]; se[0] = sh_slab[2 * rid + 1]; se[1] = sh_slab[2 * rid + 2]; }
+    else { sb[0] = ix.slab_off[2 * rid]; se[0] = ix.slab_off[2 * rid + 1]; se[1] = ix.slab_off[2 * rid + 2]; }
+    sb[1] = se[0];
+
+    // candidate rows of read exon 0 from the bucket tables (see k_project)
+    uint32_t lo[2] = {0, 0}, hi[2] = {0, 0};
+    {
+      uint32_t tw[4];
+      const uint32_t bo = slab_in_lds ? sh_bin[rid] : ix.bin_off[rid];
+      const uint32_t nb = (slab_in_lds ? sh_bin[rid + 1] : ix.bin_off[rid + 1]) - bo - 1;
+      uint32_t bh = q0.y >> ix.bin_shift, bl = q0.x >> ix.bin_shift;
+      bh = bh < nb - 1 ? bh : nb - 1; bl = bl < nb - 1 ? bl : nb - 1;
+      {
+        const uint4 tl = ix.t_bin[bo + bl], th = ix.t_bin[bo + bh + 1];
+        tw[0] = tl.x; tw[1] = th.y; tw[2] = tl.z; tw[3] = th.w;
+      }
+#pragma unroll
+      for (int s = 0; s < 2; s++) {
+        const bool use = ((smode >> s) & 1u) && sb[s] != se[s];
+        hi[s] = use ? tw[2 * s + 1] : sb[s];
+        lo[s] = use ? (tw[2 * s] < hi[s] ? tw[2 * s] : hi[s]) : sb[s];
+      }
+      if ((hi[0] - lo[0]) + (hi[1] - lo[1]) > 64u) {
+        uint32_t ra[4], rb[4];  // 0/1: hi/lo on '+', 2/3: hi/lo on '-'
+        const uint4 th0 = ix.t_bin[bo + bh], tl1 = ix.t_bin[bo + bl + 1];
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+          ra[2 * s] = rb[2 * s] = ra[2 * s + 1] = rb[2 * s + 1] = sb[s];
+          if (!((smode >> s) & 1u) || sb[s] == se[s]) continue;
+          ra[2 * s] = s ? th0.w : th0.y; rb[2 * s] = hi[s];
+          ra[2 * s + 1] = tw[2 * s]; rb[2 * s + 1] = s ? tl1.z : tl1.x;
+        }
+        uint32_t res[4] = {ra[0], ra[1], ra[2], ra[3]};
+        for (uint32_t itx = 0;; itx += G) {
+          bool any = false;
+#pragma unroll
+          for (int k = 0; k < 4; k++) any |= (ra[k] + itx) < rb[k];
+          if (!any) break;
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            uint32_t r = ra[k] + itx + (uint32_t)gl;
+            bool in = r < rb[k];
+            uint32_t v = in ? ((k & 1) ? ix.s_pmax[r] : ix.s_start[r]) : 0u;
+            bool t = in && ((k & 1) ? (v <= q0.x) : (v < q0.y));
+            res[k] += (uint32_t)__popcll((__ballot(t) >> gbase) & gmask);
+          }
+        }
+        hi[0] = res[0]; lo[0] = res[1] < res[0] ? res[1] : res[0];
+        hi[1] = res[2]; lo[1] = res[3] < res[2] ? res[3] : res[2];
+      }
+    }
+    const uint32_t n0 = hi[0] - lo[0], n1 = hi[1] - lo[1];
+    const uint32_t n_items = n0 + n1;
+
+    ReadCtx rd;
+    rd.n_seg = n_seg; rd.seg = nullptr; rd.real = nullptr; rd.n_real = 0; rd.q12 = hd2;
+    if (MODE == 2 && n_seg > 3) {
+      const uint32_t c0 = A.cigar_off[a];
+      rd.seg = A.seg + (size_t)c0 + (size_t)a;
+      rd.real = A.cigar + c0;
+    }
+    uint32_t total = 0;
+    bool defer = false;
+    for (uint32_t base = 0; base < n_items; base += G) {
+      const uint32_t item = base + (uint32_t)gl;
+      bool alive = false;
+      int s = 0; uint32_t row = 0, tid = 0;
+      if (item < n_items) {
+        s = item < n0 ? 0 : 1;
+        row = s == 0 ? lo[0] + item : lo[1] + (item - n0);
+        const uint4 r_a = ix.s_row[2 * (size_t)row], r_b = ix.s_row[2 * (size_t)row + 1];
+        const uint32_t gs = r_a.x, gend = r_a.y, nxt = r_a.z, nxe = r_b.w;
+        const uint4 pay = make_uint4(r_b.x, r_b.y, r_a.w, r_b.z);
+        tid = pay.x;
+        Hit h0;
+        if (gend > q0.x && gs < q0.y && classify(s == 1, st0, q0.x, q0.y, gs, gend, pay.z, cfg, h0)) {
+          const uint4 *E = ix.tx_ex + pay.w;
+          const uint32_t i0 = pay.y & 0x7fffffffu;
+          bool superseded = false;   // first-exon duplicate tid: the LAST passing row of the tid wins (src/evaluate.cpp:218-224)
+          if (nxt < q0.y) {
+            for (uint32_t i = i0 + 1;; i++) {
+              const uint4 e = E[i];
+              if (e.x >= q0.y) break;
+              Hit hx;
+              if (e.y > q0.x && classify(s == 1, st0, q0.x, q0.y, e.x, e.y, e.z, cfg, hx)) { superseded = true; break; }
+            }
+          }
+          if (!superseded) {
+            if (n_seg == 1) alive = true;
+            else if (MODE == 1 && n_seg == 2 && (nxt >= hd2.y || nxe >= hd2.y)) {
+              // two read exons and the scan of the second ends at the exon after the candidate's: survival without the walk
+              const uint32_t qs1 = hd2.x, qe1 = hd2.y;
+              Hit hh;
+              if (gend < qe1 && !(qs1 == q0.x && qe1 == q0.y)) {
+                const bool c0 = gend > qs1 && classify(s == 1, ST_LAST, qs1, qe1, gs, gend, pay.z, cfg, hh);
+                const uint4 e1 = next_row(make_uint4(gs, gend, pay.z, 0), make_uint2(nxt, nxe), s == 1);
+                const bool c1 = nxt < qe1 && nxe > qs1 && classify(s == 1, ST_LAST, qs1, qe1, e1.x, e1.y, e1.z, cfg, hh);
+                alive = c1 && !c0;
+              }
+            }
+            else if (MODE == 1 && !cfg.long_reads && !cfg.ignore_small_exons && !(pay.y >> 31)) {
+              // defer only what can still survive (see k_project MODE 1)
+              const uint32_t qs1 = hd2.x, qe1 = hd2.y;
+              const int st1 = n_seg == 2 ? ST_LAST : ST_MIDDLE;
+              Hit hh;
+              if (gend < qe1 && !(qs1 == q0.x && qe1 == q0.y)) {
+                const bool c0 = gend > qs1 && classify(s == 1, st1, qs1, qe1, gs, gend, pay.z, cfg, hh);
+                const uint4 e1 = next_row(make_uint4(gs, gend, pay.z, 0), make_uint2(nxt, nxe), s == 1);
+                const bool c1 = nxt < qe1 && nxe > qs1 && classify(s == 1, st1, qs1, qe1, e1.x, e1.y, e1.z, cfg, hh);
+                if (c1 && !c0) defer = true;
+              }
+            }
+            else if (MODE == 1) defer = true;
+            else alive = walk_pass1(ix, cfg, rd, E, s == 1, sb[s], se[s], i0, make_uint4(gs, gend, pay.z, 0), make_uint2(nxt, nxe), q0, h0).alive;
+          }
+        }
+      }
+      const uint64_t m = (__ballot(alive) >> gbase) & gmask;
+      if (alive) {
+        const uint32_t k = total + (uint32_t)__popcll(m & ((1ull << gl) - 1ull));
+        if (k < P1_STASH) sh_st[grp][k] = ((uint64_t)tid << 32) | ((uint64_t)s << 31) | row;
+      }
+      total += (uint32_t)__popcll(m);
+    }
+    bool deferred = false;
+    if (MODE == 1) deferred = ((__ballot(defer) >> gbase) & gmask) != 0;
+    if (deferred) {
+      if (gl == 0) {
+        uint32_t k = atomicAdd(&sh_wn, 1u);
+        if (k < WALK1_LDS) sh_wl[MODE == 1 ? k : 0] = a;
+        else { uint32_t k2 = atomicAdd(A.n_walk, 1u); A.walk_list[k2] = a; }   // LDS list full: rare, slow, correct
+      }
+      total = 0;
+    }
+    // ---- placement: what the wave's alignments need, summed over its groups ----
+    const bool big = total != 0 && (n_items > 64u || total > P1_STASH);   // left to k_project<64,true> (needs ranges / arena slots)
+    const bool fast = (ff >> 31) != 0;
+    const uint32_t cap = ff & 0x7fffffffu;
+    const uint32_t need_m = total, need_w = (fast || big) ? 0u : total;
+    const uint64_t need_c = (!fast || big) ? (uint64_t)total * cap : 0;
+    uint32_t inc_m, inc_w; uint64_t inc_c;
+    const bool wide = __any(big || cap > 0xffffu);   // wave-uniform
+    if (!wide) {   // two 32-bit scans: <= 32 matches per group, cap <= 65535
+      const uint32_t x = wave_group_scan<G, uint32_t>(need_m | (need_w << 16), lane);
+      inc_m = x & 0xffffu; inc_w = x >> 16;
+      inc_c = wave_group_scan<G, uint32_t>((uint32_t)need_c, lane);
+    } else {
+      inc_m = wave_group_scan<G, uint32_t>(need_m, lane);
+      inc_w = wave_group_scan<G, uint32_t>(need_w, lane);
+      inc_c = wave_group_scan<G, uint64_t>(need_c, lane);
+    }
+    const uint32_t tot_m = rfl(__shfl(inc_m, 63, 64)), tot_w = rfl(__shfl(inc_w, 63, 64));
+    const uint64_t tot_c = rfl64(__shfl(inc_c, 63, 64));
+    if (gl == 0 && valid && !deferred) A.n_matches[a] = total;
+    if (tot_m == 0) continue;   // wave-uniform: nothing found by any group
+    // hole markers for the work-list entries a page switch leaves behind (k_emit_wl walks the list densely)
+    if (tot_w != 0 && (uint64_t)w_cur + tot_w > (uint64_t)w_end && !ovf) for (uint32_t i = w_cur + lane; i < w_end; i += 64) A.wl[i] = make_uint4(0xffffffffu, 0, 0, 0);
+    const uint32_t m0 = page_take32(m_cur, m_end, tot_m, A.p1 + P1_M, P1_PAGE_M, A.cap_m, ovf, lane) + (inc_m - need_m);
+    const uint32_t w0 = page_take32(w_cur, w_end, tot_w, A.p1 + P1_W, P1_PAGE_W, A.cap_w, ovf, lane) + (inc_w - need_w);
+    const uint64_t c0 = page_take64(c_cur, c_end, tot_c, A.p1 + P1_C, P1_PAGE_C, A.cap_c, ovf, lane) + (inc_c - need_c);
+    found_m += tot_m; found_w += tot_w;
+    if (gl == 0 && valid && !deferred) {
+      if (total && !ovf) {
+        A.match_off_w[a] = m0;
+        if (!fast || big) A.cig_base_w[a] = c0;
+        if (big) {
+          A.ranges[a] = make_uint4(lo[0], hi[0], lo[1], hi[1]);
+          uint32_t k = atomicAdd(A.n_big, 1u); A.big_list[k] = a;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // ---- every survivor ranks itself by tid and is written ----
+    const uint32_t n_emit = (big || ovf) ? 0u : total;
+    for (uint32_t kb = 0; __any(kb < n_emit); kb += G) {   // wave-uniform trip count (the arena page below is the wave's)
+      const uint32_t k = kb + (uint32_t)gl;
+      const bool act = k < n_emit;
+      uint32_t w_3 = 0;
+      uint32_t rowS = 0, tid = 0, rank = 0;
+      Hit h0; uint32_t gs = 0, gend = 0;
+      h0.pos = 0; h0.left_ins = h0.right_ins = h0.left_gap = h0.right_gap = 0;
+      if (act) {
+        const uint64_t e = sh_st[grp][k];
+        tid = (uint32_t)(e >> 32); rowS = (uint32_t)e;
+        for (uint32_t j = 0; j < n_emit; j++) rank += ((uint32_t)(sh_st[grp][j] >> 32) < tid) ? 1u : 0u;
+        if (fast) {
+          const uint4 r_a = ix.s_row[2 * (size_t)(rowS & 0x7fffffffu)];   // the group loaded this line a moment ago
+          gs = r_a.x; gend = r_a.y;
+          classify((rowS >> 31) != 0, ST_ONLY, q0.x, q0.y, gs, gend, r_a.w, cfg, h0);
+          w_3 = (h0.left_ins && h0.right_ins) ? 3u : 0u;
+        } else {
+          A.wl[w0 + k] = make_uint4(a, rowS, m0 + rank, rank);
+        }
+      }
+      if (!__any(act && fast)) continue;
+      // three-op CIGARs ([S] M [S] with both clips) live in the arena: three words each from the wave's page
+      const uint64_t m3 = __ballot(w_3 != 0);
+      uint64_t c3 = 0;
+      if (m3) {
+        bool ovf3 = false;
+        c3 = page_take64(c_cur, c_end, 3ull * (uint64_t)__popcll(m3), A.p1 + P1_C, P1_PAGE_C, A.cap_c, ovf3, lane) + 3ull * (uint64_t)__popcll(m3 & ((1ull << lane) - 1ull));
+        if (ovf3) { ovf = true; continue; }
+      }
+      if (act && fast) {
+        // one read exon from a single M op: the ideal CIGAR is [S left_ins] M [S right_ins] and merging it with "<len>M"
+        // returns it unchanged (see k_emit_dense)
+        const uint32_t os = q0.x > gs ? q0.x : gs, oe = q0.y < gend ? q0.y : gend;
+        const uint32_t ml = oe - os;
+        uint32_t c_w0, c_w1 = 0, n_out;
+        if (h0.left_ins) { c_w0 = CIG_GEN(h0.left_ins, OP_S); c_w1 = CIG_GEN(ml, OP_M); n_out = h0.right_ins ? 3u : 2u; }
+        else { c_w0 = CIG_GEN(ml, OP_M); n_out = 1; if (h0.right_ins) { c_w1 = CIG_GEN(h0.right_ins, OP_S); n_out = 2; } }
+        const uint32_t junc = ((h0.left_ins == 0 && h0.left_gap == 0) ? 1u : 0u) + ((h0.right_ins == 0 && h0.right_gap == 0) ? 1u : 0u);
+        uint64_t cref = (uint64_t)c_w0 | ((uint64_t)c_w1 << 32);
+        if (n_out == 3) {
+          cref = c3;
+          uint32_t *slot = A.cig_arena + c3;
+          slot[0] = c_w0; slot[1] = c_w1; slot[2] = CIG_GEN(h0.right_ins, OP_S);
+        }
+        const uint32_t mo = m0 + rank;
+        A.m_tid[mo] = tid;
+        A.m_p[mo] = make_uint2(h0.pos, n_out | (rowS & 0x80000000u));
+        A.m_x[mo] = make_uint2(junc, ml);
+        A.m_cigoff[mo] = cref;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();   // the stash is rewritten by the next alignment
+   }
+  }
+  // the rest of the wave's work-list page: hole markers
+  if (!ovf) for (uint32_t i = w_cur + lane; i < w_end; i += 64) A.wl[i] = make_uint4(0xffffffffu, 0, 0, 0);
+  if (lane == 0) {
+    if (found_m) atomicAdd((unsigned long long *)(A.p1 + P1_NM), (unsigned long long)found_m);
+    if (found_w) atomicAdd((unsigned long long *)(A.p1 + P1_NW), (unsigned long long)found_w);
+    if (ovf) A.p1[P1_OVF] = 1;
+  }
+  if (MODE == 1) {
+    __syncthreads();
+    const uint32_t n_loc = sh_wn < WALK1_LDS ? sh_wn : WALK1_LDS;
+    if (threadIdx.x == 0) sh_wbase = n_loc ? atomicAdd(A.n_walk, n_loc) : 0u;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_loc; i += blockDim.x) A.walk_list[sh_wbase + i] = sh_wl[MODE == 1 ? i : 0];
+  }
+}
+
+// k_emit_wl: one lane per work item of the general class (written by k_project1): the item names the alignment, the
+// candidate's slab row and strand, its match slot and its rank; what is left is the walk (pass 2), the ideal CIGAR, the
+// merge with the real CIGAR and the match record -- k_emit_dense<false, 2> without its mask / range / rank stage.
+__global__ void __launch_bounds__(256, 6) k_emit_wl(ProjectArgs A, int64_t n_entries) {
+  __shared__ uint32_t sh_cig[256 * LDS_SLOT];
+  __shared__ uint16_t sh_mops[256];
+  sh_mops[threadIdx.x] = (uint16_t)((merge_action(threadIdx.x >> 4, threadIdx.x & 15u) << 8) | merge_ops(threadIdx.x >> 4, threadIdx.x & 15u));
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_entries) return;
+  const uint4 item = A.wl[i];
+  if (item.x == 0xffffffffu) return;
+  const DevIndex &ix = A.ix;
+  const DevCfg &cfg = A.cfg;
+  const uint32_t a = item.x, row = item.y & 0x7fffffffu, rank = item.w;
+  const int s = (int)(item.y >> 31);
+  const uint4 hd = A.head[a];
+  const uint4 hd2 = A.head2[a];
+  const uint32_t c0 = A.cigar_off[a], c1 = A.cigar_off[a + 1];
+  const uint4 r_a = ix.s_row[2 * (size_t)row], r_b = ix.s_row[2 * (size_t)row + 1];
+  const uint32_t n_seg = hd.z, rid = hd.w >> 2;
+  const uint2 q0 = make_uint2(hd.x, hd.y);
+  const int st0 = (n_seg == 1) ? ST_ONLY : ST_FIRST;
+  RealCig rc;
+  rc.fetch(A.cigar + c0, c1 - c0);
+  const uint32_t gs = r_a.x, gend = r_a.y;
+  const uint4 pay = make_uint4(r_b.x, r_b.y, r_a.w, r_b.z);
+  Hit h0;
+  classify(s == 1, st0, q0.x, q0.y, gs, gend, pay.z, cfg, h0);
+  ReadCtx rd;
+  rd.n_seg = n_seg; rd.seg = A.seg + (size_t)c0 + (size_t)a; rd.real = A.cigar + c0; rd.n_real = c1 - c0; rd.q12 = hd2;
+  const uint4 *E = ix.tx_ex + pay.w;
+  const uint32_t i0 = pay.y & 0x7fffffffu;
+  CandOut p1;
+  bool plain = false;
+  const uint32_t sb = ix.slab_off[2 * rid + s], se = ix.slab_off[2 * rid + s + 1];
+  if (n_seg == 1) { p1.alive = true; p1.fwpos = h0.pos; p1.rcpos = h0.pos; p1.n_seg = 1; p1.n_gex = 1; p1.i_lastm = i0; p1.last_right_ins = h0.right_ins; p1.last_right_gap = h0.right_gap; }
+  else if (!cfg.long_reads && !cfg.ignore_small_exons) {
+    plain = true;   // see k_emit_dense: pass 1's counts are the read's exon count
+    p1.alive = true; p1.fwpos = h0.pos; p1.rcpos = h0.pos; p1.n_seg = n_seg; p1.n_gex = n_seg; p1.i_lastm = i0;
+    p1.last_right_ins = 0; p1.last_right_gap = 0;
+  }
+  else p1 = walk_pass1(ix, cfg, rd, E, s == 1, sb, se, i0, make_uint4(gs, gend, pay.z, 0), make_uint2(r_a.z, r_b.w), q0, h0);
+  const uint32_t ideal_cap = 4u * n_seg + 2u;
+  const uint32_t cap = rd.n_real + 2u * ideal_cap;
+  uint32_t *lds = &sh_cig[threadIdx.x * LDS_SLOT];
+  const bool ideal_lds = ideal_cap <= LDS_IDEAL;
+  // the arena slot (cig_base[a] + rank * cap) is looked up only by the lanes that need it
+  uint32_t *slot = nullptr; uint64_t slot_off = 0;
+  if (!ideal_lds) { slot_off = A.cig_base[a] + (uint64_t)rank * cap; slot = A.cig_arena + slot_off; }
+  uint32_t *ideal = ideal_lds ? lds : slot + rd.n_real + ideal_cap;
+  Acc acc; IdealSink sk;
+  sk.init(ideal);
+  walk_pass2(ix, cfg, rd, E, s == 1, sb, se, i0, q0, make_uint4(gs, gend, pay.z, 0), make_uint2(r_a.z, r_b.w), h0, p1, acc, sk, no_clip(), no_clip());
+  const uint32_t n_ideal = sk.finish();
+  const bool out_lds = ideal_lds && (rd.n_real + n_ideal <= LDS_SLOT - LDS_IDEAL);
+  if (!out_lds && !slot) { slot_off = A.cig_base[a] + (uint64_t)rank * cap; slot = A.cig_arena + slot_off; }
+  uint32_t *outp = out_lds ? lds + LDS_IDEAL : slot;
+  const uint32_t n_out = merge_cigars(rc, rd.n_real, ideal, n_ideal, outp, sh_mops);
+  uint64_t cig_ref;
+  if (n_out <= 2) cig_ref = (uint64_t)(n_out > 0 ? outp[0] : 0u) | ((uint64_t)(n_out > 1 ? outp[1] : 0u) << 32);
+  else {
+    if (!slot) { slot_off = A.cig_base[a] + (uint64_t)rank * cap; slot = A.cig_arena + slot_off; }
+    if (out_lds) for (uint32_t q = 0; q < n_out; q++) slot[q] = outp[q];
+    cig_ref = slot_off;
+  }
+  const uint32_t mo = item.z;
+  A.m_tid[mo] = pay.x;
+  A.m_p[mo] = make_uint2((s == 0) ? p1.fwpos : (plain ? acc.last_pos : p1.rcpos), n_out | ((uint32_t)s << 31));
+  A.m_x[mo] = make_uint2((uint32_t)acc.junc_hits, (uint32_t)acc.ref_consumed);
+  A.m_cigoff[mo] = cig_ref;
+}
+
+// ---------------------------------------------------------------------------
 // exclusive scans.  Tile = 256 threads x 8 items.
 // ---------------------------------------------------------------------------
 #define SCAN_ITEMS 8
@@ -1429,10 +1858,20 @@ __global__ void __launch_bounds__(256) k_pair(PairArgs P) {
     const int lane = threadIdx.x & 63;
     const int64_t w0 = i64 - lane;
     if (w0 < P.n_aln) {
-      const int64_t w1 = w0 + 64 < P.n_aln ? w0 + 64 : P.n_aln;
-      t0 = P.match_off[w0];
-      const uint32_t n = P.match_off[w1] - t0;
-      if (n <= PAIR_TIDS) { t_n = n; for (uint32_t k = lane; k < n; k += 64) sh_tid[wv_][k] = P.m_tid[t0 + k]; }
+      // the window [t0, t0 + t_n): from the first non-empty list of the wave to the end of the last list that still ends
+      // inside PAIR_TIDS entries.  (Scanned offsets ascend over the wave; with the single-pass placement they ascend until
+      // the producing wave changed its page -- lists beyond that point fail the test and are read from memory.)
+      const uint32_t ni_ = i64 < P.n_aln ? P.n_matches[i64] : 0u;
+      const uint32_t mo_ = ni_ ? P.match_off[i64] : 0u;
+      const uint64_t have = __ballot(ni_ != 0u);
+      if (have) {
+        t0 = __shfl(mo_, (int)__builtin_ctzll(have));
+        const uint32_t e = mo_ - t0 + ni_;
+        const uint64_t okm = __ballot(ni_ != 0u && mo_ >= t0 && e <= PAIR_TIDS);
+        t_n = __shfl(e, 63 - (int)__builtin_clzll(okm));   // (the first non-empty lane always passes when its list fits)
+        if (!okm) t_n = 0;
+        for (uint32_t k = lane; k < t_n; k += 64) sh_tid[wv_][k] = P.m_tid[t0 + k];
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -1874,9 +2313,13 @@ __global__ void __launch_bounds__(256) k_stats(StatsArgs T) {
   }
 }
 
-__global__ void __launch_bounds__(256) k_sum_ncig(const uint2 *m_p, int64_t n, uint64_t *out) {
+// (per alignment: with the single-pass placement the match table has unused slots between the waves' pages)
+__global__ void __launch_bounds__(256) k_sum_ncig(const uint2 *m_p, const uint32_t *match_off, const uint32_t *n_matches, int64_t n, uint64_t *out) {
   unsigned long long acc = 0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) acc += m_p[i].y & 0x7fffffffu;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t nm = n_matches[i], m0 = nm ? match_off[i] : 0u;
+    for (uint32_t k = 0; k < nm; k++) acc += m_p[m0 + k].y & 0x7fffffffu;
+  }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) acc += __shfl_down(acc, d, 64);
   if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long *)out, acc);
@@ -1961,6 +2404,29 @@ void launch_project(hipStream_t st, const ProjectArgs &A, bool emit, int group_l
   }
 }
 
+template <int G>
+static void launch_project1_g(hipStream_t st, const ProjectArgs &A, int n_blocks, int part) {
+  if (part == 1) hipLaunchKernelGGL((k_project1<G, 1>), dim3(n_blocks), dim3(256), 0, st, A);
+  else hipLaunchKernelGGL((k_project1<G, 2>), dim3(n_blocks), dim3(256), 0, st, A);
+}
+void launch_project1(hipStream_t st, const ProjectArgs &A, int group_lanes, int n_blocks, int part) {
+  if (A.n_aln <= 0) return;
+  if (A.ix.n_rows == 0) {   // empty annotation: nothing can match (and the kernel's clamped loads need one row)
+    if (part == 1) (void)hipMemsetAsync(A.n_matches, 0, (size_t)A.n_aln * 4, st);
+    return;
+  }
+  const int64_t need = (A.n_aln + P1_CHUNK - 1) / P1_CHUNK / 4 + 1;   // a wave per chunk
+  if (need < n_blocks) n_blocks = (int)need;
+  if (n_blocks < 1) n_blocks = 1;
+  switch (group_lanes) {
+    case 16: launch_project1_g<16>(st, A, n_blocks, part); break;
+    default: launch_project1_g<8>(st, A, n_blocks, part); break;
+  }
+}
+void launch_emit_wl(hipStream_t st, const ProjectArgs &A, int64_t n_entries) {
+  if (n_entries > 0) hipLaunchKernelGGL(k_emit_wl, dim3(grid_for(n_entries, 256)), dim3(256), 0, st, A, n_entries);
+}
+
 void launch_expand(hipStream_t st, const ProjectArgs &A) {
   if (A.n_aln <= 0) return;
   hipLaunchKernelGGL(k_expand, dim3(grid_for(A.n_aln, 256)), dim3(256), 0, st, A);
@@ -2017,9 +2483,9 @@ void launch_scan3(hipStream_t st, ScanArgs S, uint32_t *match_off, uint64_t *cig
   hipLaunchKernelGGL(k_scan3_apply, g, b, 0, st, S, match_off, cig_base, fast_pre);
 }
 
-void launch_stats(hipStream_t st, const StatsArgs &T, const uint2 *m_p, int64_t n_matches) {
+void launch_stats(hipStream_t st, const StatsArgs &T, const uint2 *m_p, const uint32_t *match_off, const uint32_t *n_matches) {
   if (T.n_aln > 0) hipLaunchKernelGGL(k_stats, dim3(grid_for(T.n_aln, 256)), dim3(256), 0, st, T);
-  if (n_matches > 0) hipLaunchKernelGGL(k_sum_ncig, dim3(1024), dim3(256), 0, st, m_p, n_matches, T.out + 7);
+  if (T.n_aln > 0 && m_p) hipLaunchKernelGGL(k_sum_ncig, dim3(1024), dim3(256), 0, st, m_p, match_off, n_matches, T.n_aln, T.out + 7);
 }
 
 void launch_group_ids(hipStream_t st, int64_t n_groups, const uint32_t *group_off, uint32_t *aln_group) {

@@ -509,7 +509,10 @@ const char *br_bgzf_codec(void); /* "libdeflate" (bound at run time when present
 #define BR_K_COUNT_WALK 15 /* k_project<G,false,false,2>: the deferred alignments of the split count pass, with the exon walk */
 #define BR_K_EXPAND 16    /* k_expand (emit work list) */
 #define BR_K_GROUP_IDS 17 /* k_group_ids */
-#define BR_K_NUM 18
+#define BR_K_P1 18        /* k_project1<G,1>: single-pass count + emit, main kernel (simple class written, general class listed) */
+#define BR_K_P1_WALK 19   /* k_project1<G,2>: the alignments that need the exon walk */
+#define BR_K_EMIT_WL 20   /* k_emit_wl: the general class from the single pass's work list */
+#define BR_K_NUM 21
 /* When enabled, every launch is bracketed by hipEvents on the launch stream. */
 int br_ctx_set_profiling(br_ctx *, int enabled);
 /* Launch tuning: "group_lanes" (8|16|32|64 lanes cooperating on one alignment),

@@ -362,3 +362,45 @@ def test_single_kernel_forms_of_the_split_passes(key):
             assert_rows_equal(prod, orc)
             ctx.close()
         idx.close()
+
+
+def test_single_pass_variant_equals_oracle():
+    """"single_pass" = 1: count and emit in one sweep (k_project1 places every alignment's matches from wave-owned pages,
+    writes the simple class at once and lists the general class for k_emit_wl).  The variant lost its A/B (DESIGN
+    section 10) and is off by default; it stays selectable, so it stays bit-exact: short-read presets, both group
+    widths, a dense locus (> 64 candidate rows, > 32 survivors), small first-call capacities that overflow and retry."""
+    cases = []
+    s_ann = synth.Annotation("S")
+    for mode, flags in (("se", {}), ("pe", {}), ("pe", {"strict": 1}), ("pe", {"fr": 1}), ("pe", {"max_clip": 2, "max_junc_ins": 3, "max_junc_gap": 3}),
+                        ("pe", {"max_error_exon": 30})):
+        cases.append((s_ann.as_dict(), s_ann.reads(10000, mode), flags))
+    g_ann = synth.Annotation("G", n_genes=4000, n_refs=4)
+    cases.append((g_ann.as_dict(), g_ann.reads(40000, "pe"), {}))
+    cases.append((g_ann.as_dict(), g_ann.reads(3000, "hifi"), {}))      # long CIGARs under the short-read preset: every alignment walks
+    b_un = g_ann.reads(20000, "pe")
+    b_un["flags"] = (b_un["flags"] & ~np.uint16(0x1)).astype(np.uint16)  # every match emitted
+    cases.append((g_ann.as_dict(), b_un, {}))
+    txs = []
+    for t in range(150):
+        ex = [[1000, 1200 + (t % 4)], [2000 + 5 * (t % 7), 2300], [3000, 3100 + t]]
+        txs.append({"id": "iso%d" % t, "ref_id": 0, "strand": "+" if t % 3 else "-", "exons": ex[:2] if t % 5 == 0 else ex})
+    txs.append({"id": "solo", "ref_id": 0, "strand": "+", "exons": [[10000, 10500]]})
+    recs = []
+    rng = np.random.RandomState(11)
+    for i in range(600):
+        st = 1100 + int(rng.randint(0, 50))
+        recs.append([{"name": "r%d" % i, "ref_id": 0, "ref_start": 1000 + int(rng.randint(0, 120)), "cigar": "80M"},
+                     {"name": "r%d" % i, "ref_id": 0, "ref_start": st, "cigar": "%dM%dN60M" % (1200 - st, 800)},
+                     {"name": "r%d" % i, "ref_id": 0, "ref_start": 10000 + int(rng.randint(0, 400)), "cigar": "3S87M"}][i % 3])
+    cases.append(({"refnames": ["chr1"], "transcripts": txs}, make_batch(recs), {}))
+    for ann, b, flags in cases:
+        orc, _, _ = ob.run(ob.OracleIndex(ann), ob.make_flags(**flags), b, want_matches=False)
+        idx = lib.Index(ann, device=0)
+        for gl in (8, 16):
+            ctx = lib.Context(idx)
+            ctx.set_param("group_lanes", gl)
+            ctx.set_param("single_pass", 1)
+            for _ in range(2):   # the second call starts from the first one's high-water marks
+                assert_rows_equal(ctx.project_batch(lib.make_config(**flags), b), orc)
+            ctx.close()
+        idx.close()
