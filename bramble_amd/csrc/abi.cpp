@@ -1252,14 +1252,16 @@ static int bam_encode_impl(br_ctx *c, const br_config *cfg, const br_device_reco
   RC(pf.end());
   HIPCHK(hipMemcpyAsync(c->h_totals + 10, c->totals.as<uint64_t>() + 6, 16, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
-  if (nr && c->h_totals[10]) { pf.collect(); return BR_ERR_UNSUPPORTED; }  // > 65535 CIGAR ops in one record
+  // (h_totals[10], "a spilled CIGAR spans 2^28 reference bases or more", is set by the encoder: checked after it)
   uint64_t total = nr ? c->h_totals[11] : 0;
   RC(c->bam_out.ensure(std::max<size_t>(total, 16)));
   B.out = c->bam_out.as<uint8_t>();
   RC(pf.begin(BR_K_BAM));
   launch_bam_encode(st, B, c->bam_lanes);
   RC(pf.end());
+  HIPCHK(hipMemcpyAsync(c->h_totals + 10, c->totals.as<uint64_t>() + 6, 8, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
+  if (nr && c->h_totals[10]) { pf.collect(); return BR_ERR_UNSUPPORTED; }  // bam_write1 refuses such a record too
   RC(pf.collect());
   out->data = c->bam_out.as<uint8_t>(); out->n_bytes = total; out->row_off = c->bam_off.as<uint64_t>();
   return BR_OK;
@@ -1322,7 +1324,6 @@ extern "C" int br_project_bam_device(br_ctx *c, const br_config *cfg, const br_d
   BamArgs B{};
   B.n_aln = n; B.long_reads = dc.long_reads ? 1 : 0; B.blob = recs->blob; B.rec_off = recs->rec_off; B.rec_len = recs->rec_len;
   B.aux = (BamAux *)c->bam_aux.p; B.base_len = c->bam_base.as<uint32_t>(); B.xs_out = c->b_xs.as<int8_t>(); B.ts_out = c->b_ts.as<int8_t>();
-  B.cg_flag = c->p_small.as<uint32_t>() + 3;
   RC(c->bam_end.ensure(8)); B.blob_end = c->bam_end.as<uint64_t>();
   HIPCHK(hipMemsetAsync(B.blob_end, 0, 8, st));
 
@@ -1360,10 +1361,7 @@ extern "C" int br_project_bam_device(br_ctx *c, const br_config *cfg, const br_d
   launch_rec_copy(st, P);
   launch_mates(st, P);
   RC(pf.end());
-  HIPCHK(hipStreamWaitEvent(st, c->aux_ev[1], 0));   // k_bam_scan: XS / ts characters, the aux table, the CG flag
-  HIPCHK(hipMemcpyAsync(c->h_totals + 21, c->p_small.as<uint32_t>() + 2, 8, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
-  if (c->h_totals[21] >> 32) { pf.collect(); return BR_ERR_UNSUPPORTED; }  // a CIGAR spilled into a CG:B,I tag (> 65535 ops)
+  HIPCHK(hipStreamWaitEvent(st, c->aux_ev[1], 0));   // k_bam_scan: XS / ts characters, the aux table
 
   br_device_batch db{};
   if (fa_mode) {

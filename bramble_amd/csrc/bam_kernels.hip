@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "bam_cg.h"
 #include "kernels.h"
 
 namespace br {
@@ -27,42 +28,11 @@ namespace br {
 struct __attribute__((packed, aligned(1))) W4 { uint32_t a, b, c, d; };
 typedef uint32_t u32u __attribute__((aligned(1)));
 typedef uint16_t u16u __attribute__((aligned(1)));
-__device__ __forceinline__ uint32_t ld_u16(const uint8_t *p) { return *(const u16u *)p; }
-__device__ __forceinline__ uint32_t ld_u32(const uint8_t *p) { return *(const u32u *)p; }
-
 __device__ __forceinline__ uint32_t fix_nib(uint32_t x) {   // nibbles that are not one of 1, 2, 4, 8 become 15 (comp_table, src/bam.cpp:658-667)
   uint32_t pop = (x & 0x11111111u) + ((x >> 1) & 0x11111111u) + ((x >> 2) & 0x11111111u) + ((x >> 3) & 0x11111111u);
   uint32_t y = pop ^ 0x11111111u;
   uint32_t bad = (y | (y >> 1) | (y >> 2) | (y >> 3)) & 0x11111111u;
   return x | (bad * 15u);
-}
-
-// htslib skip_aux: size of the value of a tag of `type` at p (p = first value byte), or -1
-__device__ int64_t aux_value_len(uint8_t type, const uint8_t *p, const uint8_t *end) {
-  switch (type) {
-    case 'A': case 'c': case 'C': return 1;
-    case 's': case 'S': return 2;
-    case 'i': case 'I': case 'f': return 4;
-    case 'd': return 8;
-    case 'Z': case 'H': {   // up to and including the NUL: four bytes per load while four are left
-      const uint8_t *q = p;
-      while (end - q >= 4) {
-        const uint32_t w = ld_u32(q), z = (w - 0x01010101u) & ~w & 0x80808080u;
-        if (z) return (q - p) + (__builtin_ctz(z) >> 3) + 1;
-        q += 4;
-      }
-      while (q < end && *q) q++;
-      return q < end ? (q - p) + 1 : -1;
-    }
-    case 'B': {
-      if (end - p < 5) return -1;
-      uint8_t st = p[0]; uint32_t n = ld_u32(p + 1);
-      int sz = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : (st == 'i' || st == 'I' || st == 'f') ? 4 : 0;
-      if (!sz) return -1;
-      return 5 + (int64_t)n * sz;
-    }
-    default: return -1;
-  }
 }
 
 __device__ __forceinline__ uint32_t row_base_len(const BamArgs &B, const BamAux &x);
@@ -73,7 +43,7 @@ __device__ __forceinline__ void bam_scan_one(const BamArgs &B, int64_t a) {
   int8_t xs_c = 0, ts_c = 0;
   bool have_xs = false, have_ts = false;
   for (int k = 0; k < 4; k++) { x.off[k] = 0xffffffffu; x.len[k] = 0; }
-  x.as_val = 0; x.aux_start = 0; x.aux_len = 0; x.c_a = x.c_b = x.c_c = 0; x.qual_present = 0;
+  x.as_val = 0; x.aux_start = 0; x.aux_len = 0; x.c_a = x.c_b = x.c_c = 0; x.qual_present = 0; x.cg_len = 0;
   if (rlen >= 32) {
     x.c_a = ld_u32(rec + 8); x.c_b = ld_u32(rec + 12);
     uint32_t l_qname = x.c_a & 0xffu, n_cig = x.c_b & 0xffffu;
@@ -103,14 +73,17 @@ __device__ __forceinline__ void bam_scan_one(const BamArgs &B, int64_t a) {
       const uint8_t *s = rec + start, *end = rec + rlen;
       // slots: 0 NH, 1 XS (short) / ts (long), 2 HI, 3 AS (long reads only)
       bool have[4] = {false, false, false, false};
-      bool have_cg = false;
+      bool have_cg = false, cg_ok = false; uint32_t cg_len = 0;
       while (end - s >= 3) {
         // tag, type and the first value byte in one load (a tag without room for a value ends the walk below)
         const uint32_t tw = end - s >= 4 ? ld_u32(s) : (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16);
         const uint8_t t0 = (uint8_t)tw, t1 = (uint8_t)(tw >> 8), ty = (uint8_t)(tw >> 16), b3 = (uint8_t)(tw >> 24);
         int64_t vl = aux_value_len(ty, s + 3, end);
         if (vl < 0 || s + 3 + vl > end) break;  // malformed: htslib stops here too
-        if (t0 == 'C' && t1 == 'G' && ty == 'B' && b3 == 'I') have_cg = true;
+        if (t0 == 'C' && t1 == 'G' && !have_cg) {   // the first CG tag (bam_aux_get): a spilled CIGAR when of type B,I / B,i with enough entries
+          have_cg = true;
+          if (ty == 'B' && (b3 == 'I' || b3 == 'i') && end - s >= 8) { const uint32_t n = ld_u32(s + 4); cg_ok = n >= n_cig && n < (1u << 29); cg_len = (uint32_t)(3 + vl); }
+        }
         // tag_char1 (gclib/GSam.cpp:310-318): first value byte of the first XS / ts tag when A or Z
         if (t0 == 'X' && t1 == 'S' && !have_xs) { have_xs = true; if (ty == 'A' || ty == 'Z') xs_c = (int8_t)b3; }
         if (t0 == 't' && t1 == 's' && !have_ts) { have_ts = true; if (ty == 'A' || ty == 'Z') ts_c = (int8_t)b3; }
@@ -138,13 +111,10 @@ __device__ __forceinline__ void bam_scan_one(const BamArgs &B, int64_t a) {
         }
         s += 3 + vl;
       }
-      // A CIGAR of more than 65535 ops lives in a CG:B,I tag behind the placeholder <l_seq>S<ref_len>N (SAM spec 4.2.2);
-      // htslib's bam_read1 restores it for the reference, this reader does not: the bundle is refused.
-      if (have_cg && n_cig == 2 && B.cg_flag) {
-        const uint8_t *cg = rec + 32 + l_qname;
-        const uint32_t w0 = ld_u32(cg), w1 = ld_u32(cg + 4);
-        if ((w0 & 0xfu) == 4u && (w0 >> 4) == (uint32_t)l_seq && (w1 & 0xfu) == 3u) *B.cg_flag = 1u;
-      }
+      // A CIGAR of more than 65535 ops lives in a CG:B,I tag behind the placeholder <l_seq>S<ref_len>N (bam_cg.h): htslib's
+      // bam_read1 moves it into place and drops the tag, so the tag's bytes leave every output row of this record
+      // (encode_row finds the tag again; the fast task kernel hands such rows to it)
+      x.cg_len = (cg_ok && cg_candidate(rec, rlen, l_qname, n_cig, l_seq)) ? cg_len : 0u;
       // sort the (at most four) removal intervals by offset: a tiny insertion sort
       for (int i = 1; i < 4; i++)
         for (int j = i; j > 0 && x.off[j] < x.off[j - 1]; j--) {
@@ -180,7 +150,7 @@ __device__ __forceinline__ uint32_t row_base_len(const BamArgs &B, const BamAux 
   uint32_t l_qname = x.c_a & 0xffu;
   int32_t l_seq = (int32_t)x.c_c;
   uint32_t ls = l_seq > 0 ? (uint32_t)l_seq : 0;
-  uint32_t removed = x.len[0] + x.len[1] + x.len[2] + x.len[3];
+  uint32_t removed = x.len[0] + x.len[1] + x.len[2] + x.len[3] + x.cg_len;
   uint32_t added = 7u + 7u + (B.long_reads ? 7u : 0u);  // NH:i, HI:i, AS:i
   return 4u + 32u + l_qname + (ls + 1) / 2 + ls + (x.aux_len - removed) + added;
 }
@@ -190,8 +160,8 @@ __global__ void __launch_bounds__(256) k_bam_size(BamArgs B) {
   if (r >= B.n_rows) return;
   int32_t a = (int32_t)((const uint32_t *)(B.r_rec + r))[1];
   const uint32_t n_cig = ((const uint32_t *)(B.r_a + r))[2] & RM_NCIG;
-  B.out_len[r] = B.base_len[a] + 4u * n_cig;
-  if (n_cig > 65535u) *B.too_long = 1;  // would need htslib's CG:B,I spill-over; refused by the host
+  // more than 65535 ops: bam_write1's placeholder (8 bytes) in the CIGAR field, "CGBI" + count + the ops behind the aux area
+  B.out_len[r] = B.base_len[a] + 4u * n_cig + (n_cig > 65535u ? 16u : 0u);
 }
 
 // 4-bit base complement of reverse_complement_bam (src/bam.cpp:658-667)
@@ -251,6 +221,9 @@ __device__ __forceinline__ void encode_row(const BamArgs &B, int64_t r, int lane
   const uint4 ra = B.r_a[r];
   const uint32_t meta = ra.z, nh = ra.w, hi = ((const uint32_t *)(B.r_rec + r))[3] & RR_HI;
   uint32_t n_cig = meta & RM_NCIG;
+  // more than 65535 ops: what htslib's bam_write1 does -- the CIGAR field holds <l_seq>S<ref_len>N, the ops follow the
+  // aux area as a CG:B,I tag
+  const bool spill = n_cig > 65535u;
   bool minus = meta & RM_MINUS;
   bool paired = meta & RM_PAIRED, same = meta & RM_SAME;
   // flags: secondary (src/core.cpp:142-143), reverse (bam.cpp:698), mate bits (bam.cpp:531-588)
@@ -278,7 +251,7 @@ __device__ __forceinline__ void encode_row(const BamArgs &B, int64_t r, int lane
     h0.d = l_qname | (mapq << 8) | (bin << 16);                              // l_read_name, mapq, bin (kept)
     *(W4 *)out = h0;
   } else if (lane == 1) {
-    W4 h1; h1.a = (n_cig & 0xffffu) | (flag << 16); h1.b = (uint32_t)l_seq; h1.c = (uint32_t)mtid; h1.d = (uint32_t)mpos;
+    W4 h1; h1.a = (spill ? 2u : n_cig) | (flag << 16); h1.b = (uint32_t)l_seq; h1.c = (uint32_t)mtid; h1.d = (uint32_t)mpos;
     *(W4 *)(out + 16) = h1;
   } else if (lane == 2) {
     *(u32u *)(out + 32) = (uint32_t)tlen;
@@ -287,16 +260,24 @@ __device__ __forceinline__ void encode_row(const BamArgs &B, int64_t r, int lane
   copy_fwd<G>(out + o, rec + 32, l_qname, lane);                            // read name
   o += l_qname;
   // rewritten CIGAR (op order reversed on '-', bam.cpp:688-695)
-  {
-    const uint2 c = B.r_c[r];   // the ops themselves (<= 2), or their offset in the pool
+  const uint2 c = B.r_c[r];   // the ops themselves (<= 2), or their offset in the pool
+  const uint32_t *cgp = B.pool + (((uint64_t)c.y << 32) | c.x);
+  if (spill) {
+    uint32_t part = 0;        // bam_cigar2rlen: M, D, N, =, X consume the reference
+    for (uint32_t k = lane; k < n_cig; k += G) { const uint32_t w = cgp[k], op = w & 0xfu; if (op == 0u || op == 2u || op == 3u || op == 7u || op == 8u) part += w >> 4; }
+#pragma unroll
+    for (int d = G / 2; d; d >>= 1) part += (uint32_t)__shfl_xor((int)part, d, G);
+    if (part >= (1u << 28) && lane == 0) *B.too_long = 1;   // bam_write1 fails on such a record
+    if (lane == 0) { *(u32u *)(out + o) = ((uint32_t)l_seq << 4) | 4u; *(u32u *)(out + o + 4) = (part << 4) | 3u; }
+    o += 8;
+  } else {
     if (n_cig <= 2u) {
       if (lane < (int)n_cig) *(u32u *)(out + o + 4 * lane) = ((minus ? n_cig - 1 - lane : lane) == 0) ? c.x : c.y;
     } else {
-      const uint32_t *cg = B.pool + (((uint64_t)c.y << 32) | c.x);
-      for (uint32_t k = lane; k < n_cig; k += G) *(u32u *)(out + o + 4 * k) = cg[minus ? n_cig - 1 - k : k];
+      for (uint32_t k = lane; k < n_cig; k += G) *(u32u *)(out + o + 4 * k) = cgp[minus ? n_cig - 1 - k : k];
     }
+    o += 4 * n_cig;
   }
-  o += 4 * n_cig;
   // sequence: reverse-complemented nibbles on '-' (bam.cpp:671-678; the pad nibble of an odd length stays 0)
   const uint8_t *seq = rec + 32 + l_qname + 4 * n_cig_in;
   uint32_t sb = (ls + 1) / 2;
@@ -327,12 +308,17 @@ __device__ __forceinline__ void encode_row(const BamArgs &B, int64_t r, int lane
   // aux: original minus the first NH, XS|ts, HI (and AS for long reads): up to five kept pieces ...
   const uint8_t *aux = rec + x.aux_start;
   uint32_t src = 0;
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    if (x.off[k] == 0xffffffffu) break;
-    uint32_t piece = x.off[k] - src;
+  // ... and minus the CG:B,I tag of a record whose CIGAR was restored from it (bam_read1 drops it): a fifth interval
+  uint32_t cg_off = 0xffffffffu;
+  if (x.cg_len) { CgTag t; if (cg_find(rec, (uint64_t)x.aux_start + x.aux_len, l_qname, n_cig_in, l_seq, t)) cg_off = t.tag_at - x.aux_start; }
+  uint32_t k4 = 0;
+  for (int k = 0; k < 5; k++) {   // the four sorted intervals with the tag's merged in where it belongs
+    uint32_t ko = k4 < 4u ? x.off[k4] : 0xffffffffu, kl = k4 < 4u ? x.len[k4] : 0u;
+    if (cg_off < ko) { ko = cg_off; kl = x.cg_len; cg_off = 0xffffffffu; } else k4++;
+    if (ko == 0xffffffffu) break;
+    const uint32_t piece = ko - src;
     copy_fwd<G>(out + o, aux + src, piece, lane);
-    o += piece; src = x.off[k] + x.len[k];
+    o += piece; src = ko + kl;
   }
   copy_fwd<G>(out + o, aux + src, x.aux_len - src, lane);
   o += x.aux_len - src;
@@ -351,6 +337,12 @@ __device__ __forceinline__ void encode_row(const BamArgs &B, int64_t r, int lane
       *(u32u *)t = t01 | ((uint32_t)'i' << 16) | (val << 24);
       *(u32u *)(t + 3) = val;
     }
+    o += 7u * (uint32_t)n_tags;
+  }
+  if (spill) {   // "CG" 'B' 'I' count ops (op order reversed on '-', like the CIGAR field)
+    if (lane == 0) { *(u32u *)(out + o) = (uint32_t)'C' | ((uint32_t)'G' << 8) | ((uint32_t)'B' << 16) | ((uint32_t)'I' << 24); *(u32u *)(out + o + 4) = n_cig; }
+    o += 8;
+    for (uint32_t k = lane; k < n_cig; k += G) *(u32u *)(out + o + 4 * k) = cgp[minus ? n_cig - 1 - k : k];
   }
 }
 
@@ -416,6 +408,7 @@ __global__ void __launch_bounds__(256) k_bam_tasks(BamArgs B) {
   uint32_t row_at = 0, o_cig = 0, o_tags = 0, n_cig = 0, c_x = 0, c_y = 0;
   uint32_t tag_nh = 0, tag_hi = 0, tag_as = 0, row_tasks = 0;
   bool minus = false;
+  bool slow = false;   // a record whose CIGAR came out of a CG tag, or a row whose CIGAR must go into one: encode_row, below
   if (lane < nr) {
     const int64_t r = r0 + lane;
     const uint4 rr = B.r_rec[r];
@@ -456,6 +449,7 @@ __global__ void __launch_bounds__(256) k_bam_tasks(BamArgs B) {
     h4 = (n_cig & 0xffffu) | (flag << 16); h5 = (uint32_t)l_seq; h6 = (uint32_t)mtid; h7 = (uint32_t)mpos; h8 = (uint32_t)tlen;
     tag_nh = nh; tag_hi = rr.w & RR_HI;
     if (B.long_reads) tag_as = (uint32_t)(int32_t)(((double)x.as_val + (double)(B.r_clip ? B.r_clip[r] : 0)) * (B.r_sim ? B.r_sim[r] : 0.0));  // set_as_tag
+    slow = x.cg_len != 0u || n_cig > 65535u;
     BamTaskRow &D = L.d[lane];
     int ns = 0;
     uint32_t o = 36u, prev_mode = 0xffu, prev_end = 0, prev_len = 0, prev_o = 0;
@@ -475,6 +469,7 @@ __global__ void __launch_bounds__(256) k_bam_tasks(BamArgs B) {
       }                                                                                                                 \
     } while (0)
     uint32_t prev_tp = 0;
+    if (!slow) {
     BT_SEG(l_qname, BM_COPY, 32u);
     o_cig = o;
     o += 4u * n_cig;
@@ -489,6 +484,7 @@ __global__ void __launch_bounds__(256) k_bam_tasks(BamArgs B) {
       src = x.off[k] + x.len[k];
     }
     BT_SEG(x.aux_len - src, BM_COPY, x.aux_start + src);
+    }
     o_tags = o;
     D.tp[ns] = row_tasks;
     for (int k = ns + 1; k < 12; k++) D.tp[k] = 0xffffffffu;
@@ -612,7 +608,7 @@ __global__ void __launch_bounds__(256) k_bam_tasks(BamArgs B) {
   }
 
   // ---- 3. the synthesized bytes ----
-  if (lane < nr) {
+  if (lane < nr && !slow) {
     uint8_t *w = out + row_at;
     W4 x0; x0.a = h0; x0.b = h1; x0.c = h2; x0.d = h3; *(W4 *)w = x0;
     W4 x1; x1.a = h4; x1.b = h5; x1.c = h6; x1.d = h7; *(W4 *)(w + 16) = x1;
@@ -633,13 +629,22 @@ __global__ void __launch_bounds__(256) k_bam_tasks(BamArgs B) {
     *(u32u *)(t + 10) = tag_hi;
   }
   // CIGARs of more than two ops: the whole wave, row by row
-  uint64_t big = __ballot(lane < nr && n_cig > 2u);
+  uint64_t big = __ballot(lane < nr && n_cig > 2u && !slow);
   while (big) {
     const int i = __builtin_ctzll(big);
     big &= big - 1;
     const uint32_t at = L.d[i].cig_at, cn = L.d[i].cig_n, n = cn & 0x7fffffffu;
     const uint32_t *cg = B.pool + L.d[i].cig_src;
     for (uint32_t k2 = lane; k2 < n; k2 += 64) *(u32u *)(out + at + 4u * k2) = cg[(cn >> 31) ? n - 1u - k2 : k2];
+  }
+  // rows around a CG tag (ultra-long reads: rare), row by row with the whole wave: the generic encoder
+  uint64_t slowm = __ballot(lane < nr && slow);
+  while (slowm) {
+    const int i = __builtin_ctzll(slowm);
+    slowm &= slowm - 1;
+    const int64_t r = r0 + i;
+    const int32_t a = (int32_t)((const uint32_t *)(B.r_rec + r))[1];
+    encode_row<64>(B, r, lane, B.blob + B.rec_off[a], B.aux[a], B.out + B.out_off[r], (uint32_t)(B.out_off[r + 1] - B.out_off[r]));
   }
 }
 

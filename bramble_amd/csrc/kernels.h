@@ -220,6 +220,7 @@ struct BamAux {
   // the input: l_read_name | mapq << 8 | bin << 16, n_cigar_op | flag << 16, l_seq (record bytes 8..19); and whether
   // qualities are present (first QUAL byte != 0xff, src/bam.cpp:680)
   uint32_t c_a, c_b, c_c, qual_present;
+  uint32_t cg_len;          // bytes of the CG:B,I tag that holds the record's real CIGAR (0: none), see bam_cg.h
 };
 struct BamArgs {
   int64_t n_aln, n_rows;
@@ -230,7 +231,6 @@ struct BamArgs {
   int8_t *xs_out, *ts_out;   // [n_aln] or null: tag_char1("XS") / tag_char1("ts") of every record
   BamAux *aux;               // [n_aln]
   uint32_t *base_len;        // [n_aln] bytes of an output row of this record without its CIGAR (k_bam_scan -> k_bam_size)
-  uint32_t *cg_flag;         // set when a record's real CIGAR sits in a CG:B,I tag (null: not checked)
   const uint4 *r_a; const uint2 *r_c; const uint4 *r_rec;  // packed rows + the records behind them (PairArgs)
   const double *r_sim; const int32_t *r_clip;              // null: all zero
   const uint32_t *pool;
@@ -238,7 +238,7 @@ struct BamArgs {
   uint32_t *out_len;         // [n_rows]
   const uint64_t *out_off;   // [n_rows + 1]
   uint8_t *out;
-  uint64_t *too_long;        // set when a row's CIGAR exceeds the 16-bit n_cigar_op field
+  uint64_t *too_long;        // set when a spilled CIGAR's reference length does not fit the placeholder's 28 bits (bam_write1 fails there)
   uint64_t *blob_end;        // k_bam_scan: end (byte offset in blob) of the record that ends last; k_bam_tasks never loads past it
 };
 void launch_bam_scan(hipStream_t st, const BamArgs &B);

@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "bam_cg.h"
 #include "kernels.h"
 
 namespace br {
@@ -61,6 +62,8 @@ __global__ void __launch_bounds__(256) k_rec_fields(ParseArgs P) {
       const uint8_t *nm = rec + 32;
       // leading / trailing soft clips (sizing of the rescue buffers): S is only legal next to the ends (after H)
       const uint8_t *cg = rec + 32 + l_qname;
+      // a CIGAR spilled into a CG:B,I tag (more than 65535 ops): the real ops are the tag's array (bam_cg.h)
+      if (cg_candidate(rec, rlen, l_qname, ncig, l_seq)) { CgTag t; if (cg_find(rec, rlen, l_qname, ncig, l_seq, t)) { ncig = t.n; cg = rec + t.tag_at + 8; } }
       if (ncig) {
         uint32_t w = *(const u32u *)cg;
         if ((w & 0xfu) == 5u && ncig > 1) w = *(const u32u *)(cg + 4);
@@ -115,6 +118,12 @@ __global__ void __launch_bounds__(256) k_rec_copy(ParseArgs P) {
   if (nc == 0 && nl == 0) return;
   uint32_t l_qname = rec[8];
   const uint8_t *cg = rec + 32 + l_qname;
+  {   // the real CIGAR of a record whose CIGAR field holds the CG placeholder (k_rec_fields counted the tag's ops)
+    const uint32_t nf = ld_u16(rec + 12);
+    const int32_t l_seq = (int32_t)ld_u32(rec + 16);
+    const uint64_t rlen = rec_length(P, i);
+    if (nc != nf && cg_candidate(rec, rlen, l_qname, nf, l_seq)) { CgTag t; if (cg_find(rec, rlen, l_qname, nf, l_seq, t)) cg = rec + t.tag_at + 8; }
+  }
   uint32_t *dst = P.cigar + P.cigar_off[i];
   for (uint32_t k = lane; k < nc; k += G) dst[k] = *(const u32u *)(cg + 4 * k);
   uint8_t *nd = P.names + P.name_off[i];

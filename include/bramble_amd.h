@@ -396,8 +396,12 @@ typedef struct br_device_bam {
 /* Replaces the per-record byte work of write_to_bam (src/core.cpp:96-212: update_cigar,
  * NH/HI/AS tags, XS/ts deletion, reverse_complement_bam, set_mate_info; src/bam.cpp:474-702)
  * for every row of the LAST br_project_batch_device call on this context.  The rows must have
- * been produced with read names (is_primary decides the secondary flag).  CIGARs longer than
- * 65535 ops are not supported (BR_ERR_UNSUPPORTED). */
+ * been produced with read names (is_primary decides the secondary flag).  A rewritten CIGAR of more
+ * than 65535 ops is written the way htslib's bam_write1 writes it: <l_seq>S<ref_len>N in the CIGAR
+ * field, the ops in a CG:B,I tag behind the other tags (SAM spec 4.2.2); an input record in that form
+ * is read from its tag and loses it, as after bam_read1 (the reference sees records only through
+ * htslib, include/bramble.h:29-85).  BR_ERR_UNSUPPORTED only when such a CIGAR spans 2^28 reference
+ * bases or more (bam_write1 fails there too). */
 int br_bam_encode_device(br_ctx *, const br_config *, const br_device_records *, void *stream,
                          br_device_bam *out);
 

@@ -31,21 +31,43 @@ struct Bam1 {  // bam1_t: core + data (qname | cigar | seq | qual | aux)
 static inline uint32_t rd32(const uint8_t *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
 static inline void wr32(std::vector<uint8_t> &o, uint32_t v) { for (int k = 0; k < 4; k++) o.push_back((uint8_t)(v >> (8 * k))); }
 
+static inline void bam_tag2cigar(Bam1 &b);
+// bam_read1: the record as it sits in the file, then htslib's restore of a CIGAR that was spilled into a CG:B,I tag
+// (more than 65535 ops, SAM spec 4.2.2) -- the reference reads every record through it (include/bramble.h:29-85 over
+// gclib/GSam.cpp), so bam_get_cigar (gclib/GSam.cpp:197-201) already sees the real ops
 static inline Bam1 bam_parse(const uint8_t *r, size_t len) {  // BAM record from refID on
   Bam1 b;
   b.tid = (int32_t)rd32(r); b.pos = (int32_t)rd32(r + 4); b.l_qname = r[8]; b.qual = r[9];
   b.bin = (uint16_t)(r[10] | r[11] << 8); b.n_cigar = (uint32_t)(r[12] | r[13] << 8); b.flag = (uint16_t)(r[14] | r[15] << 8);
   b.l_qseq = (int32_t)rd32(r + 16); b.mtid = (int32_t)rd32(r + 20); b.mpos = (int32_t)rd32(r + 24); b.isize = (int32_t)rd32(r + 28);
   b.data.assign(r + 32, r + len);
+  bam_tag2cigar(b);
   return b;
 }
-static inline void bam_serialize(const Bam1 &b, std::vector<uint8_t> &o) {  // [block_size][record]
-  wr32(o, (uint32_t)(32 + b.data.size()));
+// bam_write1: [block_size][record]; a CIGAR of more than 65535 ops is written as the placeholder <l_qseq>S<ref_len>N with
+// the real ops in a CG:B,I tag behind everything else (htslib 1.22 sam.c, restated from its published behaviour: the
+// source is not in the reference tree -> parity unpinned)
+static inline void bam_serialize(const Bam1 &b, std::vector<uint8_t> &o) {
+  const bool spill = b.n_cigar > 0xffffu;
+  wr32(o, (uint32_t)(32 + b.data.size() + (spill ? 16 : 0)));
   wr32(o, (uint32_t)b.tid); wr32(o, (uint32_t)b.pos);
   o.push_back(b.l_qname); o.push_back(b.qual); o.push_back((uint8_t)b.bin); o.push_back((uint8_t)(b.bin >> 8));
-  o.push_back((uint8_t)b.n_cigar); o.push_back((uint8_t)(b.n_cigar >> 8)); o.push_back((uint8_t)b.flag); o.push_back((uint8_t)(b.flag >> 8));
+  const uint32_t nc = spill ? 2u : b.n_cigar;
+  o.push_back((uint8_t)nc); o.push_back((uint8_t)(nc >> 8)); o.push_back((uint8_t)b.flag); o.push_back((uint8_t)(b.flag >> 8));
   wr32(o, (uint32_t)b.l_qseq); wr32(o, (uint32_t)b.mtid); wr32(o, (uint32_t)b.mpos); wr32(o, (uint32_t)b.isize);
-  o.insert(o.end(), b.data.begin(), b.data.end());
+  if (!spill) { o.insert(o.end(), b.data.begin(), b.data.end()); return; }
+  uint64_t reflen = 0;   // bam_cigar2rlen: M, D, N, =, X consume the reference
+  for (uint32_t k = 0; k < b.n_cigar; k++) {
+    const uint32_t w = rd32(&b.data[b.cigar_at() + 4 * (size_t)k]), op = w & 0xf;
+    if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) reflen += w >> 4;
+  }
+  o.insert(o.end(), b.data.begin(), b.data.begin() + b.cigar_at());
+  wr32(o, ((uint32_t)b.l_qseq << 4) | 4u);             // <l_qseq>S
+  wr32(o, ((uint32_t)reflen << 4) | 3u);               // <ref_len>N
+  o.insert(o.end(), b.data.begin() + b.seq_at(), b.data.end());
+  o.push_back('C'); o.push_back('G'); o.push_back('B'); o.push_back('I');
+  wr32(o, b.n_cigar);
+  o.insert(o.end(), b.data.begin() + b.cigar_at(), b.data.begin() + b.seq_at());
 }
 
 // htslib skip_aux: bytes of the value after the type byte, -1 when malformed
@@ -79,6 +101,27 @@ static inline long aux_get(const Bam1 &b, const char tag[2]) {
     s += 3 + (size_t)vl;
   }
   return -1;
+}
+// htslib bam_tag2cigar (called by bam_read1): when the first CIGAR op is a soft clip of the whole read and a CG tag of
+// type B,I (or B,i) with at least n_cigar entries exists, the tag's array IS the CIGAR; it moves into place, the tag goes
+static inline void bam_tag2cigar(Bam1 &b) {
+  if (b.n_cigar == 0 || b.tid < 0 || b.pos < 0) return;
+  if (b.cigar_at() + 4u * (size_t)b.n_cigar > b.data.size()) return;
+  const uint32_t w0 = rd32(&b.data[b.cigar_at()]);
+  if ((w0 & 0xfu) != 4u || (w0 >> 4) != (uint32_t)b.l_qseq) return;
+  if (b.aux_at() > b.data.size()) return;
+  const long at = aux_get(b, "CG");
+  if (at < 0) return;
+  if (b.data[(size_t)at] != 'B' || !(b.data[(size_t)at + 1] == 'I' || b.data[(size_t)at + 1] == 'i')) return;
+  const uint32_t cg_len = rd32(&b.data[(size_t)at + 2]);
+  if (cg_len < b.n_cigar || cg_len >= (1u << 29)) return;
+  std::vector<uint8_t> real(b.data.begin() + (at + 6), b.data.begin() + (at + 6 + 4 * (long)cg_len));
+  std::vector<uint8_t> nd(b.data.begin(), b.data.begin() + b.cigar_at());
+  nd.insert(nd.end(), real.begin(), real.end());
+  nd.insert(nd.end(), b.data.begin() + b.seq_at(), b.data.begin() + (at - 2));                     // SEQ, QUAL, aux in front of the tag
+  nd.insert(nd.end(), b.data.begin() + (at + 6 + 4 * (long)cg_len), b.data.end());                 // aux behind it
+  b.data.swap(nd);
+  b.n_cigar = cg_len;
 }
 static inline void aux_del(Bam1 &b, long type_at) {
   long vl = aux_skip(b.data, (size_t)type_at);

@@ -99,3 +99,57 @@ def guide_order(ann):
         ex = sorted(txs[t]["exons"])
         return (ann["refnames"][txs[t]["ref_id"]].encode(), ex[0][0], ex[-1][1] - 1, txs[t]["id"].encode())
     return sorted(range(len(txs)), key=key)
+
+
+def bam_record(name, ref_id, pos0, cigar, l_seq, flag=0, aux=b"", mapq=30, mate=(-1, -1, 0), spill=None, seq=None, qual=None):
+    """One BAM record (from refID on, without block_size), assembled from the SAM/BAM specification, independent of the
+    product and of the oracle.  cigar: BAM-packed uint32 ops.  A CIGAR of more than 65535 ops is stored the way the
+    specification (4.2.2) and htslib's writer do: <l_seq>S<ref_len>N in the CIGAR field, the real ops in a CG:B,I tag
+    behind the other tags (spill=True forces that form for a short CIGAR, spill=False forbids it)."""
+    cigar = [int(w) for w in cigar]
+    if spill is None:
+        spill = len(cigar) > 65535
+    nm = name + b"\0"
+    field = cigar
+    tail = b""
+    if spill:
+        reflen = sum(w >> 4 for w in cigar if (w & 0xF) in (0, 2, 3, 7, 8))
+        field = [(l_seq << 4) | 4, (reflen << 4) | 3]
+        tail = b"CGBI" + struct.pack("<I", len(cigar)) + np.asarray(cigar, dtype="<u4").tobytes()
+    body = struct.pack("<iiBBHHHiiii", ref_id, pos0, len(nm), mapq, 4680, len(field), flag, l_seq, mate[0], mate[1], mate[2]) + nm
+    body += np.asarray(field, dtype="<u4").tobytes()
+    body += seq if seq is not None else bytes([0x12] * ((l_seq + 1) // 2))      # A C A C ...
+    body += qual if qual is not None else bytes([(30 + k) % 40 for k in range(l_seq)])
+    return body + aux + tail
+
+
+def frame(records):
+    """[block_size][record]... as numpy uint8 (the uncompressed alignment section)."""
+    return np.frombuffer(b"".join(struct.pack("<I", len(r)) + r for r in records), dtype=np.uint8)
+
+
+def split_stream(stream):
+    """-> list of record bytes (without block_size) of an uncompressed alignment section"""
+    data = bytes(stream)
+    out, p = [], 0
+    while p < len(data):
+        n = struct.unpack_from("<I", data, p)[0]
+        out.append(data[p + 4:p + 4 + n])
+        p += 4 + n
+    return out
+
+
+def record_fields(rec):
+    """the pieces of one BAM record: dict with n_cigar_field, cigar (the CIGAR field's words), aux (bytes), l_seq ..."""
+    ref_id, pos, l_qname, mapq, bin_, n_cig, flag, l_seq, mtid, mpos, tlen = struct.unpack_from("<iiBBHHHiiii", rec, 0)
+    p = 32
+    name = rec[p:p + l_qname - 1]
+    p += l_qname
+    cigar = list(np.frombuffer(rec[p:p + 4 * n_cig], dtype="<u4"))
+    p += 4 * n_cig
+    seq = rec[p:p + (l_seq + 1) // 2]
+    p += (l_seq + 1) // 2
+    qual = rec[p:p + l_seq]
+    p += l_seq
+    return {"ref_id": ref_id, "pos": pos, "name": name, "mapq": mapq, "bin": bin_, "flag": flag, "l_seq": l_seq, "mtid": mtid,
+            "mpos": mpos, "tlen": tlen, "n_cigar_field": n_cig, "cigar": cigar, "seq": seq, "qual": qual, "aux": rec[p:]}

@@ -60,35 +60,3 @@ def test_bundle_with_wrong_record_offsets_is_rejected_on_the_host():
         ctx.project_bam_bundle(lib.make_config(), blob, np.array([4], np.uint64), np.array([400], np.uint32), np.array([0], np.int32))
     ctx.close()
     idx.close()
-
-
-def test_cigar_spilled_into_a_cg_tag_is_refused_not_projected_from_the_placeholder():
-    """A record with more than 65535 CIGAR ops stores <l_seq>S<ref_len>N in the CIGAR field and the real ops in a
-    CG:B,I tag (SAM spec 4.2.2); htslib restores them for the reference (bam_read1).  This reader does not decode the
-    tag: the bundle must fail with BR_ERR_UNSUPPORTED, never be projected from the placeholder.  The same record
-    without the tag, and an ordinary record carrying a CG tag, are not refused."""
-    import struct
-    idx = lib.Index(ANN, device=0)
-    ctx = lib.Context(idx)
-
-    def rec(name, cigar, l_seq, aux):
-        nm = name + b"\0"
-        body = struct.pack("<iiBBHHHiiii", 0, 149, len(nm), 30, 4680, len(cigar), 0, l_seq, -1, -1, 0) + nm
-        body += b"".join(struct.pack("<I", w) for w in cigar) + bytes((l_seq + 1) // 2) + bytes([30] * l_seq) + aux
-        return body
-
-    cg_tag = b"CGBI" + struct.pack("<I", 3) + struct.pack("<III", 20 << 4, (10 << 4) | 2, 30 << 4)
-    placeholder = [(50 << 4) | 4, (60 << 4) | 3]
-    cases = [(rec(b"long", placeholder, 50, cg_tag), True),
-             (rec(b"plain", placeholder, 50, b""), False),
-             (rec(b"tagged", [50 << 4], 50, cg_tag), False)]
-    for body, refused in cases:
-        stream = np.frombuffer(struct.pack("<I", len(body)) + body, dtype=np.uint8)
-        off, ln, _, _ = lib.bam_split(stream)
-        if refused:
-            with pytest.raises(lib.BrambleError, match="unsupported"):
-                ctx.project_bam_bundle(lib.make_config(lr=1), stream, off, ln, np.array([0], np.int32))
-        else:
-            ctx.project_bam_bundle(lib.make_config(lr=1), stream, off, ln, np.array([0], np.int32))
-    ctx.close()
-    idx.close()
