@@ -39,15 +39,9 @@ def setup():
     return ann, idx, ctx, batch
 
 
-def test_full_size_properties(setup):
-    ann, idx, ctx, batch = setup
-    cfg = lib.make_config()
-    db = brdev.upload_batch(batch, "cuda:0")
-    rows = ctx.project_batch_device(cfg, db, 0)
-    t = brdev.rows_as_tensors(ctx)
+def _check_row_properties(t, batch):
+    """size-independent properties of one projected batch (t = the wide device view of its rows)"""
     n = t["n_rows"]
-    assert n > 5 * PAIRS and rows.total_processed == batch["n_aln"]
-
     # query length of every rewritten CIGAR == l_qseq of its input record
     w = t["cigar"].to(torch.int64) & 0xFFFFFFFF
     op = w & 0xF
@@ -68,6 +62,19 @@ def test_full_size_properties(setup):
     first_row = torch.cumsum(per_group, 0) - per_group
     assert bool((t["hi"].to(torch.int64) == torch.arange(n, device=g.device) - first_row[g] + 1).all())
     assert bool((g[1:] >= g[:-1]).all())
+    # a name with exactly one record is what total_unique counts (src/core.cpp:314-315); names with none are dropped
+    return int((per_group == 1).sum().item()), int((per_group > 0).sum().item())
+
+
+def test_full_size_properties(setup):
+    ann, idx, ctx, batch = setup
+    cfg = lib.make_config()
+    db = brdev.upload_batch(batch, "cuda:0")
+    rows = ctx.project_batch_device(cfg, db, 0)
+    t = brdev.rows_as_tensors(ctx)
+    n = t["n_rows"]
+    assert n > 5 * PAIRS and rows.total_processed == batch["n_aln"]
+    _check_row_properties(t, batch)
 
     cs1 = _checksums(t)
     # idempotence
@@ -352,5 +359,41 @@ def test_full_size_config4_hifi_similarity_filter():
     thr = float(np.float32(0.95))
     x = np.sqrt(prod["similarity_score"] / (prod["junc_hits"].astype(np.float64) + 1.0))
     assert (thr + x * (1.0 - thr) > thr).all()
+    ctx.close()
+    idx.close()
+
+
+def test_config3_eight_shards_of_12_5m_pairs():
+    """BASELINE.json configs[3]: 100 M paired-end short reads, input batch-sharded across 8 x MI355X.  The driver owns the
+    8-GPU node; here the eight 12.5 M-pair shards -- each rank's own seeded batch, exactly what `bench.py --gpus 8
+    --pairs 12500000` gives rank r -- go through the ONE card one after the other, every shard at full size: query-length
+    conservation, NH = records per read name, HI = 1..NH, and the counters of src/bramble.cpp:729-736 add up over the
+    shards the way the reference's workers add theirs (threads.cpp:114-162: no shared state but those sums)."""
+    ann = synth.Annotation("G")
+    idx = lib.Index.from_flat(ann.flat, device=0)
+    ctx = lib.Context(idx)
+    cfg = lib.make_config()
+    pairs = 12_500_000
+    tot = {"processed": 0, "complete": 0, "unique": 0, "dropped": 0, "groups": 0, "n_aln": 0, "rows": 0}
+    per_shard_rows = []
+    for rank in range(8):
+        batch = ann.reads(pairs, "pe", seed=(synth.SEED ^ 0x51ED) + 7919 * rank)     # bench.py's shard of rank `rank`
+        db = brdev.upload_batch(batch, "cuda:0")
+        rows = ctx.project_batch_device(cfg, db, 0)
+        t = brdev.rows_as_tensors(ctx)
+        assert t["n_rows"] == rows.n_rows and rows.n_rows > 5 * pairs and rows.total_processed == batch["n_aln"]
+        uniq, named = _check_row_properties(t, batch)
+        n_groups = int(db["n_groups"]) if isinstance(db, dict) and "n_groups" in db else pairs
+        assert rows.total_complete == rows.n_rows and rows.total_unique == uniq
+        # dropped = names none of whose alignments matched anything; a name can also match and still emit nothing (mates.cpp:153)
+        assert 0 < rows.dropped_reads <= n_groups - named
+        tot["processed"] += rows.total_processed; tot["complete"] += rows.total_complete; tot["unique"] += rows.total_unique
+        tot["dropped"] += rows.dropped_reads; tot["groups"] += n_groups; tot["n_aln"] += int(batch["n_aln"]); tot["rows"] += int(rows.n_rows)
+        per_shard_rows.append(int(rows.n_rows))
+        del t, rows, db, batch
+        torch.cuda.empty_cache()
+    assert tot["processed"] == tot["n_aln"] and tot["complete"] == tot["rows"] and tot["n_aln"] > 2 * 8 * pairs
+    assert tot["unique"] + tot["dropped"] < tot["groups"]
+    assert len(set(per_shard_rows)) == 8        # eight different shards, not one batch eight times
     ctx.close()
     idx.close()
