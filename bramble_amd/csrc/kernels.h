@@ -47,7 +47,14 @@ struct ProjectArgs {
   uint4 *wl;             // work list of the general class: {alignment, slab row | strand << 31, match slot, rank}; ~0u in .x: hole
   uint64_t *p1;          // device counters, see P1_* below
   uint64_t cap_m, cap_w, cap_c;   // capacities of the match table (slots), the work list (entries) and the arena (words)
+  // small batches without host round trips: the scan totals stay on the device (tot[0] matches, tot[1] arena words,
+  // tot[2] matches of the simple class), the tables were sized from upper bounds lim_m / lim_c, and a kernel that finds the
+  // totals beyond them does nothing (the host sees the same totals at the end and takes the ordinary path).  null: the
+  // host read the totals and passes them by value
+  const uint64_t *tot;
+  uint64_t lim_m, lim_c;
 };
+__device__ __forceinline__ bool tot_over(const uint64_t *tot, uint64_t lim_m, uint64_t lim_c) { return tot && (tot[0] > lim_m || tot[1] > lim_c); }
 // k_project1's counters (u64 each): the three allocators' high-water marks, "a capacity was exceeded", matches found,
 // work-list entries written
 // (the three allocators sit in different 128-byte lines: same-line atomics serialise in one L2 channel)
@@ -161,6 +168,8 @@ struct PairArgs {
   double *r_sim;            // aux presets only (similarity filter on)
   int32_t *r_clip;
   uint64_t *counters;       // [4] total_complete, total_unique, dropped_reads, a field overflowed its packed width
+  const uint64_t *tot;      // small batches (see ProjectArgs): tot[0..1] against lim_m / lim_c, tot[3] = records (n_rows_total is then the tables' capacity)
+  uint64_t lim_m, lim_c;
 };
 #define RR_HI 0x0fffffffu        // r_rec.w bits 0..27: HI
 #define RR_PRIMARY (1u << 28)
@@ -307,10 +316,15 @@ void launch_seq_ascii(hipStream_t st, const ParseArgs &P);
 void launch_bam_size(hipStream_t st, const BamArgs &B);
 void launch_bam_encode(hipStream_t st, const BamArgs &B, int lanes);
 
+// chores k_segment can take along for a small batch (null / 0: none): read-name group labels, zeroing of device counters
+struct SegExtra {
+  const uint32_t *group_off; uint32_t *aln_group; int64_t n_groups;
+  uint64_t *zero_a; int n_zero_a; uint64_t *zero_b; int n_zero_b;
+};
 void launch_segment(hipStream_t st, int64_t n_aln, const int32_t *ref_id, const int32_t *ref_start,
                     const uint16_t *flags, const int8_t *xs, const int8_t *ts, const uint32_t *cigar_off,
                     const uint32_t *cigar, const DevCfg &cfg, uint32_t n_refs, uint2 *seg, AlnMeta *meta,
-                    uint4 *head, uint4 *head2, uint32_t *fast_flag);
+                    uint4 *head, uint4 *head2, uint32_t *fast_flag, const SegExtra *extra = nullptr);
 // part: see launch_project_g (0 = everything)
 void launch_project(hipStream_t st, const ProjectArgs &A, bool emit, int group_lanes, int n_blocks, int part = 0);
 void launch_project_fa(hipStream_t st, const ProjectArgs &A, const FaArgs &F, int mode, int n_blocks);
@@ -335,8 +349,8 @@ int64_t scan_tiles_for(int64_t n);
 // 3: n_matches * CIGAR slot capacity with the per-alignment ideal_cap[] of the -S path
 void launch_scan(hipStream_t st, const ScanArgs &S, int mode, void *out, bool out64, uint64_t *total_out);
 void launch_group_ids(hipStream_t st, int64_t n_groups, const uint32_t *group_off, uint32_t *aln_group);
-void launch_scan3(hipStream_t st, ScanArgs S, uint32_t *match_off, uint64_t *cig_base, uint32_t *fast_pre,
-                  uint64_t *total_out3);
+bool launch_scan3(hipStream_t st, ScanArgs S, uint32_t *match_off, uint64_t *cig_base, uint32_t *fast_pre,
+                  uint64_t *total_out3, const ProjectArgs *expand = nullptr);
 void launch_pair(hipStream_t st, const PairArgs &P, bool emit);  // count pass: records per leader alignment; emit pass: r_rec
 // primary record per read name (RR_PRIMARY) + the per-group counters; names may be null (no primary flags)
 void launch_primary(hipStream_t st, const PairArgs &P, const uint32_t *name_off, const uint8_t *names, bool has_scores);

@@ -47,8 +47,12 @@ __global__ void __launch_bounds__(256) k_segment(int64_t n_aln, const int32_t *_
                                                  const uint32_t *__restrict__ cigar, DevCfg cfg,
                                                  uint32_t n_refs, uint2 *__restrict__ seg,
                                                  AlnMeta *__restrict__ meta, uint4 *__restrict__ head,
-                                                 uint4 *__restrict__ head2, uint32_t *__restrict__ fast_flag) {
+                                                 uint4 *__restrict__ head2, uint32_t *__restrict__ fast_flag, SegExtra X) {
   int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // small batches: two chores that would otherwise be launches of their own ride along -- the alignments' read-name group
+  // labels (k_group_ids) and the zeroing of the batch's few device counters
+  if (X.aln_group && a < X.n_groups) for (uint32_t i = X.group_off[a]; i < X.group_off[a + 1]; i++) X.aln_group[i] = (uint32_t)a;
+  if (a == 0) { for (int k = 0; k < X.n_zero_a; k++) X.zero_a[k] = 0; for (int k = 0; k < X.n_zero_b; k++) X.zero_b[k] = 0; }
   if (a >= n_aln) return;
   uint32_t c0 = cigar_off[a], c1 = cigar_off[a + 1];
   uint32_t n_cigar = c1 - c0;
@@ -699,6 +703,7 @@ __global__ void __launch_bounds__(256, EMIT ? 4 : 8) k_project(ProjectArgs A) {
 
   // EMIT: only the alignments with more than 64 candidate rows come here (the
   // rest is written by k_emit_dense); the count pass listed them in big_list.
+  if (EMIT && tot_over(A.tot, A.lim_m, A.lim_c)) return;
   const int64_t n_work = EMIT ? (int64_t)*A.n_big : MODE == 2 ? (int64_t)*A.n_walk : A.n_aln;
   for (int64_t w = gid; w < n_work; w += groups_total) {
     const int64_t a = EMIT ? (int64_t)A.big_list[w] : MODE == 2 ? (int64_t)A.walk_list[w] : w;
@@ -976,13 +981,12 @@ __global__ void __launch_bounds__(256, EMIT ? 4 : 8) k_project(ProjectArgs A) {
 // (alignment, k-th survivor) pairs, simple alignments first so that whole waves of
 // k_emit_dense take the short path.  Alignments with > 64 candidate rows are left
 // to the group kernel (~0u entries).
-__global__ void __launch_bounds__(256) k_expand(ProjectArgs A) {
+// (a = the thread's alignment; every wave of the block calls it, whole waves at a time)
+__device__ __forceinline__ void expand_chunk(const ProjectArgs &A, int64_t a, uint32_t (*sh_pre)[64], uint32_t (*sh_v)[64]) {
   // A wave takes 64 alignments.  Their entries of one class are one contiguous run of the list (the class offsets are
   // prefix sums over the alignments), so the wave writes the run with all its lanes -- entry e belongs to the alignment
   // whose exclusive count prefix is the last one <= e -- instead of every lane writing its own n_matches entries one by one.
-  __shared__ uint32_t sh_pre[4][64], sh_v[4][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t nm = 0, pos = 0, v = 0;
   bool fast = false;
   if (a < A.n_aln) nm = A.n_matches[a];
@@ -1016,6 +1020,12 @@ __global__ void __launch_bounds__(256) k_expand(ProjectArgs A) {
       A.m_aln[first + e] = sh_v[wv][l];
     }
   }
+  __builtin_amdgcn_wave_barrier();   // (the next chunk of a looping caller rewrites sh_v)
+}
+__global__ void __launch_bounds__(256) k_expand(ProjectArgs A) {
+  __shared__ uint32_t sh_pre[4][64], sh_v[4][64];
+  if (tot_over(A.tot, A.lim_m, A.lim_c)) return;
+  expand_chunk(A, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, sh_pre, sh_v);
 }
 
 // k_emit_dense: one lane per match.  Match mi of alignment a is the k-th set bit
@@ -1034,6 +1044,10 @@ __global__ void __launch_bounds__(256, CLS == 1 ? 8 : 6) k_emit_dense(ProjectArg
   if (CLS != 1) {
     sh_mops[threadIdx.x] = (uint16_t)((merge_action(threadIdx.x >> 4, threadIdx.x & 15u) << 8) | merge_ops(threadIdx.x >> 4, threadIdx.x & 15u));
     __syncthreads();
+  }
+  if (A.tot) {   // small batches: the totals never left the device (CLS 0 only: one launch over the whole list)
+    if (tot_over(A.tot, A.lim_m, A.lim_c)) return;
+    n_matches = (int64_t)A.tot[0];
   }
   int64_t mi64 = first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (mi64 >= n_matches) return;
@@ -1818,6 +1832,75 @@ __global__ void __launch_bounds__(256) k_scan3_apply(ScanArgs S, uint32_t *match
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) { match_off[S.n] = (uint32_t)ex[0]; cig_base[S.n] = ex[1]; fast_pre[S.n] = (uint32_t)ex[2]; }
 }
 
+// Small inputs (at most SCAN_SMALL_TILES tiles): the whole scan by ONE block, tile after tile with a running carry -- one
+// launch instead of three (tile sums, their scan, apply): what a batch of a few thousand alignments spends its time on is
+// launches, not bytes.
+#define SCAN_SMALL_TILES 4
+#define EXPAND_SMALL_N 1024   // the scanning block writes the work list too up to this many alignments (four chunks of its 256 threads)
+template <int MODE, typename OutT>
+__global__ void __launch_bounds__(256) k_scan_small(ScanArgs S, OutT *out, uint64_t *total_out) {
+  __shared__ uint64_t sh[4];
+  uint64_t carry = 0;
+  for (int64_t t0 = 0; t0 < S.n || t0 == 0; t0 += SCAN_TILE) {
+    const int64_t base = t0 + (int64_t)threadIdx.x * SCAN_ITEMS;
+    uint64_t v[SCAN_ITEMS];
+    uint64_t sum = 0;
+    if (MODE == 0 || MODE == 2) {
+      uint32_t w[SCAN_ITEMS];
+      load8(S.src32, base, S.n, w);
+#pragma unroll
+      for (int k = 0; k < SCAN_ITEMS; k++) { v[k] = w[k]; sum += v[k]; }
+    } else {
+#pragma unroll
+      for (int k = 0; k < SCAN_ITEMS; k++) { int64_t i = base + k; v[k] = i < S.n ? scan_value<MODE>(S, i) : 0; sum += v[k]; }
+    }
+    uint64_t tot;
+    uint64_t ex = block_excl_scan_256(sum, sh, tot) + carry;
+    OutT o[SCAN_ITEMS];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) { o[k] = (OutT)ex; ex += v[k]; }
+    store8(out, base, S.n, o);
+    carry += tot;
+  }
+  if (threadIdx.x == 0) { out[S.n] = (OutT)carry; total_out[0] = carry; }
+}
+// EXPAND: the emit work list too (k_expand's job), by the same block once its offsets are in place
+template <bool EXPAND>
+__global__ void __launch_bounds__(256) k_scan3_small(ScanArgs S, uint32_t *match_off, uint64_t *cig_base, uint32_t *fast_pre, uint64_t *total_out,
+                                                     ProjectArgs A) {
+  __shared__ uint64_t sh[4];
+  __shared__ uint32_t sh_pre[EXPAND ? 4 : 1][64], sh_v[EXPAND ? 4 : 1][64];
+  uint64_t carry[3] = {0, 0, 0};
+  for (int64_t t0 = 0; t0 < S.n || t0 == 0; t0 += SCAN_TILE) {
+    const int64_t base = t0 + (int64_t)threadIdx.x * SCAN_ITEMS;
+    Scan3 v[SCAN_ITEMS];
+    uint64_t sum[3] = {0, 0, 0};
+    scan3_load(S, base, v);
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) { sum[0] += v[k].v[0]; sum[1] += v[k].v[1]; sum[2] += v[k].v[2]; }
+    uint64_t ex[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) { uint64_t tot; ex[c] = block_excl_scan_256(sum[c], sh, tot) + carry[c]; carry[c] += tot; }
+    uint32_t o0[SCAN_ITEMS], o2[SCAN_ITEMS]; uint64_t o1[SCAN_ITEMS];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+      o0[k] = (uint32_t)ex[0]; o1[k] = ex[1]; o2[k] = (uint32_t)ex[2];
+      ex[0] += v[k].v[0]; ex[1] += v[k].v[1]; ex[2] += v[k].v[2];
+    }
+    store8(match_off, base, S.n, o0); store8(cig_base, base, S.n, o1); store8(fast_pre, base, S.n, o2);
+  }
+  if (threadIdx.x == 0) {
+    match_off[S.n] = (uint32_t)carry[0]; cig_base[S.n] = carry[1]; fast_pre[S.n] = (uint32_t)carry[2];
+    total_out[0] = carry[0]; total_out[1] = carry[1]; total_out[2] = carry[2];
+  }
+  if (EXPAND) {
+    if (carry[0] > A.lim_m || carry[1] > A.lim_c) return;   // (every thread holds the totals)
+    __threadfence_block();
+    __syncthreads();                                        // the offsets above are read below, by other threads
+    for (int64_t base = 0; base < S.n; base += 256) expand_chunk(A, base + threadIdx.x, sh_pre, sh_v);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // k_pair<EMIT>: one lane per read-name group.
 //   src/core.cpp:343-426 (which alignments pair up), src/mates.cpp:150-261
@@ -1847,6 +1930,7 @@ __global__ void __launch_bounds__(256) k_group_ids(int64_t n_groups, const uint3
 template <bool EMIT>
 __global__ void __launch_bounds__(256) k_pair(PairArgs P) {
   int64_t i64 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tot_over(P.tot, P.lim_m, P.lim_c)) { if (!EMIT && i64 < P.n_aln) { P.n_rows[i64] = 0; P.pbit[i64] = 0; } return; }
   // count pass: the merge of two mates' tid lists is a chain of dependent loads, two per step.  The lists of a wave's 64
   // alignments are one contiguous piece of m_tid (match_off is a prefix sum) and mates sit next to each other, so the wave
   // copies that piece to LDS first (coalesced) and the chains run on LDS latency; lists outside the piece, or a piece that
@@ -1967,6 +2051,7 @@ __global__ void __launch_bounds__(256) k_pair_emit(PairArgs P) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t i64 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t i = (uint32_t)i64;
+  if (tot_over(P.tot, P.lim_m, P.lim_c)) return;
   uint4 *__restrict__ rec = P.r_rec;
   uint32_t rows = 0, kind = 0, mi0 = 0, mm0 = 0, ni = 0, nm = 0, nh = 0, hi0 = 0;
   int32_t m = -1;
@@ -2056,6 +2141,7 @@ template <bool SCORES>
 __global__ void __launch_bounds__(256) k_primary(PairArgs P, const uint32_t *__restrict__ name_off,
                                                  const uint8_t *__restrict__ names) {
   unsigned long long uniq = 0, dropped = 0;
+  if (tot_over(P.tot, P.lim_m, P.lim_c)) return;
   uint32_t *flagw = (uint32_t *)P.r_rec + 3;   // flag word of record r: flagw[4 * r]
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < P.n_groups; g += (int64_t)gridDim.x * blockDim.x) {
     const uint32_t a0 = P.group_off[g], a1 = P.group_off[g + 1];
@@ -2156,7 +2242,8 @@ __global__ void __launch_bounds__(256) k_primary(PairArgs P, const uint32_t *__r
 template <bool AUX>
 __global__ void __launch_bounds__(256) k_rows(PairArgs P) {
   int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= P.n_rows_total) return;
+  if (P.tot) { if (tot_over(P.tot, P.lim_m, P.lim_c) || r >= (int64_t)P.tot[3]) return; }   // small batches: the record count is on the device
+  else if (r >= P.n_rows_total) return;
   const uint4 rec = P.r_rec[r];
   const uint32_t x = rec.x;
   const uint32_t tid = P.m_tid[x];
@@ -2359,10 +2446,12 @@ static inline int grid_for(int64_t n, int per_block) { return (int)((n + per_blo
 void launch_segment(hipStream_t st, int64_t n_aln, const int32_t *ref_id, const int32_t *ref_start,
                     const uint16_t *flags, const int8_t *xs, const int8_t *ts, const uint32_t *cigar_off,
                     const uint32_t *cigar, const DevCfg &cfg, uint32_t n_refs, uint2 *seg, AlnMeta *meta,
-                    uint4 *head, uint4 *head2, uint32_t *fast_flag) {
+                    uint4 *head, uint4 *head2, uint32_t *fast_flag, const SegExtra *extra) {
   if (n_aln <= 0) return;
+  SegExtra X{};
+  if (extra) X = *extra;
   hipLaunchKernelGGL(k_segment, dim3(grid_for(n_aln, 256)), dim3(256), 0, st, n_aln, ref_id, ref_start, flags,
-                     xs, ts, cigar_off, cigar, cfg, n_refs, seg, meta, head, head2, fast_flag);
+                     xs, ts, cigar_off, cigar, cfg, n_refs, seg, meta, head, head2, fast_flag, X);
 }
 
 // part (count pass of the presets without the similarity filter, walk_list set): 0 = both kernels, 1 = the main one, 2 = the
@@ -2454,6 +2543,14 @@ void launch_scan(hipStream_t st, const ScanArgs &S, int mode, void *out, bool ou
   int64_t tiles = scan_tiles_for(S.n);
   if (tiles < 1) tiles = 1;
   dim3 g((unsigned)tiles), b(256);
+  if (tiles <= SCAN_SMALL_TILES) {   // one launch
+    const dim3 one(1);
+    if (mode == 1) hipLaunchKernelGGL((k_scan_small<1, uint64_t>), one, b, 0, st, S, (uint64_t *)out, total_out);
+    else if (mode == 3) hipLaunchKernelGGL((k_scan_small<3, uint64_t>), one, b, 0, st, S, (uint64_t *)out, total_out);
+    else if (out64) hipLaunchKernelGGL((k_scan_small<2, uint64_t>), one, b, 0, st, S, (uint64_t *)out, total_out);
+    else hipLaunchKernelGGL((k_scan_small<2, uint32_t>), one, b, 0, st, S, (uint32_t *)out, total_out);
+    return;
+  }
   if (mode == 0) hipLaunchKernelGGL((k_scan_tiles<0>), g, b, 0, st, S);
   else if (mode == 1) hipLaunchKernelGGL((k_scan_tiles<1>), g, b, 0, st, S);
   else if (mode == 3) hipLaunchKernelGGL((k_scan_tiles<3>), g, b, 0, st, S);
@@ -2472,15 +2569,24 @@ void launch_scan(hipStream_t st, const ScanArgs &S, int mode, void *out, bool ou
   }
 }
 
-void launch_scan3(hipStream_t st, ScanArgs S, uint32_t *match_off, uint64_t *cig_base, uint32_t *fast_pre,
-                  uint64_t *total_out3) {
+// expand (small batches): the work list as well; returns whether it was written (one launch did both), else the caller
+// launches k_expand
+bool launch_scan3(hipStream_t st, ScanArgs S, uint32_t *match_off, uint64_t *cig_base, uint32_t *fast_pre,
+                  uint64_t *total_out3, const ProjectArgs *expand) {
   int64_t tiles = scan_tiles_for(S.n);
   if (tiles < 1) tiles = 1;
   S.n_tiles = tiles;
   dim3 g((unsigned)tiles), b(256);
+  if (tiles <= SCAN_SMALL_TILES) {
+    if (expand && S.n <= EXPAND_SMALL_N) { hipLaunchKernelGGL((k_scan3_small<true>), dim3(1), b, 0, st, S, match_off, cig_base, fast_pre, total_out3, *expand); return true; }
+    const ProjectArgs none{};
+    hipLaunchKernelGGL((k_scan3_small<false>), dim3(1), b, 0, st, S, match_off, cig_base, fast_pre, total_out3, none);
+    return false;
+  }
   hipLaunchKernelGGL(k_scan3_tiles, g, b, 0, st, S);
   hipLaunchKernelGGL(k_scan3_top, dim3(1), b, 0, st, S.tile_sums, tiles, total_out3);
   hipLaunchKernelGGL(k_scan3_apply, g, b, 0, st, S, match_off, cig_base, fast_pre);
+  return false;
 }
 
 void launch_stats(hipStream_t st, const StatsArgs &T, const uint2 *m_p, const uint32_t *match_off, const uint32_t *n_matches) {

@@ -58,6 +58,8 @@ def run(rounds, seed, verbose=True, read_counts=(500, 3000, 9000), gene_counts=(
         b = ann.reads(n_reads, mode, with_records=1, with_seq=1 if with_genome else 0, seed=int(rng.randint(1, 1 << 30)), xs_tag=bool(xs), **kw)
         idx = lib.Index(annd, device=0)
         ctx = lib.Context(idx)
+        ctx.set_param("small_batch", it & 1)        # the path without host round trips on odd rounds, the ordinary one on even rounds
+        desc["small_batch"] = it & 1
         ctx.set_param("group_lanes", int(rng.choice([8, 16, 32, 64])))
         cfg = lib.make_config(**flags)
         oi = ob.OracleIndex(annd)

@@ -18,6 +18,11 @@ def run_both(ann_dict, batch, group_lanes=64, **flags):
     prod = ctx.project_batch(lib.make_config(**flags), batch)
     oi = ob.OracleIndex(ann_dict)
     orc, _, _ = ob.run(oi, ob.make_flags(**flags), batch, want_matches=False)
+    # batches of up to 65536 alignments take the path without host round trips (run_device_small) by default: the
+    # ordinary pipeline must give the same rows on the same input
+    if batch["n_aln"] <= 65536:
+        ctx.set_param("small_batch", 0)
+        assert_rows_equal(ctx.project_batch(lib.make_config(**flags), batch), orc)
     ctx.close()
     idx.close()
     return prod, orc
