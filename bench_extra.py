@@ -6,6 +6,9 @@
   python bench_extra.py bam [--reads N]  re-encode the rows of configs[1] as BAM records (device part)
   python bench_extra.py bundle [--reads N]  raw BAM records resident in HBM -> projected BAM records (br_project_bam_device)
   python bench_extra.py cli [--reads N] [--threads T]  the command line file to file (BGZF inflate, device path, BGZF deflate)
+  python bench_extra.py small            small calls: us per device-resident step at 1 .. 52 000 pairs (without the per-kernel
+                                         events bench.py keeps on), the path without host round trips against the ordinary one,
+                                         and br_project_group / br_project_groups host to host from plain C (profiles/group_latency.c)
 
 Same protocol as bench.py: inputs resident in HBM, warmup, hipEvent kernel times, one JSON line.
 """
@@ -20,7 +23,7 @@ import time
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("config", choices=["c3", "c5", "bam", "bundle", "cli"])
+    ap.add_argument("config", choices=["c3", "c5", "bam", "bundle", "cli", "small"])
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--reads", type=int, default=0)
     ap.add_argument("--steps", type=int, default=3)
@@ -29,6 +32,41 @@ def main():
     import torch
     from bramble_amd import device as brdev
     from bramble_amd import lib, synth
+    if args.config == "small":
+        import subprocess
+        root = os.path.dirname(os.path.abspath(__file__))
+        ann = synth.Annotation("G")
+        idx = lib.Index.from_flat(ann.flat, device=0)
+        cfg = lib.make_config()
+        out = {"config": "small", "unit": "us per call", "device_resident_step": {}}
+        for pairs in (1, 32, 1000, 5000, 30000, 52000):
+            batch = ann.reads(pairs, "pe", seed=1234 + pairs)
+            db = brdev.upload_batch(batch, "cuda:0")
+            row = {"alignments": int(batch["n_aln"])}
+            for small in (1, 0):
+                ctx = lib.Context(idx)
+                ctx.set_param("small_batch", small)
+                for _ in range(20):
+                    ctx.project_batch_device(cfg, db, 0)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                k = 300
+                for _ in range(k):
+                    ctx.project_batch_device(cfg, db, 0)
+                torch.cuda.synchronize()
+                row["no_host_round_trips" if small else "ordinary_pipeline"] = round((time.perf_counter() - t0) / k * 1e6, 1)
+                ctx.close()
+            out["device_resident_step"]["pairs=%d" % pairs] = row
+        exe = "/tmp/group_latency"
+        try:
+            subprocess.check_call(["gcc", "-O2", "-std=c99", "-I", os.path.join(root, "include"), os.path.join(root, "profiles", "group_latency.c"),
+                                   "-o", exe, "-L", os.path.join(root, "bramble_amd"), "-lbramble_amd", "-Wl,-rpath," + os.path.join(root, "bramble_amd")])
+            runs = [json.loads(subprocess.run([exe], check=True, capture_output=True, text=True, timeout=300).stdout.strip().splitlines()[-1]) for _ in range(3)]
+            out["host_to_host_from_c"] = {k: [r[k] for r in runs] for k in runs[0]}
+        except Exception as e:   # no compiler on the box: the device-resident numbers stand alone
+            out["host_to_host_from_c"] = "not measured: %s" % e
+        print(json.dumps(out))
+        return
     if args.config == "bam":
         # re-encode the rows of configs[1] as BAM records: HBM-bound byte streaming
         n = args.reads or 10_000_000

@@ -494,6 +494,10 @@ struct br_ctx {
   PinnedVec<double> h_sim;
   PinnedVec<uint8_t> h_primary, h_paired, h_same, h_first;
   std::vector<br_projected> h_proj;
+  // br_project_group(s): one packed upload of the call's alignments, and the packed rows / their CIGAR words back
+  PinnedVec<uint8_t> g_host; DevBuf g_dev;
+  PinnedVec<uint4> g_a, g_x; PinnedVec<uint2> g_c; PinnedVec<uint32_t> g_pool, g_cig; PinnedVec<double> g_sim;
+  bool rows_to_host = false, rows_at_host = false;   // br_project_group(s): the small path's row kernel writes g_a / g_c / g_x / g_sim (pinned host memory) itself
   DevBuf *all() { return &seg; }
 };
 
@@ -534,7 +538,7 @@ extern "C" void br_ctx_free(br_ctx *c) {
                     &c->r_ncig, &c->r_strand, &c->r_sim, &c->r_clip, &c->r_junc, &c->r_refc, &c->r_cigoff,
                     &c->cigar_out, &c->r_paired, &c->r_same, &c->r_first, &c->r_primary, &c->b_name_off, &c->b_names, &c->b_ref_id, &c->b_ref_start,
                     &c->b_flags, &c->b_xs, &c->b_ts, &c->b_cigar_off, &c->b_cigar, &c->b_mate_idx,
-                    &c->b_group_off, &c->b_lqseq, &c->walk_list, &c->pmask, &c->pbit, &c->pick, &c->wl, &c->p1,
+                    &c->b_group_off, &c->b_lqseq, &c->walk_list, &c->pmask, &c->pbit, &c->pick, &c->wl, &c->p1, &c->g_dev,
                     &c->fa_srcs, &c->fa_want, &c->ksw_desc, &c->ksw_dp, &c->ksw_left, &c->ksw_cnt, &c->ksw_group, &c->ksw_tape, &c->ksw_raw};
   for (DevBuf *b : bufs) b->release();
   for (auto &e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -560,6 +564,7 @@ extern "C" void br_ctx_free(br_ctx *c) {
   c->h_isize.release(); c->h_tid.release(); c->h_pos.release(); c->h_nh.release(); c->h_hi.release(); c->h_mapq.release(); c->h_group.release();
   c->h_cigar.release(); c->h_strand.release(); c->h_cigoff.release(); c->h_sim.release(); c->h_primary.release(); c->h_paired.release();
   c->h_same.release(); c->h_first.release();
+  c->g_host.release(); c->g_a.release(); c->g_x.release(); c->g_c.release(); c->g_pool.release(); c->g_cig.release(); c->g_sim.release();
   delete c;
 }
 
@@ -869,6 +874,16 @@ static int run_device_small(br_ctx *c, const DevCfg &dc, const br_device_batch *
   P.n_rows_total = (int64_t)cap_m; P.r_rec = c->r_rec.as<uint4>();
   P.r_a = c->pk_a.as<uint4>(); P.r_c = c->pk_c.as<uint2>(); P.r_x = nullptr;
   P.r_sim = aux_cols ? c->pk_sim.as<double>() : nullptr; P.r_clip = aux_cols ? c->pk_clip.as<int32_t>() : nullptr;
+  // a caller that wants the few rows of a small call on the host (br_project_group): the row kernel writes the packed rows
+  // and their detail column straight into pinned host memory -- no download, no second wait
+  c->rows_at_host = false;
+  if (c->rows_to_host) {
+    RC(c->g_a.resize(cap_m)); RC(c->g_c.resize(cap_m)); RC(c->g_x.resize(cap_m));
+    if (aux_cols) RC(c->g_sim.resize(cap_m));
+    P.r_a = c->g_a.p; P.r_c = c->g_c.p; P.r_x = c->g_x.p;
+    if (aux_cols) P.r_sim = c->g_sim.p;
+    c->rows_at_host = true;
+  }
   const uint8_t *names = (b->names && b->name_off) ? b->names : nullptr;
   if (!aux_cols) {   // the primary choice needs row_off and the pair bits only: before the records exist, its pick applied by k_rows
     P.pick = c->pick.as<uint64_t>();
@@ -896,8 +911,8 @@ static int run_device_small(br_ctx *c, const DevCfg &dc, const br_device_batch *
   if (c->h_totals[7]) return BR_ERR_UNSUPPORTED;  // a rewritten CIGAR with more than 2^24 - 1 ops
   out->n_matches = (int64_t)n_matches; out->n_rows = (int64_t)n_rows; out->n_pool_words = (int64_t)n_cig_arena;
   out->total_complete = n_rows; out->total_unique = c->h_totals[5]; out->dropped_reads = c->h_totals[6];
-  out->a = (const br_row_a *)c->pk_a.p; out->cigar = (const uint64_t *)c->pk_c.p; out->x = nullptr;
-  out->similarity_score = aux_cols ? c->pk_sim.as<double>() : nullptr;
+  out->a = (const br_row_a *)P.r_a; out->cigar = (const uint64_t *)P.r_c; out->x = (const br_row_x *)P.r_x;
+  out->similarity_score = aux_cols ? P.r_sim : nullptr;
   out->clip_score = aux_cols ? c->pk_clip.as<int32_t>() : nullptr;
   out->pool = c->cig_arena.as<uint32_t>(); out->row_off = c->row_off.as<uint64_t>();
   c->counters[6] = n_matches;
@@ -1943,6 +1958,135 @@ extern "C" int br_project_batch(br_ctx *c, const br_config *cfg, const br_batch 
   return BR_OK;
 }
 
+extern "C" uint32_t br_row_mapq(uint32_t nh, int long_reads);
+static int project_groups_lean(br_ctx *c, const br_config *cfg, const br_batch &b, const std::vector<uint64_t> &kept,
+                               const std::vector<char> &read_strand, const br_projected **out, size_t *n_out) {
+  const size_t n = (size_t)b.n_aln;
+  const uint64_t n_words = b.cigar_off[n], n_name = b.name_off[n], n_seq = b.seq_off ? b.seq_off[n] : 0;
+  if (n_words >= 0x7fffffffull || n_name >= 0x7fffffffull || n_seq >= 0x7fffffffull) return BR_RETRY_ORDINARY;
+  HIPCHK(hipSetDevice(c->ix->device));
+  RC(ensure_streams(c));
+  hipStream_t st = c->run_stream;
+  // the contract on the host (src/core.cpp:347-380, src/bramble.cpp:272-311, src/core.cpp:353-378)
+  std::vector<int32_t> mate_idx(n), seq_src;
+  std::vector<uint32_t> group_off(n + 1);
+  int64_t ng = 0;
+  RC(br_batch_prepare(&b, mate_idx.data(), group_off.data(), &ng));
+  if (b.seq_off) { seq_src.resize(n); RC(br_batch_seq_source(&b, group_off.data(), ng, seq_src.data())); }
+  // one packed upload: every array at a 16-byte aligned offset
+  size_t at = 0;
+  auto place = [&](size_t bytes) { const size_t o = at; at = (at + bytes + 15) & ~(size_t)15; return o; };
+  const size_t o_ref = place(4 * n), o_start = place(4 * n), o_flags = place(2 * n), o_xs = place(n), o_ts = place(n),
+               o_coff = place(4 * (n + 1)), o_cig = place(4 * (size_t)n_words), o_mate = place(4 * n), o_goff = place(4 * ((size_t)ng + 1)),
+               o_lq = place(4 * n), o_noff = place(4 * (n + 1)), o_names = place((size_t)n_name),
+               o_soff = place(b.seq_off ? 4 * (n + 1) : 0), o_seqs = place((size_t)n_seq), o_ssrc = place(b.seq_off ? 4 * n : 0);
+  RC(c->g_host.resize(at + 16));
+  RC(c->g_dev.ensure(at + 16));
+  uint8_t *h = c->g_host.data();
+  memcpy(h + o_ref, b.ref_id, 4 * n); memcpy(h + o_start, b.ref_start, 4 * n); memcpy(h + o_flags, b.flags, 2 * n);
+  memcpy(h + o_xs, b.xs, n); memcpy(h + o_ts, b.ts, n);
+  int32_t max_nc = 0, max_clip = 0;
+  for (size_t i = 0; i <= n; i++) { ((uint32_t *)(h + o_coff))[i] = (uint32_t)b.cigar_off[i]; ((uint32_t *)(h + o_noff))[i] = (uint32_t)b.name_off[i]; }
+  for (size_t i = 0; i < n; i++) {
+    const uint64_t c0 = b.cigar_off[i], c1 = b.cigar_off[i + 1];
+    max_nc = std::max<int32_t>(max_nc, (int32_t)(c1 - c0));
+    if (c1 > c0) {   // leading / trailing soft clips (sizing of the rescue buffers), as k_soa_fields
+      uint32_t w = b.cigar[c0];
+      if ((w & 0xfu) == 5u && c1 - c0 > 1) w = b.cigar[c0 + 1];
+      if ((w & 0xfu) == 4u) max_clip = std::max<int32_t>(max_clip, (int32_t)(w >> 4));
+      w = b.cigar[c1 - 1];
+      if ((w & 0xfu) == 5u && c1 - c0 > 1) w = b.cigar[c1 - 2];
+      if ((w & 0xfu) == 4u) max_clip = std::max<int32_t>(max_clip, (int32_t)(w >> 4));
+    }
+  }
+  memcpy(h + o_cig, b.cigar, 4 * (size_t)n_words); memcpy(h + o_mate, mate_idx.data(), 4 * n);
+  memcpy(h + o_goff, group_off.data(), 4 * ((size_t)ng + 1));
+  if (b.l_qseq) memcpy(h + o_lq, b.l_qseq, 4 * n); else memset(h + o_lq, 0, 4 * n);
+  memcpy(h + o_names, b.names, (size_t)n_name);
+  if (b.seq_off) {
+    for (size_t i = 0; i <= n; i++) ((uint32_t *)(h + o_soff))[i] = (uint32_t)b.seq_off[i];
+    memcpy(h + o_seqs, b.seqs, (size_t)n_seq); memcpy(h + o_ssrc, seq_src.data(), 4 * n);
+  }
+  HIPCHK(hipMemcpyAsync(c->g_dev.p, h, at, hipMemcpyHostToDevice, st));
+  const uint8_t *d = c->g_dev.as<uint8_t>();
+  br_device_batch db{};
+  db.n_aln = (int64_t)n; db.n_groups = ng;
+  db.ref_id = (const int32_t *)(d + o_ref); db.ref_start = (const int32_t *)(d + o_start); db.flags = (const uint16_t *)(d + o_flags);
+  db.xs = (const int8_t *)(d + o_xs); db.ts = (const int8_t *)(d + o_ts); db.cigar_off = (const uint32_t *)(d + o_coff);
+  db.cigar = (const uint32_t *)(d + o_cig); db.mate_idx = (const int32_t *)(d + o_mate); db.group_off = (const uint32_t *)(d + o_goff);
+  db.l_qseq = (const int32_t *)(d + o_lq); db.name_off = (const uint32_t *)(d + o_noff); db.names = d + o_names;
+  db.n_cigar_words = (int64_t)n_words; db.max_n_cigar = max_nc;
+  if (b.seq_off) { db.seq_off = (const uint32_t *)(d + o_soff); db.seqs = d + o_seqs; db.seq_src = (const int32_t *)(d + o_ssrc); db.max_soft_clip = max_clip; }
+  br_device_rows pr;
+  c->rows_to_host = true;
+  const int rrc = run_device(c, cfg, &db, st, &pr);   // returns with the stream drained
+  c->rows_to_host = false;
+  RC(rrc);
+  const size_t nr = (size_t)pr.n_rows, np = (size_t)pr.n_pool_words;
+  if (np > (1u << 20)) return BR_RETRY_ORDINARY;   // a CIGAR arena of more than 4 MB: the dense pool of the batch path
+  bool pool_home = false;
+  if (!c->rows_at_host) {   // the call went down the ordinary pipeline (-S, or a dense locus): fetch the rows
+    RC(ensure_detail(c, st));
+    RC(d2h(c->g_a, pr.a, nr, st)); RC(d2h(c->g_c, pr.cigar, nr, st)); RC(d2h(c->g_x, c->pk_x.p, nr, st));
+    if (pr.similarity_score) RC(d2h(c->g_sim, pr.similarity_score, nr, st));
+    HIPCHK(hipStreamSynchronize(st));
+  }
+  else c->last_n_rows = 0;   // the context's device row tables were not written: nothing for br_device_rows_expand / br_bam_encode_device to find
+  c->rows_at_host = false;
+  size_t n_cig_words = 0;
+  for (size_t r = 0; r < nr; r++) n_cig_words += c->g_a.p[r].z & RM_NCIG;
+  RC(c->g_cig.resize(n_cig_words + 1));
+  c->h_proj.resize(nr);
+  size_t cw = 0;
+  const int long_reads = (cfg->lr || cfg->lr_hq) ? 1 : 0;
+  for (size_t r = 0; r < nr; r++) {
+    const uint4 a = c->g_a.p[r], x = c->g_x.p[r];
+    const uint2 cr = c->g_c.p[r];
+    const uint32_t meta = a.z, nc = meta & RM_NCIG;
+    br_projected &p = c->h_proj[r];
+    p.transcript_id = a.x; p.transcript_start = a.y;
+    p.aligned_len = (uint32_t)std::max<int32_t>((int32_t)x.z, 0);
+    uint64_t e = (uint64_t)p.transcript_start + p.aligned_len;  // saturating add, then saturating sub 1
+    if (e > 0xffffffffull) e = 0xffffffffull;
+    p.transcript_end = e ? (uint32_t)(e - 1) : 0;
+    uint32_t *cg = c->g_cig.p + cw;
+    if (nc <= 2) { if (nc > 0) cg[0] = cr.x; if (nc > 1) cg[1] = cr.y; }
+    else {
+      if (!pool_home) {   // the arena's used part, once, when a record has more than two ops
+        RC(d2h(c->g_pool, pr.pool, np, st));
+        HIPCHK(hipStreamSynchronize(st));
+        pool_home = true;
+      }
+      const uint64_t off = ((uint64_t)cr.y << 32) | cr.x;
+      if (off + nc > np) return BR_ERR_HIP;
+      memcpy(cg, c->g_pool.p + off, 4 * (size_t)nc);
+    }
+    cw += nc;
+    uint32_t qa = 0;
+    for (uint32_t k = 0; k < nc; k++) {
+      const uint32_t op = cg[k] & 0xf;
+      if (op == OP_M || op == OP_EQ || op == OP_X || op == OP_I || op == OP_MATCH_OVR || op == OP_INS_OVR) qa += cg[k] >> 4;
+    }
+    p.query_aligned_len = qa;
+    const size_t bi = (size_t)x.x;
+    p.transcript_strand = (meta & RM_MINUS) ? '-' : '+';
+    p.is_reverse = p.transcript_strand != read_strand[bi];   // api.rs:453 <- evaluate.rs:1062 (see project_groups_impl)
+    p.similarity_score = pr.similarity_score ? c->g_sim.p[r] : 0.0;
+    p.nh = a.w; p.hi = x.w; p.is_primary = (meta & RM_PRIMARY) ? 1 : 0;
+    p.same_transcript_as_mate = (meta & RM_SAME) ? 1 : 0; p.is_paired_out = (meta & RM_PAIRED) ? 1 : 0;
+    int32_t isize = 0;   // set_mate_info (src/bam.cpp:531-588): the pair's other record is the adjacent row
+    if ((meta & RM_PAIRED) && (meta & RM_SAME)) {
+      const uint4 o = c->g_a.p[(meta & RM_FIRST) ? r + 1 : r - 1];
+      const int32_t my_pos = (int32_t)a.y, mate_pos = (int32_t)o.y, lq = b.l_qseq ? b.l_qseq[bi] : 0;
+      isize = (my_pos <= mate_pos) ? (mate_pos + lq) - my_pos : -((my_pos + lq) - mate_pos);
+    }
+    p.insert_size = isize; p.input_index = kept[bi];
+    p.mapq = br_row_mapq(a.w, long_reads); p.cigar = cg; p.n_cigar = nc;
+  }
+  *out = c->h_proj.data(); *n_out = nr;
+  return BR_OK;
+}
+
 // project_group_with (bramble-rs/src/api.rs:285-464), AoS in/out.  Shape and field meanings are the Rust library's;
 // the values are the C++ path's: mates pair up by the C++ rule (name + position hash, src/bramble.cpp:272-311
 // = k_mates), not by find_mate_pairs' mutual pointers (groups.rs:126-190), and hit_index is carried for layout parity
@@ -1995,6 +2139,15 @@ static int project_groups_impl(br_ctx *c, const br_config *cfg, const br_alignme
   b.names = names.data(); b.l_qseq = lq.data();
   if (any_seq) { b.seq_off = soff.data(); b.seqs = seqs.data(); }
   else if (cfg->use_fasta && (cfg->lr || cfg->lr_hq)) { seqs.assign(1, 'N'); b.seq_off = soff.data(); b.seqs = seqs.data(); }  // no sequence: nothing to rescue
+  // The lean way (a call that carries a name group or a few dozen of them): the input contract -- read-name groups, mate
+  // index, the group's shared sequence -- on the host (a few alignments), ONE upload of everything, the device path
+  // (without host round trips at this size), the packed rows and the CIGAR words they point at back in a handful of small
+  // copies, and the record fields put together here.  The staged batch path (a dozen uploads, the contract on the device,
+  // the wide row view, twenty-one downloads) is built for bundles; it stays the route for large calls.
+  if (nk <= 8192) {
+    int rc = project_groups_lean(c, cfg, b, kept, read_strand, out, n_out);
+    if (rc != BR_RETRY_ORDINARY) return rc;
+  }
   br_rows rows;
   RC(br_project_batch(c, cfg, &b, &rows));
   c->h_proj.resize((size_t)rows.n_rows);

@@ -2261,6 +2261,7 @@ __global__ void __launch_bounds__(256) k_rows(PairArgs P) {
                         ((f & RR_SAME) ? RM_SAME : 0u) | ((f & RR_FIRST) ? RM_FIRST : 0u) | (primary ? RM_PRIMARY : 0u);
   P.r_a[r] = make_uint4(tid, ma.x, meta, rec.z);
   P.r_c[r] = make_uint2((uint32_t)cg, (uint32_t)(cg >> 32));
+  if (P.r_x) { const uint2 mx = P.m_x[x]; P.r_x[r] = make_uint4(rec.y, mx.x, mx.y, rec.w & RR_HI); }   // the detail column at once (small calls that want it)
   if (AUX) {
     const uint4 mb = P.m_b[x];
     P.r_clip[r] = (int32_t)mb.x;
