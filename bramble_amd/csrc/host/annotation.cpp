@@ -26,8 +26,11 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <chrono>
 #include <map>
 #include <string>
+#include <string_view>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -66,7 +69,7 @@ void add_segment(std::vector<std::pair<uint32_t, uint32_t>> &v, uint32_t s, uint
   }
 }
 
-std::string lower(const char *s) { std::string o(s); for (auto &c : o) c = (char)tolower((unsigned char)c); return o; }
+
 bool ends_with(const std::string &s, const char *suf) { size_t n = strlen(suf); return s.size() >= n && s.compare(s.size() - n, n, suf) == 0; }
 bool starts_with(const std::string &s, const char *pre) { return s.compare(0, strlen(pre), pre) == 0; }
 
@@ -88,165 +91,265 @@ Kind classify(const std::string &f) {  // gff.cpp:478-533
   return K_OTHER;
 }
 
-// GTF attribute: name at a token start, value quoted or bare up to ';'
-bool gtf_attr(const char *info, const char *name, std::string &out) {
+typedef std::string_view sv;
+
+// GTF attribute: name at a token start, value quoted or bare up to ';' (info = [p, end))
+bool gtf_attr(const char *p, const char *end, const char *name, sv &out) {
   size_t nl = strlen(name);
-  const char *p = info;
-  while (*p) {
-    while (*p == ' ' || *p == ';' || *p == '\t') p++;
-    if (!*p) break;
+  while (p < end) {
+    while (p < end && (*p == ' ' || *p == ';' || *p == '\t')) p++;
+    if (p >= end) break;
     const char *tok = p;
-    while (*p && *p != ' ' && *p != ';' && *p != '=') p++;
+    while (p < end && *p != ' ' && *p != ';' && *p != '=') p++;
     bool match = (size_t)(p - tok) == nl && strncmp(tok, name, nl) == 0;
-    while (*p == ' ' || *p == '=') p++;
+    while (p < end && (*p == ' ' || *p == '=')) p++;
     const char *vs = p, *ve;
-    if (*p == '"') { vs = ++p; while (*p && *p != '"') p++; ve = p; if (*p) p++; }
-    else { while (*p && *p != ';') p++; ve = p; while (ve > vs && ve[-1] == ' ') ve--; }
-    if (match) { out.assign(vs, ve); return true; }
-    while (*p && *p != ';') p++;
+    if (p < end && *p == '"') { vs = ++p; while (p < end && *p != '"') p++; ve = p; if (p < end) p++; }
+    else { while (p < end && *p != ';') p++; ve = p; while (ve > vs && ve[-1] == ' ') ve--; }
+    if (match) { out = sv(vs, (size_t)(ve - vs)); return true; }
+    while (p < end && *p != ';') p++;
   }
   return false;
 }
 
 // GFF3 attribute "Name=" (case-sensitive, at a field start)
-bool gff_attr(const char *info, const char *name_eq, std::string &out) {
+bool gff_attr(const char *p, const char *end, const char *name_eq, sv &out) {
   size_t nl = strlen(name_eq);
-  const char *p = info;
-  while (*p) {
-    while (*p == ' ' || *p == ';') p++;
-    if (strncmp(p, name_eq, nl) == 0) {
+  while (p < end) {
+    while (p < end && (*p == ' ' || *p == ';')) p++;
+    if ((size_t)(end - p) >= nl && strncmp(p, name_eq, nl) == 0) {
       const char *vs = p + nl, *ve = vs;
-      while (*ve && *ve != ';') ve++;
+      while (ve < end && *ve != ';') ve++;
       while (ve > vs && (ve[-1] == ' ' || ve[-1] == '\r')) ve--;
       if (ve - vs >= 2 && *vs == '"' && ve[-1] == '"') { vs++; ve--; }
-      out.assign(vs, ve);
+      out = sv(vs, (size_t)(ve - vs));
       return true;
     }
-    while (*p && *p != ';') p++;
+    while (p < end && *p != ';') p++;
   }
   return false;
 }
 
+// One line of the file, taken apart (views into the block it came from).  Taking lines apart is the loader's time (1.9 M
+// lines, 170 MB for a GENCODE-sized GTF) and independent line by line: worker threads do it for a block of the file at a
+// time; what the lines MEAN depends on the lines before them (first appearance of a reference, features "read before",
+// the format the first attribute decides), so the pass that applies them stays sequential, in file order.
+struct Rec {
+  uint8_t state;      // 0 skipped before any decision (comment, too few fields, no number, "match" features), 1 a bad strand character, 2 usable
+  uint8_t kind; char strand;
+  bool has_id, has_par, has_tid, has_gid;
+  uint32_t fs, fe;
+  sv seq, id, parent, tid, gid;
+};
+
+void parse_line(const char *b, const char *e, Rec &r) {
+  r.state = 0;
+  while (e > b && (e[-1] == '\n' || e[-1] == '\r')) e--;
+  if (b == e || *b == '#') return;
+  const char *t[9], *te[9]; int nt = 0;
+  t[nt] = b;
+  for (const char *p = b; p < e && nt < 8; p++) if (*p == '\t') { te[nt] = p; nt++; t[nt] = p + 1; }
+  te[nt] = e; nt++;                       // (the ninth field runs to the end of the line, tabs included)
+  if (nt < 8) return;
+  const char *ib = nt >= 9 ? t[8] : e, *ie = e;
+  auto number = [](const char *p, const char *pe, unsigned long &v) {   // strtoul(.., 10): leading blanks, optional sign, digits
+    while (p < pe && (*p == ' ' || *p == '\t')) p++;
+    bool neg = false;
+    if (p < pe && (*p == '+' || *p == '-')) { neg = *p == '-'; p++; }
+    if (p >= pe || *p < '0' || *p > '9') return false;
+    unsigned long x = 0;
+    while (p < pe && *p >= '0' && *p <= '9') { x = x * 10 + (unsigned long)(*p - '0'); p++; }
+    v = neg ? (unsigned long)(-(long)x) : x;
+    return true;
+  };
+  unsigned long fs, fe;
+  if (!number(t[3], te[3], fs) || !number(t[4], te[4], fe)) return;
+  if (fe < fs) std::swap(fs, fe);
+  const char strand = t[6] < te[6] ? t[6][0] : 0;
+  if (strand != '+' && strand != '-' && strand != '.') { r.state = 1; return; }
+  std::string f(t[2], (size_t)(te[2] - t[2]));
+  for (auto &c : f) c = (char)tolower((unsigned char)c);
+  const Kind kind = classify(f);
+  if (kind == K_SKIP) return;
+  r.state = 2; r.kind = (uint8_t)kind; r.strand = strand; r.fs = (uint32_t)fs; r.fe = (uint32_t)fe;
+  r.seq = sv(t[0], (size_t)(te[0] - t[0]));
+  r.has_id = gff_attr(ib, ie, "ID=", r.id); r.has_par = gff_attr(ib, ie, "Parent=", r.parent);
+  r.has_tid = gtf_attr(ib, ie, "transcript_id", r.tid); r.has_gid = gtf_attr(ib, ie, "gene_id", r.gid);
+}
+
 }  // namespace
 
-extern "C" int br_annotation_load(const char *path, br_annotation **out) {
+extern "C" int br_annotation_load_mt(const char *path, int threads, br_annotation **out) {
   if (!path || !out) return BR_ERR_INVALID_ARG;
   *out = nullptr;
   gzFile f = gzopen(path, "rb");  // plain text or gzip
   if (!f) { fprintf(stderr, "[bramble_amd] cannot open annotation %s\n", path); return BR_ERR_ANNOTATION; }
   gzbuffer(f, 1 << 20);
+  if (threads < 1) threads = 1;
+  if (threads > 64) threads = 64;
   std::vector<Tx> txs;
-  std::unordered_map<std::string, size_t> by_key;       // id + '\t' + seqname + strand
+  std::unordered_map<std::string, size_t> by_key;       // id + '\t' + seqname
   std::unordered_map<std::string, int> feat_level;      // ids of the gene / transcript features read so far -> gff_level
   std::vector<std::string> refnames;
   std::unordered_map<std::string, int> ref_of;
   int fmt = 0;  // 0 unknown, 1 GFF3, 2 GTF
-  std::string line;
-  std::vector<char> buf(1 << 16);
-  auto get_tx = [&](const std::string &id, const char *seq, char strand) -> Tx & {
-    std::string key = id; key.push_back('\t'); key += seq;
+  std::string key;
+  size_t last_tx = (size_t)-1;   // consecutive lines of a file mostly name the same transcript: no hashing for those
+  auto get_tx = [&](sv id, sv seq, char strand) -> Tx & {
+    if (last_tx != (size_t)-1 && txs[last_tx].id == id && txs[last_tx].seqname == seq) return txs[last_tx];
+    key.assign(id.data(), id.size()); key.push_back('\t'); key.append(seq.data(), seq.size());
     auto it = by_key.find(key);
-    if (it != by_key.end()) return txs[it->second];
+    if (it != by_key.end()) { last_tx = it->second; return txs[last_tx]; }
     by_key.emplace(key, txs.size());
-    Tx t; t.id = id; t.seqname = seq; t.strand = strand;
+    Tx t; t.id.assign(id.data(), id.size()); t.seqname.assign(seq.data(), seq.size()); t.strand = strand;
     txs.push_back(std::move(t));
-    if (!ref_of.count(seq)) { ref_of.emplace(seq, (int)refnames.size()); refnames.push_back(seq); }
+    if (!ref_of.count(txs.back().seqname)) { ref_of.emplace(txs.back().seqname, (int)refnames.size()); refnames.push_back(txs.back().seqname); }
+    last_tx = txs.size() - 1;
     return txs.back();
   };
-  for (;;) {
-    line.clear();
-    bool got = false;
-    for (;;) {  // lines of any length
-      if (!gzgets(f, buf.data(), (int)buf.size())) break;
-      got = true;
-      line += buf.data();
-      if (!line.empty() && line.back() == '\n') break;
+  // level of a gene / transcript feature: one below the last of its parents that was read before it
+  auto level_under = [&](sv parents) -> int {
+    int lv = 0;
+    size_t a = 0;
+    while (a <= parents.size() && !parents.empty()) {
+      size_t b = parents.find(',', a);
+      if (b == sv::npos) b = parents.size();
+      sv pid = parents.substr(a, b - a);
+      while (!pid.empty() && pid.back() == ' ') pid.remove_suffix(1);
+      auto it = feat_level.find(std::string(pid));
+      if (it != feat_level.end()) lv = it->second + 1;
+      a = b + 1;
     }
-    if (!got) break;
-    while (!line.empty() && (line.back() == '\n' || line.back() == '\r')) line.pop_back();
-    if (line.empty() || line[0] == '#') { if (line == "##FASTA") break; continue; }
-    char *t[9]; int nt = 0;
-    char *s = &line[0];
-    t[nt++] = s;
-    for (char *p = s; *p && nt < 9; p++) if (*p == '\t') { *p = 0; t[nt++] = p + 1; }
-    if (nt < 9) { if (nt < 8) continue; }
-    const char *info = nt >= 9 ? t[8] : "";
-    char *endp = nullptr;
-    unsigned long fs = strtoul(t[3], &endp, 10); if (endp == t[3]) continue;
-    unsigned long fe = strtoul(t[4], &endp, 10); if (endp == t[4]) continue;
-    if (fe < fs) std::swap(fs, fe);
-    char strand = t[6][0];
-    if (strand != '+' && strand != '-' && strand != '.') { gzclose(f); fprintf(stderr, "[bramble_amd] bad strand in annotation line\n"); return BR_ERR_ANNOTATION; }
-    Kind kind = classify(lower(t[2]));
-    if (kind == K_SKIP) continue;
-    std::string id, parent;
-    if (fmt != 2) {
-      bool has_id = gff_attr(info, "ID=", id), has_par = gff_attr(info, "Parent=", parent);
-      if (fmt == 0) {
-        if (has_id || has_par) fmt = 1;
-        else {
-          std::string tmp;
-          if (gtf_attr(info, "transcript_id", tmp) || gtf_attr(info, "gene_id", tmp)) fmt = 2; else continue;
-        }
-      }
+    return lv;
+  };
+  // what one usable line means, given everything before it (the body of the old line loop); false: stop with an error
+  auto apply = [&](const Rec &r) {
+    const Kind kind = (Kind)r.kind;
+    if (fmt != 2 && fmt == 0) {
+      if (r.has_id || r.has_par) fmt = 1;
+      else if (r.has_tid || r.has_gid) fmt = 2;
+      else return;
     }
     if (fmt == 1) {
-      // level of a gene / transcript feature: one below the last of its parents that was read before it
-      auto level_under = [&](const std::string &parents) -> int {
-        int lv = 0;
-        size_t a = 0;
-        while (a <= parents.size() && !parents.empty()) {
-          size_t b = parents.find(',', a);
-          if (b == std::string::npos) b = parents.size();
-          std::string pid = parents.substr(a, b - a);
-          while (!pid.empty() && pid.back() == ' ') pid.pop_back();
-          auto it = feat_level.find(pid);
-          if (it != feat_level.end()) lv = it->second + 1;
-          a = b + 1;
-        }
-        return lv;
-      };
-      if (kind == K_GENE) { if (!id.empty()) feat_level.emplace(id, level_under(parent)); continue; }
+      const sv id = r.has_id ? r.id : sv(), parent = r.has_par ? r.parent : sv();
+      if (kind == K_GENE) { if (!id.empty()) feat_level.emplace(std::string(id), level_under(parent)); return; }
       if (kind == K_TRANSCRIPT) {
-        if (id.empty()) continue;
-        Tx &tx = get_tx(id, t[0], strand);
-        tx.has_line = true; tx.strand = strand; tx.start = (uint32_t)fs; tx.end = (uint32_t)fe;
+        if (id.empty()) return;
+        Tx &tx = get_tx(id, r.seq, r.strand);
+        tx.has_line = true; tx.strand = r.strand; tx.start = r.fs; tx.end = r.fe;
         tx.level = level_under(parent);
-        feat_level[id] = tx.level;
+        feat_level[std::string(id)] = tx.level;
       } else if (kind == K_EXONLIKE) {
-        if (parent.empty()) continue;
+        if (parent.empty()) return;
         size_t a = 0;
         while (a <= parent.size()) {  // Parent=id1,id2
           size_t b = parent.find(',', a);
-          if (b == std::string::npos) b = parent.size();
-          std::string pid = parent.substr(a, b - a);
-          while (!pid.empty() && pid.back() == ' ') pid.pop_back();
+          if (b == sv::npos) b = parent.size();
+          sv pid = parent.substr(a, b - a);
+          while (!pid.empty() && pid.back() == ' ') pid.remove_suffix(1);
           if (!pid.empty()) {
-            Tx &tx = get_tx(pid, t[0], strand);
-            if (!tx.has_line && tx.segs.empty()) tx.strand = strand;
-            add_segment(tx.segs, (uint32_t)fs, (uint32_t)fe);
+            Tx &tx = get_tx(pid, r.seq, r.strand);
+            if (!tx.has_line && tx.segs.empty()) tx.strand = r.strand;
+            add_segment(tx.segs, r.fs, r.fe);
           }
           a = b + 1;
         }
       }
     } else {  // GTF: unrecognised features are dropped when only transcripts are loaded (gff.cpp:696-698)
-      if (kind == K_OTHER) continue;
+      if (kind == K_OTHER) return;
       if (kind == K_GENE) {   // its ID is the transcript_id when it has one, else the gene_id (gff.cpp:704-721)
-        std::string gid;
-        if ((gtf_attr(info, "transcript_id", gid) && !gid.empty()) || (gtf_attr(info, "gene_id", gid) && !gid.empty())) feat_level.emplace(gid, 0);
-        continue;
+        if (r.has_tid && !r.tid.empty()) feat_level.emplace(std::string(r.tid), 0);
+        else if (r.has_gid && !r.gid.empty()) feat_level.emplace(std::string(r.gid), 0);
+        return;
       }
-      if (!gtf_attr(info, "transcript_id", id) || id.empty()) continue;
-      Tx &tx = get_tx(id, t[0], strand);
+      if (!r.has_tid || r.tid.empty()) return;
+      Tx &tx = get_tx(r.tid, r.seq, r.strand);
       if (kind == K_TRANSCRIPT) {
-        tx.has_line = true; tx.strand = strand; tx.start = (uint32_t)fs; tx.end = (uint32_t)fe;
-        std::string gid;   // a `transcript` line names its gene as parent (gff.cpp:733-741)
-        if (gtf_attr(info, "gene_id", gid)) { auto it = feat_level.find(gid); if (it != feat_level.end()) tx.level = it->second + 1; }
+        tx.has_line = true; tx.strand = r.strand; tx.start = r.fs; tx.end = r.fe;
+        // a `transcript` line names its gene as parent (gff.cpp:733-741)
+        if (r.has_gid) { auto it = feat_level.find(std::string(r.gid)); if (it != feat_level.end()) tx.level = it->second + 1; }
       }
-      else { if (!tx.has_line && tx.segs.empty()) tx.strand = strand; add_segment(tx.segs, (uint32_t)fs, (uint32_t)fe); }
+      else { if (!tx.has_line && tx.segs.empty()) tx.strand = r.strand; add_segment(tx.segs, r.fs, r.fe); }
     }
+  };
+
+  // the file in blocks of whole lines; a block's lines are taken apart by the worker threads, then applied in order
+  const size_t BLOCK = 64u << 20;
+  double T_read = 0, T_parse = 0, T_apply = 0; auto T0 = std::chrono::steady_clock::now();
+  auto lap = [&](double &acc) { auto n = std::chrono::steady_clock::now(); acc += std::chrono::duration<double>(n - T0).count(); T0 = n; };
+  std::string data, carry;
+  std::vector<std::vector<Rec>> recs((size_t)threads);
+  bool eof = false, fasta = false;
+  while (!eof && !fasta) {
+    data.assign(carry); carry.clear();
+    const size_t had = data.size();
+    data.resize(had + BLOCK);
+    size_t got = 0;
+    while (got < BLOCK) {
+      const int n = gzread(f, &data[had + got], (unsigned)std::min<size_t>(BLOCK - got, 1u << 30));
+      if (n <= 0) { eof = true; break; }
+      got += (size_t)n;
+    }
+    data.resize(had + got);
+    if (!eof) {   // keep the unfinished last line for the next block
+      const size_t nl = data.rfind('\n');
+      if (nl == std::string::npos) { carry.swap(data); continue; }   // (a line longer than a block: read on)
+      carry.assign(data, nl + 1, std::string::npos);
+      data.resize(nl + 1);
+    }
+    if (data.empty()) break;
+    lap(T_read);
+    // "##FASTA" ends the annotation (the sequence section of a GFF3 file)
+    {
+      size_t p = 0;
+      while ((p = data.find("##FASTA", p)) != std::string::npos) {
+        const bool at_start = p == 0 || data[p - 1] == '\n';
+        size_t q = p + 7;
+        while (q < data.size() && data[q] == '\r') q++;
+        if (at_start && (q == data.size() || data[q] == '\n')) { data.resize(p); fasta = true; break; }
+        p += 7;
+      }
+    }
+    // thread t takes the lines that START in its slice of the block
+    const char *base = data.data(), *end = base + data.size();
+    std::vector<const char *> cut((size_t)threads + 1);
+    cut[0] = base; cut[(size_t)threads] = end;
+    for (int t = 1; t < threads; t++) {
+      const char *p = base + data.size() * (size_t)t / (size_t)threads;
+      if (p < cut[(size_t)t - 1]) p = cut[(size_t)t - 1];
+      while (p < end && p > base && p[-1] != '\n') p++;
+      cut[(size_t)t] = p;
+    }
+    auto work = [&](int t) {
+      std::vector<Rec> &v = recs[(size_t)t];
+      v.clear();
+      const char *p = cut[(size_t)t], *pe = cut[(size_t)t + 1];
+      while (p < pe) {
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        const char *le = nl ? nl + 1 : end;
+        Rec r;
+        parse_line(p, le, r);
+        if (r.state) v.push_back(r);
+        p = le;
+      }
+    };
+    if (threads == 1) work(0);
+    else {
+      std::vector<std::thread> th;
+      for (int t = 1; t < threads; t++) th.emplace_back(work, t);
+      work(0);
+      for (auto &x : th) x.join();
+    }
+    lap(T_parse);
+    for (int t = 0; t < threads; t++)
+      for (const Rec &r : recs[(size_t)t]) {
+        if (r.state == 1) { gzclose(f); fprintf(stderr, "[bramble_amd] bad strand in annotation line\n"); return BR_ERR_ANNOTATION; }
+        apply(r);
+      }
+    lap(T_apply);
   }
   gzclose(f);
+  if (getenv("BRAMBLE_AMD_TIMING")) fprintf(stderr, "[annotation] read %.3f parse %.3f apply %.3f\n", T_read, T_parse, T_apply);
   // exonless transcripts get one exon over the feature; ids that only ever appeared as gene features are not transcripts
   std::vector<Tx *> order;
   for (auto &tx : txs) {
@@ -263,6 +366,8 @@ extern "C" int br_annotation_load(const char *path, br_annotation **out) {
     if (a->end != b->end) return a->end < b->end;
     return strcmp(a->id.c_str(), b->id.c_str()) < 0;
   });
+  lap(T_read);
+  if (getenv("BRAMBLE_AMD_TIMING")) fprintf(stderr, "[annotation] sort %.3f\n", T_read);
   br_annotation *A = new br_annotation();
   A->refnames = refnames;
   for (Tx *tx : order) {
@@ -276,6 +381,11 @@ extern "C" int br_annotation_load(const char *path, br_annotation **out) {
   for (auto &r : A->refnames) A->refname_view.push_back(r.c_str());
   *out = A;
   return BR_OK;
+}
+
+extern "C" int br_annotation_load(const char *path, br_annotation **out) {
+  unsigned hw = std::thread::hardware_concurrency();
+  return br_annotation_load_mt(path, (int)std::min<unsigned>(hw ? hw : 1u, 16u), out);
 }
 
 extern "C" void br_annotation_free(br_annotation *a) { delete a; }

@@ -262,7 +262,7 @@ extern "C" int br_cli_main(int argc, char **argv) {
   brio::ByteBuf buf; size_t pos = 0;
   BamHeader hdr; std::string err;
   if (!read_header(rd, buf, pos, hdr, err)) { fprintf(stderr, "error: %s: %s\n", o.in_bam.c_str(), err.c_str()); return 1; }
-  Slot<Bundle> to_gpu(4);      // the reader runs ahead while the guides are parsed and the indexes are built
+  Slot<Bundle> to_gpu(8);      // the reader runs ahead while the guides are parsed and the indexes are built (eight bundles: about 3 GB of records)
   // consumed bundle buffers go back to the reader: their pages are already faulted in
   std::mutex pool_m; std::vector<std::unique_ptr<brio::ByteBuf>> pool;
   uint64_t total_reads = 0, unmapped_reads = 0, next_seq = 0;
@@ -355,7 +355,8 @@ extern "C" int br_cli_main(int argc, char **argv) {
   // the reader is already inflating while the guides are parsed and the indexes are built
   auto stop_reader = [&]() -> int { cancel = true; while (to_gpu.take()) {} reader.join(); return 1; };
   br_annotation *ann = nullptr;
-  int rc = br_annotation_load(o.gff.c_str(), &ann);
+  int rc = br_annotation_load_mt(o.gff.c_str(), std::max(1, std::min(o.threads, 32)), &ann);   // the lines are taken apart by -p threads
+  const double t_guides = since();
   if (rc) { fprintf(stderr, "error: could not load reference annotation %s: %s\n", o.gff.c_str(), br_strerror(rc)); return stop_reader(); }
   size_t n_tx = br_annotation_num_transcripts(ann), n_refs = br_annotation_num_refs(ann);
   const char *const *refnames = br_annotation_refnames(ann);
@@ -407,6 +408,7 @@ extern "C" int br_cli_main(int argc, char **argv) {
   }
   for (auto &w : workers)
     if (w->build_rc) { fprintf(stderr, "error: index build failed on device %d: %s\n", w->device, br_strerror(w->build_rc)); free_all(); return stop_reader(); }
+  const double t_index = since() - t_guides;
   fa = Fasta();  // the indexes hold the exon sequences now
   const br_index *ix0 = workers[0]->ix;
 
@@ -547,8 +549,8 @@ extern "C" int br_cli_main(int argc, char **argv) {
     printf("# dropped alignments: %llu\n", (unsigned long long)dropped);
     printf("# total alignments:   %llu\n", (unsigned long long)total_complete);
     printf("# unique alignments:  %llu\n\n", (unsigned long long)total_unique);
-    printf("[bramble] %llu bundles on %zu device worker(s), %.2fs on the device path (upload + kernels + download, summed), %.2fs wall (setup %.2fs, codec %s)\n",
-           (unsigned long long)n_bundles, n_workers, gpu_seconds, since(), t_setup, brio::codec_name());
+    printf("[bramble] %llu bundles on %zu device worker(s), %.2fs on the device path (upload + kernels + download, summed), %.2fs wall (setup %.2fs: guides %.2fs + index %.2fs, codec %s)\n",
+           (unsigned long long)n_bundles, n_workers, gpu_seconds, since(), t_setup, t_guides, t_index, brio::codec_name());
     printf("[bramble] release of device / pinned memory: %.2fs\n", t_freed - t_done);
     printf("[bramble] stage busy time: inflate %.2fs, split %.2fs, bundle copy %.2fs, upload %.2fs, device %.2fs (waited for input %.2fs), deflate+write %.2fs\n",
            t_inflate, t_split, t_copy, t_upload, gpu_seconds, t_wait_gpu_in, t_deflate);

@@ -473,6 +473,9 @@ int br_bgzf_deflate_device(br_ctx *, const uint8_t *src, uint64_t n, void *strea
  * feed br_index_build directly. */
 typedef struct br_annotation br_annotation;
 int br_annotation_load(const char *path, br_annotation **out);
+/* the same with `threads` workers taking the lines apart (br_annotation_load: up to 16); what the lines mean depends on
+ * the lines before them and is applied in file order whatever the thread count */
+int br_annotation_load_mt(const char *path, int threads, br_annotation **out);
 void br_annotation_free(br_annotation *);
 size_t br_annotation_num_transcripts(const br_annotation *);
 const br_transcript *br_annotation_transcripts(const br_annotation *);
