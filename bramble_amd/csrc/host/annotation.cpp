@@ -52,6 +52,8 @@ struct Tx {
   char strand = '.';
   uint32_t start = 0, end = 0;                   // feature line coordinates (used when exonless)
   bool has_line = false;
+  bool by_exon = false;                          // GffObj::createdByExon: the record began with an exon-like line (never cleared, gff.cpp:1486)
+  uint32_t cur_start = 0;                        // GffObj::start while the file is read: what gfoFind measures the locus distance from
   int level = 0;                                 // GffObj::gff_level
   std::vector<std::pair<uint32_t, uint32_t>> segs;  // sorted, merged, 1-based inclusive
 };
@@ -188,24 +190,61 @@ extern "C" int br_annotation_load_mt(const char *path, int threads, br_annotatio
   if (threads < 1) threads = 1;
   if (threads > 64) threads = 64;
   std::vector<Tx> txs;
-  std::unordered_map<std::string, size_t> by_key;       // id + '\t' + seqname
   std::unordered_map<std::string, int> feat_level;      // ids of the gene / transcript features read so far -> gff_level
   std::vector<std::string> refnames;
   std::unordered_map<std::string, int> ref_of;
   int fmt = 0;  // 0 unknown, 1 GFF3, 2 GTF
+  // Records are found by ID within a LOCUS (gfoFind, gclib/gff.cpp:1405-1434): same reference, same strand (a record
+  // without a strand takes any), start within GFF_MAX_LOCUS = 7 000 000 bases of the record's current start; the first
+  // record of the ID, in order of creation, that qualifies.  The same ID further away, or on the other strand, is another
+  // transcript (RefSeq-style annotations place one accession at several loci).
+  const int64_t MAX_LOCUS = 7000000;
+  std::unordered_map<std::string, std::vector<size_t>> by_key;   // id + '\t' + seqname -> its records, oldest first
   std::string key;
-  size_t last_tx = (size_t)-1;   // consecutive lines of a file mostly name the same transcript: no hashing for those
-  auto get_tx = [&](sv id, sv seq, char strand) -> Tx & {
-    if (last_tx != (size_t)-1 && txs[last_tx].id == id && txs[last_tx].seqname == seq) return txs[last_tx];
+  std::vector<size_t> *last_list = nullptr; std::string last_id_s, last_seq_s;   // consecutive lines mostly name the same transcript
+  auto list_of = [&](sv id, sv seq) -> std::vector<size_t> & {
+    if (last_list && last_id_s == id && last_seq_s == seq) return *last_list;
     key.assign(id.data(), id.size()); key.push_back('\t'); key.append(seq.data(), seq.size());
-    auto it = by_key.find(key);
-    if (it != by_key.end()) { last_tx = it->second; return txs[last_tx]; }
-    by_key.emplace(key, txs.size());
-    Tx t; t.id.assign(id.data(), id.size()); t.seqname.assign(seq.data(), seq.size()); t.strand = strand;
+    last_list = &by_key[key];
+    last_id_s.assign(id.data(), id.size()); last_seq_s.assign(seq.data(), seq.size());
+    return *last_list;
+  };
+  auto find_tx = [&](std::vector<size_t> &lst, char strand, uint32_t fstart) -> Tx * {
+    for (size_t i : lst) {
+      Tx &t = txs[i];
+      if (t.strand != '.' && strand != t.strand) continue;
+      if (fstart > 0 && std::llabs((int64_t)(int32_t)fstart - (int64_t)(int32_t)t.cur_start) > MAX_LOCUS) continue;
+      return &t;
+    }
+    return nullptr;
+  };
+  auto new_tx = [&](std::vector<size_t> &lst, sv id, sv seq, char strand, uint32_t fstart) -> Tx & {
+    lst.push_back(txs.size());
+    Tx t; t.id.assign(id.data(), id.size()); t.seqname.assign(seq.data(), seq.size()); t.strand = strand; t.cur_start = fstart;
     txs.push_back(std::move(t));
     if (!ref_of.count(txs.back().seqname)) { ref_of.emplace(txs.back().seqname, (int)refnames.size()); refnames.push_back(txs.back().seqname); }
-    last_tx = txs.size() - 1;
     return txs.back();
+  };
+  // an exon-like line for the transcript `id` (readAll, gff.cpp:1763-1836; readExonFeature, :1503-1533): it joins the record
+  // of that ID in its locus; without one, it starts a record of its own ("new GTF-like record starting directly here")
+  auto exon_line = [&](sv id, const Rec &r) {
+    std::vector<size_t> &lst = list_of(id, r.seq);
+    Tx *tx = find_tx(lst, r.strand, r.fs);
+    if (!tx) { Tx &n = new_tx(lst, id, r.seq, r.strand, r.fs); n.by_exon = true; tx = &n; }
+    else if (tx->strand == '.') tx->strand = r.strand;            // (find_tx lets a line through only on the record's strand, or on none)
+    add_segment(tx->segs, r.fs, r.fe);
+    tx->cur_start = std::min(tx->cur_start, std::min(r.fs, r.fe));
+  };
+  // a transcript line with that ID (gff.cpp:1684-1733): it completes a record that exon lines began; a record that already
+  // came from a transcript line stays as it is and the line becomes a separate record under the same ID (a discontinuous
+  // feature in the GFF3 sense) -- exon lines that follow still go to the first record of the locus
+  auto transcript_line = [&](sv id, const Rec &r) -> Tx & {
+    std::vector<size_t> &lst = list_of(id, r.seq);
+    Tx *tx = find_tx(lst, r.strand, r.fs);
+    if (tx && tx->by_exon) { tx->has_line = true; tx->start = r.fs; tx->end = r.fe; tx->cur_start = r.fs; return *tx; }   // updateGffRec (:1484-1501)
+    Tx &n = new_tx(lst, id, r.seq, r.strand, r.fs);
+    n.has_line = true; n.start = r.fs; n.end = r.fe;
+    return n;
   };
   // level of a gene / transcript feature: one below the last of its parents that was read before it
   auto level_under = [&](sv parents) -> int {
@@ -235,8 +274,7 @@ extern "C" int br_annotation_load_mt(const char *path, int threads, br_annotatio
       if (kind == K_GENE) { if (!id.empty()) feat_level.emplace(std::string(id), level_under(parent)); return; }
       if (kind == K_TRANSCRIPT) {
         if (id.empty()) return;
-        Tx &tx = get_tx(id, r.seq, r.strand);
-        tx.has_line = true; tx.strand = r.strand; tx.start = r.fs; tx.end = r.fe;
+        Tx &tx = transcript_line(id, r);
         tx.level = level_under(parent);
         feat_level[std::string(id)] = tx.level;
       } else if (kind == K_EXONLIKE) {
@@ -247,11 +285,7 @@ extern "C" int br_annotation_load_mt(const char *path, int threads, br_annotatio
           if (b == sv::npos) b = parent.size();
           sv pid = parent.substr(a, b - a);
           while (!pid.empty() && pid.back() == ' ') pid.remove_suffix(1);
-          if (!pid.empty()) {
-            Tx &tx = get_tx(pid, r.seq, r.strand);
-            if (!tx.has_line && tx.segs.empty()) tx.strand = r.strand;
-            add_segment(tx.segs, r.fs, r.fe);
-          }
+          if (!pid.empty()) exon_line(pid, r);
           a = b + 1;
         }
       }
@@ -263,13 +297,12 @@ extern "C" int br_annotation_load_mt(const char *path, int threads, br_annotatio
         return;
       }
       if (!r.has_tid || r.tid.empty()) return;
-      Tx &tx = get_tx(r.tid, r.seq, r.strand);
       if (kind == K_TRANSCRIPT) {
-        tx.has_line = true; tx.strand = r.strand; tx.start = r.fs; tx.end = r.fe;
+        Tx &tx = transcript_line(r.tid, r);
         // a `transcript` line names its gene as parent (gff.cpp:733-741)
         if (r.has_gid) { auto it = feat_level.find(std::string(r.gid)); if (it != feat_level.end()) tx.level = it->second + 1; }
       }
-      else { if (!tx.has_line && tx.segs.empty()) tx.strand = r.strand; add_segment(tx.segs, r.fs, r.fe); }
+      else exon_line(r.tid, r);
     }
   };
 

@@ -184,3 +184,51 @@ def test_guide_order_level_comes_before_end(tmp_path):
     ]) + "\n")
     txs, _ = load(gtf)
     assert [t[0] for t in txs] == ["t_exons_only", "t_gene_line_missing", "t_short_with_line", "t_with_line"]
+
+
+def _write(tmp_path, name, lines):
+    p = tmp_path / name
+    p.write_text("\n".join("\t".join(str(x) for x in ln) for ln in lines) + "\n")
+    return p
+
+
+def test_same_id_in_another_locus_or_on_the_other_strand_is_another_transcript(tmp_path):
+    """gclib finds a record by ID only within a locus (gfoFind, gclib/gff.cpp:1405-1434: same reference, same strand,
+    start within GFF_MAX_LOCUS = 7 000 000 of the record's start); an exon line whose transcript_id has no record there
+    starts a record of its own (readAll, :1810-1836).  RefSeq-style files place one accession at several loci.
+    Hand-derived: NM_1 has exons at 1000-1100 / 2000-2100 (+), at 9 000 000-9 000 100 (+, 8.99 Mb on: another record),
+    at 3000-3100 (-, the other strand: another record) and at 5 000 000-5 000 050 (+, 4.99 Mb from the first record's
+    start: the same record).  Guide order = reference, start, ... (gfo_cmpByLoc)."""
+    a = 'gene_id "g"; transcript_id "NM_1";'
+    p = _write(tmp_path, "loci.gtf", [
+        ("chr1", "t", "exon", 1000, 1100, ".", "+", ".", a), ("chr1", "t", "exon", 2000, 2100, ".", "+", ".", a),
+        ("chr1", "t", "exon", 9000000, 9000100, ".", "+", ".", a), ("chr1", "t", "exon", 3000, 3100, ".", "-", ".", a),
+        ("chr1", "t", "exon", 5000000, 5000050, ".", "+", ".", a), ("chr1", "t", "exon", 9000200, 9000300, ".", "+", ".", a)])
+    txs, refs = load(p)
+    assert [(t[0], t[2], t[3]) for t in txs] == [
+        ("NM_1", "+", [(1000, 1101), (2000, 2101), (5000000, 5000051)]),
+        ("NM_1", "-", [(3000, 3101)]),
+        ("NM_1", "+", [(9000000, 9000101), (9000200, 9000301)])]
+
+
+def test_second_transcript_line_with_the_same_id_is_a_separate_record(tmp_path):
+    """A transcript line whose ID already belongs to a record that came from a transcript line does not touch it: it becomes
+    a separate record under the same ID (a discontinuous feature, gclib/gff.cpp:1700-1726); exon lines that follow go to
+    the FIRST record of the locus (gfoFind returns the first that qualifies), so the second one stays without exons and
+    gets one exon over its own span (finalize, :2079-2086).  A record that exon lines began is completed by the transcript
+    line instead (updateGffRec, :1484-1501; the created-by-exon mark is never cleared, :1486).
+    Hand-derived for the GFF3 below: rnaA#1 = exons 100-200, 300-400, 900-950; rnaA#2 (600-1000) = one exon 600-1000;
+    rnaB (exon first, then its mRNA line twice) stays ONE record with its exon."""
+    p = _write(tmp_path, "dup.gff3", [
+        ("chr1", "t", "gene", 100, 2000, ".", "+", ".", "ID=g1"),
+        ("chr1", "t", "mRNA", 100, 400, ".", "+", ".", "ID=rnaA;Parent=g1"),
+        ("chr1", "t", "exon", 100, 200, ".", "+", ".", "Parent=rnaA"),
+        ("chr1", "t", "mRNA", 600, 1000, ".", "+", ".", "ID=rnaA;Parent=g1"),
+        ("chr1", "t", "exon", 300, 400, ".", "+", ".", "Parent=rnaA"),
+        ("chr1", "t", "exon", 900, 950, ".", "+", ".", "Parent=rnaA"),
+        ("chr1", "t", "exon", 1500, 1600, ".", "+", ".", "Parent=rnaB"),
+        ("chr1", "t", "mRNA", 1500, 1700, ".", "+", ".", "ID=rnaB;Parent=g1"),
+        ("chr1", "t", "mRNA", 1500, 1700, ".", "+", ".", "ID=rnaB;Parent=g1")])
+    txs, refs = load(p)
+    assert [(t[0], t[3]) for t in txs] == [("rnaA", [(100, 201), (300, 401), (900, 951)]), ("rnaA", [(600, 1001)]),
+                                                     ("rnaB", [(1500, 1601)])]
