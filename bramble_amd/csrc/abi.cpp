@@ -444,6 +444,9 @@ struct br_ctx {
   int deflate_dynamic = 1;
   int emit_split = 1;
   int count_split = 1;   // count pass as two kernels: the main one without the exon walk, a second one for the alignments that need it
+  int64_t speculate_n = 4194304;
+  int speculate = 1;         // large batches are launched from the last call's counts, checked once at the end (run_device_small, big)
+  int64_t hist_n = 0; uint64_t hist[4] = {0, 0, 0, 0}; bool hist_simf = false;   // the last call: alignments; matches, arena words, simple-class matches, records
   int small_batch = 1;       // batches of at most small_n alignments run without a host round trip before the final one (run_device_small)
   int64_t small_n = 65536;
   int single_pass = 0;   // short-read presets: count and emit in one sweep (k_project1 + k_emit_wl) instead of count / scan / expand / emit.
@@ -516,6 +519,8 @@ extern "C" int br_ctx_new(const br_index *ix, br_ctx **out) {
   HIPCHK(hipHostMalloc((void **)&c->h_totals, 192 * sizeof(uint64_t), hipHostMallocDefault));   // [0..31] scan totals and counters, [96..] the single pass's counters
   const char *bl = getenv("BRAMBLE_AMD_BAM_LANES");
   if (bl) { int v = atoi(bl); if (v == 0 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) c->bam_lanes = v; }
+  const char *spec = getenv("BRAMBLE_AMD_SPECULATE");      // A/B: 0 = large batches always through the ordinary pipeline (three host round trips)
+  if (spec) c->speculate = atoi(spec) != 0;
   const char *sp = getenv("BRAMBLE_AMD_SINGLE_PASS");   // A/B: 0 = the two-pass count / scan / expand / emit path
   if (sp) c->single_pass = atoi(sp) != 0;
   const char *g = getenv("BRAMBLE_AMD_GROUP_LANES");
@@ -576,6 +581,8 @@ extern "C" int br_ctx_set_param(br_ctx *c, const char *key, int64_t v) {
   if (!strcmp(key, "count_split")) { c->count_split = v != 0; return BR_OK; }
   if (!strcmp(key, "single_pass")) { c->single_pass = v != 0; return BR_OK; }
   if (!strcmp(key, "small_batch")) { c->small_batch = v != 0; return BR_OK; }
+  if (!strcmp(key, "speculate")) { c->speculate = v != 0; return BR_OK; }
+  if (!strcmp(key, "speculate_n")) { if (v < 0) return BR_ERR_INVALID_ARG; c->speculate_n = v; return BR_OK; }
   if (!strcmp(key, "small_n")) { if (v < 0) return BR_ERR_INVALID_ARG; c->small_n = v; return BR_OK; }
   if (!strcmp(key, "deflate_dynamic")) { c->deflate_dynamic = v != 0; return BR_OK; }
   if (!strcmp(key, "bam_lanes")) { if (v != 0 && v != 4 && v != 8 && v != 16 && v != 32 && v != 64) return BR_ERR_INVALID_ARG; c->bam_lanes = (int)v; return BR_OK; }
@@ -787,13 +794,31 @@ static int run_ksw(br_ctx *c, hipStream_t st, const KswRun &R) {
 // split kernels run in their single-launch forms, everything goes down ONE stream, and the host waits once, at the end.
 // A batch that does not fit the bounds (a dense locus) comes back as BR_RETRY_ORDINARY and takes the ordinary path.
 #define BR_RETRY_ORDINARY 1000
+// LARGE batches take the same route when the context has projected a batch before (`big`): the tables are what earlier calls
+// left behind (grown with a quarter of headroom), the launch grids of the two emit classes and of the row kernel come from
+// the LAST call's counts scaled to this batch's size (+15 %), the kernels keep their split, two-stream forms -- and the
+// host, instead of stopping three times, checks once at the end that nothing outgrew its table or its grid.  A batch that
+// did is redone the ordinary way, which also grows the tables.
 static int run_device_small(br_ctx *c, const DevCfg &dc, const br_device_batch *b, hipStream_t st, br_device_rows *out, Prof &pf,
-                            bool keep_events) {
+                            bool keep_events, bool big) {
   const br_index *ix = c->ix;
   const int64_t n = b->n_aln, ng = b->n_groups;
-  const uint64_t cap_m = 32ull * (uint64_t)n + 8192;
+  const bool aux_cols = dc.filter_by_similarity != 0;
+  uint64_t cap_m = 32ull * (uint64_t)n + 8192;
   const uint64_t per = 9ull * (uint64_t)std::min<int32_t>(std::max<int32_t>(b->max_n_cigar, 4), 64) + 12ull;   // n_real + 2 (4 n_seg + 2) <= 9 n_cigar + 12
-  const uint64_t cap_c = std::min<uint64_t>(cap_m * per, 1ull << 28);
+  uint64_t cap_c = std::min<uint64_t>(cap_m * per, 1ull << 28);
+  uint64_t cap_r = cap_m, cover_m = cap_m, cover_s = cap_m, cover_g = cap_m, cover_r = cap_m;   // tables' capacities; what the emit / row grids cover (all matches, simple class, general class, records)
+  if (big) {
+    const double f = 1.15 * (double)n / (double)std::max<int64_t>(c->hist_n, 1);
+    cover_m = (uint64_t)(f * (double)c->hist[0]) + 4096; cover_s = (uint64_t)(f * (double)c->hist[2]) + 4096; cover_r = (uint64_t)(f * (double)c->hist[3]) + 4096;
+    cover_g = (uint64_t)(f * (double)(c->hist[0] - std::min(c->hist[0], c->hist[2]))) + 4096;
+    const uint64_t need_c = (uint64_t)(f * (double)c->hist[1]) + 4096;
+    cap_m = std::min<uint64_t>({c->m_tid.cap / 4, c->m_aux.cap / 4, c->m_p.cap / 8, c->m_x.cap / 8, c->m_b.cap / 16, c->m_cigoff.cap / 8, c->m_aln.cap / 4});
+    cap_c = c->cig_arena.cap / 4;
+    cap_r = std::min<uint64_t>({c->r_rec.cap / 16, c->pk_a.cap / 16, c->pk_c.cap / 8});
+    if (aux_cols) cap_r = std::min<uint64_t>({cap_r, c->pk_sim.cap / 8, c->pk_clip.cap / 4});
+    if (cover_m > cap_m || need_c > cap_c || cover_r > cap_r) return BR_RETRY_ORDINARY;   // the tables have to grow: the ordinary path does that
+  }
   const int64_t tiles = std::max<int64_t>(scan_tiles_for(std::max<int64_t>(n, ng) + 1), 1);
   RC(c->seg.ensure((size_t)(b->n_cigar_words + n) * sizeof(uint2)));
   RC(c->meta.ensure((size_t)n * sizeof(AlnMeta))); RC(c->head.ensure((size_t)n * sizeof(uint4))); RC(c->head2.ensure((size_t)n * sizeof(uint4)));
@@ -803,16 +828,20 @@ static int run_device_small(br_ctx *c, const DevCfg &dc, const br_device_batch *
   RC(c->cig_base.ensure((size_t)(n + 1) * 8)); RC(c->tile_sums.ensure((size_t)tiles * 8 * 3));
   RC(c->totals.ensure(16 * 8)); RC(c->counters_d.ensure(4 * 8));
   RC(c->big_list.ensure((size_t)n * 4)); RC(c->n_big.ensure(16));
-  RC(c->m_tid.ensure(cap_m * 4)); RC(c->m_aux.ensure(cap_m * 4)); RC(c->m_p.ensure(cap_m * sizeof(uint2))); RC(c->m_x.ensure(cap_m * sizeof(uint2)));
-  RC(c->m_b.ensure(cap_m * sizeof(uint4))); RC(c->m_cigoff.ensure(cap_m * 8)); RC(c->m_aln.ensure(cap_m * 4));
-  RC(c->cig_arena.ensure(cap_c * 4));
+  if (!big) {
+    RC(c->m_tid.ensure(cap_m * 4)); RC(c->m_aux.ensure(cap_m * 4)); RC(c->m_p.ensure(cap_m * sizeof(uint2))); RC(c->m_x.ensure(cap_m * sizeof(uint2)));
+    RC(c->m_b.ensure(cap_m * sizeof(uint4))); RC(c->m_cigoff.ensure(cap_m * 8)); RC(c->m_aln.ensure(cap_m * 4));
+    RC(c->cig_arena.ensure(cap_c * 4));
+  }
   if (c->rows_busy_set) HIPCHK(hipEventSynchronize(c->rows_busy));   // a queued packed download of the last call may still read the row tables
   RC(c->n_rows.ensure((size_t)n * 4)); RC(c->row_off.ensure((size_t)(n + 1) * 8)); RC(c->aln_group.ensure((size_t)n * 4));
   RC(c->pmask.ensure((size_t)n * 8)); RC(c->pbit.ensure((size_t)n));
-  const bool aux_cols = dc.filter_by_similarity != 0;
-  RC(c->r_rec.ensure(cap_m * sizeof(uint4))); RC(c->pk_a.ensure(cap_m * sizeof(uint4))); RC(c->pk_c.ensure(cap_m * sizeof(uint2)));
-  if (aux_cols) { RC(c->pk_sim.ensure(cap_m * 8)); RC(c->pk_clip.ensure(cap_m * 4)); }
-  else { RC(c->pick.ensure((size_t)std::max<int64_t>(ng, 1) * 8)); }
+  if (!big) {
+    RC(c->r_rec.ensure(cap_m * sizeof(uint4))); RC(c->pk_a.ensure(cap_m * sizeof(uint4))); RC(c->pk_c.ensure(cap_m * sizeof(uint2)));
+    if (aux_cols) { RC(c->pk_sim.ensure(cap_m * 8)); RC(c->pk_clip.ensure(cap_m * 4)); }
+  }
+  if (!aux_cols) RC(c->pick.ensure((size_t)std::max<int64_t>(ng, 1) * 8));
+  if (big) { RC(c->walk_list.ensure((size_t)n * 4)); RC(ensure_aux_stream(c)); }
   uint64_t *d_tot = c->totals.as<uint64_t>();
 
   // (the per-batch counters sit behind the totals, d_tot[8..11]: one download brings both home; k_segment zeroes them and
@@ -836,9 +865,16 @@ static int run_device_small(br_ctx *c, const DevCfg &dc, const br_device_batch *
   A.m_x = c->m_x.as<uint2>(); A.m_b = c->m_b.as<uint4>(); A.m_cigoff = c->m_cigoff.as<uint64_t>(); A.cig_arena = c->cig_arena.as<uint32_t>();
   A.tot = d_tot; A.lim_m = cap_m; A.lim_c = cap_c;
   const int n_blocks = c->n_cu * c->blocks_per_cu;
+  const bool split = big && c->count_split && !dc.filter_by_similarity;
+  if (split) { A.walk_list = c->walk_list.as<uint32_t>(); A.n_walk = c->n_big.as<uint32_t>() + 1; }
   RC(pf.begin(BR_K_COUNT));
-  launch_project(st, A, false, c->group_lanes, n_blocks, 0);   // one kernel, the exon walk inline
+  launch_project(st, A, false, c->group_lanes, n_blocks, split ? 1 : 0);   // small: one kernel, the exon walk inline
   RC(pf.end());
+  if (split) {
+    RC(pf.begin(BR_K_COUNT_WALK));
+    launch_project(st, A, false, c->group_lanes, n_blocks, 2);
+    RC(pf.end());
+  }
   ScanArgs S{};
   S.n = n; S.src32 = c->n_matches.as<uint32_t>(); S.cigar_off = b->cigar_off; S.head = c->head.as<uint4>();
   S.tile_sums = c->tile_sums.as<uint64_t>(); S.fast_flag = c->fast_flag.as<uint32_t>();
@@ -850,10 +886,33 @@ static int run_device_small(br_ctx *c, const DevCfg &dc, const br_device_batch *
     launch_expand(st, A);
     RC(pf.end());
   }
-  RC(pf.begin(BR_K_EMIT));
-  launch_emit_dense(st, A, (int64_t)cap_m, -1, 0);            // one launch over the whole list; the kernel stops at tot[0]
-  launch_project(st, A, true, 64, std::min(c->n_cu, 64));     // alignments with > 64 candidate rows (reads *n_big)
-  RC(pf.end());
+  if (!big) {
+    RC(pf.begin(BR_K_EMIT));
+    launch_emit_dense(st, A, (int64_t)cover_m, -1, 0);          // one launch over the whole list; the kernel stops at tot[0]
+    launch_project(st, A, true, 64, std::min(c->n_cu, 64));     // alignments with > 64 candidate rows (reads *n_big)
+    RC(pf.end());
+  } else {
+    // as the ordinary path: the dense-locus kernel on the second stream beside the two classes of the work list
+    HIPCHK(hipEventRecord(c->aux_ev[0], st));
+    HIPCHK(hipStreamWaitEvent(c->ksw_stream, c->aux_ev[0], 0));
+    RC(pf.begin(BR_K_EMIT_AUX, c->ksw_stream));
+    launch_project(c->ksw_stream, A, true, 64, c->n_cu);
+    RC(pf.end());
+    HIPCHK(hipEventRecord(c->aux_ev[1], c->ksw_stream));
+    if (c->emit_split && !dc.filter_by_similarity) {
+      RC(pf.begin(BR_K_EMIT_SIMPLE));
+      launch_emit_dense(st, A, (int64_t)cover_m, (int64_t)cover_s, 1);
+      RC(pf.end());
+      RC(pf.begin(BR_K_EMIT));
+      launch_emit_dense(st, A, (int64_t)(cover_g + cover_s), (int64_t)cover_s, 2);   // (its grid: cover_g entries of the general class)
+      RC(pf.end());
+    } else {
+      RC(pf.begin(BR_K_EMIT));
+      launch_emit_dense(st, A, (int64_t)cover_m, -1, 0);
+      RC(pf.end());
+    }
+    HIPCHK(hipStreamWaitEvent(st, c->aux_ev[1], 0));
+  }
 
   PairArgs P{};
   P.n_groups = ng; P.n_aln = n; P.long_reads = dc.long_reads; P.group_off = b->group_off; P.mate_idx = b->mate_idx;
@@ -862,7 +921,7 @@ static int run_device_small(br_ctx *c, const DevCfg &dc, const br_device_batch *
   P.m_cigoff = A.m_cigoff;
   P.n_rows = c->n_rows.as<uint32_t>(); P.row_off = c->row_off.as<uint64_t>(); P.counters = d_cnt;
   P.pmask = c->pmask.as<uint64_t>(); P.pbit = c->pbit.as<uint8_t>();
-  P.tot = d_tot; P.lim_m = cap_m; P.lim_c = cap_c;
+  P.tot = d_tot; P.lim_m = cap_m; P.lim_c = cap_c; P.lim_r = std::min(cap_r, cover_r);
   RC(pf.begin(BR_K_PAIR_COUNT));
   launch_pair(st, P, false);
   RC(pf.end());
@@ -871,7 +930,7 @@ static int run_device_small(br_ctx *c, const DevCfg &dc, const br_device_batch *
   RC(pf.begin(BR_K_SCAN));
   launch_scan(st, S2, 2, c->row_off.p, true, d_tot + 3);
   RC(pf.end());
-  P.n_rows_total = (int64_t)cap_m; P.r_rec = c->r_rec.as<uint4>();
+  P.n_rows_total = (int64_t)P.lim_r; P.r_rec = c->r_rec.as<uint4>();
   P.r_a = c->pk_a.as<uint4>(); P.r_c = c->pk_c.as<uint2>(); P.r_x = nullptr;
   P.r_sim = aux_cols ? c->pk_sim.as<double>() : nullptr; P.r_clip = aux_cols ? c->pk_clip.as<int32_t>() : nullptr;
   // a caller that wants the few rows of a small call on the host (br_project_group): the row kernel writes the packed rows
@@ -887,13 +946,21 @@ static int run_device_small(br_ctx *c, const DevCfg &dc, const br_device_batch *
   const uint8_t *names = (b->names && b->name_off) ? b->names : nullptr;
   if (!aux_cols) {   // the primary choice needs row_off and the pair bits only: before the records exist, its pick applied by k_rows
     P.pick = c->pick.as<uint64_t>();
-    RC(pf.begin(BR_K_PRIMARY));
-    launch_primary(st, P, b->name_off, names, false);
+    hipStream_t ps = st;
+    if (big) {   // ... and beside the emit pass, on the second stream
+      ps = c->ksw_stream;
+      HIPCHK(hipEventRecord(c->aux_ev[0], st));
+      HIPCHK(hipStreamWaitEvent(ps, c->aux_ev[0], 0));
+    }
+    RC(pf.begin(BR_K_PRIMARY, ps));
+    launch_primary(ps, P, b->name_off, names, false);
     RC(pf.end());
+    if (big) HIPCHK(hipEventRecord(c->aux_ev[1], ps));
   }
   RC(pf.begin(BR_K_PAIR_EMIT));
   launch_pair(st, P, true);
   RC(pf.end());
+  if (big && !aux_cols) HIPCHK(hipStreamWaitEvent(st, c->aux_ev[1], 0));
   if (aux_cols) {
     RC(pf.begin(BR_K_PRIMARY));
     launch_primary(st, P, b->name_off, names, true);
@@ -905,8 +972,12 @@ static int run_device_small(br_ctx *c, const DevCfg &dc, const br_device_batch *
   HIPCHK(hipMemcpyAsync(c->h_totals + 32, d_tot, 12 * 8, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   for (int k = 0; k < 4; k++) { c->h_totals[k] = c->h_totals[32 + k]; c->h_totals[4 + k] = c->h_totals[40 + k]; }
-  const uint64_t n_matches = c->h_totals[0], n_cig_arena = c->h_totals[1], n_rows = c->h_totals[3];
-  if (n_matches > cap_m || n_cig_arena > cap_c) return BR_RETRY_ORDINARY;   // nothing was written past a table: the kernels checked the same totals
+  const uint64_t n_matches = c->h_totals[0], n_cig_arena = c->h_totals[1], n_simple = c->h_totals[2], n_rows = c->h_totals[3];
+  // nothing was written past a table or left out by a grid: the kernels checked the same totals and did nothing then
+  if (n_matches > cap_m || n_cig_arena > cap_c || n_rows > P.lim_r) return BR_RETRY_ORDINARY;
+  if (big && (c->emit_split && !dc.filter_by_similarity ? (n_simple > cover_s || n_matches - n_simple > cover_g) : n_matches > cover_m)) return BR_RETRY_ORDINARY;
+  c->hist_simf = dc.filter_by_similarity != 0;
+  c->hist_n = n; c->hist[0] = n_matches; c->hist[1] = n_cig_arena; c->hist[2] = n_simple; c->hist[3] = n_rows;
   if (!keep_events) RC(pf.collect());
   if (c->h_totals[7]) return BR_ERR_UNSUPPORTED;  // a rewritten CIGAR with more than 2^24 - 1 ops
   out->n_matches = (int64_t)n_matches; out->n_rows = (int64_t)n_rows; out->n_pool_words = (int64_t)n_cig_arena;
@@ -945,10 +1016,17 @@ static int run_device_impl(br_ctx *c, const br_config *cfg, const br_device_batc
   c->last_n_rows = 0; c->last_n_aln = n; c->last_n_pool = 0; c->wide_valid = false; c->last_aux_cols = false;
   c->last_l_qseq = b->l_qseq; c->last_long_reads = dc.long_reads;
   if (n == 0) { pf.collect(); return BR_OK; }
-  if (!fa_mode && c->small_batch && n <= c->small_n && ix->dev.n_rows != 0) {
-    const int rc = run_device_small(c, dc, b, st, out, pf, keep_events);
-    if (rc != BR_RETRY_ORDINARY) return rc;
-    if (!keep_events) c->events_used = 0;
+  if (!fa_mode && c->small_batch && ix->dev.n_rows != 0) {
+    // small batches always; large ones when an earlier call left tables and counts to predict from (same preset class)
+    const bool small = n <= c->small_n;
+    // (up to speculate_n alignments: at 20 M alignments the three waits are 2 % of the step and the 15 % of empty blocks in
+    // the predicted grids cost as much, profiles/r03/ab_speculate.log; at 0.1-1 M alignments the step gets 6-13 % shorter)
+    const bool big = !small && n <= c->speculate_n && c->speculate && c->hist_n > 0 && c->hist_simf == (dc.filter_by_similarity != 0) && !c->single_pass;
+    if (small || big) {
+      const int rc = run_device_small(c, dc, b, st, out, pf, keep_events, big);
+      if (rc != BR_RETRY_ORDINARY) return rc;
+      if (!keep_events) c->events_used = 0;
+    }
   }
 
   int64_t tiles = std::max<int64_t>(scan_tiles_for(std::max<int64_t>(n, ng) + 1), 1);
@@ -1248,6 +1326,10 @@ static int run_device_impl(br_ctx *c, const br_config *cfg, const br_device_batc
   out->total_complete = n_rows; out->total_unique = c->h_totals[5]; out->dropped_reads = c->h_totals[6];
   if (fa_mode && c->rescue_stats[0]) { c->rescue_stats[1] = c->h_totals[8]; c->rescue_stats[2] = c->h_totals[9]; }
 
+  // what a later large batch is predicted from (run_device_small, big)
+  c->hist_n = n; c->hist[0] = n_matches; c->hist[1] = n_cig_arena; c->hist[2] = n_simple >= 0 ? (uint64_t)n_simple : 0; c->hist[3] = n_rows;
+  c->hist_simf = dc.filter_by_similarity != 0;
+  if (fa_mode) c->hist_n = 0;
   out->a = (const br_row_a *)c->pk_a.p; out->cigar = (const uint64_t *)c->pk_c.p; out->x = nullptr;   // br_device_rows_detail
   out->similarity_score = aux_cols ? c->pk_sim.as<double>() : nullptr;
   out->clip_score = aux_cols ? c->pk_clip.as<int32_t>() : nullptr;

@@ -53,6 +53,7 @@ struct ProjectArgs {
   // host read the totals and passes them by value
   const uint64_t *tot;
   uint64_t lim_m, lim_c;
+  uint64_t cover;        // work-list entries the launch's grid covers (large batches launched from predicted counts): more -> nothing is done
 };
 __device__ __forceinline__ bool tot_over(const uint64_t *tot, uint64_t lim_m, uint64_t lim_c) { return tot && (tot[0] > lim_m || tot[1] > lim_c); }
 // k_project1's counters (u64 each): the three allocators' high-water marks, "a capacity was exceeded", matches found,
@@ -170,7 +171,9 @@ struct PairArgs {
   uint64_t *counters;       // [4] total_complete, total_unique, dropped_reads, a field overflowed its packed width
   const uint64_t *tot;      // small batches (see ProjectArgs): tot[0..1] against lim_m / lim_c, tot[3] = records (n_rows_total is then the tables' capacity)
   uint64_t lim_m, lim_c;
+  uint64_t lim_r;           // records the row tables (and the row kernel's grid) hold; tot[3] beyond it -> the kernels behind the row scan do nothing
 };
+__device__ __forceinline__ bool rows_over(const uint64_t *tot, uint64_t lim_r) { return tot && tot[3] > lim_r; }
 #define RR_HI 0x0fffffffu        // r_rec.w bits 0..27: HI
 #define RR_PRIMARY (1u << 28)
 #define RR_PAIRED (1u << 29)

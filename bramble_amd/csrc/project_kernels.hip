@@ -1045,9 +1045,11 @@ __global__ void __launch_bounds__(256, CLS == 1 ? 8 : 6) k_emit_dense(ProjectArg
     sh_mops[threadIdx.x] = (uint16_t)((merge_action(threadIdx.x >> 4, threadIdx.x & 15u) << 8) | merge_ops(threadIdx.x >> 4, threadIdx.x & 15u));
     __syncthreads();
   }
-  if (A.tot) {   // small batches: the totals never left the device (CLS 0 only: one launch over the whole list)
+  if (A.tot) {   // the totals never left the device: the whole list (CLS 0), its simple prefix (1) or the rest (2) from tot[]
     if (tot_over(A.tot, A.lim_m, A.lim_c)) return;
-    n_matches = (int64_t)A.tot[0];
+    n_matches = CLS == 1 ? (int64_t)A.tot[2] : (int64_t)A.tot[0];
+    first = CLS == 2 ? (int64_t)A.tot[2] : 0;
+    if ((uint64_t)(n_matches - first) > A.cover) return;   // the grid was sized from a prediction that fell short: the host sees the same and redoes the batch
   }
   int64_t mi64 = first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (mi64 >= n_matches) return;
@@ -2051,7 +2053,7 @@ __global__ void __launch_bounds__(256) k_pair_emit(PairArgs P) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t i64 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t i = (uint32_t)i64;
-  if (tot_over(P.tot, P.lim_m, P.lim_c)) return;
+  if (tot_over(P.tot, P.lim_m, P.lim_c) || rows_over(P.tot, P.lim_r)) return;
   uint4 *__restrict__ rec = P.r_rec;
   uint32_t rows = 0, kind = 0, mi0 = 0, mm0 = 0, ni = 0, nm = 0, nh = 0, hi0 = 0;
   int32_t m = -1;
@@ -2141,7 +2143,7 @@ template <bool SCORES>
 __global__ void __launch_bounds__(256) k_primary(PairArgs P, const uint32_t *__restrict__ name_off,
                                                  const uint8_t *__restrict__ names) {
   unsigned long long uniq = 0, dropped = 0;
-  if (tot_over(P.tot, P.lim_m, P.lim_c)) return;
+  if (tot_over(P.tot, P.lim_m, P.lim_c) || rows_over(P.tot, P.lim_r)) return;
   uint32_t *flagw = (uint32_t *)P.r_rec + 3;   // flag word of record r: flagw[4 * r]
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < P.n_groups; g += (int64_t)gridDim.x * blockDim.x) {
     const uint32_t a0 = P.group_off[g], a1 = P.group_off[g + 1];
@@ -2242,7 +2244,7 @@ __global__ void __launch_bounds__(256) k_primary(PairArgs P, const uint32_t *__r
 template <bool AUX>
 __global__ void __launch_bounds__(256) k_rows(PairArgs P) {
   int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (P.tot) { if (tot_over(P.tot, P.lim_m, P.lim_c) || r >= (int64_t)P.tot[3]) return; }   // small batches: the record count is on the device
+  if (P.tot) { if (tot_over(P.tot, P.lim_m, P.lim_c) || rows_over(P.tot, P.lim_r) || r >= (int64_t)P.tot[3]) return; }   // the record count is on the device
   else if (r >= P.n_rows_total) return;
   const uint4 rec = P.r_rec[r];
   const uint32_t x = rec.x;
@@ -2522,8 +2524,12 @@ void launch_expand(hipStream_t st, const ProjectArgs &A) {
   hipLaunchKernelGGL(k_expand, dim3(grid_for(A.n_aln, 256)), dim3(256), 0, st, A);
 }
 
-void launch_emit_dense(hipStream_t st, const ProjectArgs &A, int64_t n_matches, int64_t n_simple, int part) {
-  if (A.n_aln <= 0 || n_matches <= 0) return;
+// With A.tot set, n_matches / n_simple are what the GRIDS cover (predictions or capacities); the kernels take the real counts
+// from the device and give up when a grid falls short (A.cover).
+void launch_emit_dense(hipStream_t st, const ProjectArgs &A0, int64_t n_matches, int64_t n_simple, int part) {
+  if (A0.n_aln <= 0 || n_matches <= 0) return;
+  ProjectArgs A = A0;
+  if (A.tot) A.cover = (uint64_t)(part == 1 ? n_simple : part == 2 ? n_matches - n_simple : n_matches);
   const FaArgs F{};
   if (A.cfg.filter_by_similarity) { hipLaunchKernelGGL((k_emit_dense<true, 0>), dim3(grid_for(n_matches, 256)), dim3(256), 0, st, A, (int64_t)0, n_matches, F); return; }
   if (part == 0 || n_simple < 0) { hipLaunchKernelGGL((k_emit_dense<false, 0>), dim3(grid_for(n_matches, 256)), dim3(256), 0, st, A, (int64_t)0, n_matches, F); return; }

@@ -409,3 +409,30 @@ def test_single_pass_variant_equals_oracle():
                 assert_rows_equal(ctx.project_batch(lib.make_config(**flags), b), orc)
             ctx.close()
         idx.close()
+
+
+def test_large_batches_launched_from_the_last_calls_counts():
+    """Batches beyond `small_n` alignments on a context that has projected before are launched without the three host round
+    trips of the ordinary pipeline: tables as earlier calls left them, emit / row grids from the LAST call's counts scaled to the
+    batch (+15 %), one check at the end, the ordinary pipeline again when a table or a grid fell short.  Same rows as the
+    oracle whatever the order of batches: equal ones (prediction exact), a smaller one, one with far more matches per alignment
+    than predicted (falls back and grows the tables), and the long-read preset in between (other kernels, other tables)."""
+    ann = synth.Annotation("G", n_genes=4000, n_refs=4)
+    annd = ann.as_dict()
+    oi = ob.OracleIndex(annd)
+    batches = {"a": ann.reads(40000, "pe"), "b": ann.reads(34000, "pe", seed=77), "c": ann.reads(45000, "pe", seed=78, p_multimap=0.5),
+               "h": ann.reads(70000, "hifi", seed=79)}
+    for k in ("a", "b", "c"):
+        assert batches[k]["n_aln"] > 65536
+    want = {}
+    for k, flags in (("a", {}), ("b", {}), ("c", {}), ("h", {"lr_hq": 1})):
+        want[k], _, _ = ob.run(oi, ob.make_flags(**flags), batches[k], want_matches=False)
+    idx = lib.Index(annd, device=0)
+    for spec in (1, 0):
+        ctx = lib.Context(idx)
+        ctx.set_param("speculate", spec)
+        for k in ("a", "a", "b", "c", "a", "h", "h", "c", "b"):
+            flags = {"lr_hq": 1} if k == "h" else {}
+            assert_rows_equal(ctx.project_batch(lib.make_config(**flags), batches[k]), want[k])
+        ctx.close()
+    idx.close()
