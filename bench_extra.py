@@ -216,6 +216,8 @@ def main():
     ctx = lib.Context(idx)
     if os.environ.get("KSW_FAST") is not None:
         ctx.set_param("ksw_fast", int(os.environ["KSW_FAST"]))
+    if os.environ.get("KSW_TAPE_MB") is not None:
+        ctx.set_param("ksw_tape_mb", int(os.environ["KSW_TAPE_MB"]))
     db = brdev.upload_batch(batch, "cuda:0")
     stream = torch.cuda.current_stream().cuda_stream
     for _ in range(args.warmup):

@@ -833,7 +833,10 @@ static int run_device_small(br_ctx *c, const DevCfg &dc, const br_device_batch *
     RC(c->m_b.ensure(cap_m * sizeof(uint4))); RC(c->m_cigoff.ensure(cap_m * 8)); RC(c->m_aln.ensure(cap_m * 4));
     RC(c->cig_arena.ensure(cap_c * 4));
   }
-  if (c->rows_busy_set) HIPCHK(hipEventSynchronize(c->rows_busy));   // a queued packed download of the last call may still read the row tables
+  // a queued packed download of the last call (br_project_staged) may still read the row tables: small batches wait for it here;
+  // large ones keep the overlap -- their tables are not reallocated (checked above) -- and make the row scan wait instead
+  const bool rows_busy_wait = c->rows_busy_set && big && c->row_off.cap >= (size_t)(n + 1) * 8;
+  if (c->rows_busy_set && !rows_busy_wait) HIPCHK(hipEventSynchronize(c->rows_busy));
   RC(c->n_rows.ensure((size_t)n * 4)); RC(c->row_off.ensure((size_t)(n + 1) * 8)); RC(c->aln_group.ensure((size_t)n * 4));
   RC(c->pmask.ensure((size_t)n * 8)); RC(c->pbit.ensure((size_t)n));
   if (!big) {
@@ -927,6 +930,7 @@ static int run_device_small(br_ctx *c, const DevCfg &dc, const br_device_batch *
   RC(pf.end());
   ScanArgs S2{};
   S2.n = n; S2.src32 = c->n_rows.as<uint32_t>(); S2.tile_sums = c->tile_sums.as<uint64_t>();
+  if (rows_busy_wait) HIPCHK(hipStreamWaitEvent(st, c->rows_busy, 0));
   RC(pf.begin(BR_K_SCAN));
   launch_scan(st, S2, 2, c->row_off.p, true, d_tot + 3);
   RC(pf.end());

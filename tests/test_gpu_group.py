@@ -227,3 +227,34 @@ def test_plain_c_program_against_the_header(tmp_path, golden):
     assert out[0] == "unspliced tx1 50 149 100 100 + nh=1 hi=1 mapq=255 primary=1 cigar=" + exp["unspliced"]["out"]
     assert out[1] == "spliced tx2 51 150 100 100 + nh=1 hi=1 mapq=255 primary=1 cigar=" + exp["spliced"]["out"]
     assert out[2] == "mixed-names rc=-1"
+
+
+def test_project_group_at_a_dense_locus_takes_the_ordinary_pipeline():
+    """A read with more than 32 matches per alignment does not fit the small path's tables: the call falls back to the
+    ordinary pipeline inside the same entry point (and fetches its rows instead of finding them in pinned memory).  Same
+    records as br_project_batch and the oracle."""
+    txs = []
+    for t in range(150):
+        ex = [[1000, 1200 + (t % 4)], [2000 + 5 * (t % 7), 2300], [3000, 3100 + t]]
+        txs.append({"id": "iso%d" % t, "ref_id": 0, "strand": "+" if t % 3 else "-", "exons": ex[:2] if t % 5 == 0 else ex})
+    ann = {"refnames": ["chr1"], "transcripts": txs}
+    recs = [{"name": "dense", "ref_id": 0, "ref_start": 1050, "cigar": "80M"},
+            {"name": "dense", "ref_id": 0, "ref_start": 1120, "cigar": "80M3S"}]
+    b = make_batch(recs)
+    idx = lib.Index(ann, device=0)
+    ctx = lib.Context(idx)
+    cfg = lib.make_config()
+    orc, _, _ = ob.run(ob.OracleIndex(ann), ob.make_flags(), b, want_matches=False)
+    assert orc["n_rows"] > 100
+    res = ctx.project_group(cfg, _group_alignments(b, 0, 2))
+    assert len(res) == orc["n_rows"]
+    for p, r in zip(res, range(orc["n_rows"])):
+        c0, c1 = int(orc["cigar_off"][r]), int(orc["cigar_off"][r + 1])
+        assert (p["transcript_id"], p["transcript_start"], p["nh"], p["hi"], p["input_index"]) == \
+               (orc["tid"][r], orc["pos"][r], orc["nh"][r], orc["hi"][r], orc["input_index"][r])
+        assert np.array_equal(p["cigar"], orc["cigar"][c0:c1]) and p["is_primary"] == orc["primary"][r]
+    # and a small call right after it goes the short way again
+    one = ctx.project_group(cfg, [_group_alignments(b, 0, 1)[0]])
+    assert len(one) > 32
+    ctx.close()
+    idx.close()
