@@ -742,18 +742,23 @@ static int run_ksw(br_ctx *c, hipStream_t st, const KswRun &R) {
     const uint64_t *h_rows = (const uint64_t *)(h_cnt + 8);
     // tape: a row = one step of a wave (512 or 1024 B); a bin's waves run (tape rows of its problems) / (groups per wave) steps when
     // its groups stay equally busy (they share one queue), 15 % on top, and every wave rounds up to chunks and drains
-    uint64_t tape_bytes = 0; uint32_t n_groups_total = 0;
+    uint64_t tape_bytes = 0, tape_fixed = 0; uint32_t n_groups_total = 0;   // tape_fixed: what every wave rounds up and drains, whatever the piece holds
     for (int b = 0; b < KSW_N_BINS; b++) {
       A.n_bin[b] = h_cnt[b];
       A.n_groups[b] = std::min<uint32_t>(max_groups[b], (h_cnt[b] + 7u) / 8u);   // a group takes its problems eight at a time
       n_groups_total += A.n_groups[b];
       const uint64_t gpw = 64u / (uint64_t)KSW_BIN_G(b), waves = (A.n_groups[b] + gpw - 1) / gpw;
-      const uint64_t rows = h_rows[b] / gpw + h_rows[b] / gpw / 7 + waves * (1ull * KSW_CHUNK_ROWS + KSW_BIN_W(b) + 64);
-      if (A.n_bin[b]) tape_bytes += rows * (uint64_t)KSW_BIN_ROWBYTES(b);
+      const uint64_t fixed = waves * (1ull * KSW_CHUNK_ROWS + KSW_BIN_W(b) + 64);
+      const uint64_t rows = h_rows[b] / gpw + h_rows[b] / gpw / 7 + fixed;
+      if (A.n_bin[b]) { tape_bytes += rows * (uint64_t)KSW_BIN_ROWBYTES(b); tape_fixed += fixed * (uint64_t)KSW_BIN_ROWBYTES(b); }
     }
     if (tape_bytes > tape_budget && n >= 2048) {
-      uint64_t mid = p0 + n / 2;
-      todo.emplace_back(mid, p1); todo.emplace_back(p0, mid);
+      // as few pieces as fit: the part of the tape that scales with the problems over what a piece has left for it (halves
+      // when the fixed part alone nearly fills the budget); a piece that still does not fit is cut again
+      uint64_t k = 2;
+      if (tape_budget > tape_fixed + tape_fixed / 4) k = ((tape_bytes - tape_fixed) + (tape_budget - tape_fixed) - 1) / (tape_budget - tape_fixed);
+      k = std::min<uint64_t>(std::max<uint64_t>(k, 2), std::min<uint64_t>(64, n / 1024));
+      for (uint64_t i = k; i-- > 0;) todo.emplace_back(p0 + n * i / k, p0 + n * (i + 1) / k);
       continue;
     }
     const uint32_t n_left = h_cnt[KSW_N_BINS];

@@ -353,9 +353,15 @@ __global__ void __launch_bounds__(256) k_ksw_dp(KswDpArgs A) {
   auto seq_off_of = [](uint4 d) { return (uint64_t)d.z | ((uint64_t)d.w << 32); };
   // feeder only: the next problem of the bin (the queue is shared by every group of the launch)
   // (claimed eight at a time: one atomic per problem on a single address is ~15 ns of queueing each)
+  // ... while the queue is long; over its last stretch (fewer than sixteen problems per group left, judged by what the last
+  // claim returned) one at a time: a group that sits on eight claimed problems while its neighbours have run dry is the
+  // kernel's tail, paid once per shape and piece
   uint32_t cl_next = 0, cl_end = 0;
   auto claim = [&]() {
-    if (cl_next == cl_end) { cl_next = atomicAdd(A.queue, 8u); cl_end = cl_next + 8u; }
+    if (cl_next == cl_end) {
+      const uint32_t want = (cl_end < A.n && A.n - cl_end > 16u * A.n_groups) ? 8u : 1u;
+      cl_next = atomicAdd(A.queue, want); cl_end = cl_next + want;
+    }
     const uint32_t k = cl_next++;
     return k < A.n ? k : KSW_NO_PROB;
   };
