@@ -179,22 +179,39 @@ def main():
         prep = time.perf_counter() - t0
         exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bramble_amd", "bin", "bramble")
         res = {}
-        levels = [x if x == "device" else int(x) for x in os.environ.get("CLI_LEVELS", "1,6,device").split(",")]
-        for level in levels:
+        # CLI_LEVELS entries: a host codec level or "device", optionally "@NAME=VALUE[@...]" environment for that run (A/B on one input)
+        for entry in os.environ.get("CLI_LEVELS", "1,6,device").split(","):
+            parts = entry.split("@")
+            level = parts[0] if parts[0] == "device" else int(parts[0])
+            run_env = dict(os.environ)
+            run_env.update(dict(kv.split("=", 1) for kv in parts[1:]))
+            os.sync()   # the previous run's output is on its way to the disk: not this run's business
+            time.sleep(float(os.environ.get("CLI_GAP_S", "0")))   # ... and the driver is still taking the previous process apart
             out_bam = os.path.join(tmp, "out%s.bam" % level)
+            if os.path.exists(out_bam):
+                os.remove(out_bam)
             t0 = time.perf_counter()
+            e0 = time.time()
+            import resource
+            ru0 = resource.getrusage(resource.RUSAGE_CHILDREN)
             codec = ["--device-deflate"] if level == "device" else ["--compression-level", str(level)]
-            r = subprocess.run([exe, in_bam, "-G", gtf, "-o", out_bam, "-p", str(args.threads)] + codec,
-                               capture_output=True, text=True)
+            extra = os.environ.get("CLI_EXTRA", "").split()
+            r = subprocess.run([exe, in_bam, "-G", gtf, "-o", out_bam, "-p", str(args.threads)] + codec + extra,
+                               capture_output=True, text=True, env=run_env)
             wall = time.perf_counter() - t0
+            e1 = time.time()
+            if os.environ.get("BRAMBLE_AMD_TIMING"):
+                print("%s: spawn at %.3f, child gone at %.3f\n%s" % (entry, e0, e1, r.stderr), file=sys.stderr)
             if r.returncode != 0:
                 print(r.stderr, file=sys.stderr)
                 sys.exit(1)
             tail = [l for l in r.stdout.splitlines() if "bundles" in l or "stage busy" in l or "release of" in l]
-            key = "level%s" % level
+            key = "level%s" % entry
             while key in res:
                 key += "'"
-            res[key] = {"wall_s": round(wall, 2), "alignments_per_s": len(rlen) / wall, "out_bam_bytes": os.path.getsize(out_bam),
+            ru1 = resource.getrusage(resource.RUSAGE_CHILDREN)
+            res[key] = {"wall_s": round(wall, 2), "user_s": round(ru1.ru_utime - ru0.ru_utime, 2), "sys_s": round(ru1.ru_stime - ru0.ru_stime, 2),
+                        "max_rss_gb": round(ru1.ru_maxrss / 1048576.0, 2), "alignments_per_s": len(rlen) / wall, "out_bam_bytes": os.path.getsize(out_bam),
                                        "report": " | ".join(tail)}
         print(json.dumps({"config": "cli", "workload": "%d paired-end alignments, BAM file -> BAM file, -p %d, GENCODE-shaped GTF (%d transcripts)" % (len(rlen), args.threads, len(annd["transcripts"])),
                           "in_bam_bytes": os.path.getsize(in_bam), "uncompressed_in_bytes": int(stream_h.size), "results": res,

@@ -2345,6 +2345,16 @@ extern "C" uint32_t br_row_mapq(uint32_t nh, int long_reads) {  // src/core.cpp:
   return nh > 1 ? 0u : 3u;
 }
 
+// First touch of a device (runtime start-up, context creation: a few tenths of a second) -- something a caller can do on a
+// thread of its own while it is busy elsewhere (the command line does, while the guides are parsed).
+extern "C" int br_device_warmup(int device) {
+  int rc = check_device(device);
+  if (rc) return rc;
+  HIPCHK(hipSetDevice(device));
+  HIPCHK(hipFree(nullptr));
+  return BR_OK;
+}
+
 extern "C" const char *br_version(void) { return "bramble_amd 0.3.0 (gfx950, ABI 3)"; }
 extern "C" const char *br_strerror(int code) {
   switch (code) {

@@ -7,12 +7,22 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 
 #include <string>
 #include <utility>
 #include <vector>
 
 namespace brio {
+
+// Large host buffers ask for transparent huge pages (the boxes run THP in "madvise" mode): a 20.9 M-record file is 3.3 GB
+// of record bytes first touched by the reader threads, and 4 KB faults were 1.3 s of system time per run.
+inline void advise_huge(void *p, size_t n) {
+  static const bool on = [] { const char *e = getenv("BRAMBLE_AMD_HUGE_PAGES"); return !e || atoi(e) != 0; }();
+  if (!on) return;
+  const uintptr_t a = ((uintptr_t)p + 4095) & ~(uintptr_t)4095, e = ((uintptr_t)p + n) & ~(uintptr_t)4095;
+  if (e > a && e - a >= ((size_t)4 << 20)) (void)madvise((void *)a, e - a, MADV_HUGEPAGE);
+}
 
 // growable byte buffer without value-initialisation (std::vector<uint8_t>::resize zero-fills gigabytes here)
 class ByteBuf {
@@ -24,13 +34,20 @@ class ByteBuf {
   uint8_t *data() { return p_; }
   const uint8_t *data() const { return p_; }
   size_t size() const { return n_; }
+  size_t capacity() const { return cap_; }
   uint8_t &operator[](size_t i) { return p_[i]; }
   const uint8_t &operator[](size_t i) const { return p_[i]; }
   void resize(size_t n) {
-    if (n > cap_) { size_t c = cap_ + cap_ / 2; if (c < n) c = n; if (c < 4096) c = 4096; p_ = (uint8_t *)realloc(p_, c); if (!p_) abort(); cap_ = c; }
+    if (n > cap_) { size_t c = cap_ + cap_ / 2; if (c < n) c = n; if (c < 4096) c = 4096; p_ = (uint8_t *)realloc(p_, c); if (!p_) abort(); cap_ = c; advise_huge(p_, c); }
     n_ = n;
   }
-  void reserve(size_t c) { if (c > cap_) { p_ = (uint8_t *)realloc(p_, c); if (!p_) abort(); cap_ = c; } }
+  void reserve(size_t c) {
+    if (c <= cap_) return;
+    if (n_ == 0) { free(p_); p_ = (uint8_t *)malloc(c); }   // nothing to carry over: a fresh mapping, not a moved one
+    else p_ = (uint8_t *)realloc(p_, c);
+    if (!p_) abort();
+    cap_ = c; advise_huge(p_, c);
+  }
   void erase_front(size_t k) { if (k >= n_) { n_ = 0; return; } memmove(p_, p_ + k, n_ - k); n_ -= k; }
   void swap(ByteBuf &o) { std::swap(p_, o.p_); std::swap(n_, o.n_); std::swap(cap_, o.cap_); }
   void clear() { n_ = 0; }

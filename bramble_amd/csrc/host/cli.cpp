@@ -11,6 +11,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <atomic>
@@ -41,7 +43,7 @@ struct Options {
   br_config cfg;
   int threads = 1, level = 6;
   std::vector<int> devices{0};  // --device N / --devices a,b,...: one worker (index replica + context + host threads) per entry
-  int64_t bundle_records = 2000000;
+  int64_t bundle_records = 1000000;   // (1 M: 1.20 s inside the program for 20.9 M alignments, 2 M: 1.38 s, 0.5 M: 1.47 s; the pinned result buffers scale with it)
   bool quiet = false;
   bool device_deflate = true;   // BGZF blocks made on the GPU unless a host level is asked for
 };
@@ -245,6 +247,9 @@ const uint8_t *rec_name(const brio::ByteBuf &b, uint64_t off, uint32_t &l) { l =
 
 }  // namespace
 
+static std::atomic<int> g_exit_at_end{0};
+extern "C" void br_cli_exit_at_end(int on) { g_exit_at_end.store(on ? 1 : 0); }
+
 extern "C" int br_cli_main(int argc, char **argv) {
   Options o;
   int prc = parse_args(argc, argv, o);
@@ -257,18 +262,22 @@ extern "C" int br_cli_main(int argc, char **argv) {
   if (o.out_bam == "-") o.quiet = true;   // the BAM stream owns standard output
   if (!o.quiet) { printf("\n[bramble] starting version: %s (bramble_amd %s)\n", BRAMBLE_REF_VERSION, br_version()); printf("[bramble] loading reference annotation...\n"); }
 
+  // the devices' first touch (runtime start-up, contexts) happens beside the guide parsing, not in front of the index build
+  std::vector<std::thread> warm;
+  for (int d : o.devices) warm.emplace_back([d]() { (void)br_device_warmup(d); });
+  struct WarmJoin { std::vector<std::thread> &t; ~WarmJoin() { for (auto &x : t) if (x.joinable()) x.join(); } } warm_join{warm};
   BgzfReader rd;
   if (!rd.open(o.in_bam.c_str(), o.threads)) { fprintf(stderr, "error: %s\n", rd.error().c_str()); return 1; }
   brio::ByteBuf buf; size_t pos = 0;
   BamHeader hdr; std::string err;
   if (!read_header(rd, buf, pos, hdr, err)) { fprintf(stderr, "error: %s: %s\n", o.in_bam.c_str(), err.c_str()); return 1; }
-  Slot<Bundle> to_gpu(8);      // the reader runs ahead while the guides are parsed and the indexes are built (eight bundles: about 3 GB of records)
+  Slot<Bundle> to_gpu(16);     // the reader runs ahead while the guides are parsed and the indexes are built (sixteen bundles: about 3 GB of records)
   // consumed bundle buffers go back to the reader: their pages are already faulted in
   std::mutex pool_m; std::vector<std::unique_ptr<brio::ByteBuf>> pool;
   uint64_t total_reads = 0, unmapped_reads = 0, next_seq = 0;
   std::string reader_err, writer_err;
   std::atomic<bool> cancel{false};
-  double t_inflate = 0, t_split = 0, t_copy = 0, t_deflate = 0;
+  double t_inflate = 0, t_split = 0, t_copy = 0, t_deflate = 0, t_reserve = 0, t_put = 0, t_reader = 0;
   auto now = []() { return std::chrono::steady_clock::now(); };
   auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
 
@@ -282,7 +291,20 @@ extern "C" int br_cli_main(int argc, char **argv) {
     size_t valid = buf.size();
     const size_t CHUNK = 64u << 20;
     std::future<int64_t> fut; bool inflight = false;
-    auto launch = [&]() { buf.reserve(buf.size() + CHUNK + (1u << 20)); fut = std::async(std::launch::async, [&]() { return rd.read(buf, CHUNK); }); inflight = true; };
+    size_t bundle_bytes = 0;   // size of the largest bundle cut so far: the next buffer is reserved whole instead of growing chunk by chunk
+    uint64_t split_bytes = 0, split_recs = 0;   // running mean record length: tells whether the bytes at hand already hold the next cut
+    auto tr0 = now();
+    struct ReaderClock { double &t; std::chrono::steady_clock::time_point t0; ~ReaderClock() { t = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } reader_clock{t_reader, tr0};
+    auto launch = [&]() {
+      auto tv0 = now();
+      const size_t need = buf.size() + CHUNK + (1u << 20);
+      if (need > buf.capacity()) {   // only the first bundles get here (later buffers are reserved whole): one move, from the mean record length
+        size_t est = split_recs ? (size_t)std::min<uint64_t>((split_bytes / split_recs + 1) * ((uint64_t)o.bundle_records + 64), (uint64_t)1 << 30) : 0;
+        buf.reserve(std::max(std::max(need, est + 2 * CHUNK), std::max(bundle_bytes + 2 * CHUNK, buf.capacity() + buf.capacity() / 2)));
+      }
+      t_reserve += secs(tv0, now());
+      fut = std::async(std::launch::async, [&]() { return rd.read(buf, CHUNK); }); inflight = true;
+    };
     auto land = [&]() -> bool {
       auto ti0 = now();
       int64_t got = fut.get(); inflight = false;
@@ -292,13 +314,20 @@ extern "C" int br_cli_main(int argc, char **argv) {
       valid = buf.size();
       return true;
     };
+    // do the bytes already inflated reach past the next cut?  Then they are split first and the next read starts in the NEXT
+    // bundle's buffer (beside the copy of this one's tail) instead of landing behind the cut and being copied over with it.
+    auto cut_expected = [&]() -> bool {
+      if (!split_recs) return false;
+      const uint64_t mean = split_bytes / split_recs + 1;
+      return off.size() + (valid - scanned) / mean > (size_t)o.bundle_records + 64;
+    };
     for (;;) {
       if (cancel) break;
       // split what is there; read more until a cut point exists
       int64_t cut = -1;
       size_t searched = std::max<size_t>((size_t)o.bundle_records, 1);  // records below this index cannot be a cut
       for (;;) {
-        if (!eof && !inflight) launch();
+        if (!eof && !inflight && !cut_expected()) launch();
         size_t cap = (size_t)(valid - scanned) / 36 + 1;
         size_t base = off.size();
         off.resize(base + cap); len.resize(base + cap);
@@ -309,6 +338,7 @@ extern "C" int br_cli_main(int argc, char **argv) {
         for (int64_t i = 0; i < n; i++) off[base + (size_t)i] += scanned;
         off.resize(base + (size_t)n); len.resize(base + (size_t)n);
         total_reads += (uint64_t)(n + un); unmapped_reads += (uint64_t)un;
+        split_bytes += used; split_recs += (uint64_t)(n + un);
         scanned += used;
         // cut: first record >= bundle_records whose name differs from its predecessor's
         for (size_t i = searched; i < off.size(); i++) {
@@ -319,6 +349,7 @@ extern "C" int br_cli_main(int argc, char **argv) {
         t_split += secs(ts0, now());
         if (cut >= 0) break;
         if (inflight) { if (!land()) { to_gpu.finish(); return; } continue; }
+        if (!eof) { launch(); if (!land()) { to_gpu.finish(); return; } continue; }   // the estimate was short of the cut
         // end of stream, nothing in flight
         if (scanned != valid) { reader_err = "truncated BAM record at end of file"; to_gpu.finish(); return; }
         break;
@@ -333,22 +364,30 @@ extern "C" int br_cli_main(int argc, char **argv) {
         // the bundle takes the buffer; only the tail (records past the cut, < one read chunk) is copied over
         brio::ByteBuf tail;
         { std::lock_guard<std::mutex> l(pool_m); if (!pool.empty()) { tail.swap(*pool.back()); pool.pop_back(); } }
-        tail.resize(buf.size() - byte_end);
-        if (tail.size()) memcpy(tail.data(), buf.data() + byte_end, tail.size());
+        bundle_bytes = std::max(bundle_bytes, byte_end);
+        tail.clear(); tail.reserve(bundle_bytes + 2 * CHUNK);   // whole, while it is empty: growing it later moves the mapping
+        const size_t tail_bytes = buf.size() - byte_end;
+        tail.resize(tail_bytes);
         buf.resize(byte_end);
         b->blob.swap(buf);
         buf.swap(tail);
-        valid = buf.size();
+        valid = tail_bytes;
         scanned -= byte_end;
         std::vector<uint64_t> noff(off.begin() + (ptrdiff_t)n_take, off.end()); std::vector<uint32_t> nlen(len.begin() + (ptrdiff_t)n_take, len.end());
         for (auto &x : noff) x -= byte_end;
         off.swap(noff); len.swap(nlen);
+        // the next read lands behind the tail's place in the new buffer while the tail itself is still on its way there
+        if (!eof && !cut_expected()) launch();
+        if (tail_bytes) memcpy(buf.data(), b->blob.data() + byte_end, tail_bytes);   // (launch() may have moved the buffer; the read itself never does)
         t_copy += secs(tc0, now());
         b->seq = next_seq++;   // the writer restores this order whatever worker projects the bundle
+        auto tp0 = now();
         to_gpu.put(std::move(b));
+        t_put += secs(tp0, now());
       }
-      if (cut < 0 && eof) break;
+      if (cut < 0 && eof && !inflight) break;
     }
+    if (inflight) (void)fut.get();
     to_gpu.finish();
   });
 
@@ -540,7 +579,10 @@ extern "C" int br_cli_main(int argc, char **argv) {
     total_complete += w->total_complete; total_unique += w->total_unique; dropped += w->dropped; n_bundles += w->n_bundles;
     gpu_seconds += w->gpu_seconds; t_upload += w->t_upload; t_wait_gpu_in += w->t_wait_in;
   }
-  free_all();
+  // the command line's process ends here: handing tens of gigabytes of device and pinned memory back piece by piece is
+  // 0.12-0.16 s that the process exit does for nothing (bramble-cli keeps its index in a ManuallyDrop for the same reason,
+  // bramble-cli/src/main.rs:56-60); a host that calls br_cli_main as a function sets BRAMBLE_AMD_CLI_CLEANUP=1
+  if (getenv("BRAMBLE_AMD_CLI_CLEANUP")) free_all();
   double t_freed = since();
   if (!o.quiet) {  // src/bramble.cpp:727-736
     printf("\n[bramble] final report:\n");
@@ -554,6 +596,19 @@ extern "C" int br_cli_main(int argc, char **argv) {
     printf("[bramble] release of device / pinned memory: %.2fs\n", t_freed - t_done);
     printf("[bramble] stage busy time: inflate %.2fs, split %.2fs, bundle copy %.2fs, upload %.2fs, device %.2fs (waited for input %.2fs), deflate+write %.2fs\n",
            t_inflate, t_split, t_copy, t_upload, gpu_seconds, t_wait_gpu_in, t_deflate);
+  }
+  if (getenv("BRAMBLE_AMD_TIMING")) {   // where the resident memory is: anonymous (record buffers), file, shared (pinned / device-visible)
+    if (FILE *f = fopen("/proc/self/status", "r")) {
+      char line[256];
+      while (fgets(line, sizeof line, f)) if (!strncmp(line, "VmHWM", 5) || !strncmp(line, "VmRSS", 5) || !strncmp(line, "Rss", 3) || !strncmp(line, "AnonHuge", 8)) fprintf(stderr, "[bramble] %s", line);
+      fclose(f);
+    }
+  }
+  if (getenv("BRAMBLE_AMD_TIMING")) fprintf(stderr, "[bramble] reader thread: %.2fs in all, %.2fs reserving buffers, %.2fs waiting for a free queue slot\n", t_reader, t_reserve, t_put);
+  // the unwinding below this line (record buffers, worker contexts, reader and writer pools) was 0.5 s of a 1.9 s run
+  if (g_exit_at_end.load()) {
+    if (getenv("BRAMBLE_AMD_TIMING")) { struct timespec t; clock_gettime(CLOCK_REALTIME, &t); fprintf(stderr, "[bramble] leaving at %.3f\n", (double)t.tv_sec + 1e-9 * (double)t.tv_nsec); }
+    fflush(stdout); fflush(stderr); _exit(failed);
   }
   return failed;
 }
