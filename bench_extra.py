@@ -158,7 +158,8 @@ def main():
         annd = ann.as_dict()
         batch = ann.reads(n, "pe", with_records=1)
         stream_h, roff, rlen = synth.Annotation.frame_records(batch)
-        tmp = tempfile.mkdtemp(prefix="bramble_cli_")
+        tmp = os.environ.get("CLI_TMP") or tempfile.mkdtemp(prefix="bramble_cli_")   # CLI_TMP: keep guides.gtf / in.bam where a profiler run finds them
+        os.makedirs(tmp, exist_ok=True)
         gtf, in_bam = os.path.join(tmp, "guides.gtf"), os.path.join(tmp, "in.bam")
         bamio.write_gtf(gtf, annd)
         refs = [(r, 250_000_000) for r in annd["refnames"]]

@@ -1672,12 +1672,14 @@ static int deflate_device_impl(br_ctx *c, const uint8_t *src, uint64_t n, hipStr
   A.src = src; A.n_bytes = n; A.n_blocks = nb; A.slots = c->z_slots.as<uint8_t>(); A.sizes = c->z_sizes.as<uint32_t>();
   A.crc_tab = c->z_tabs.as<uint32_t>(); A.crc_shift = c->z_tabs.as<uint32_t>() + 256;
   int dyn_waves = 0;
-  if (c->deflate_dynamic) {  // persistent waves: as many as the chip holds (up to 8 workgroups of 4 waves per CU), a token list each
-    uint64_t want = (uint64_t)c->n_cu * 32;
+  if (c->deflate_dynamic) {  // persistent waves: as many as the chip holds (6 workgroups of 4 waves per CU by their LDS), a token list each
+    uint64_t want = (uint64_t)c->n_cu * 24;
     dyn_waves = (int)std::min<uint64_t>((nb + 3) / 4 * 4, want / 4 * 4);
     if (dyn_waves < 4) dyn_waves = 4;
     RC(c->z_tokens.ensure((size_t)dyn_waves * DEFLATE_PAYLOAD * 4));
     A.tokens = c->z_tokens.as<uint32_t>();
+    A.queue = (uint32_t *)(c->totals.as<uint64_t>() + 15);
+    HIPCHK(hipMemsetAsync(A.queue, 0, 8, st));
   }
   RC(pf.begin(BR_K_CODEC));
   launch_deflate(st, A, dyn_waves);

@@ -392,12 +392,17 @@ __global__ void __launch_bounds__(256) k_deflate_dynamic(DeflateArgs A) {
   for (int i = threadIdx.x; i < 256; i += 256) sh_crc[i] = A.crc_tab[i];
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const uint64_t wave_id = (uint64_t)blockIdx.x * 4 + wave, n_waves = (uint64_t)gridDim.x * 4;
+  const uint64_t wave_id = (uint64_t)blockIdx.x * 4 + wave;
   uint16_t *tab = sh_tab[wave];
   uint32_t *fll = sh_fll[wave], *fd = sh_fd[wave];
   uint8_t *lll = sh_lll[wave], *ld = sh_ld[wave];
   uint32_t *tokens = A.tokens + wave_id * DEFLATE_PAYLOAD;
-  for (uint64_t blk = wave_id; blk < A.n_blocks; blk += n_waves) {   // persistent waves: the token scratch is per wave
+  for (;;) {   // persistent waves (the token scratch is per wave) taking blocks off one counter: a command-line bundle is
+               // only 3.4 blocks per resident wave, and a fixed stride left the chip to the slowest quarter of the grid
+    uint32_t take = 0;
+    if (lane == 0) take = atomicAdd(A.queue, 1u);
+    const uint64_t blk = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)take);
+    if (blk >= A.n_blocks) break;
     const uint8_t *in = A.src + blk * DEFLATE_PAYLOAD;
     uint64_t left = A.n_bytes - blk * DEFLATE_PAYLOAD;
     const uint32_t n = left < DEFLATE_PAYLOAD ? (uint32_t)left : DEFLATE_PAYLOAD;

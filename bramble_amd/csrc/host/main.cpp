@@ -16,5 +16,6 @@ int main(int argc, char **argv) {
   if (timing) fprintf(stderr, "[bramble] main leaving at %.3f\n", epoch());
   fflush(stdout);
   fflush(stderr);
+  if (getenv("BRAMBLE_AMD_CLI_CLEANUP")) return rc;   // everything was released inside: exit handlers (a profiler's among them) run
   _exit(rc);
 }

@@ -267,6 +267,7 @@ struct DeflateArgs {
   const uint32_t *crc_tab;     // [256] reflected CRC-32 table
   const uint32_t *crc_shift;   // [4][256] "append DEFLATE_CRC_CHUNK zero bytes" operator
   uint32_t *tokens;            // dynamic Huffman: DEFLATE_PAYLOAD words per resident wave
+  uint32_t *queue;             // dynamic Huffman: next block to take (zeroed before the launch)
 };
 // dynamic_waves: 0 = fixed Huffman (one wave per block); > 0 = dynamic Huffman with that many persistent waves
 void launch_deflate(hipStream_t st, const DeflateArgs &A, int dynamic_waves);
