@@ -4,6 +4,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
+#include <mutex>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -440,7 +443,9 @@ struct br_ctx {
   hipEvent_t rows_busy = nullptr;   // recorded after the last packed download was queued: k_rows of the next call waits for it
   bool rows_busy_set = false;
   int host_detail = 0;              // br_host_rows carries the x (detail) array
-  DevBuf z_slots, z_sizes, z_off, z_dense, z_tabs, z_tokens;
+  DevBuf z_slots, z_sizes, z_off, z_dense, z_dense_alt, z_tabs, z_tokens;
+  int z_dense_which = 0;           // br_project_bam_staged_nowait: the packed blocks of call j are still on their way home while call j + 1 packs its own
+  hipStream_t down_stream = nullptr; hipEvent_t ev_home[2] = {nullptr, nullptr}; std::atomic<bool> home_pending[2] = {{false}, {false}};
   int deflate_dynamic = 1;
   int emit_split = 1;
   int count_split = 1;   // count pass as two kernels: the main one without the exon walk, a second one for the alignments that need it
@@ -535,7 +540,7 @@ extern "C" void br_ctx_free(br_ctx *c) {
   DevBuf *bufs[] = {&c->seg, &c->meta, &c->head, &c->head2, &c->fast_flag, &c->fast_pre, &c->n_matches, &c->ranges, &c->mask, &c->match_off, &c->cig_base,
                     &c->tile_sums, &c->totals, &c->counters_d, &c->m_tid, &c->m_aux, &c->m_p, &c->m_x, &c->m_b,
                     &c->m_cigoff, &c->cig_arena, &c->big_list, &c->n_big, &c->m_aln,
-                    &c->bam_aux, &c->bam_base, &c->bam_len, &c->bam_off, &c->bam_out, &c->bam_end, &c->z_slots, &c->z_sizes, &c->z_off, &c->z_dense, &c->z_tabs, &c->z_tokens, &c->p_ncig, &c->p_name_len, &c->p_isnew, &c->p_group_pre, &c->p_small, &c->p_big, &c->p_seq_len, &c->p_ref_map, &c->fa_stats, &c->fa_n_prob, &c->fa_seq_bytes, &c->fa_prob_off, &c->fa_seqarena_off, &c->fa_probs, &c->fa_results,
+                    &c->bam_aux, &c->bam_base, &c->bam_len, &c->bam_off, &c->bam_out, &c->bam_end, &c->z_slots, &c->z_sizes, &c->z_off, &c->z_dense, &c->z_dense_alt, &c->z_tabs, &c->z_tokens, &c->p_ncig, &c->p_name_len, &c->p_isnew, &c->p_group_pre, &c->p_small, &c->p_big, &c->p_seq_len, &c->p_ref_map, &c->fa_stats, &c->fa_n_prob, &c->fa_seq_bytes, &c->fa_prob_off, &c->fa_seqarena_off, &c->fa_probs, &c->fa_results,
                     &c->fa_seq_arena, &c->fa_clip_ops, &c->fa_ideal_cap, &c->fa_scratch, &c->b_seq_off, &c->b_seqs, &c->b_seq_src,
                     &c->r_rec, &c->pk_a, &c->pk_c, &c->pk_x, &c->pk_sim, &c->pk_clip, &c->pool, &c->pool_sizes, &c->pool_off, &c->pk_ch,
                     &c->n_rows, &c->row_off, &c->aln_group, &c->r_input, &c->r_nh, &c->r_hi, &c->r_mapq,
@@ -565,6 +570,8 @@ extern "C" void br_ctx_free(br_ctx *c) {
   if (c->run_stream) (void)hipStreamDestroy(c->run_stream);
   if (c->d2h_stream) (void)hipStreamDestroy(c->d2h_stream);
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+  if (c->down_stream) (void)hipStreamDestroy(c->down_stream);
+  for (int k = 0; k < 2; k++) if (c->ev_home[k]) (void)hipEventDestroy(c->ev_home[k]);
   c->h_input.release(); c->h_clip.release(); c->h_junc.release(); c->h_refc.release(); c->h_mate_tid.release(); c->h_mate_pos.release();
   c->h_isize.release(); c->h_tid.release(); c->h_pos.release(); c->h_nh.release(); c->h_hi.release(); c->h_mapq.release(); c->h_group.release();
   c->h_cigar.release(); c->h_strand.release(); c->h_cigoff.release(); c->h_sim.release(); c->h_primary.release(); c->h_paired.release();
@@ -1676,7 +1683,10 @@ static int deflate_device_impl(br_ctx *c, const uint8_t *src, uint64_t n, hipStr
     uint64_t want = (uint64_t)c->n_cu * 24;
     dyn_waves = (int)std::min<uint64_t>((nb + 3) / 4 * 4, want / 4 * 4);
     if (dyn_waves < 4) dyn_waves = 4;
-    RC(c->z_tokens.ensure((size_t)dyn_waves * DEFLATE_PAYLOAD * 4));
+    RC(c->z_tokens.ensure((size_t)dyn_waves * DEFLATE_PAYLOAD * 4 + 64));
+#ifdef DEFLATE_PROFILE
+    HIPCHK(hipMemsetAsync(c->z_tokens.as<uint8_t>() + (size_t)dyn_waves * DEFLATE_PAYLOAD * 4, 0, 64, st));
+#endif
     A.tokens = c->z_tokens.as<uint32_t>();
     A.queue = (uint32_t *)(c->totals.as<uint64_t>() + 15);
     HIPCHK(hipMemsetAsync(A.queue, 0, 8, st));
@@ -1684,6 +1694,16 @@ static int deflate_device_impl(br_ctx *c, const uint8_t *src, uint64_t n, hipStr
   RC(pf.begin(BR_K_CODEC));
   launch_deflate(st, A, dyn_waves);
   RC(pf.end());
+#ifdef DEFLATE_PROFILE
+  if (dyn_waves) {
+    uint64_t pt[8];
+    HIPCHK(hipMemcpyAsync(pt, c->z_tokens.as<uint8_t>() + (size_t)dyn_waves * DEFLATE_PAYLOAD * 4, 64, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    double tot = 0; for (int k = 0; k < 8; k++) tot += (double)pt[k];
+    static const char *nm[8] = {"clear", "parse_step", "tokens+hist", "code build", "header", "replay", "crc+frame", "claim"};
+    for (int k = 0; k < 8; k++) fprintf(stderr, "[deflate profile] %-12s %5.1f %%\n", nm[k], 100.0 * (double)pt[k] / tot);
+  }
+#endif
   ScanArgs S{}; S.n = (int64_t)nb; S.src32 = A.sizes; S.tile_sums = c->tile_sums.as<uint64_t>();
   RC(pf.begin(BR_K_SCAN));
   launch_scan(st, S, 2, c->z_off.p, true, c->totals.as<uint64_t>() + 5);
@@ -1691,12 +1711,13 @@ static int deflate_device_impl(br_ctx *c, const uint8_t *src, uint64_t n, hipStr
   HIPCHK(hipMemcpyAsync(c->h_totals + 24, c->totals.as<uint64_t>() + 5, 8, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   uint64_t total = c->h_totals[24];
-  RC(c->z_dense.ensure((size_t)total + 16));
+  DevBuf &dense = c->z_dense_which ? c->z_dense_alt : c->z_dense;
+  RC(dense.ensure((size_t)total + 16));
   RC(pf.begin(BR_K_CODEC));
-  launch_bgzf_compact(st, A, c->z_off.as<uint64_t>(), c->z_dense.as<uint8_t>());
+  launch_bgzf_compact(st, A, c->z_off.as<uint64_t>(), dense.as<uint8_t>());
   RC(pf.end());
   if (!keep_events) { HIPCHK(hipStreamSynchronize(st)); RC(pf.collect()); }
-  *out = c->z_dense.as<uint8_t>(); *out_bytes = total;
+  *out = dense.as<uint8_t>(); *out_bytes = total;
   return BR_OK;
 }
 
@@ -1752,7 +1773,7 @@ extern "C" int br_bam_bundle_stage(br_ctx *c, const br_bam_bundle *bb, int slot)
   return BR_OK;
 }
 
-extern "C" int br_project_bam_staged(br_ctx *c, const br_config *cfg, const br_bam_bundle *bb, int slot, br_host_bam *out) {
+static int project_bam_staged_impl(br_ctx *c, const br_config *cfg, const br_bam_bundle *bb, int slot, br_host_bam *out, bool nowait) {
   if (!c || !cfg || !bb || !out || slot < 0 || slot > 2) return BR_ERR_INVALID_ARG;
   memset(out, 0, sizeof(*out));
   br_ctx::StageSlot &S = c->stage[slot];
@@ -1761,28 +1782,66 @@ extern "C" int br_project_bam_staged(br_ctx *c, const br_config *cfg, const br_b
   hipStream_t st = nullptr;
   int64_t n = S.n;
   out->total_processed = (uint64_t)n;
+  static const bool timing = getenv("BRAMBLE_AMD_TIMING") != nullptr;
+  auto tnow = []() { return std::chrono::steady_clock::now(); };
+  auto tms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  auto t0 = tnow();
   HIPCHK(hipEventSynchronize(S.ready));
+  auto t1 = tnow();
   if (n == 0) return BR_OK;
   br_device_records dr{S.blob.as<uint8_t>(), S.off.as<uint64_t>(), n, S.len.as<uint32_t>()};
   br_device_rows rows; br_device_bam db;
   RC(br_project_bam_device(c, cfg, &dr, bb->ref_map, bb->n_ref_map, st, &rows, &db));
+  auto t2 = tnow();
+  int hs = c->h_bam_next; c->h_bam_next ^= 1;
+  if (c->home_pending[hs]) { HIPCHK(hipEventSynchronize(c->ev_home[hs])); c->home_pending[hs] = false; }   // (a caller that never asked)
+  const bool later = nowait && bb->bgzf_on_device && db.n_bytes;
   if (bb->bgzf_on_device && db.n_bytes) {
+    c->z_dense_which = hs;
     const uint8_t *z = nullptr; uint64_t zn = 0;
     RC(deflate_device_impl(c, db.data, db.n_bytes, st, &z, &zn, false));
     db.data = z; db.n_bytes = zn;
   }
-  int hs = c->h_bam_next; c->h_bam_next ^= 1;
+  auto t3 = tnow();
   if (db.n_bytes > c->h_bam_cap[hs]) {
     if (c->h_bam[hs]) { HIPCHK(hipHostFree(c->h_bam[hs])); c->h_bam[hs] = nullptr; c->h_bam_cap[hs] = 0; }
     size_t want = (size_t)db.n_bytes + (size_t)db.n_bytes / 4 + 4096;
     HIPCHK(hipHostMalloc((void **)&c->h_bam[hs], want, hipHostMallocDefault));
     c->h_bam_cap[hs] = want;
   }
-  if (db.n_bytes) HIPCHK(hipMemcpyAsync(c->h_bam[hs], db.data, (size_t)db.n_bytes, hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
+  if (later) {
+    // everything on `st` is complete (the deflate step ends with the block sizes on the host): the copy goes to a stream of its
+    // own and the caller asks for it with br_host_bam_wait, so the next bundle's kernels start without the 4 ms of PCIe in front
+    if (!c->down_stream) HIPCHK(hipStreamCreateWithFlags(&c->down_stream, hipStreamNonBlocking));
+    if (!c->ev_home[hs]) HIPCHK(hipEventCreateWithFlags(&c->ev_home[hs], hipEventDisableTiming));
+    HIPCHK(hipMemcpyAsync(c->h_bam[hs], db.data, (size_t)db.n_bytes, hipMemcpyDeviceToHost, c->down_stream));
+    HIPCHK(hipEventRecord(c->ev_home[hs], c->down_stream));
+    c->home_pending[hs] = true;
+  } else {
+    if (db.n_bytes) HIPCHK(hipMemcpyAsync(c->h_bam[hs], db.data, (size_t)db.n_bytes, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+  }
+  if (timing) fprintf(stderr, "[bundle] %lld records: upload wait %.1f ms, records -> records %.1f ms, deflate %.1f ms, download of %.0f MB %.1f ms\n", (long long)n, tms(t0, t1), tms(t1, t2), tms(t2, t3), (double)db.n_bytes / 1e6, tms(t3, tnow()));
   out->data = c->h_bam[hs]; out->n_bytes = db.n_bytes; out->n_rows = db.n_rows;
   out->total_complete = rows.total_complete; out->total_unique = rows.total_unique;
   out->dropped_reads = rows.dropped_reads; out->total_processed = rows.total_processed;
+  return BR_OK;
+}
+
+extern "C" int br_project_bam_staged(br_ctx *c, const br_config *cfg, const br_bam_bundle *bb, int slot, br_host_bam *out) {
+  return project_bam_staged_impl(c, cfg, bb, slot, out, false);
+}
+extern "C" int br_project_bam_staged_nowait(br_ctx *c, const br_config *cfg, const br_bam_bundle *bb, int slot, br_host_bam *out) {
+  return project_bam_staged_impl(c, cfg, bb, slot, out, true);
+}
+extern "C" int br_host_bam_wait(br_ctx *c, const br_host_bam *hb) {
+  if (!c || !hb) return BR_ERR_INVALID_ARG;
+  for (int k = 0; k < 2; k++)
+    if (hb->data && hb->data == c->h_bam[k] && c->home_pending[k]) {
+      HIPCHK(hipSetDevice(c->ix->device));
+      HIPCHK(hipEventSynchronize(c->ev_home[k]));
+      c->home_pending[k] = false;
+    }
   return BR_OK;
 }
 

@@ -382,7 +382,16 @@ __device__ __forceinline__ void build_codes(const uint8_t *lens, uint32_t *enc, 
   __builtin_amdgcn_wave_barrier();
 }
 
-__global__ void __launch_bounds__(256) k_deflate_dynamic(DeflateArgs A) {
+// make EXTRA=-DDEFLATE_PROFILE: wave time per section, summed over the waves and printed by the host after every launch
+#ifdef DEFLATE_PROFILE
+#define TICK(k) do { uint64_t t_ = __builtin_readcyclecounter(); pt[k] += t_ - t_last; t_last = t_; } while (0)
+#else
+#define TICK(k) do { } while (0)
+#endif
+__device__ __forceinline__ void deflate_dynamic_body(const DeflateArgs &A) {
+#ifdef DEFLATE_PROFILE
+  uint64_t pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t t_last = __builtin_readcyclecounter();
+#endif
   __shared__ uint16_t sh_tab[4][HASH_SIZE];
   __shared__ uint32_t sh_obuf[4][OBUF_WORDS];
   __shared__ uint32_t sh_crc[256];
@@ -403,6 +412,7 @@ __global__ void __launch_bounds__(256) k_deflate_dynamic(DeflateArgs A) {
     if (lane == 0) take = atomicAdd(A.queue, 1u);
     const uint64_t blk = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)take);
     if (blk >= A.n_blocks) break;
+    TICK(7);
     const uint8_t *in = A.src + blk * DEFLATE_PAYLOAD;
     uint64_t left = A.n_bytes - blk * DEFLATE_PAYLOAD;
     const uint32_t n = left < DEFLATE_PAYLOAD ? (uint32_t)left : DEFLATE_PAYLOAD;
@@ -412,6 +422,7 @@ __global__ void __launch_bounds__(256) k_deflate_dynamic(DeflateArgs A) {
     for (int i = lane; i < DYN_LL + 2; i += 64) fll[i] = 0;
     for (int i = lane; i < DYN_D + 2; i += 64) fd[i] = 0;
     __builtin_amdgcn_wave_barrier();
+    TICK(0);
     // ---- parse: tokens + histograms
     uint32_t skip_until = 0, n_tok = 0;
     uint32_t wn0 = (lane + 4u <= n) ? *(const u32u *)(in + lane) : 0u, wn1 = (lane + 68u <= n) ? *(const u32u *)(in + lane + 64u) : 0u;
@@ -421,6 +432,7 @@ __global__ void __launch_bounds__(256) k_deflate_dynamic(DeflateArgs A) {
       if (p + lane + 192u + 4u <= n) wn1 = *(const u32u *)(in + p + lane + 192u);
       Token tk2[2];
       parse_step(in, n, p, lane, tab, w0, w1, skip_until, tk2[0], tk2[1]);
+      TICK(1);
 #pragma unroll
       for (int hh = 0; hh < 2; hh++) {
         const Token tk = tk2[hh];
@@ -436,6 +448,7 @@ __global__ void __launch_bounds__(256) k_deflate_dynamic(DeflateArgs A) {
         }
         n_tok += (uint32_t)__builtin_popcountll(sel);
       }
+      TICK(2);
     }
     if (lane == 0) fll[256] = 1;                      // end of block
     __builtin_amdgcn_wave_barrier();
@@ -446,6 +459,7 @@ __global__ void __launch_bounds__(256) k_deflate_dynamic(DeflateArgs A) {
     build_codes(lll, fll, DYN_LL, lane, sh_nc[wave]);  // the histograms become the encode tables
     build_codes(ld, fd, DYN_D, lane, sh_nc[wave]);
     __builtin_amdgcn_wave_barrier();
+    TICK(3);
     // ---- header: BFINAL 1, BTYPE 10, HLIT 29 (286), HDIST 29 (30), HCLEN 15 (19); code-length code: symbols 0..15 get
     // four bits each (flat, complete), 16/17/18 unused; order 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
     BitWriter bw{sh_obuf[wave], out + 18, 0u, 0u, 0u};
@@ -461,6 +475,7 @@ __global__ void __launch_bounds__(256) k_deflate_dynamic(DeflateArgs A) {
       if (i < DYN_LL + DYN_D) { uint32_t l = i < DYN_LL ? lll[i] : ld[i - DYN_LL]; va = bitrev(l, 4); na = 4; }
       bw.round(lane, va, na, 0, 0);
     }
+    TICK(4);
     // ---- tokens through the codes
     for (uint32_t t0 = 0; t0 < n_tok; t0 += 64) {
       uint32_t t = t0 + lane;
@@ -481,10 +496,20 @@ __global__ void __launch_bounds__(256) k_deflate_dynamic(DeflateArgs A) {
     }
     { uint32_t e = fll[256]; bw.round(lane, lane == 0 ? (e & 0xffffu) : 0u, lane == 0 ? (e >> 16) : 0u, 0, 0); }
     uint32_t nbytes = bw.finish(lane);
+    TICK(5);
     finish_block(A, blk, in, n, out, nbytes, lane, sh_crc);
     __builtin_amdgcn_wave_barrier();
+    TICK(6);
   }
+#ifdef DEFLATE_PROFILE
+  if (lane == 0) for (int k = 0; k < 8; k++) atomicAdd((unsigned long long *)(A.tokens + (uint64_t)gridDim.x * 4 * DEFLATE_PAYLOAD) + k, (unsigned long long)pt[k]);
+#endif
 }
+
+// Six waves per SIMD (80 VGPRs, ten of them spilled) against the four the compiler settles on by itself (105 VGPRs): the parse
+// is a chain of dependent scalar and vector instructions (2.3 SALU + 1.8 VALU per input byte, profiles/r03/pmc_deflate.txt),
+// and the fifth wave is what fills the issue slots: 19.9 -> 17.0 ms per 2.4 GB (five waves: 17.1; LDS allows six workgroups).
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) k_deflate_dynamic(DeflateArgs A) { deflate_dynamic_body(A); }
 
 __global__ void __launch_bounds__(256) k_bgzf_compact(DeflateArgs A, const uint64_t *off, uint8_t *dense) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;

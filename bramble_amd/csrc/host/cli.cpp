@@ -494,6 +494,11 @@ extern "C" int br_cli_main(int argc, char **argv) {
         c = it->second; out_map.erase(it); out_next++;
       }
       auto td0 = now();
+      if (c.n) {   // the chunk's bytes may still be on their way from the device
+        br_host_bam hb; memset(&hb, 0, sizeof(hb)); hb.data = c.data; hb.n_bytes = c.n;
+        int wrc = br_host_bam_wait(workers[(size_t)c.worker]->ctx, &hb);
+        if (wrc && writer_err.empty()) { writer_err = std::string("download failed: ") + br_strerror(wrc); raise_fail(); }
+      }
       if (writer_err.empty() && c.n && !(o.device_deflate ? wr.write_raw(c.data, (size_t)c.n) : wr.write(c.data, (size_t)c.n))) {
         writer_err = wr.error();
         raise_fail();                      // nothing projected from here on could be written: the runners drain
@@ -541,7 +546,7 @@ extern "C" int br_cli_main(int argc, char **argv) {
           { std::unique_lock<std::mutex> l(w->done_m); w->done_cv.wait(l, [&] { return w->written + 2 > w->produced || fail; }); }
           br_bam_bundle bb{b->blob.data(), b->blob.size(), b->off.data(), b->len.data(), (int64_t)b->off.size(), ref_map.data(), (int32_t)ref_map.size(), o.device_deflate ? 1 : 0};
           auto t0 = now();
-          int prc2 = fail ? 0 : br_project_bam_staged(w->ctx, &o.cfg, &bb, st->slot, &hb);
+          int prc2 = fail ? 0 : br_project_bam_staged_nowait(w->ctx, &o.cfg, &bb, st->slot, &hb);   // the writer waits for the bytes
           w->gpu_seconds += secs(t0, now());
           if (prc2) { fprintf(stderr, "error: projection failed on device %d: %s\n", w->device, br_strerror(prc2)); raise_fail(); }
         }

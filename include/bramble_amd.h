@@ -449,6 +449,13 @@ int br_project_bam_bundle(br_ctx *, const br_config *, const br_bam_bundle *, br
  * stay valid until then. */
 int br_bam_bundle_stage(br_ctx *, const br_bam_bundle *, int slot /* 0..2 */);
 int br_project_bam_staged(br_ctx *, const br_config *, const br_bam_bundle *, int slot, br_host_bam *out);
+/* br_project_bam_staged that does not wait for its result to arrive: with bgzf_on_device the counters, n_bytes and the
+ * address in out->data are final when the call returns, the bytes behind it may still be crossing PCIe (on a stream of
+ * their own, beside the next bundle's kernels).  br_host_bam_wait(ctx, out) -- from any one thread -- returns when they are
+ * there; the buffer rule of br_host_bam (valid until the second next call) is unchanged.  Without bgzf_on_device the call
+ * is br_project_bam_staged. */
+int br_project_bam_staged_nowait(br_ctx *, const br_config *, const br_bam_bundle *, int slot, br_host_bam *out);
+int br_host_bam_wait(br_ctx *, const br_host_bam *);
 
 /* Walks the block_size chain of an uncompressed BAM alignment section (host): fills rec_off /
  * rec_len for up to `cap` MAPPED records (unmapped ones are counted and skipped like
