@@ -452,7 +452,7 @@ int br_project_bam_staged(br_ctx *, const br_config *, const br_bam_bundle *, in
 /* br_project_bam_staged that does not wait for its result to arrive: with bgzf_on_device the counters, n_bytes and the
  * address in out->data are final when the call returns, the bytes behind it may still be crossing PCIe (on a stream of
  * their own, beside the next bundle's kernels).  br_host_bam_wait(ctx, out) -- from any one thread -- returns when they are
- * there; the buffer rule of br_host_bam (valid until the second next call) is unchanged.  Without bgzf_on_device the call
+ * there; the buffer rule of the br_host_bam structure -- valid until the second next call -- is unchanged.  Without bgzf_on_device the call
  * is br_project_bam_staged. */
 int br_project_bam_staged_nowait(br_ctx *, const br_config *, const br_bam_bundle *, int slot, br_host_bam *out);
 int br_host_bam_wait(br_ctx *, const br_host_bam *);
