@@ -21,6 +21,7 @@
 
 #include "bam_cg.h"
 #include "kernels.h"
+#include "records_inl.h"
 
 namespace br {
 
@@ -28,105 +29,7 @@ namespace br {
 struct __attribute__((packed, aligned(1))) W4 { uint32_t a, b, c, d; };
 typedef uint32_t u32u __attribute__((aligned(1)));
 typedef uint16_t u16u __attribute__((aligned(1)));
-__device__ __forceinline__ uint32_t fix_nib(uint32_t x) {   // nibbles that are not one of 1, 2, 4, 8 become 15 (comp_table, src/bam.cpp:658-667)
-  uint32_t pop = (x & 0x11111111u) + ((x >> 1) & 0x11111111u) + ((x >> 2) & 0x11111111u) + ((x >> 3) & 0x11111111u);
-  uint32_t y = pop ^ 0x11111111u;
-  uint32_t bad = (y | (y >> 1) | (y >> 2) | (y >> 3)) & 0x11111111u;
-  return x | (bad * 15u);
-}
-
-__device__ __forceinline__ uint32_t row_base_len(const BamArgs &B, const BamAux &x);
-__device__ __forceinline__ void bam_scan_one(const BamArgs &B, int64_t a) {
-  const uint8_t *rec = B.blob + B.rec_off[a];
-  uint64_t rlen = B.rec_len ? (uint64_t)B.rec_len[a] : B.rec_off[a + 1] - B.rec_off[a];
-  BamAux x;
-  int8_t xs_c = 0, ts_c = 0;
-  bool have_xs = false, have_ts = false;
-  for (int k = 0; k < 4; k++) { x.off[k] = 0xffffffffu; x.len[k] = 0; }
-  x.as_val = 0; x.aux_start = 0; x.aux_len = 0; x.c_a = x.c_b = x.c_c = 0; x.qual_present = 0; x.cg_len = 0;
-  if (rlen >= 32) {
-    x.c_a = ld_u32(rec + 8); x.c_b = ld_u32(rec + 12);
-    uint32_t l_qname = x.c_a & 0xffu, n_cig = x.c_b & 0xffffu;
-    int32_t l_seq = (int32_t)ld_u32(rec + 16);
-    uint64_t ls = l_seq > 0 ? (uint64_t)l_seq : 0;
-    uint64_t start = 32 + (uint64_t)l_qname + 4ull * n_cig + (ls + 1) / 2 + ls;
-    x.c_c = (uint32_t)l_seq;
-    if (start <= rlen) {
-      if (ls > 0) x.qual_present = rec[32 + (uint64_t)l_qname + 4ull * n_cig + (ls + 1) / 2] != 0xff;
-      {
-        // bit 1: every base code is one of 1, 2, 4, 8, 15 (A C G T N) -- then the reverse complement of the record is a
-        // plain bit reversal and k_bam_tasks skips the per-nibble repair of the other codes
-        const uint8_t *sq = rec + 32 + (uint64_t)l_qname + 4ull * n_cig;
-        const uint64_t sb = (ls + 1) / 2, full = ls / 2;   // bytes with two bases
-        uint32_t dirty = 0;
-        uint64_t i = 0;
-        for (; i + 16 <= full; i += 16) {
-          const W4 v = *(const W4 *)(sq + i);
-          dirty |= (fix_nib(v.a) ^ v.a) | (fix_nib(v.b) ^ v.b) | (fix_nib(v.c) ^ v.c) | (fix_nib(v.d) ^ v.d);
-        }
-        for (; i + 4 <= full; i += 4) { uint32_t v = *(const u32u *)(sq + i); dirty |= fix_nib(v) ^ v; }
-        for (; i < full; i++) { uint32_t v = sq[i] | 0x11111100u; dirty |= fix_nib(v) ^ v; }
-        if (sb > full) { uint32_t v = (sq[full] >> 4) | 0x11111110u; dirty |= fix_nib(v) ^ v; }
-        if (!dirty) x.qual_present |= 2u;
-      }
-      x.aux_start = (uint32_t)start; x.aux_len = (uint32_t)(rlen - start);
-      const uint8_t *s = rec + start, *end = rec + rlen;
-      // slots: 0 NH, 1 XS (short) / ts (long), 2 HI, 3 AS (long reads only)
-      bool have[4] = {false, false, false, false};
-      bool have_cg = false, cg_ok = false; uint32_t cg_len = 0;
-      while (end - s >= 3) {
-        // tag, type and the first value byte in one load (a tag without room for a value ends the walk below)
-        const uint32_t tw = end - s >= 4 ? ld_u32(s) : (uint32_t)s[0] | ((uint32_t)s[1] << 8) | ((uint32_t)s[2] << 16);
-        const uint8_t t0 = (uint8_t)tw, t1 = (uint8_t)(tw >> 8), ty = (uint8_t)(tw >> 16), b3 = (uint8_t)(tw >> 24);
-        int64_t vl = aux_value_len(ty, s + 3, end);
-        if (vl < 0 || s + 3 + vl > end) break;  // malformed: htslib stops here too
-        if (t0 == 'C' && t1 == 'G' && !have_cg) {   // the first CG tag (bam_aux_get): a spilled CIGAR when of type B,I / B,i with enough entries
-          have_cg = true;
-          if (ty == 'B' && (b3 == 'I' || b3 == 'i') && end - s >= 8) { const uint32_t n = ld_u32(s + 4); cg_ok = n >= n_cig && n < (1u << 29); cg_len = (uint32_t)(3 + vl); }
-        }
-        // tag_char1 (gclib/GSam.cpp:310-318): first value byte of the first XS / ts tag when A or Z
-        if (t0 == 'X' && t1 == 'S' && !have_xs) { have_xs = true; if (ty == 'A' || ty == 'Z') xs_c = (int8_t)b3; }
-        if (t0 == 't' && t1 == 's' && !have_ts) { have_ts = true; if (ty == 'A' || ty == 'Z') ts_c = (int8_t)b3; }
-        int slot = -1;
-        if (t0 == 'N' && t1 == 'H') slot = 0;
-        else if (!B.long_reads && t0 == 'X' && t1 == 'S') slot = 1;
-        else if (B.long_reads && t0 == 't' && t1 == 's') slot = 1;
-        else if (t0 == 'H' && t1 == 'I') slot = 2;
-        else if (B.long_reads && t0 == 'A' && t1 == 'S') slot = 3;
-        if (slot >= 0 && !have[slot]) {
-          have[slot] = true;
-          x.off[slot] = (uint32_t)(s - (rec + start)); x.len[slot] = (uint32_t)(3 + vl);
-          if (slot == 3) {  // bam_aux2i
-            const uint8_t *v = s + 3;
-            switch (ty) {
-              case 'c': x.as_val = (int8_t)v[0]; break;
-              case 'C': x.as_val = v[0]; break;
-              case 's': x.as_val = (int16_t)ld_u16(v); break;
-              case 'S': x.as_val = (int32_t)ld_u16(v); break;
-              case 'i': x.as_val = (int32_t)ld_u32(v); break;
-              case 'I': x.as_val = (int32_t)ld_u32(v); break;
-              default: x.as_val = 0; break;
-            }
-          }
-        }
-        s += 3 + vl;
-      }
-      // A CIGAR of more than 65535 ops lives in a CG:B,I tag behind the placeholder <l_seq>S<ref_len>N (bam_cg.h): htslib's
-      // bam_read1 moves it into place and drops the tag, so the tag's bytes leave every output row of this record
-      // (encode_row finds the tag again; the fast task kernel hands such rows to it)
-      x.cg_len = (cg_ok && cg_candidate(rec, rlen, l_qname, n_cig, l_seq)) ? cg_len : 0u;
-      // sort the (at most four) removal intervals by offset: a tiny insertion sort
-      for (int i = 1; i < 4; i++)
-        for (int j = i; j > 0 && x.off[j] < x.off[j - 1]; j--) {
-          uint32_t t = x.off[j]; x.off[j] = x.off[j - 1]; x.off[j - 1] = t;
-          t = x.len[j]; x.len[j] = x.len[j - 1]; x.len[j - 1] = t;
-        }
-    }
-  }
-  B.aux[a] = x;
-  B.base_len[a] = row_base_len(B, x);
-  if (B.xs_out) { B.xs_out[a] = xs_c; B.ts_out[a] = ts_c; }
-}
+__device__ __forceinline__ uint32_t fix_nib(uint32_t x) { return rec_fix_nib(x); }   // records_inl.h
 
 __global__ void __launch_bounds__(256) k_bam_scan(BamArgs B) {
   __shared__ unsigned long long sh_end[4];
@@ -141,18 +44,7 @@ __global__ void __launch_bounds__(256) k_bam_scan(BamArgs B) {
     for (int w = 1; w < 4; w++) e = sh_end[w] > e ? sh_end[w] : e;
     atomicMax((unsigned long long *)B.blob_end, e);
   }
-  if (a < B.n_aln) bam_scan_one(B, a);
-}
-
-// what a record contributes to the length of each of its output rows, whatever their CIGAR (k_bam_scan leaves it per
-// record, so that k_bam_size reads four bytes per row instead of the aux table's 64)
-__device__ __forceinline__ uint32_t row_base_len(const BamArgs &B, const BamAux &x) {
-  uint32_t l_qname = x.c_a & 0xffu;
-  int32_t l_seq = (int32_t)x.c_c;
-  uint32_t ls = l_seq > 0 ? (uint32_t)l_seq : 0;
-  uint32_t removed = x.len[0] + x.len[1] + x.len[2] + x.len[3] + x.cg_len;
-  uint32_t added = 7u + 7u + (B.long_reads ? 7u : 0u);  // NH:i, HI:i, AS:i
-  return 4u + 32u + l_qname + (ls + 1) / 2 + ls + (x.aux_len - removed) + added;
+  if (a < B.n_aln) bam_scan_one(B, a, GlobalRec{B.blob + B.rec_off[a]}, B.rec_len ? (uint64_t)B.rec_len[a] : B.rec_off[a + 1] - B.rec_off[a]);
 }
 
 __global__ void __launch_bounds__(256) k_bam_size(BamArgs B) {

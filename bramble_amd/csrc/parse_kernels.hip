@@ -21,6 +21,7 @@
 
 #include "bam_cg.h"
 #include "kernels.h"
+#include "records_inl.h"
 
 namespace br {
 
@@ -44,48 +45,9 @@ __global__ void __launch_bounds__(256) k_rec_fields(ParseArgs P) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t ncig = 0, max_s = 0;
   if (i < P.n) {
-    const uint8_t *rec = P.blob + P.rec_off[i];
-    uint32_t rlen = rec_length(P, i);
-    int32_t ref = -1, start = 0, lq = 0;
-    uint32_t flag = 0, nlen = 0, isnew = 1;
-    if (rlen >= 32) {
-      P4 w0 = *(const P4 *)rec;          // refID, pos, l_read_name|mapq|bin, n_cigar_op|flag
-      int32_t l_seq = (int32_t)*(const u32u *)(rec + 16);
-      int32_t raw_ref = (int32_t)w0.a;
-      ref = (raw_ref >= 0 && raw_ref < P.n_ref_map) ? P.ref_map[raw_ref] : -1;
-      start = (int32_t)w0.b + 1;         // GSamRecord::start is 1-based
-      uint32_t l_qname = w0.c & 0xffu;
-      ncig = w0.d & 0xffffu; flag = w0.d >> 16;
-      if (32ull + l_qname + 4ull * ncig > rlen) { ncig = 0; l_qname = 0; }  // br_bam_split rejects these; stay in bounds anyway
-      nlen = l_qname ? l_qname - 1 : 0;  // without the NUL
-      lq = l_seq;
-      const uint8_t *nm = rec + 32;
-      // leading / trailing soft clips (sizing of the rescue buffers): S is only legal next to the ends (after H)
-      const uint8_t *cg = rec + 32 + l_qname;
-      // a CIGAR spilled into a CG:B,I tag (more than 65535 ops): the real ops are the tag's array (bam_cg.h)
-      if (cg_candidate(rec, rlen, l_qname, ncig, l_seq)) { CgTag t; if (cg_find(rec, rlen, l_qname, ncig, l_seq, t)) { ncig = t.n; cg = rec + t.tag_at + 8; } }
-      if (ncig) {
-        uint32_t w = *(const u32u *)cg;
-        if ((w & 0xfu) == 5u && ncig > 1) w = *(const u32u *)(cg + 4);
-        if ((w & 0xfu) == 4u) max_s = w >> 4;
-        w = *(const u32u *)(cg + 4 * (ncig - 1));
-        if ((w & 0xfu) == 5u && ncig > 1) w = *(const u32u *)(cg + 4 * (ncig - 2));
-        if ((w & 0xfu) == 4u) max_s = max(max_s, w >> 4);
-      }
-      if (i > 0) {
-        const uint8_t *prev = P.blob + P.rec_off[i - 1];
-        uint32_t plen = rec_length(P, i - 1);
-        if (plen >= 32) {
-          uint32_t pw = *(const u32u *)(prev + 8), pc = *(const u16u *)(prev + 12);
-          uint32_t pl = pw & 0xffu;
-          if (32ull + pl + 4ull * pc > plen) pl = 0;
-          uint32_t pn = pl ? pl - 1 : 0;
-          if (pn == nlen && (nlen == 0 || same_bytes(prev + 32, nm, nlen))) isnew = 0;
-        }
-      }
-    }
-    P.ref_id[i] = ref; P.ref_start[i] = start; P.flags[i] = (uint16_t)flag; P.l_qseq[i] = lq;
-    P.ncig[i] = ncig; P.name_len[i] = nlen; P.isnew[i] = isnew;
+    const GlobalRec rec{P.blob + P.rec_off[i]};
+    const GlobalRec prev{P.blob + (i > 0 ? P.rec_off[i - 1] : 0)};
+    rec_fields_one(P, i, rec, rec_length(P, i), prev, i > 0 ? rec_length(P, i - 1) : 0u, ncig, max_s);   // records_inl.h
   }
   // batch maxima: one atomic per wave
   for (int o = 32; o > 0; o >>= 1) {
