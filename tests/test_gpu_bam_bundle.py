@@ -275,6 +275,65 @@ def test_staged_bundles_equal_one_shot_calls():
     idx.close()
 
 
+def test_results_that_come_home_later_equal_the_waiting_call():
+    """br_project_bam_staged_nowait + br_host_bam_wait (the command line's form: the BGZF blocks of bundle k cross PCIe beside
+    the kernels of bundle k + 1, from a second device buffer) against br_project_bam_staged, bundle by bundle: the same bytes
+    and counters, also when nobody ever waits for a result before its buffer comes round again."""
+    import ctypes as C
+    import zlib
+    ann = synth.Annotation("G", n_genes=600, n_refs=3)
+    idx = lib.Index(ann.as_dict(), device=0)
+    ctx = lib.Context(idx)
+    cfg = lib.make_config()
+    L = lib.lib()
+    L.br_bam_bundle_stage.argtypes = [C.c_void_p, C.POINTER(lib.BrBamBundle), C.c_int]
+    sig = [C.c_void_p, C.POINTER(lib.BrConfig), C.POINTER(lib.BrBamBundle), C.c_int, C.POINTER(lib.BrHostBam)]
+    L.br_project_bam_staged.argtypes = sig
+    L.br_project_bam_staged_nowait.argtypes = sig
+    L.br_host_bam_wait.argtypes = [C.c_void_p, C.POINTER(lib.BrHostBam)]
+    ref_map = np.arange(3, dtype=np.int32)
+    keep, bundles = [], []
+    for k, n in enumerate((1800, 300, 2500, 900, 1200)):
+        b = ann.reads(n, "pe", with_records=1, seed=501 + k)
+        stream, roff, rlen = synth.Annotation.frame_records(b)
+        keep.append((stream, roff, rlen))
+        bundles.append(lib.BrBamBundle(stream.ctypes.data, stream.size, roff.ctypes.data, rlen.ctypes.data, len(rlen), ref_map.ctypes.data, 3, 1))
+    take = lambda o: np.ctypeslib.as_array(C.cast(o.data, C.POINTER(C.c_uint8)), shape=(int(o.n_bytes),)).copy()
+    fields = ("n_bytes", "n_rows", "total_complete", "total_unique", "dropped_reads", "total_processed")
+    expect = []
+    for k, bb in enumerate(bundles):
+        out = lib.BrHostBam()
+        assert L.br_bam_bundle_stage(ctx.h, C.byref(bb), k % 3) == 0
+        assert L.br_project_bam_staged(ctx.h, C.byref(cfg), C.byref(bb), k % 3, C.byref(out)) == 0
+        expect.append((take(out), tuple(int(getattr(out, f)) for f in fields)))
+        assert out.n_bytes > 0
+    # one call ahead, as the command line's writer does: wait for bundle k only after bundle k + 1 has been launched
+    outs = [lib.BrHostBam() for _ in bundles]
+    for k, bb in enumerate(bundles):
+        assert L.br_bam_bundle_stage(ctx.h, C.byref(bb), k % 3) == 0
+        assert L.br_project_bam_staged_nowait(ctx.h, C.byref(cfg), C.byref(bb), k % 3, C.byref(outs[k])) == 0
+        assert tuple(int(getattr(outs[k], f)) for f in fields) == expect[k][1]
+        if k:
+            assert L.br_host_bam_wait(ctx.h, C.byref(outs[k - 1])) == 0
+            assert np.array_equal(take(outs[k - 1]), expect[k - 1][0])
+    assert L.br_host_bam_wait(ctx.h, C.byref(outs[-1])) == 0
+    last = take(outs[-1])
+    assert np.array_equal(last, expect[-1][0])
+    assert L.br_host_bam_wait(ctx.h, C.byref(outs[-1])) == 0             # a second wait is a no-op
+    # the blocks inflate to a BAM record stream (any inflater: tests/test_gpu_codec.py checks the codec itself)
+    raw = zlib.decompressobj(31).decompress(bytes(last[:int.from_bytes(bytes(last[16:18]), "little") + 1]))
+    assert len(raw) > 36 and int.from_bytes(raw[:4], "little") >= 32
+    # nobody waits: the context itself waits before a download buffer is used again
+    for k, bb in enumerate(bundles):
+        o = lib.BrHostBam()
+        assert L.br_bam_bundle_stage(ctx.h, C.byref(bb), k % 3) == 0
+        assert L.br_project_bam_staged_nowait(ctx.h, C.byref(cfg), C.byref(bb), k % 3, C.byref(o)) == 0
+    assert L.br_host_bam_wait(ctx.h, C.byref(o)) == 0
+    assert np.array_equal(take(o), expect[-1][0])
+    ctx.close()
+    idx.close()
+
+
 @pytest.mark.parametrize("seed,flags", [(11, {}), (12, {"lr": 1}), (13, {"strict": 1})])
 def test_bam_tasks_random_records(seed, flags):
     """k_bam_tasks (a wave per 32 rows, their byte regions as 16-byte copy tasks) on records built to hit every segment kind:
