@@ -328,18 +328,24 @@ extern "C" int br_cli_main(int argc, char **argv) {
       size_t searched = std::max<size_t>((size_t)o.bundle_records, 1);  // records below this index cannot be a cut
       for (;;) {
         if (!eof && !inflight && !cut_expected()) launch();
-        size_t cap = (size_t)(valid - scanned) / 36 + 1;
-        size_t base = off.size();
-        off.resize(base + cap); len.resize(base + cap);
-        int64_t n = 0, un = 0; uint64_t used = 0;
         auto ts0 = now();
-        int r = br_bam_split(buf.data() + scanned, valid - scanned, (int64_t)cap, off.data() + base, len.data() + base, &n, &un, &used);
-        if (r) { if (inflight) (void)fut.get(); reader_err = "malformed BAM record"; to_gpu.finish(); return; }
-        for (int64_t i = 0; i < n; i++) off[base + (size_t)i] += scanned;
-        off.resize(base + (size_t)n); len.resize(base + (size_t)n);
-        total_reads += (uint64_t)(n + un); unmapped_reads += (uint64_t)un;
-        split_bytes += used; split_recs += (uint64_t)(n + un);
-        scanned += used;
+        for (;;) {
+          // room for the records to come: from the mean record length (the worst case, 36 bytes a record, is a table six
+          // times too large, value-initialised on every pass); a piece that fills its room is followed by another
+          const size_t left = valid - scanned, worst = left / 36 + 1;
+          size_t cap = split_recs ? std::min<size_t>(worst, (size_t)(left / (split_bytes / split_recs + 1)) * 5 / 4 + 4096) : worst;
+          const size_t base = off.size();
+          off.resize(base + cap); len.resize(base + cap);
+          int64_t n = 0, un = 0; uint64_t used = 0;
+          int r = br_bam_split(buf.data() + scanned, left, (int64_t)cap, off.data() + base, len.data() + base, &n, &un, &used);
+          if (r) { if (inflight) (void)fut.get(); reader_err = "malformed BAM record"; to_gpu.finish(); return; }
+          for (int64_t i = 0; i < n; i++) off[base + (size_t)i] += scanned;
+          off.resize(base + (size_t)n); len.resize(base + (size_t)n);
+          total_reads += (uint64_t)(n + un); unmapped_reads += (uint64_t)un;
+          split_bytes += used; split_recs += (uint64_t)(n + un);
+          scanned += used;
+          if ((size_t)n < cap || used == 0) break;   // the bytes ran out (or end in a partial record), not the room
+        }
         // cut: first record >= bundle_records whose name differs from its predecessor's
         for (size_t i = searched; i < off.size(); i++) {
           uint32_t la, lb; const uint8_t *a = rec_name(buf, off[i - 1], la), *b = rec_name(buf, off[i], lb);
@@ -373,9 +379,8 @@ extern "C" int br_cli_main(int argc, char **argv) {
         buf.swap(tail);
         valid = tail_bytes;
         scanned -= byte_end;
-        std::vector<uint64_t> noff(off.begin() + (ptrdiff_t)n_take, off.end()); std::vector<uint32_t> nlen(len.begin() + (ptrdiff_t)n_take, len.end());
-        for (auto &x : noff) x -= byte_end;
-        off.swap(noff); len.swap(nlen);
+        off.erase(off.begin(), off.begin() + (ptrdiff_t)n_take); len.erase(len.begin(), len.begin() + (ptrdiff_t)n_take);   // (the tables keep their capacity)
+        for (auto &x : off) x -= byte_end;
         // the next read lands behind the tail's place in the new buffer while the tail itself is still on its way there
         if (!eof && !cut_expected()) launch();
         if (tail_bytes) memcpy(buf.data(), b->blob.data() + byte_end, tail_bytes);   // (launch() may have moved the buffer; the read itself never does)
