@@ -444,6 +444,7 @@ struct br_ctx {
   bool rows_busy_set = false;
   int host_detail = 0;              // br_host_rows carries the x (detail) array
   DevBuf z_slots, z_sizes, z_off, z_dense, z_dense_alt, z_tabs, z_tokens;
+  DevBuf inf_out, inf_blocks, inf_tabs, inf_cnt; bool inf_tabs_ready = false;   // br_bgzf_inflate_device
   int z_dense_which = 0;           // br_project_bam_staged_nowait: the packed blocks of call j are still on their way home while call j + 1 packs its own
   hipStream_t down_stream = nullptr; hipEvent_t ev_home[2] = {nullptr, nullptr}; std::atomic<bool> home_pending[2] = {{false}, {false}};
   int deflate_dynamic = 1;
@@ -540,7 +541,7 @@ extern "C" void br_ctx_free(br_ctx *c) {
   DevBuf *bufs[] = {&c->seg, &c->meta, &c->head, &c->head2, &c->fast_flag, &c->fast_pre, &c->n_matches, &c->ranges, &c->mask, &c->match_off, &c->cig_base,
                     &c->tile_sums, &c->totals, &c->counters_d, &c->m_tid, &c->m_aux, &c->m_p, &c->m_x, &c->m_b,
                     &c->m_cigoff, &c->cig_arena, &c->big_list, &c->n_big, &c->m_aln,
-                    &c->bam_aux, &c->bam_base, &c->bam_len, &c->bam_off, &c->bam_out, &c->bam_end, &c->z_slots, &c->z_sizes, &c->z_off, &c->z_dense, &c->z_dense_alt, &c->z_tabs, &c->z_tokens, &c->p_ncig, &c->p_name_len, &c->p_isnew, &c->p_group_pre, &c->p_small, &c->p_big, &c->p_seq_len, &c->p_ref_map, &c->fa_stats, &c->fa_n_prob, &c->fa_seq_bytes, &c->fa_prob_off, &c->fa_seqarena_off, &c->fa_probs, &c->fa_results,
+                    &c->bam_aux, &c->bam_base, &c->bam_len, &c->bam_off, &c->bam_out, &c->bam_end, &c->z_slots, &c->z_sizes, &c->z_off, &c->z_dense, &c->z_dense_alt, &c->inf_out, &c->inf_blocks, &c->inf_tabs, &c->inf_cnt, &c->z_tabs, &c->z_tokens, &c->p_ncig, &c->p_name_len, &c->p_isnew, &c->p_group_pre, &c->p_small, &c->p_big, &c->p_seq_len, &c->p_ref_map, &c->fa_stats, &c->fa_n_prob, &c->fa_seq_bytes, &c->fa_prob_off, &c->fa_seqarena_off, &c->fa_probs, &c->fa_results,
                     &c->fa_seq_arena, &c->fa_clip_ops, &c->fa_ideal_cap, &c->fa_scratch, &c->b_seq_off, &c->b_seqs, &c->b_seq_src,
                     &c->r_rec, &c->pk_a, &c->pk_c, &c->pk_x, &c->pk_sim, &c->pk_clip, &c->pool, &c->pool_sizes, &c->pool_off, &c->pk_ch,
                     &c->n_rows, &c->row_off, &c->aln_group, &c->r_input, &c->r_nh, &c->r_hi, &c->r_mapq,
@@ -1726,6 +1727,92 @@ extern "C" int br_bgzf_deflate_device(br_ctx *c, const uint8_t *src, uint64_t n,
   if (!c || (!src && n) || !out || !out_bytes) return BR_ERR_INVALID_ARG;
   HIPCHK(hipSetDevice(c->ix->device));
   return deflate_device_impl(c, src, n, (hipStream_t)stream, out, out_bytes, false);
+}
+
+// ---------------------------------------------------------------------------
+// BGZF inflate on the device
+// ---------------------------------------------------------------------------
+static_assert(sizeof(br_bgzf_block) == sizeof(InflateBlock), "br_bgzf_block is the kernel's block descriptor");
+
+extern "C" int br_bgzf_scan(const uint8_t *data, uint64_t n_bytes, int64_t cap, br_bgzf_block *blocks, int64_t *n_blocks,
+                            uint64_t *consumed, uint64_t *out_bytes) {
+  if ((!data && n_bytes) || !blocks || !n_blocks || !consumed || !out_bytes || cap < 0) return BR_ERR_INVALID_ARG;
+  uint64_t p = 0, total = 0; int64_t n = 0;
+  while (n < cap && p + 18 <= n_bytes) {
+    const uint8_t *h = data + p;
+    if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return BR_ERR_INVALID_ARG;   // not a BGZF block
+    const uint32_t xlen = h[10] | ((uint32_t)h[11] << 8);
+    if (p + 12 + xlen > n_bytes) break;
+    int64_t bsize = -1;
+    for (uint32_t q = 0; q + 4 <= xlen;) {
+      const uint8_t *x = h + 12 + q;
+      const uint32_t slen = x[2] | ((uint32_t)x[3] << 8);
+      if (x[0] == 'B' && x[1] == 'C' && slen == 2 && q + 6 <= xlen) bsize = (x[4] | (x[5] << 8)) + 1;
+      q += 4 + slen;
+    }
+    if (bsize < (int64_t)(12 + xlen + 8)) return BR_ERR_INVALID_ARG;            // no BC subfield
+    if (p + (uint64_t)bsize > n_bytes) break;                                     // partial block: next call
+    const uint8_t *t = h + bsize - 8;
+    const uint32_t crc = t[0] | (t[1] << 8) | (t[2] << 16) | ((uint32_t)t[3] << 24), ulen = t[4] | (t[5] << 8) | (t[6] << 16) | ((uint32_t)t[7] << 24);
+    if (ulen > 65536) return BR_ERR_INVALID_ARG;
+    if (ulen) {   // (empty blocks -- the EOF marker -- are stepped over)
+      br_bgzf_block &b = blocks[n++];
+      b.src_off = p + 12 + xlen; b.dst_off = total; b.clen = (uint32_t)(bsize - 12 - xlen - 8); b.ulen = ulen; b.crc = crc; b.pad = 0;
+      total += ulen;
+    }
+    p += (uint64_t)bsize;
+  }
+  *n_blocks = n; *consumed = p; *out_bytes = total;
+  return BR_OK;
+}
+
+extern "C" int br_bgzf_inflate_device(br_ctx *c, const uint8_t *src, uint64_t n_src, const br_bgzf_block *blocks, int64_t n_blocks,
+                                      void *stream, const uint8_t **out, uint64_t *out_bytes) {
+  if (!c || (!src && n_src) || (!blocks && n_blocks) || n_blocks < 0 || !out || !out_bytes) return BR_ERR_INVALID_ARG;
+  *out = nullptr; *out_bytes = 0;
+  if (n_blocks == 0) return BR_OK;
+  HIPCHK(hipSetDevice(c->ix->device));
+  hipStream_t st = (hipStream_t)stream;
+  uint64_t total = 0;
+  for (int64_t i = 0; i < n_blocks; i++) {
+    const br_bgzf_block &b = blocks[i];
+    if (b.ulen > 65536 || b.src_off + b.clen + 8 > n_src) return BR_ERR_INVALID_ARG;   // (+ 8: the block's CRC32 / ISIZE trailer lies inside the buffer)
+    total = std::max<uint64_t>(total, b.dst_off + b.ulen);
+  }
+  if (!c->inf_tabs_ready) {
+    // slice-by-4 tables of the reflected CRC-32 and the operator that appends INFLATE_CRC_CHUNK zero bytes (see deflate_device_impl)
+    std::vector<uint32_t> t(1024 + 1024);
+    for (uint32_t i = 0; i < 256; i++) { uint32_t v = i; for (int k = 0; k < 8; k++) v = (v & 1u) ? 0xEDB88320u ^ (v >> 1) : v >> 1; t[i] = v; }
+    for (int k = 1; k < 4; k++) for (uint32_t i = 0; i < 256; i++) { const uint32_t p = t[256 * (k - 1) + i]; t[256 * k + i] = (p >> 8) ^ t[p & 0xffu]; }
+    uint32_t col[32];
+    for (int b = 0; b < 32; b++) { uint32_t v = 1u << b; for (uint32_t k = 0; k < INFLATE_CRC_CHUNK; k++) v = (v >> 8) ^ t[v & 0xffu]; col[b] = v; }
+    for (int byte = 0; byte < 4; byte++)
+      for (uint32_t x = 0; x < 256; x++) { uint32_t v = 0; for (int b = 0; b < 8; b++) if (x & (1u << b)) v ^= col[8 * byte + b]; t[1024 + 256 * byte + x] = v; }
+    RC(c->inf_tabs.ensure(t.size() * 4));
+    HIPCHK(hipMemcpyAsync(c->inf_tabs.p, t.data(), t.size() * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    c->inf_tabs_ready = true;
+  }
+  RC(c->inf_out.ensure((size_t)total + 16)); RC(c->inf_blocks.ensure((size_t)n_blocks * sizeof(InflateBlock))); RC(c->inf_cnt.ensure(16));
+  HIPCHK(hipMemcpyAsync(c->inf_blocks.p, blocks, (size_t)n_blocks * sizeof(InflateBlock), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemsetAsync(c->inf_cnt.p, 0, 16, st));
+  InflateArgs A{};
+  A.src = src; A.n_src = n_src; A.dst = c->inf_out.as<uint8_t>(); A.blocks = (const InflateBlock *)c->inf_blocks.p; A.n_blocks = (uint64_t)n_blocks;
+  A.queue = c->inf_cnt.as<uint32_t>(); A.n_bad = c->inf_cnt.as<uint32_t>() + 1;
+  A.crc_tab4 = c->inf_tabs.as<uint32_t>(); A.crc_shift = c->inf_tabs.as<uint32_t>() + 1024;
+  const int waves = (int)std::min<uint64_t>(((uint64_t)n_blocks + 3) / 4 * 4, (uint64_t)c->n_cu * 8);   // two workgroups of four waves per CU (their LDS)
+  Prof pf{c, st};
+  c->events_used = 0;
+  RC(pf.begin(BR_K_CODEC));
+  launch_inflate(st, A, waves);
+  RC(pf.end());
+  uint32_t bad = 0;
+  HIPCHK(hipMemcpyAsync(&bad, A.n_bad, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  RC(pf.collect());
+  if (bad) return BR_ERR_INVALID_ARG;   // a block that does not inflate to its ISIZE bytes with its CRC32
+  *out = c->inf_out.as<uint8_t>(); *out_bytes = total;
+  return BR_OK;
 }
 
 extern "C" int br_bam_split(const uint8_t *data, uint64_t n_bytes, int64_t cap, uint64_t *rec_off, uint32_t *rec_len,

@@ -273,6 +273,20 @@ struct DeflateArgs {
 void launch_deflate(hipStream_t st, const DeflateArgs &A, int dynamic_waves);
 void launch_bgzf_compact(hipStream_t st, const DeflateArgs &A, const uint64_t *off, uint8_t *dense);
 
+// BGZF inflate on the device (inflate_kernels.hip): one wave per BGZF block
+#define INFLATE_CRC_CHUNK 1024u   // 64 lane-chunks cover a 64 KiB block
+struct InflateBlock { uint64_t src_off, dst_off; uint32_t clen, ulen, crc, pad; };   // deflate payload in src; where its bytes go
+struct InflateArgs {
+  const uint8_t *src; uint64_t n_src;
+  uint8_t *dst;
+  const InflateBlock *blocks; uint64_t n_blocks;
+  uint32_t *queue;             // next block to take (zeroed before the launch)
+  uint32_t *n_bad;             // blocks that did not inflate to their ISIZE bytes with their CRC32
+  const uint32_t *crc_tab4;    // [4][256] slice-by-4 tables of the reflected CRC-32
+  const uint32_t *crc_shift;   // [4][256] "append INFLATE_CRC_CHUNK zero bytes" operator
+};
+void launch_inflate(hipStream_t st, const InflateArgs &A, int n_waves);
+
 // BAM records -> input tables (parse_kernels.hip)
 struct ParseArgs {
   int64_t n, n_groups;

@@ -133,6 +133,21 @@ class BrBamBundle(C.Structure):
                 ("n_records", C.c_int64), ("ref_map", C.c_void_p), ("n_ref_map", C.c_int32), ("bgzf_on_device", C.c_int32)]
 
 
+BGZF_BLOCK = np.dtype([("src_off", "<u8"), ("dst_off", "<u8"), ("clen", "<u4"), ("ulen", "<u4"), ("crc", "<u4"), ("pad", "<u4")])
+
+
+def bgzf_scan(data, cap=None):
+    """br_bgzf_scan over a numpy uint8 array of BGZF bytes: (block table, bytes consumed, inflated bytes)."""
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    cap = int(cap) if cap is not None else data.size // 28 + 1
+    blocks = np.zeros(cap, dtype=BGZF_BLOCK)
+    n, consumed, total = C.c_int64(), C.c_uint64(), C.c_uint64()
+    L = lib()
+    L.br_bgzf_scan.argtypes = [C.c_void_p, C.c_uint64, C.c_int64, C.c_void_p, _P(C.c_int64), _P(C.c_uint64), _P(C.c_uint64)]
+    check(L.br_bgzf_scan(data.ctypes.data, data.size, cap, blocks.ctypes.data, C.byref(n), C.byref(consumed), C.byref(total)), "br_bgzf_scan")
+    return blocks[:n.value], int(consumed.value), int(total.value)
+
+
 class BrHostBam(C.Structure):
     _fields_ = [("data", C.c_void_p), ("n_bytes", C.c_uint64), ("n_rows", C.c_int64)] + _COUNTERS
 
@@ -147,7 +162,7 @@ EXPORTS = ["br_index_build", "br_index_build_flat", "br_index_free", "br_index_n
            "br_config_long_read", "br_config_resolve", "br_batch_prepare", "br_batch_seq_source", "br_ctx_new", "br_ctx_free",
            "br_project_batch", "br_project_batch_device", "br_device_rows_expand", "br_batch_stage", "br_project_staged", "br_host_rows_wait", "br_project_batch_packed",
            "br_pin_host", "br_unpin_host", "br_project_group", "br_project_groups", "br_bam_encode_device", "br_project_bam_device", "br_project_bam_bundle", "br_bam_bundle_stage", "br_project_bam_staged", "br_bam_split", "br_annotation_load", "br_annotation_load_mt", "br_annotation_free",
-           "br_annotation_num_transcripts", "br_annotation_transcripts", "br_annotation_num_refs", "br_annotation_refnames", "br_cli_main", "br_cli_exit_at_end", "br_device_warmup", "br_project_bam_staged_nowait", "br_host_bam_wait", "br_bgzf_write_file", "br_bgzf_read_file",
+           "br_annotation_num_transcripts", "br_annotation_transcripts", "br_annotation_num_refs", "br_annotation_refnames", "br_cli_main", "br_cli_exit_at_end", "br_device_warmup", "br_project_bam_staged_nowait", "br_host_bam_wait", "br_bgzf_scan", "br_bgzf_inflate_device", "br_bgzf_write_file", "br_bgzf_read_file",
            "br_free_buffer", "br_bgzf_codec", "br_bgzf_deflate_device", "br_ctx_set_profiling",
            "br_ctx_set_param", "br_ctx_kernel_ms", "br_ctx_collect_counters", "br_ctx_last_counters", "br_ctx_rescue_stats", "br_ctx_ksw_diag", "br_device_rows_detail", "br_ctx_ksw_pairs", "br_primary_pick", "br_row_mapq", "br_version", "br_strerror"]
 
@@ -575,6 +590,21 @@ class Context:
         out, n = C.c_void_p(), C.c_uint64()
         check(lib().br_bgzf_deflate_device(self.h, C.c_void_p(src.data_ptr()), src.numel(), C.c_void_p(stream), C.byref(out),
                                            C.byref(n)), "br_bgzf_deflate_device")
+        if n.value == 0:
+            return torch.zeros(0, dtype=torch.uint8, device=src.device)
+        return torch.as_tensor(_DevArray(out.value, n.value, "|u1"), device=src.device)
+
+    def bgzf_inflate_device(self, src, blocks, stream=0):
+        """src: torch CUDA uint8 tensor holding BGZF bytes, blocks: the table bgzf_scan made of the same bytes -> torch CUDA
+        uint8 tensor view of the inflated stream (valid until the next call on this context)."""
+        import torch
+        from .device import _DevArray
+        out, n = C.c_void_p(), C.c_uint64()
+        blocks = np.ascontiguousarray(blocks, dtype=BGZF_BLOCK)
+        L = lib()
+        L.br_bgzf_inflate_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int64, C.c_void_p, _P(C.c_void_p), _P(C.c_uint64)]
+        check(L.br_bgzf_inflate_device(self.h, C.c_void_p(src.data_ptr()), src.numel(), C.c_void_p(blocks.ctypes.data), len(blocks),
+                                       C.c_void_p(stream), C.byref(out), C.byref(n)), "br_bgzf_inflate_device")
         if n.value == 0:
             return torch.zeros(0, dtype=torch.uint8, device=src.device)
         return torch.as_tensor(_DevArray(out.value, n.value, "|u1"), device=src.device)

@@ -457,6 +457,19 @@ int br_project_bam_staged(br_ctx *, const br_config *, const br_bam_bundle *, in
 int br_project_bam_staged_nowait(br_ctx *, const br_config *, const br_bam_bundle *, int slot, br_host_bam *out);
 int br_host_bam_wait(br_ctx *, const br_host_bam *);
 
+/* BGZF inflate on the device (one wave per block: the reader side of br_bgzf_deflate_device).  br_bgzf_scan (host) walks
+ * the block headers of a piece of a BGZF file -- up to `cap` complete blocks; empty ones (the EOF marker) are stepped over --
+ * and lists for every block where its DEFLATE payload lies in `data`, where its bytes go in the inflated stream (dst_off: a
+ * running sum from 0), and the CRC32 / ISIZE of its trailer; *consumed is where the next call continues.
+ * br_bgzf_inflate_device inflates the listed blocks of the same bytes in HBM (`src`, `n_src`); *out is a device pointer to
+ * the inflated stream, valid until the next call on the context.  BR_ERR_INVALID_ARG for a malformed header, or for a block
+ * that does not inflate to ISIZE bytes with its CRC32 (what htslib's bgzf_read reports as a read error). */
+typedef struct br_bgzf_block { uint64_t src_off, dst_off; uint32_t clen, ulen, crc, pad; } br_bgzf_block;
+int br_bgzf_scan(const uint8_t *data, uint64_t n_bytes, int64_t cap, br_bgzf_block *blocks, int64_t *n_blocks,
+                 uint64_t *consumed, uint64_t *out_bytes);
+int br_bgzf_inflate_device(br_ctx *, const uint8_t *src, uint64_t n_src, const br_bgzf_block *blocks, int64_t n_blocks,
+                           void *stream, const uint8_t **out, uint64_t *out_bytes);
+
 /* Walks the block_size chain of an uncompressed BAM alignment section (host): fills rec_off /
  * rec_len for up to `cap` MAPPED records (unmapped ones are counted and skipped like
  * bramble.cpp:376-379) and reports how many bytes were consumed (a trailing partial record is

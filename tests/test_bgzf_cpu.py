@@ -89,3 +89,34 @@ print("ok")
     env = dict(os.environ, BRAMBLE_AMD_NO_LIBDEFLATE="1")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr
+
+
+def _zlib_bgzf(data, level=6):
+    import struct
+    import zlib
+    out = []
+    for p in range(0, len(data), 0xff00):
+        piece = data[p:p + 0xff00]
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+        payload = c.compress(piece) + c.flush()
+        out.append(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", 18 + len(payload) + 8 - 1) + payload
+                   + struct.pack("<II", zlib.crc32(piece) & 0xffffffff, len(piece)))
+    return b"".join(out)
+
+
+def test_scan_stops_at_a_partial_block_and_refuses_what_is_not_bgzf():
+    data = np.random.RandomState(4).randint(65, 70, size=90000).astype(np.uint8).tobytes()
+    raw = _zlib_bgzf(data, 6)
+    n_full = len(lib.bgzf_scan(np.frombuffer(raw, dtype=np.uint8))[0])
+    assert n_full == 2
+    for cut in (1, 10, 17, 18, 30, 5000):
+        blocks, consumed, total = lib.bgzf_scan(np.frombuffer(raw[:len(raw) - cut], dtype=np.uint8))
+        assert len(blocks) == 1 and total == 0xff00 and raw[consumed:consumed + 4] == b"\x1f\x8b\x08\x04"
+    blocks, consumed, total = lib.bgzf_scan(np.frombuffer(raw, dtype=np.uint8), cap=1)
+    assert len(blocks) == 1 and total == 0xff00
+    with pytest.raises(lib.BrambleError):
+        lib.bgzf_scan(np.frombuffer(b"\x1f\x8b\x08\x00" + raw[4:], dtype=np.uint8))      # gzip without the extra field
+    with pytest.raises(lib.BrambleError):
+        lib.bgzf_scan(np.frombuffer(raw[:12] + b"XY" + raw[14:], dtype=np.uint8))         # no BC subfield
+
+
