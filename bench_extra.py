@@ -23,7 +23,7 @@ import time
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("config", choices=["c3", "c5", "bam", "bundle", "cli", "small"])
+    ap.add_argument("config", choices=["c3", "c5", "bam", "bundle", "cli", "small", "inflate"])
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--reads", type=int, default=0)
     ap.add_argument("--steps", type=int, default=3)
@@ -146,6 +146,48 @@ def main():
         print(json.dumps({"config": "bundle", "device_deflate": deflate, "workload": "%d raw paired-end BAM records resident in HBM -> %d projected BAM records (reader side, projection and re-encoding on the device)" % (len(rlen), int(bam.n_rows)),
                           "alignments_per_s": len(rlen) / el, "ms_per_step": el * 1e3, "input_bytes": int(stream_h.size),
                           "output_bytes": int(bam.n_bytes), "kernel_ms_per_step": {k: round(v / args.steps, 3) for k, v in kms.items() if v}}))
+        return
+    if args.config == "inflate":
+        # BGZF inflate on the device against the host codec: the raw records of N read pairs, compressed by the library's writer
+        import ctypes as C
+        import tempfile
+        n = args.reads or 10_000_000
+        ann = synth.Annotation("G")
+        batch = ann.reads(n, "pe", with_records=1)
+        stream_h, roff, rlen = synth.Annotation.frame_records(batch)
+        L = lib.lib()
+        L.br_bgzf_write_file.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int]
+        L.br_bgzf_read_file.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L.br_free_buffer.argtypes = [C.c_void_p]
+        tmp = tempfile.mkdtemp(prefix="bramble_inflate_")
+        path = os.path.join(tmp, "records.bgzf")
+        assert L.br_bgzf_write_file(path.encode(), stream_h.ctypes.data, stream_h.size, args.threads, 6) == 0
+        raw = np.fromfile(path, dtype=np.uint8)
+        t0 = time.perf_counter()
+        blocks, consumed, total = lib.bgzf_scan(raw)
+        scan_s = time.perf_counter() - t0
+        assert consumed == raw.size and total == stream_h.size
+        idx = lib.Index.from_flat(ann.flat, device=0)
+        ctx = lib.Context(idx)
+        src = torch.from_numpy(raw).to("cuda:0")
+        out = ctx.bgzf_inflate_device(src, blocks)
+        assert torch.equal(out.cpu(), torch.from_numpy(stream_h))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = ctx.bgzf_inflate_device(src, blocks)
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / args.steps
+        host = {}
+        for th in (1, args.threads):
+            p, nb = C.c_void_p(), C.c_uint64()
+            t0 = time.perf_counter()
+            assert L.br_bgzf_read_file(path.encode(), th, C.byref(p), C.byref(nb)) == 0
+            host["threads=%d" % th] = round(time.perf_counter() - t0, 3)
+            L.br_free_buffer(p)
+        print(json.dumps({"config": "inflate", "workload": "%d BAM records, %d bytes in %d BGZF blocks of %d compressed bytes (host writer, level 6)" % (len(rlen), total, len(blocks), raw.size),
+                          "device_ms": el * 1e3, "device_GBps_out": total / el / 1e9, "device_GBps_in": raw.size / el / 1e9, "block_scan_host_s": round(scan_s, 3),
+                          "host_whole_file_s (br_bgzf_read_file, includes its buffer growth)": host, "kernel_ms": {k: round(v[0], 3) for k, v in ctx.kernel_ms().items() if v[0]}}))
         return
     if args.config == "cli":
         pass

@@ -1800,7 +1800,7 @@ extern "C" int br_bgzf_inflate_device(br_ctx *c, const uint8_t *src, uint64_t n_
   A.src = src; A.n_src = n_src; A.dst = c->inf_out.as<uint8_t>(); A.blocks = (const InflateBlock *)c->inf_blocks.p; A.n_blocks = (uint64_t)n_blocks;
   A.queue = c->inf_cnt.as<uint32_t>(); A.n_bad = c->inf_cnt.as<uint32_t>() + 1;
   A.crc_tab4 = c->inf_tabs.as<uint32_t>(); A.crc_shift = c->inf_tabs.as<uint32_t>() + 1024;
-  const int waves = (int)std::min<uint64_t>(((uint64_t)n_blocks + 3) / 4 * 4, (uint64_t)c->n_cu * 8);   // two workgroups of four waves per CU (their LDS)
+  const int waves = (int)std::min<uint64_t>(((uint64_t)n_blocks + 3) / 4 * 4, (uint64_t)c->n_cu * 12);   // three workgroups of four waves per CU (their LDS)
   Prof pf{c, st};
   c->events_used = 0;
   RC(pf.begin(BR_K_CODEC));

@@ -19,7 +19,7 @@ namespace br {
 
 #define IN_RING_DW 512u          // 2 KiB of compressed input per wave
 #define IN_CHUNK 1024u           // refilled 1 KiB at a time
-#define OUT_WIN 8192u            // output window in LDS
+#define OUT_WIN 4096u            // output window in LDS
 #define OUT_PIECE 1024u          // flushed to HBM in pieces of this size
 #define OUT_NEAR (OUT_WIN - OUT_PIECE - 258u)   // a match at most this far back is served from the window
 #define LL_BITS 10
@@ -76,7 +76,7 @@ __device__ __forceinline__ bool build_tables(WaveLds &W, const uint8_t *lens, in
   return true;
 }
 
-__global__ void __launch_bounds__(256) k_inflate(InflateArgs A) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) k_inflate(InflateArgs A) {
   __shared__ WaveLds sh_w[4];
   __shared__ uint32_t sh_crc[4][256];
   for (int i = threadIdx.x; i < 1024; i += 256) sh_crc[i >> 8][i & 255] = A.crc_tab4[i];
@@ -98,15 +98,14 @@ __global__ void __launch_bounds__(256) k_inflate(InflateArgs A) {
     bool bad = false;
 
     // ---- input ring: chunk k of the block's bytes sits in ring half k & 1; chunk k + 1 is there too, chunk k + 2 on its way
+    // (eight bytes at a time: a piece that holds payload bytes ends inside the block's eight-byte trailer at the latest, so
+    // nothing is read past the buffer and nothing needs a byte loop)
     auto load_chunk = [&](uint32_t k) {
       const uint64_t o = (uint64_t)k * IN_CHUNK + 16u * (uint32_t)lane;
+      struct __attribute__((packed, aligned(1))) IW2 { uint32_t a, b; };
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (o + 16 <= src_room) { const IW4 t = *(const IW4 *)(src + o); v = make_uint4(t.a, t.b, t.c, t.d); }
-      else if (o < src_room) {
-        uint32_t t[4] = {0, 0, 0, 0};
-        for (uint32_t j = 0; j < 16 && o + j < src_room; j++) t[j >> 2] |= (uint32_t)src[o + j] << (8u * (j & 3u));
-        v = make_uint4(t[0], t[1], t[2], t[3]);
-      }
+      if (o + 8 <= src_room) { const IW2 t = *(const IW2 *)(src + o); v.x = t.a; v.y = t.b; }
+      if (o + 16 <= src_room) { const IW2 t = *(const IW2 *)(src + o + 8); v.z = t.a; v.w = t.b; }
       return v;
     };
     auto put_chunk = [&](uint32_t k, uint4 v) { *(uint4 *)(W.in + (k & 1u) * (IN_CHUNK / 4) + 4u * (uint32_t)lane) = v; };

@@ -537,7 +537,7 @@ const char *br_bgzf_codec(void); /* "libdeflate" (bound at run time when present
 #define BR_K_KSW 8        /* k_ksw (-S clip rescue DP) */
 #define BR_K_BAM 9        /* k_bam_scan + k_bam_size + k_bam_tasks (or k_bam_encode<G>) */
 #define BR_K_PARSE 10     /* k_rec_fields + k_group_off + k_rec_copy + k_mates* + k_seq_* */
-#define BR_K_CODEC 11     /* k_deflate_dynamic | k_deflate_fixed, k_bgzf_compact */
+#define BR_K_CODEC 11     /* k_deflate_dynamic | k_deflate_fixed, k_bgzf_compact; k_inflate */
 #define BR_K_EMIT_SIMPLE 12 /* k_emit_dense, simple class (one read exon from a single M op) */
 #define BR_K_PRIMARY 13   /* k_primary (+ the per-read-name counters) */
 #define BR_K_CIGAR_POOL 14 /* unused since ABI version 2 */
