@@ -445,6 +445,7 @@ struct br_ctx {
   int host_detail = 0;              // br_host_rows carries the x (detail) array
   DevBuf z_slots, z_sizes, z_off, z_dense, z_dense_alt, z_tabs, z_tokens;
   DevBuf inf_out, inf_blocks, inf_tabs, inf_cnt; bool inf_tabs_ready = false;   // br_bgzf_inflate_device
+  DevBuf sp_entry, sp_entry2, sp_exit, sp_nmap, sp_nunm, sp_ended, sp_redo, sp_pre, sp_small, sp_off, sp_len;   // br_bam_split_device
   int z_dense_which = 0;           // br_project_bam_staged_nowait: the packed blocks of call j are still on their way home while call j + 1 packs its own
   hipStream_t down_stream = nullptr; hipEvent_t ev_home[2] = {nullptr, nullptr}; std::atomic<bool> home_pending[2] = {{false}, {false}};
   int deflate_dynamic = 1;
@@ -541,7 +542,7 @@ extern "C" void br_ctx_free(br_ctx *c) {
   DevBuf *bufs[] = {&c->seg, &c->meta, &c->head, &c->head2, &c->fast_flag, &c->fast_pre, &c->n_matches, &c->ranges, &c->mask, &c->match_off, &c->cig_base,
                     &c->tile_sums, &c->totals, &c->counters_d, &c->m_tid, &c->m_aux, &c->m_p, &c->m_x, &c->m_b,
                     &c->m_cigoff, &c->cig_arena, &c->big_list, &c->n_big, &c->m_aln,
-                    &c->bam_aux, &c->bam_base, &c->bam_len, &c->bam_off, &c->bam_out, &c->bam_end, &c->z_slots, &c->z_sizes, &c->z_off, &c->z_dense, &c->z_dense_alt, &c->inf_out, &c->inf_blocks, &c->inf_tabs, &c->inf_cnt, &c->z_tabs, &c->z_tokens, &c->p_ncig, &c->p_name_len, &c->p_isnew, &c->p_group_pre, &c->p_small, &c->p_big, &c->p_seq_len, &c->p_ref_map, &c->fa_stats, &c->fa_n_prob, &c->fa_seq_bytes, &c->fa_prob_off, &c->fa_seqarena_off, &c->fa_probs, &c->fa_results,
+                    &c->bam_aux, &c->bam_base, &c->bam_len, &c->bam_off, &c->bam_out, &c->bam_end, &c->z_slots, &c->z_sizes, &c->z_off, &c->z_dense, &c->z_dense_alt, &c->inf_out, &c->inf_blocks, &c->inf_tabs, &c->inf_cnt, &c->sp_entry, &c->sp_entry2, &c->sp_exit, &c->sp_nmap, &c->sp_nunm, &c->sp_ended, &c->sp_redo, &c->sp_pre, &c->sp_small, &c->sp_off, &c->sp_len, &c->z_tabs, &c->z_tokens, &c->p_ncig, &c->p_name_len, &c->p_isnew, &c->p_group_pre, &c->p_small, &c->p_big, &c->p_seq_len, &c->p_ref_map, &c->fa_stats, &c->fa_n_prob, &c->fa_seq_bytes, &c->fa_prob_off, &c->fa_seqarena_off, &c->fa_probs, &c->fa_results,
                     &c->fa_seq_arena, &c->fa_clip_ops, &c->fa_ideal_cap, &c->fa_scratch, &c->b_seq_off, &c->b_seqs, &c->b_seq_src,
                     &c->r_rec, &c->pk_a, &c->pk_c, &c->pk_x, &c->pk_sim, &c->pk_clip, &c->pool, &c->pool_sizes, &c->pool_off, &c->pk_ch,
                     &c->n_rows, &c->row_off, &c->aln_group, &c->r_input, &c->r_nh, &c->r_hi, &c->r_mapq,
@@ -1812,6 +1813,62 @@ extern "C" int br_bgzf_inflate_device(br_ctx *c, const uint8_t *src, uint64_t n_
   RC(pf.collect());
   if (bad) return BR_ERR_INVALID_ARG;   // a block that does not inflate to its ISIZE bytes with its CRC32
   *out = c->inf_out.as<uint8_t>(); *out_bytes = total;
+  return BR_OK;
+}
+
+// br_bam_split on the device (split_kernels.hip): data = an inflated BAM alignment section in HBM that starts at a record
+extern "C" int br_bam_split_device(br_ctx *c, const uint8_t *data, uint64_t n_bytes, int32_t n_ref, void *stream, br_device_records *recs,
+                                   int64_t *n_unmapped, uint64_t *consumed) {
+  if (!c || (!data && n_bytes) || !recs || !consumed || n_ref < 0) return BR_ERR_INVALID_ARG;
+  memset(recs, 0, sizeof(*recs));
+  recs->blob = data; *consumed = 0;
+  if (n_unmapped) *n_unmapped = 0;
+  if (n_bytes == 0) return BR_OK;
+  HIPCHK(hipSetDevice(c->ix->device));
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t n_seg = (int64_t)((n_bytes + SPLIT_SEG_BYTES - 1) / SPLIT_SEG_BYTES);
+  const size_t ns = (size_t)n_seg;
+  RC(c->sp_entry.ensure(ns * 8)); RC(c->sp_entry2.ensure(ns * 8)); RC(c->sp_exit.ensure(ns * 8)); RC(c->sp_nmap.ensure(ns * 4));
+  RC(c->sp_nunm.ensure(ns * 4)); RC(c->sp_ended.ensure(ns * 4)); RC(c->sp_redo.ensure(ns * 4)); RC(c->sp_pre.ensure((ns + 1) * 8));
+  RC(c->sp_small.ensure(64));   // flags[2] (u32) | totals[2] (u64) at +16 | mapped total (u64) at +32
+  RC(c->tile_sums.ensure((size_t)std::max<int64_t>(scan_tiles_for(n_seg + 1), 1) * 8 * 3));
+  HIPCHK(hipMemsetAsync(c->sp_small.p, 0, 64, st));
+  SplitArgs S{};
+  S.data = data; S.n_bytes = n_bytes; S.n_ref = n_ref; S.seg_bytes = SPLIT_SEG_BYTES; S.n_seg = n_seg;
+  S.entry = c->sp_entry.as<uint64_t>(); S.entry_next = c->sp_entry2.as<uint64_t>(); S.exit_ = c->sp_exit.as<uint64_t>();
+  S.n_map = c->sp_nmap.as<uint32_t>(); S.n_unm = c->sp_nunm.as<uint32_t>(); S.ended = c->sp_ended.as<uint32_t>();
+  S.flags = c->sp_small.as<uint32_t>(); S.totals = (uint64_t *)(c->sp_small.as<uint8_t>() + 16);
+  uint32_t *redo = c->sp_redo.as<uint32_t>();
+  launch_split_guess(st, S);
+  launch_split_walk(st, S, nullptr);
+  for (int pass = 0;; pass++) {
+    // every guess against where the chain of the segments in front arrives; the segments that were wrong walk again
+    HIPCHK(hipMemsetAsync(S.flags + 1, 0, 4, st));
+    launch_split_check(st, S, redo);
+    uint32_t changed = 0;
+    HIPCHK(hipMemcpyAsync(&changed, S.flags + 1, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    std::swap(S.entry, S.entry_next);
+    if (!changed) break;
+    if (pass > n_seg + 2) return BR_ERR_INVALID_ARG;   // (cannot happen: every pass settles at least the first wrong segment)
+    launch_split_walk(st, S, redo);
+  }
+  ScanArgs SC{}; SC.n = n_seg; SC.src32 = S.n_map; SC.tile_sums = c->tile_sums.as<uint64_t>();
+  launch_scan(st, SC, 2, c->sp_pre.p, true, (uint64_t *)(c->sp_small.as<uint8_t>() + 32));
+  uint64_t n_mapped = 0;
+  HIPCHK(hipMemcpyAsync(&n_mapped, c->sp_small.as<uint8_t>() + 32, 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  RC(c->sp_off.ensure(std::max<size_t>((size_t)n_mapped, 1) * 8)); RC(c->sp_len.ensure(std::max<size_t>((size_t)n_mapped, 1) * 4));
+  S.map_pre = c->sp_pre.as<uint64_t>(); S.rec_off = c->sp_off.as<uint64_t>(); S.rec_len = c->sp_len.as<uint32_t>();
+  launch_split_emit(st, S);
+  launch_split_totals(st, S);
+  struct { uint32_t flags[4]; uint64_t totals[2]; } h;
+  HIPCHK(hipMemcpyAsync(&h, c->sp_small.p, 32, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (h.flags[0] & 1u) return BR_ERR_INVALID_ARG;      // a record whose fixed fields overrun its block_size (as br_bam_split)
+  recs->rec_off = S.rec_off; recs->rec_len = S.rec_len; recs->n_aln = (int64_t)n_mapped;
+  if (n_unmapped) *n_unmapped = (int64_t)h.totals[0];
+  *consumed = h.totals[1];
   return BR_OK;
 }
 

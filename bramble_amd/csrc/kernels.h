@@ -287,6 +287,24 @@ struct InflateArgs {
 };
 void launch_inflate(hipStream_t st, const InflateArgs &A, int n_waves);
 
+// record boundaries of an inflated BAM stream (split_kernels.hip)
+#define SPLIT_SEG_BYTES 32768u
+struct SplitArgs {
+  const uint8_t *data; uint64_t n_bytes;   // starts at a record
+  int32_t n_ref; uint32_t seg_bytes; int64_t n_seg;
+  uint64_t *entry, *entry_next, *exit_;    // [n_seg] first record start in the segment (~0: none), what the check makes of it; where its walk ends
+  uint32_t *n_map, *n_unm, *ended;         // [n_seg] mapped / unmapped records that start in the segment; 1: the walk met the end of the data, 2: a malformed record
+  uint32_t *flags;                         // [0] a malformed record, [1] entries the check replaced
+  const uint64_t *map_pre;                 // [n_seg] exclusive scan of n_map
+  uint64_t *rec_off; uint32_t *rec_len;    // mapped records: offset of the refID field, block_size
+  uint64_t *totals;                        // [0] unmapped records, [1] bytes consumed
+};
+void launch_split_guess(hipStream_t st, const SplitArgs &S);
+void launch_split_walk(hipStream_t st, const SplitArgs &S, const uint32_t *redo);
+void launch_split_check(hipStream_t st, const SplitArgs &S, uint32_t *redo);
+void launch_split_emit(hipStream_t st, const SplitArgs &S);
+void launch_split_totals(hipStream_t st, const SplitArgs &S);
+
 // BAM records -> input tables (parse_kernels.hip)
 struct ParseArgs {
   int64_t n, n_groups;

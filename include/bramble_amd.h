@@ -457,6 +457,15 @@ int br_project_bam_staged(br_ctx *, const br_config *, const br_bam_bundle *, in
 int br_project_bam_staged_nowait(br_ctx *, const br_config *, const br_bam_bundle *, int slot, br_host_bam *out);
 int br_host_bam_wait(br_ctx *, const br_host_bam *);
 
+/* br_bam_split on the device: `data` is an inflated BAM alignment section in HBM that starts at a record (n_bytes of it);
+ * n_ref = the header's reference count (the boundary search tests reference ids against it).  recs->blob = data, rec_off /
+ * rec_len = device arrays of the MAPPED records in stream order (owned by the context, valid until its next call),
+ * *n_unmapped the records skipped, *consumed the first byte that belongs to no complete record.  Segments of the stream
+ * guess their first record and a verification pass against the real chain makes the result exact (split_kernels.hip).
+ * BR_ERR_INVALID_ARG on a record whose fixed fields overrun its block_size. */
+int br_bam_split_device(br_ctx *, const uint8_t *data, uint64_t n_bytes, int32_t n_ref, void *stream, br_device_records *recs,
+                        int64_t *n_unmapped, uint64_t *consumed);
+
 /* BGZF inflate on the device (one wave per block: the reader side of br_bgzf_deflate_device).  br_bgzf_scan (host) walks
  * the block headers of a piece of a BGZF file -- up to `cap` complete blocks; empty ones (the EOF marker) are stepped over --
  * and lists for every block where its DEFLATE payload lies in `data`, where its bytes go in the inflated stream (dst_off: a

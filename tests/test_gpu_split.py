@@ -1,0 +1,124 @@
+"""br_bam_split_device (segments guess their first record, a verification pass against the real chain makes it exact) against
+br_bam_split (host, the serial chain walk): offsets, lengths, unmapped counts and the bytes consumed, on streams with
+unmapped records, records longer than a segment, a partial record at the end, payloads that look like record headers, tiny
+inputs; a malformed record is refused like on the host."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from bramble_amd import lib, synth
+from bramble_amd.device import _DevArray
+from tests import bamio
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx():
+    idx = lib.Index({"refnames": ["chr1"], "transcripts": [{"id": "t", "ref_id": 0, "strand": "+", "exons": [[10, 50]]}]}, device=0)
+    return idx, lib.Context(idx)
+
+
+def host_split(stream):
+    L = lib.lib()
+    L.br_bam_split.argtypes = [C.c_void_p, C.c_uint64, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]
+    cap = stream.size // 36 + 1
+    off = np.zeros(cap, dtype=np.uint64); ln = np.zeros(cap, dtype=np.uint32)
+    n, un, used = C.c_int64(), C.c_int64(), C.c_uint64()
+    rc = L.br_bam_split(stream.ctypes.data, stream.size, cap, off.ctypes.data, ln.ctypes.data, C.byref(n), C.byref(un), C.byref(used))
+    return rc, off[:n.value].copy(), ln[:n.value].copy(), un.value, used.value
+
+
+def device_split(ctx, stream, n_ref):
+    L = lib.lib()
+    L.br_bam_split_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.POINTER(lib.BrDeviceRecords), C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]
+    d = torch.from_numpy(stream.copy()).to("cuda:0") if stream.size else torch.zeros(1, dtype=torch.uint8, device="cuda:0")
+    recs = lib.BrDeviceRecords(); un, used = C.c_int64(), C.c_uint64()
+    rc = L.br_bam_split_device(ctx.h, C.c_void_p(d.data_ptr()), stream.size, n_ref, None, C.byref(recs), C.byref(un), C.byref(used))
+    if rc:
+        return rc, None, None, None, None
+    n = int(recs.n_aln)
+    off = torch.as_tensor(_DevArray(recs.rec_off, n, "<u8"), device="cuda:0").cpu().numpy().copy() if n else np.zeros(0, np.uint64)
+    ln = torch.as_tensor(_DevArray(recs.rec_len, n, "<u4"), device="cuda:0").cpu().numpy().copy() if n else np.zeros(0, np.uint32)
+    return rc, off.astype(np.uint64), ln.astype(np.uint32), un.value, used.value
+
+
+def check(ctx, stream, n_ref=3):
+    stream = np.ascontiguousarray(stream, dtype=np.uint8)
+    h = host_split(stream)
+    d = device_split(ctx, stream, n_ref)
+    assert d[0] == h[0]
+    if h[0] == 0:
+        assert np.array_equal(d[1], h[1]) and np.array_equal(d[2], h[2]) and d[3] == h[3] and d[4] == h[4]
+    return h
+
+
+def records_stream(n_pairs, seed, n_refs=3):
+    ann = synth.Annotation("G", n_genes=300, n_refs=n_refs)
+    b = ann.reads(n_pairs, "pe", with_records=1, seed=seed)
+    stream, roff, rlen = synth.Annotation.frame_records(b)
+    return stream
+
+
+def test_short_read_streams_and_every_tail():
+    idx, ctx = _ctx()
+    stream = records_stream(4000, 3)
+    h = check(ctx, stream)
+    assert len(h[1]) > 7000 and h[4] == stream.size
+    for cut in (1, 3, 4, 5, 35, 36, 37, 200, 32768, 40000):      # a partial record (or a partial length field) at the end
+        check(ctx, stream[:stream.size - cut])
+    for n in (0, 1, 3, 4, 36, 200):                                # less than a record
+        check(ctx, stream[:n])
+    ctx.close(); idx.close()
+
+
+def test_unmapped_records_and_records_longer_than_a_segment():
+    idx, ctx = _ctx()
+    rng = np.random.RandomState(8)
+    recs = []
+    for k in range(3000):
+        l_seq = int(rng.choice([50, 100, 151, 3000, 40000, 90000], p=[0.3, 0.3, 0.3, 0.05, 0.03, 0.02]))
+        flag = 4 if k % 7 == 3 else (16 if k % 2 else 0)
+        recs.append(bamio.bam_record(("r%05d" % (k // 2)).encode(), int(rng.randint(0, 3)), int(rng.randint(0, 10 ** 6)), [(l_seq << 4) | 0], l_seq, flag=flag,
+                                     seq=rng.randint(0, 256, size=(l_seq + 1) // 2).astype(np.uint8).tobytes(), qual=rng.randint(0, 42, size=l_seq).astype(np.uint8).tobytes(),
+                                     aux=b"NHC\x01"))
+    stream = bamio.frame(recs)
+    h = check(ctx, stream)
+    assert h[3] == sum(1 for k in range(3000) if k % 7 == 3) and h[4] == stream.size
+    check(ctx, stream[:stream.size - 12345])
+    ctx.close(); idx.close()
+
+
+def test_payloads_that_look_like_records_do_not_fool_the_result():
+    """Qualities are free bytes: a run of them shaped like a record's fixed fields (and a chain of three) sits where a segment
+    starts looking.  The guess takes the bait; the verification pass does not."""
+    idx, ctx = _ctx()
+    fake = bamio.frame([bamio.bam_record(b"x", 0, 5, [(4 << 4) | 0], 4, qual=b"\x05" * 4)]).tobytes()
+    bait = (fake * 12)
+    recs = []
+    for k in range(600):
+        l_seq = 400
+        qual = bytearray(np.random.RandomState(k).randint(0, 42, size=l_seq).astype(np.uint8).tobytes())
+        qual[7:7 + len(bait)] = bait[:l_seq - 7]
+        recs.append(bamio.bam_record(("q%04d" % k).encode(), 1, 100 + k, [(l_seq << 4) | 0], l_seq, qual=bytes(qual), aux=b"NHC\x01"))
+    stream = bamio.frame(recs)
+    h = check(ctx, stream)
+    assert len(h[1]) == 600
+    ctx.close(); idx.close()
+
+
+def test_a_malformed_record_is_refused_like_on_the_host():
+    idx, ctx = _ctx()
+    stream = records_stream(600, 5).copy()
+    h = host_split(stream)
+    k = len(h[1]) // 2
+    at = int(h[1][k]) - 4
+    bad = stream.copy(); bad[at:at + 4] = np.frombuffer((20).to_bytes(4, "little"), dtype=np.uint8)      # block_size < 32
+    assert host_split(bad)[0] != 0
+    assert device_split(ctx, bad, 3)[0] != 0
+    bad = stream.copy(); bad[at + 4 + 8] = 0                                                               # l_read_name = 0
+    assert host_split(bad)[0] != 0
+    assert device_split(ctx, bad, 3)[0] != 0
+    check(ctx, stream)                                                                                     # the context still works
+    ctx.close(); idx.close()
