@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <memory>
 #include <mutex>
 #include <atomic>
 #include <cstdio>
@@ -1767,13 +1768,11 @@ extern "C" int br_bgzf_scan(const uint8_t *data, uint64_t n_bytes, int64_t cap, 
   return BR_OK;
 }
 
-extern "C" int br_bgzf_inflate_device(br_ctx *c, const uint8_t *src, uint64_t n_src, const br_bgzf_block *blocks, int64_t n_blocks,
-                                      void *stream, const uint8_t **out, uint64_t *out_bytes) {
-  if (!c || (!src && n_src) || (!blocks && n_blocks) || n_blocks < 0 || !out || !out_bytes) return BR_ERR_INVALID_ARG;
+// dst_ext: where the inflated bytes go (room for every block's dst_off + ulen), or null: the context's own buffer
+static int inflate_impl(br_ctx *c, const uint8_t *src, uint64_t n_src, const br_bgzf_block *blocks, int64_t n_blocks, hipStream_t st,
+                        uint8_t *dst_ext, const uint8_t **out, uint64_t *out_bytes) {
   *out = nullptr; *out_bytes = 0;
   if (n_blocks == 0) return BR_OK;
-  HIPCHK(hipSetDevice(c->ix->device));
-  hipStream_t st = (hipStream_t)stream;
   uint64_t total = 0;
   for (int64_t i = 0; i < n_blocks; i++) {
     const br_bgzf_block &b = blocks[i];
@@ -1794,11 +1793,12 @@ extern "C" int br_bgzf_inflate_device(br_ctx *c, const uint8_t *src, uint64_t n_
     HIPCHK(hipStreamSynchronize(st));
     c->inf_tabs_ready = true;
   }
-  RC(c->inf_out.ensure((size_t)total + 16)); RC(c->inf_blocks.ensure((size_t)n_blocks * sizeof(InflateBlock))); RC(c->inf_cnt.ensure(16));
+  if (!dst_ext) RC(c->inf_out.ensure((size_t)total + 16));
+  RC(c->inf_blocks.ensure((size_t)n_blocks * sizeof(InflateBlock))); RC(c->inf_cnt.ensure(16));
   HIPCHK(hipMemcpyAsync(c->inf_blocks.p, blocks, (size_t)n_blocks * sizeof(InflateBlock), hipMemcpyHostToDevice, st));
   HIPCHK(hipMemsetAsync(c->inf_cnt.p, 0, 16, st));
   InflateArgs A{};
-  A.src = src; A.n_src = n_src; A.dst = c->inf_out.as<uint8_t>(); A.blocks = (const InflateBlock *)c->inf_blocks.p; A.n_blocks = (uint64_t)n_blocks;
+  A.src = src; A.n_src = n_src; A.dst = dst_ext ? dst_ext : c->inf_out.as<uint8_t>(); A.blocks = (const InflateBlock *)c->inf_blocks.p; A.n_blocks = (uint64_t)n_blocks;
   A.queue = c->inf_cnt.as<uint32_t>(); A.n_bad = c->inf_cnt.as<uint32_t>() + 1;
   A.crc_tab4 = c->inf_tabs.as<uint32_t>(); A.crc_shift = c->inf_tabs.as<uint32_t>() + 1024;
   const int waves = (int)std::min<uint64_t>(((uint64_t)n_blocks + 3) / 4 * 4, (uint64_t)c->n_cu * 12);   // three workgroups of four waves per CU (their LDS)
@@ -1812,20 +1812,25 @@ extern "C" int br_bgzf_inflate_device(br_ctx *c, const uint8_t *src, uint64_t n_
   HIPCHK(hipStreamSynchronize(st));
   RC(pf.collect());
   if (bad) return BR_ERR_INVALID_ARG;   // a block that does not inflate to its ISIZE bytes with its CRC32
-  *out = c->inf_out.as<uint8_t>(); *out_bytes = total;
+  *out = A.dst; *out_bytes = total;
   return BR_OK;
 }
 
+extern "C" int br_bgzf_inflate_device(br_ctx *c, const uint8_t *src, uint64_t n_src, const br_bgzf_block *blocks, int64_t n_blocks,
+                                      void *stream, const uint8_t **out, uint64_t *out_bytes) {
+  if (!c || (!src && n_src) || (!blocks && n_blocks) || n_blocks < 0 || !out || !out_bytes) return BR_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(c->ix->device));
+  return inflate_impl(c, src, n_src, blocks, n_blocks, (hipStream_t)stream, nullptr, out, out_bytes);
+}
+
 // br_bam_split on the device (split_kernels.hip): data = an inflated BAM alignment section in HBM that starts at a record
-extern "C" int br_bam_split_device(br_ctx *c, const uint8_t *data, uint64_t n_bytes, int32_t n_ref, void *stream, br_device_records *recs,
-                                   int64_t *n_unmapped, uint64_t *consumed) {
-  if (!c || (!data && n_bytes) || !recs || !consumed || n_ref < 0) return BR_ERR_INVALID_ARG;
+static int split_impl(br_ctx *c, const uint8_t *data, uint64_t n_bytes, int32_t n_ref, hipStream_t st, br_device_records *recs,
+                      int64_t *n_unmapped, uint64_t *consumed, SplitArgs *S_out) {
   memset(recs, 0, sizeof(*recs));
   recs->blob = data; *consumed = 0;
   if (n_unmapped) *n_unmapped = 0;
+  if (S_out) *S_out = SplitArgs{};
   if (n_bytes == 0) return BR_OK;
-  HIPCHK(hipSetDevice(c->ix->device));
-  hipStream_t st = (hipStream_t)stream;
   const int64_t n_seg = (int64_t)((n_bytes + SPLIT_SEG_BYTES - 1) / SPLIT_SEG_BYTES);
   const size_t ns = (size_t)n_seg;
   RC(c->sp_entry.ensure(ns * 8)); RC(c->sp_entry2.ensure(ns * 8)); RC(c->sp_exit.ensure(ns * 8)); RC(c->sp_nmap.ensure(ns * 4));
@@ -1869,6 +1874,156 @@ extern "C" int br_bam_split_device(br_ctx *c, const uint8_t *data, uint64_t n_by
   recs->rec_off = S.rec_off; recs->rec_len = S.rec_len; recs->n_aln = (int64_t)n_mapped;
   if (n_unmapped) *n_unmapped = (int64_t)h.totals[0];
   *consumed = h.totals[1];
+  if (S_out) *S_out = S;
+  return BR_OK;
+}
+
+extern "C" int br_bam_split_device(br_ctx *c, const uint8_t *data, uint64_t n_bytes, int32_t n_ref, void *stream, br_device_records *recs,
+                                   int64_t *n_unmapped, uint64_t *consumed) {
+  if (!c || (!data && n_bytes) || !recs || !consumed || n_ref < 0) return BR_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(c->ix->device));
+  return split_impl(c, data, n_bytes, n_ref, (hipStream_t)stream, recs, n_unmapped, consumed, nullptr);
+}
+
+// ---------------------------------------------------------------------------
+// br_bam_reader: BGZF bytes of a BAM file in, bundles of device-resident records of whole read-name groups out.  What the host
+// reader of the command line does with sixteen inflate threads and a serial chain walk (inflate -> br_bam_split -> cut at a
+// read-name change -> upload), done where the records are needed: the compressed bytes go up as they are, k_inflate and
+// k_split_* make records of them, and the bytes behind the last complete name group wait in HBM for the next piece.
+// It needs no index (the command line runs it beside the guide parsing and the index build).
+// ---------------------------------------------------------------------------
+struct br_bam_reader {
+  br_index shell;                  // carries the device for the private context below; never used for projection
+  br_ctx *c = nullptr;
+  int32_t n_ref = 0;
+  uint64_t skip = 0;               // inflated bytes still to skip (the BAM header in front of the first record)
+  int64_t max_blocks = 3072;       // BGZF blocks per piece (about 200 MB inflated)
+  hipStream_t st = nullptr;
+  struct Chunk { DevBuf data, off, len; int64_t id = -1; bool out = false; };   // out: handed to the caller, not yet released
+  std::vector<std::unique_ptr<Chunk>> chunks;
+  std::mutex m;
+  Chunk *carry_from = nullptr; uint64_t carry_off = 0, carry_len = 0;
+  DevBuf comp, small;
+  std::vector<br_bgzf_block> blocks;
+  int64_t next_id = 0;
+  bool finished = false;
+};
+
+extern "C" int br_bam_reader_new(int device, int32_t n_ref, uint64_t header_bytes, br_bam_reader **out) {
+  if (!out || n_ref < 0) return BR_ERR_INVALID_ARG;
+  *out = nullptr;
+  int rc = check_device(device);
+  if (rc) return rc;
+  auto r = std::make_unique<br_bam_reader>();
+  r->shell.device = device; r->n_ref = n_ref; r->skip = header_bytes;
+  RC(br_ctx_new(&r->shell, &r->c));
+  HIPCHK(hipStreamCreateWithFlags(&r->st, hipStreamNonBlocking));
+  *out = r.release();
+  return BR_OK;
+}
+
+extern "C" int br_bam_reader_set_piece_blocks(br_bam_reader *r, int64_t blocks) {
+  if (!r || blocks < 1 || blocks > (1 << 20)) return BR_ERR_INVALID_ARG;
+  r->max_blocks = blocks;
+  return BR_OK;
+}
+
+extern "C" void br_bam_reader_free(br_bam_reader *r) {
+  if (!r) return;
+  (void)hipSetDevice(r->shell.device);
+  for (auto &ch : r->chunks) { ch->data.release(); ch->off.release(); ch->len.release(); }
+  r->comp.release(); r->small.release();
+  if (r->st) (void)hipStreamDestroy(r->st);
+  if (r->c) br_ctx_free(r->c);
+  delete r;
+}
+
+extern "C" int br_bam_reader_release(br_bam_reader *r, int64_t id) {
+  if (!r) return BR_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> l(r->m);
+  for (auto &ch : r->chunks) if (ch->id == id) { ch->out = false; return BR_OK; }
+  return BR_ERR_INVALID_ARG;
+}
+
+extern "C" int br_bam_reader_next(br_bam_reader *r, const uint8_t *data, uint64_t n_bytes, int last, uint64_t *consumed,
+                                  br_device_records *bundle, int64_t *id, int64_t *n_unmapped) {
+  if (!r || (!data && n_bytes) || !consumed || !bundle || !id || !n_unmapped) return BR_ERR_INVALID_ARG;
+  memset(bundle, 0, sizeof(*bundle));
+  *consumed = 0; *id = -1; *n_unmapped = 0;
+  if (r->finished) return BR_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(r->shell.device));
+  hipStream_t st = r->st;
+  // the complete blocks of this piece
+  r->blocks.resize((size_t)r->max_blocks);
+  int64_t nb = 0; uint64_t used = 0, total = 0;
+  RC(br_bgzf_scan(data, n_bytes, r->max_blocks, r->blocks.data(), &nb, &used, &total));
+  *consumed = used;
+  const bool at_end = last && used == n_bytes;       // nothing of the file is left behind this piece
+  if (last && nb < r->max_blocks && used != n_bytes) return BR_ERR_INVALID_ARG;   // a truncated block at the end of the file
+  if (nb == 0 && !at_end) return BR_OK;              // (only empty blocks so far)
+  // a chunk to hold: what the last piece left over + this piece's bytes
+  br_bam_reader::Chunk *ch = nullptr;
+  {
+    std::lock_guard<std::mutex> l(r->m);
+    for (auto &x : r->chunks) if (!x->out && x.get() != r->carry_from) { ch = x.get(); break; }
+    if (!ch) { r->chunks.push_back(std::make_unique<br_bam_reader::Chunk>()); ch = r->chunks.back().get(); }
+  }
+  RC(ch->data.ensure((size_t)(r->carry_len + total) + 64));
+  if (r->carry_len) HIPCHK(hipMemcpyAsync(ch->data.p, r->carry_from->data.as<uint8_t>() + r->carry_off, (size_t)r->carry_len, hipMemcpyDeviceToDevice, st));
+  if (nb) {
+    RC(r->comp.ensure((size_t)used + 64));
+    HIPCHK(hipMemcpyAsync(r->comp.p, data, (size_t)used, hipMemcpyHostToDevice, st));
+    const uint8_t *o = nullptr; uint64_t ob = 0;
+    RC(inflate_impl(r->c, r->comp.as<uint8_t>(), used, r->blocks.data(), nb, st, ch->data.as<uint8_t>() + r->carry_len, &o, &ob));
+  }
+  uint64_t have = r->carry_len + total, start = 0;
+  if (r->skip) { start = std::min<uint64_t>(r->skip, have); r->skip -= start; }   // (the header never leaves a carry: nothing is split before it ends)
+  const uint8_t *base = ch->data.as<uint8_t>() + start;
+  const uint64_t nbytes = have - start;
+  br_device_records recs; int64_t unm_all = 0; uint64_t used_bytes = 0; SplitArgs S{};
+  RC(split_impl(r->c, base, nbytes, r->n_ref, st, &recs, &unm_all, &used_bytes, &S));
+  const int64_t n = recs.n_aln;
+  // the cut: everything in front of the last read-name group (it may go on in the next piece); at the end of the file, all
+  int64_t n_take = n; uint64_t cut = used_bytes;
+  RC(r->small.ensure(64));
+  if (!at_end && n > 0) {
+    HIPCHK(hipMemsetAsync(r->small.p, 0, 16, st));
+    launch_last_group(st, base, recs.rec_off, n, (unsigned long long *)r->small.p);
+    uint64_t g = 0;
+    HIPCHK(hipMemcpyAsync(&g, r->small.p, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    n_take = (int64_t)g;
+    uint64_t off_g = 0;
+    HIPCHK(hipMemcpyAsync(&off_g, recs.rec_off + n_take, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    cut = off_g - 4;
+  }
+  if (at_end && used_bytes != nbytes) return BR_ERR_INVALID_ARG;   // a truncated record at the end of the file
+  // unmapped records in front of the cut (the ones behind it are met again with the next piece)
+  int64_t unm = unm_all;
+  if (cut != used_bytes && S.n_seg) {
+    HIPCHK(hipMemsetAsync(r->small.as<uint8_t>() + 16, 0, 8, st));
+    launch_unmapped_before(st, S, cut, (unsigned long long *)(r->small.as<uint8_t>() + 16));
+    uint64_t u = 0;
+    HIPCHK(hipMemcpyAsync(&u, r->small.as<uint8_t>() + 16, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    unm = (int64_t)u;
+  }
+  // the bundle's tables live with the chunk (the context's are overwritten by the next piece)
+  if (n_take) {
+    RC(ch->off.ensure((size_t)n_take * 8)); RC(ch->len.ensure((size_t)n_take * 4));
+    HIPCHK(hipMemcpyAsync(ch->off.p, recs.rec_off, (size_t)n_take * 8, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(ch->len.p, recs.rec_len, (size_t)n_take * 4, hipMemcpyDeviceToDevice, st));
+  }
+  HIPCHK(hipStreamSynchronize(st));
+  {
+    std::lock_guard<std::mutex> l(r->m);
+    ch->id = r->next_id++; ch->out = true;
+    r->carry_from = ch; r->carry_off = start + cut; r->carry_len = nbytes - cut;
+  }
+  if (at_end) r->finished = true;
+  bundle->blob = base; bundle->rec_off = ch->off.as<uint64_t>(); bundle->rec_len = ch->len.as<uint32_t>(); bundle->n_aln = n_take;
+  *id = ch->id; *n_unmapped = unm;
   return BR_OK;
 }
 
@@ -1917,30 +2072,23 @@ extern "C" int br_bam_bundle_stage(br_ctx *c, const br_bam_bundle *bb, int slot)
   return BR_OK;
 }
 
-static int project_bam_staged_impl(br_ctx *c, const br_config *cfg, const br_bam_bundle *bb, int slot, br_host_bam *out, bool nowait) {
-  if (!c || !cfg || !bb || !out || slot < 0 || slot > 2) return BR_ERR_INVALID_ARG;
-  memset(out, 0, sizeof(*out));
-  br_ctx::StageSlot &S = c->stage[slot];
-  if (!S.ready || S.n != bb->n_records) return BR_ERR_INVALID_ARG;   // not staged (or another bundle was)
-  HIPCHK(hipSetDevice(c->ix->device));
-  hipStream_t st = nullptr;
-  int64_t n = S.n;
-  out->total_processed = (uint64_t)n;
+// records in HBM -> projected records (or their BGZF blocks) in pinned host memory: the part the staged and the resident
+// entry points share
+static int project_bam_tail(br_ctx *c, const br_config *cfg, const br_device_records *dr, const int32_t *ref_map, int32_t n_ref_map,
+                            bool bgzf_on_device, bool nowait, double wait_ms, br_host_bam *out) {
   static const bool timing = getenv("BRAMBLE_AMD_TIMING") != nullptr;
   auto tnow = []() { return std::chrono::steady_clock::now(); };
   auto tms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-  auto t0 = tnow();
-  HIPCHK(hipEventSynchronize(S.ready));
+  hipStream_t st = nullptr;
+  const int64_t n = dr->n_aln;
   auto t1 = tnow();
-  if (n == 0) return BR_OK;
-  br_device_records dr{S.blob.as<uint8_t>(), S.off.as<uint64_t>(), n, S.len.as<uint32_t>()};
   br_device_rows rows; br_device_bam db;
-  RC(br_project_bam_device(c, cfg, &dr, bb->ref_map, bb->n_ref_map, st, &rows, &db));
+  RC(br_project_bam_device(c, cfg, dr, ref_map, n_ref_map, st, &rows, &db));
   auto t2 = tnow();
   int hs = c->h_bam_next; c->h_bam_next ^= 1;
   if (c->home_pending[hs]) { HIPCHK(hipEventSynchronize(c->ev_home[hs])); c->home_pending[hs] = false; }   // (a caller that never asked)
-  const bool later = nowait && bb->bgzf_on_device && db.n_bytes;
-  if (bb->bgzf_on_device && db.n_bytes) {
+  const bool later = nowait && bgzf_on_device && db.n_bytes;
+  if (bgzf_on_device && db.n_bytes) {
     c->z_dense_which = hs;
     const uint8_t *z = nullptr; uint64_t zn = 0;
     RC(deflate_device_impl(c, db.data, db.n_bytes, st, &z, &zn, false));
@@ -1965,11 +2113,37 @@ static int project_bam_staged_impl(br_ctx *c, const br_config *cfg, const br_bam
     if (db.n_bytes) HIPCHK(hipMemcpyAsync(c->h_bam[hs], db.data, (size_t)db.n_bytes, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
   }
-  if (timing) fprintf(stderr, "[bundle] %lld records: upload wait %.1f ms, records -> records %.1f ms, deflate %.1f ms, download of %.0f MB %.1f ms\n", (long long)n, tms(t0, t1), tms(t1, t2), tms(t2, t3), (double)db.n_bytes / 1e6, tms(t3, tnow()));
+  if (timing) fprintf(stderr, "[bundle] %lld records: upload wait %.1f ms, records -> records %.1f ms, deflate %.1f ms, download of %.0f MB %.1f ms\n", (long long)n, wait_ms, tms(t1, t2), tms(t2, t3), (double)db.n_bytes / 1e6, tms(t3, tnow()));
   out->data = c->h_bam[hs]; out->n_bytes = db.n_bytes; out->n_rows = db.n_rows;
   out->total_complete = rows.total_complete; out->total_unique = rows.total_unique;
   out->dropped_reads = rows.dropped_reads; out->total_processed = rows.total_processed;
   return BR_OK;
+}
+
+static int project_bam_staged_impl(br_ctx *c, const br_config *cfg, const br_bam_bundle *bb, int slot, br_host_bam *out, bool nowait) {
+  if (!c || !cfg || !bb || !out || slot < 0 || slot > 2) return BR_ERR_INVALID_ARG;
+  memset(out, 0, sizeof(*out));
+  br_ctx::StageSlot &S = c->stage[slot];
+  if (!S.ready || S.n != bb->n_records) return BR_ERR_INVALID_ARG;   // not staged (or another bundle was)
+  HIPCHK(hipSetDevice(c->ix->device));
+  int64_t n = S.n;
+  out->total_processed = (uint64_t)n;
+  auto t0 = std::chrono::steady_clock::now();
+  HIPCHK(hipEventSynchronize(S.ready));
+  const double wait_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (n == 0) return BR_OK;
+  br_device_records dr{S.blob.as<uint8_t>(), S.off.as<uint64_t>(), n, S.len.as<uint32_t>()};
+  return project_bam_tail(c, cfg, &dr, bb->ref_map, bb->n_ref_map, bb->bgzf_on_device != 0, nowait, wait_ms, out);
+}
+
+extern "C" int br_project_bam_resident(br_ctx *c, const br_config *cfg, const br_device_records *recs, const int32_t *ref_map, int32_t n_ref_map,
+                                       int bgzf_on_device, int nowait, br_host_bam *out) {
+  if (!c || !cfg || !recs || !out || recs->n_aln < 0 || (recs->n_aln && (!recs->blob || !recs->rec_off))) return BR_ERR_INVALID_ARG;
+  memset(out, 0, sizeof(*out));
+  HIPCHK(hipSetDevice(c->ix->device));
+  out->total_processed = (uint64_t)recs->n_aln;
+  if (recs->n_aln == 0) return BR_OK;
+  return project_bam_tail(c, cfg, recs, ref_map, n_ref_map, bgzf_on_device != 0, nowait != 0, 0.0, out);
 }
 
 extern "C" int br_project_bam_staged(br_ctx *c, const br_config *cfg, const br_bam_bundle *bb, int slot, br_host_bam *out) {

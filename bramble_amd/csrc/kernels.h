@@ -304,6 +304,8 @@ void launch_split_walk(hipStream_t st, const SplitArgs &S, const uint32_t *redo)
 void launch_split_check(hipStream_t st, const SplitArgs &S, uint32_t *redo);
 void launch_split_emit(hipStream_t st, const SplitArgs &S);
 void launch_split_totals(hipStream_t st, const SplitArgs &S);
+void launch_last_group(hipStream_t st, const uint8_t *data, const uint64_t *rec_off, int64_t n, unsigned long long *out);
+void launch_unmapped_before(hipStream_t st, const SplitArgs &S, uint64_t limit, unsigned long long *out);
 
 // BAM records -> input tables (parse_kernels.hip)
 struct ParseArgs {

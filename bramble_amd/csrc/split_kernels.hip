@@ -134,6 +134,51 @@ __global__ void __launch_bounds__(256) k_split_totals(SplitArgs S) {
   }
 }
 
+// start of the last read-name group among records [0, n): the largest i whose name differs from record i - 1's (0 when all
+// share one name).  out[0] must be zero before the launch.
+__global__ void __launch_bounds__(256) k_last_group(const uint8_t *data, const uint64_t *rec_off, int64_t n, unsigned long long *out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  unsigned long long best = 0;
+  if (i > 0 && i < n) {
+    const uint8_t *a = data + rec_off[i - 1], *b = data + rec_off[i];
+    const uint32_t la = a[8], lb = b[8];
+    bool same = la == lb;
+    for (uint32_t k = 0; same && k < la; k++) same = a[32 + k] == b[32 + k];
+    if (!same) best = (unsigned long long)i;
+  }
+  for (int o = 32; o; o >>= 1) { const unsigned long long t = __shfl_xor(best, o); best = t > best ? t : best; }
+  if ((threadIdx.x & 63) == 0 && best) atomicMax(out, best);
+}
+
+// unmapped records that start before byte `limit` (after k_split_*: whole segments from their counts, the one that holds the
+// limit by walking it again)
+__global__ void __launch_bounds__(256) k_unmapped_before(SplitArgs S, uint64_t limit, unsigned long long *out) {
+  const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  unsigned long long n = 0;
+  if (s < S.n_seg) {
+    const uint64_t lo = (uint64_t)s * S.seg_bytes, hi = lo + S.seg_bytes;
+    if (hi <= limit) n = S.n_unm[s];
+    else if (lo < limit && S.entry[s] != ~0ull) {
+      uint64_t p = S.entry[s];
+      while (p < limit && p + 4 <= S.n_bytes) {
+        const uint32_t bs = sl32(S.data + p);
+        if (bs < 32u || p + 4 + (uint64_t)bs > S.n_bytes) break;
+        if ((sl32(S.data + p + 4 + 12) >> 16) & 0x4u) n++;
+        p += 4 + (uint64_t)bs;
+      }
+    }
+  }
+  for (int o = 32; o; o >>= 1) n += __shfl_xor(n, o);
+  if ((threadIdx.x & 63) == 0 && n) atomicAdd(out, n);
+}
+
+void launch_last_group(hipStream_t st, const uint8_t *data, const uint64_t *rec_off, int64_t n, unsigned long long *out) {
+  if (n > 1) hipLaunchKernelGGL(k_last_group, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, data, rec_off, n, out);
+}
+void launch_unmapped_before(hipStream_t st, const SplitArgs &S, uint64_t limit, unsigned long long *out) {
+  hipLaunchKernelGGL(k_unmapped_before, dim3((unsigned)((S.n_seg + 255) / 256)), dim3(256), 0, st, S, limit, out);
+}
+
 void launch_split_guess(hipStream_t st, const SplitArgs &S) { hipLaunchKernelGGL(k_split_guess, dim3((unsigned)((S.n_seg + 63) / 64)), dim3(64), 0, st, S); }
 void launch_split_walk(hipStream_t st, const SplitArgs &S, const uint32_t *redo) { hipLaunchKernelGGL(k_split_walk, dim3((unsigned)((S.n_seg + 63) / 64)), dim3(64), 0, st, S, redo); }
 void launch_split_check(hipStream_t st, const SplitArgs &S, uint32_t *redo) { hipLaunchKernelGGL(k_split_check, dim3((unsigned)((S.n_seg + 63) / 64)), dim3(64), 0, st, S, redo); }

@@ -466,6 +466,29 @@ int br_host_bam_wait(br_ctx *, const br_host_bam *);
 int br_bam_split_device(br_ctx *, const uint8_t *data, uint64_t n_bytes, int32_t n_ref, void *stream, br_device_records *recs,
                         int64_t *n_unmapped, uint64_t *consumed);
 
+/* A BAM reader on the device: BGZF bytes of the file in (host memory, e.g. the mapped file), bundles of device-resident records
+ * of whole read-name groups out -- inflate, record split and the cut at a read-name change (src/bramble.cpp:313-441 reads
+ * record by record through htslib and flushes a bundle at a name change) without the host touching an inflated byte.  Needs
+ * no index: it can run beside the guide loading.
+ *   br_bam_reader_new      header_bytes = inflated size of the BAM header (magic, text, references): the first record follows it
+ *   br_bam_reader_next     takes the complete BGZF blocks at the front of data[0 .. n_bytes) (at most ~200 MB inflated per call;
+ *                          *consumed says how far it got -- call again from there; `last` != 0: data ends with the file) and
+ *                          returns the records of every read-name group that is complete: bundle->blob / rec_off / rec_len in
+ *                          HBM (mapped records only, like br_bam_split; *n_unmapped = the ones skipped), valid until
+ *                          br_bam_reader_release(id).  The last, possibly unfinished group stays behind for the next call;
+ *                          the call that ends the file returns everything.  A bundle may be empty.
+ * BR_ERR_INVALID_ARG for malformed BGZF / BAM, a block whose CRC32 is wrong, a file that ends inside a block or a record. */
+typedef struct br_bam_reader br_bam_reader;
+int br_bam_reader_new(int device, int32_t n_ref, uint64_t header_bytes, br_bam_reader **out);
+int br_bam_reader_next(br_bam_reader *, const uint8_t *data, uint64_t n_bytes, int last, uint64_t *consumed,
+                       br_device_records *bundle, int64_t *id, int64_t *n_unmapped);
+int br_bam_reader_set_piece_blocks(br_bam_reader *, int64_t blocks);   /* BGZF blocks per br_bam_reader_next call (default 3072) */
+int br_bam_reader_release(br_bam_reader *, int64_t id);
+void br_bam_reader_free(br_bam_reader *);
+/* br_project_bam_staged / _nowait for records that are in HBM already (a br_bam_reader bundle, or br_bam_split_device's) */
+int br_project_bam_resident(br_ctx *, const br_config *, const br_device_records *recs, const int32_t *ref_map, int32_t n_ref_map,
+                            int bgzf_on_device, int nowait, br_host_bam *out);
+
 /* BGZF inflate on the device (one wave per block: the reader side of br_bgzf_deflate_device).  br_bgzf_scan (host) walks
  * the block headers of a piece of a BGZF file -- up to `cap` complete blocks; empty ones (the EOF marker) are stepped over --
  * and lists for every block where its DEFLATE payload lies in `data`, where its bytes go in the inflated stream (dst_off: a

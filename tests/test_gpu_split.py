@@ -122,3 +122,99 @@ def test_a_malformed_record_is_refused_like_on_the_host():
     assert device_split(ctx, bad, 3)[0] != 0
     check(ctx, stream)                                                                                     # the context still works
     ctx.close(); idx.close()
+
+
+def _bgzf(data, chunk=0xff00):
+    import struct
+    import zlib
+    out = []
+    for p in range(0, len(data), chunk):
+        piece = data[p:p + chunk]
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        payload = c.compress(piece) + c.flush()
+        out.append(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", 18 + len(payload) + 8 - 1) + payload
+                   + struct.pack("<II", zlib.crc32(piece) & 0xffffffff, len(piece)))
+    return b"".join(out) + bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0])
+
+
+def _read_all(L, raw, n_ref, header_bytes, piece_blocks, feed):
+    """Drives br_bam_reader over the BGZF bytes `raw`, handing it `feed` more bytes of the file at a time.  Returns the
+    bundles as host copies: (record bytes list, n_unmapped) per bundle."""
+    L.br_bam_reader_new.argtypes = [C.c_int, C.c_int32, C.c_uint64, C.POINTER(C.c_void_p)]
+    L.br_bam_reader_next.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_uint64), C.POINTER(lib.BrDeviceRecords), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.br_bam_reader_release.argtypes = [C.c_void_p, C.c_int64]
+    L.br_bam_reader_set_piece_blocks.argtypes = [C.c_void_p, C.c_int64]
+    L.br_bam_reader_free.argtypes = [C.c_void_p]
+    rd = C.c_void_p()
+    assert L.br_bam_reader_new(0, n_ref, header_bytes, C.byref(rd)) == 0
+    assert L.br_bam_reader_set_piece_blocks(rd, piece_blocks) == 0
+    arr = np.frombuffer(raw, dtype=np.uint8)
+    pos, avail, bundles, rc = 0, min(feed, arr.size), [], 0
+    while True:
+        last = 1 if avail == arr.size else 0
+        used, recs, bid, unm = C.c_uint64(), lib.BrDeviceRecords(), C.c_int64(), C.c_int64()
+        rc = L.br_bam_reader_next(rd, arr.ctypes.data + pos, avail - pos, last, C.byref(used), C.byref(recs), C.byref(bid), C.byref(unm))
+        if rc:
+            break
+        pos += used.value
+        if bid.value >= 0:
+            n = int(recs.n_aln)
+            out = []
+            if n:
+                off = torch.as_tensor(_DevArray(recs.rec_off, n, "<u8"), device="cuda:0").cpu().numpy()
+                ln = torch.as_tensor(_DevArray(recs.rec_len, n, "<u4"), device="cuda:0").cpu().numpy()
+                end = int(off[-1]) + int(ln[-1])
+                blob = torch.as_tensor(_DevArray(recs.blob, end, "|u1"), device="cuda:0").cpu().numpy()
+                out = [blob[int(o):int(o) + int(l)].tobytes() for o, l in zip(off, ln)]
+            bundles.append((out, unm.value))
+            assert L.br_bam_reader_release(rd, bid.value) == 0
+        if last and pos == arr.size:
+            break
+        if last:
+            assert used.value > 0, "no progress"
+        elif used.value == 0 or avail - pos < (1 << 16):
+            avail = min(arr.size, avail + feed)
+    L.br_bam_reader_free(rd)
+    return rc, bundles
+
+
+@pytest.mark.parametrize("piece_blocks,feed", [(3, 150_000), (1, 70_000), (40, 1 << 30), (3072, 1 << 30)])
+def test_reader_bundles_are_the_mapped_records_cut_at_name_changes(piece_blocks, feed):
+    stream = records_stream(3000, 11)
+    rng = np.random.RandomState(2)
+    # some unmapped records in between (flag bit 2 set), like a real file has
+    recs = bamio.split_stream(stream)
+    mixed = []
+    for k, r in enumerate(recs):
+        if k % 11 == 5:
+            u = bytearray(r); u[14] |= 4; mixed.append(bytes(u))
+        mixed.append(r)
+    stream = bamio.frame(mixed)
+    header = b"BAM\x01" + (25).to_bytes(4, "little") + b"@HD\tVN:1.6\tSO:unsorted\n\0\0" [:25] + (3).to_bytes(4, "little") + b"".join(
+        (5).to_bytes(4, "little") + b"chr%d\0" % k + (10 ** 8).to_bytes(4, "little") for k in range(3))
+    raw = _bgzf(header + stream.tobytes(), chunk=20000 if piece_blocks < 10 else 0xff00)
+    rc, bundles = _read_all(lib.lib(), raw, 3, len(header), piece_blocks, feed)
+    assert rc == 0
+    h = host_split(stream)
+    want = [stream[int(o):int(o) + int(l)].tobytes() for o, l in zip(h[1], h[2])]
+    got = [r for b, _ in bundles for r in b]
+    assert got == want
+    assert sum(u for _, u in bundles) == h[3]
+    name = lambda r: r[32:32 + r[8]]
+    for (a, _), (b, _) in zip([x for x in bundles if x[0]][:-1], [x for x in bundles if x[0]][1:]):
+        assert name(a[-1]) != name(b[0])          # no read-name group is split between bundles
+    if piece_blocks < 10:
+        assert len(bundles) > 10
+
+
+def test_reader_refuses_truncated_and_corrupt_files():
+    stream = records_stream(500, 12)
+    header = b"BAM\x01" + (0).to_bytes(4, "little") + (1).to_bytes(4, "little") + (5).to_bytes(4, "little") + b"chr1\0" + (10 ** 8).to_bytes(4, "little")
+    raw = _bgzf(header + stream.tobytes())
+    L = lib.lib()
+    assert _read_all(L, raw, 3, len(header), 3072, 1 << 30)[0] == 0
+    assert _read_all(L, raw[:len(raw) - 28 - 100], 3, len(header), 3072, 1 << 30)[0] != 0                 # ends inside a block
+    cut = _bgzf(header + stream.tobytes()[:stream.size - 77])
+    assert _read_all(L, cut, 3, len(header), 3072, 1 << 30)[0] != 0                                          # ends inside a record
+    bad = bytearray(raw); bad[200] ^= 0x40
+    assert _read_all(L, bytes(bad), 3, len(header), 3072, 1 << 30)[0] != 0                                   # a flipped bit
