@@ -227,7 +227,8 @@ def main():
             parts = entry.split("@")
             level = parts[0] if parts[0] == "device" else int(parts[0])
             run_env = dict(os.environ)
-            run_env.update(dict(kv.split("=", 1) for kv in parts[1:]))
+            run_env.update(dict(kv.split("=", 1) for kv in parts[1:] if not kv.startswith("ARG=")))
+            entry_args = [kv[4:] for kv in parts[1:] if kv.startswith("ARG=")]   # "@ARG=--host-reader": an extra command-line argument for that run
             os.sync()   # the previous run's output is on its way to the disk: not this run's business
             time.sleep(float(os.environ.get("CLI_GAP_S", "0")))   # ... and the driver is still taking the previous process apart
             out_bam = os.path.join(tmp, "out%s.bam" % level)
@@ -239,7 +240,7 @@ def main():
             ru0 = resource.getrusage(resource.RUSAGE_CHILDREN)
             codec = ["--device-deflate"] if level == "device" else ["--compression-level", str(level)]
             extra = os.environ.get("CLI_EXTRA", "").split()
-            r = subprocess.run([exe, in_bam, "-G", gtf, "-o", out_bam, "-p", str(args.threads)] + codec + extra,
+            r = subprocess.run([exe, in_bam, "-G", gtf, "-o", out_bam, "-p", str(args.threads)] + codec + extra + entry_args,
                                capture_output=True, text=True, env=run_env)
             wall = time.perf_counter() - t0
             e1 = time.time()

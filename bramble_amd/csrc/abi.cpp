@@ -1845,6 +1845,7 @@ static int split_impl(br_ctx *c, const uint8_t *data, uint64_t n_bytes, int32_t 
   S.flags = c->sp_small.as<uint32_t>(); S.totals = (uint64_t *)(c->sp_small.as<uint8_t>() + 16);
   uint32_t *redo = c->sp_redo.as<uint32_t>();
   launch_split_guess(st, S);
+  if (const char *sp = getenv("BRAMBLE_AMD_SPLIT_SPOIL")) launch_split_spoil(st, S, atoi(sp));   // test hook: wrong guesses on purpose
   launch_split_walk(st, S, nullptr);
   for (int pass = 0;; pass++) {
     // every guess against where the chain of the segments in front arrives; the segments that were wrong walk again
@@ -1854,6 +1855,7 @@ static int split_impl(br_ctx *c, const uint8_t *data, uint64_t n_bytes, int32_t 
     HIPCHK(hipMemcpyAsync(&changed, S.flags + 1, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     std::swap(S.entry, S.entry_next);
+    if (getenv("BRAMBLE_AMD_SPLIT_DEBUG") && (pass < 12 || !changed)) fprintf(stderr, "[split] pass %d: %u of %lld segments took another entry\n", pass, changed, (long long)n_seg);
     if (!changed) break;
     if (pass > n_seg + 2) return BR_ERR_INVALID_ARG;   // (cannot happen: every pass settles at least the first wrong segment)
     launch_split_walk(st, S, redo);
@@ -1907,6 +1909,7 @@ struct br_bam_reader {
   std::vector<br_bgzf_block> blocks;
   int64_t next_id = 0;
   bool finished = false;
+  double t_scan = 0, t_up = 0, t_inflate = 0, t_split = 0, t_cut = 0;   // BRAMBLE_AMD_TIMING
 };
 
 extern "C" int br_bam_reader_new(int device, int32_t n_ref, uint64_t header_bytes, br_bam_reader **out) {
@@ -1953,10 +1956,14 @@ extern "C" int br_bam_reader_next(br_bam_reader *r, const uint8_t *data, uint64_
   if (r->finished) return BR_ERR_INVALID_ARG;
   HIPCHK(hipSetDevice(r->shell.device));
   hipStream_t st = r->st;
+  auto tnow = []() { return std::chrono::steady_clock::now(); };
+  auto tsec = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count(); };
+  auto tp = tnow();
   // the complete blocks of this piece
   r->blocks.resize((size_t)r->max_blocks);
   int64_t nb = 0; uint64_t used = 0, total = 0;
   RC(br_bgzf_scan(data, n_bytes, r->max_blocks, r->blocks.data(), &nb, &used, &total));
+  r->t_scan += tsec(tp); tp = tnow();
   *consumed = used;
   const bool at_end = last && used == n_bytes;       // nothing of the file is left behind this piece
   if (last && nb < r->max_blocks && used != n_bytes) return BR_ERR_INVALID_ARG;   // a truncated block at the end of the file
@@ -1973,8 +1980,11 @@ extern "C" int br_bam_reader_next(br_bam_reader *r, const uint8_t *data, uint64_
   if (nb) {
     RC(r->comp.ensure((size_t)used + 64));
     HIPCHK(hipMemcpyAsync(r->comp.p, data, (size_t)used, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    r->t_up += tsec(tp); tp = tnow();
     const uint8_t *o = nullptr; uint64_t ob = 0;
     RC(inflate_impl(r->c, r->comp.as<uint8_t>(), used, r->blocks.data(), nb, st, ch->data.as<uint8_t>() + r->carry_len, &o, &ob));
+    r->t_inflate += tsec(tp); tp = tnow();
   }
   uint64_t have = r->carry_len + total, start = 0;
   if (r->skip) { start = std::min<uint64_t>(r->skip, have); r->skip -= start; }   // (the header never leaves a carry: nothing is split before it ends)
@@ -1982,6 +1992,7 @@ extern "C" int br_bam_reader_next(br_bam_reader *r, const uint8_t *data, uint64_
   const uint64_t nbytes = have - start;
   br_device_records recs; int64_t unm_all = 0; uint64_t used_bytes = 0; SplitArgs S{};
   RC(split_impl(r->c, base, nbytes, r->n_ref, st, &recs, &unm_all, &used_bytes, &S));
+  r->t_split += tsec(tp); tp = tnow();
   const int64_t n = recs.n_aln;
   // the cut: everything in front of the last read-name group (it may go on in the next piece); at the end of the file, all
   int64_t n_take = n; uint64_t cut = used_bytes;
@@ -2021,7 +2032,11 @@ extern "C" int br_bam_reader_next(br_bam_reader *r, const uint8_t *data, uint64_
     ch->id = r->next_id++; ch->out = true;
     r->carry_from = ch; r->carry_off = start + cut; r->carry_len = nbytes - cut;
   }
-  if (at_end) r->finished = true;
+  r->t_cut += tsec(tp);
+  if (at_end) {
+    r->finished = true;
+    if (getenv("BRAMBLE_AMD_TIMING")) fprintf(stderr, "[reader] block scan %.2fs, upload of the compressed bytes %.2fs, inflate %.2fs, record split %.2fs, cuts + tables %.2fs\n", r->t_scan, r->t_up, r->t_inflate, r->t_split, r->t_cut);
+  }
   bundle->blob = base; bundle->rec_off = ch->off.as<uint64_t>(); bundle->rec_len = ch->len.as<uint32_t>(); bundle->n_aln = n_take;
   *id = ch->id; *n_unmapped = unm;
   return BR_OK;

@@ -64,6 +64,9 @@ class BgzfReader {
   // appends at least `want` uncompressed bytes to `out` unless the stream ends first;
   // returns the number of bytes appended, 0 at end of stream, -1 on a corrupt block
   int64_t read(ByteBuf &out, size_t want);
+  // the mapped file (regular files only; null for a pipe): the device reader takes the compressed bytes from here
+  const uint8_t *mapped() const { return map_; }
+  size_t mapped_size() const { return map_ ? map_size_ : 0; }
   bool eof() const { return eof_; }
   const std::string &error() const { return err_; }
 

@@ -46,6 +46,7 @@ struct Options {
   int64_t bundle_records = 1000000;   // (1 M: 1.20 s inside the program for 20.9 M alignments, 2 M: 1.38 s, 0.5 M: 1.47 s; the pinned result buffers scale with it)
   bool quiet = false;
   bool device_deflate = true;   // BGZF blocks made on the GPU unless a host level is asked for
+  int device_reader = -1;       // inflate + record split on the GPU (br_bam_reader): -1 = when the input is a regular file and one device is used
 };
 
 void usage(FILE *f) {
@@ -55,7 +56,8 @@ void usage(FILE *f) {
           " [--help] [--version] [--quiet] [--fr] [--rf] [--lr] [--lr-hq] [--strict]\n"
           " [--max-soft-clip N] [--max-junction-insertion N] [--max-junction-deletion N]\n"
           " [--max-error-exon N] [--similarity-threshold X]\n"
-          " [--device-deflate | --host-deflate | --compression-level 0-9] [--bundle-size N] [--device N | --devices a,b,...]\n\n"
+          " [--device-deflate | --host-deflate | --compression-level 0-9] [--device-reader | --host-reader] [--bundle-size N]\n"
+          "               [--device N | --devices a,b,...]\n\n"
           "Project spliced genomic alignments into transcriptomic space.\n"
           "The output BGZF blocks are deflated on the GPU by default (per-block Huffman codes); --host-deflate or\n"
           "--compression-level N use the host codec (libdeflate / zlib, level 6 like the reference unless N is given).\n"
@@ -98,6 +100,8 @@ int parse_args(int argc, char **argv, Options &o) {
     else if (a == "--host-deflate") o.device_deflate = false;
     else if (a == "--bundle-size") { const char *v = value(); if (!v) return -1; o.bundle_records = atoll(v); if (o.bundle_records < 1) return -1; }
     else if (a == "--device-deflate") o.device_deflate = true;
+    else if (a == "--device-reader") o.device_reader = 1;
+    else if (a == "--host-reader") o.device_reader = 0;
     else if (a == "--device") { const char *v = value(); if (!v) return -1; o.devices.assign(1, atoi(v)); }
     else if (a == "--devices") {
       const char *v = value(); if (!v) return -1;
@@ -281,7 +285,37 @@ extern "C" int br_cli_main(int argc, char **argv) {
   auto now = []() { return std::chrono::steady_clock::now(); };
   auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
 
-  std::thread reader([&]() {
+  // Device reader (br_bam_reader): the mapped file's bytes go to the GPU as they are; inflate, the record split and the cut at
+  // a read-name change happen there, beside the guide parsing and the index build (it needs neither), and the bundles it
+  // makes stay in HBM until the runner has projected them.  One device, a regular file; else the host reader below.
+  struct DevBundle { br_device_records recs; int64_t id; uint64_t seq; };
+  Slot<DevBundle> to_dev(64);
+  br_bam_reader *dev_reader = nullptr;
+  const bool use_dev_reader = o.device_reader != 0 && o.devices.size() == 1 && rd.mapped() && (o.device_reader > 0 || rd.mapped_size() >= (1u << 20));
+  double t_dev_reader = 0;
+  std::thread reader = use_dev_reader ? std::thread([&]() {
+    auto tr0 = now();
+    struct Clock { double &t; std::chrono::steady_clock::time_point t0; ~Clock() { t = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } clock{t_dev_reader, tr0};
+    int rrc = br_bam_reader_new(o.devices[0], (int32_t)hdr.ref_names.size(), (uint64_t)pos, &dev_reader);
+    if (!rrc) rrc = br_bam_reader_set_piece_blocks(dev_reader, std::max<int64_t>(1, std::min<int64_t>(o.bundle_records * 3 / 1000, 8192)));
+    const uint8_t *file = rd.mapped(); const uint64_t size = rd.mapped_size();
+    uint64_t at = 0;
+    while (!rrc && at < size && !cancel) {
+      auto b = std::make_unique<DevBundle>();
+      uint64_t used = 0; int64_t unm = 0;
+      rrc = br_bam_reader_next(dev_reader, file + at, size - at, 1, &used, &b->recs, &b->id, &unm);
+      if (rrc) break;
+      if (used == 0 && b->id < 0) { rrc = BR_ERR_INVALID_ARG; break; }
+      at += used;
+      total_reads += (uint64_t)(b->recs.n_aln + unm); unmapped_reads += (uint64_t)unm;
+      if (b->id < 0) continue;
+      if (b->recs.n_aln == 0) { (void)br_bam_reader_release(dev_reader, b->id); continue; }
+      b->seq = next_seq++;
+      to_dev.put(std::move(b));
+    }
+    if (rrc) reader_err = std::string("malformed or truncated BAM file (") + br_strerror(rrc) + ")";
+    to_dev.finish();
+  }) : std::thread([&]() {
     buf.erase_front(pos); pos = 0;
     std::vector<uint64_t> off; std::vector<uint32_t> len;
     bool eof = false;
@@ -397,7 +431,7 @@ extern "C" int br_cli_main(int argc, char **argv) {
   });
 
   // the reader is already inflating while the guides are parsed and the indexes are built
-  auto stop_reader = [&]() -> int { cancel = true; while (to_gpu.take()) {} reader.join(); return 1; };
+  auto stop_reader = [&]() -> int { cancel = true; while (to_gpu.take()) {} while (to_dev.take()) {} reader.join(); if (dev_reader) br_bam_reader_free(dev_reader); dev_reader = nullptr; return 1; };
   br_annotation *ann = nullptr;
   int rc = br_annotation_load_mt(o.gff.c_str(), std::max(1, std::min(o.threads, 32)), &ann);   // the lines are taken apart by -p threads
   const double t_guides = since();
@@ -515,6 +549,33 @@ extern "C" int br_cli_main(int argc, char **argv) {
     }
   });
 
+  if (use_dev_reader) {
+    // one worker, no uploader: the bundles are in HBM already
+    Worker *w = workers[0].get();
+    w->runner = std::thread([&, w]() {
+      for (;;) {
+        auto tw0 = now();
+        auto b = to_dev.take();
+        w->t_wait_in += secs(tw0, now());
+        if (!b) break;
+        br_host_bam hb;
+        memset(&hb, 0, sizeof(hb));
+        if (!fail) {
+          { std::unique_lock<std::mutex> l(w->done_m); w->done_cv.wait(l, [&] { return w->written + 2 > w->produced || fail; }); }
+          auto t0 = now();
+          int prc2 = fail ? 0 : br_project_bam_resident(w->ctx, &o.cfg, &b->recs, ref_map.data(), (int32_t)ref_map.size(), o.device_deflate ? 1 : 0, 1, &hb);
+          w->gpu_seconds += secs(t0, now());
+          if (prc2) { fprintf(stderr, "error: projection failed on device %d: %s\n", w->device, br_strerror(prc2)); raise_fail(); }
+        }
+        (void)br_bam_reader_release(dev_reader, b->id);
+        if (fail) continue;  // drain
+        w->total_complete += hb.total_complete; w->total_unique += hb.total_unique; w->dropped += hb.dropped_reads; w->n_bundles++;
+        { std::lock_guard<std::mutex> l(w->done_m); w->produced++; }
+        { std::lock_guard<std::mutex> l(out_m); out_map[b->seq] = OutChunk{hb.data, hb.n_bytes, w->id}; }
+        out_cv.notify_all();
+      }
+    });
+  } else
   for (auto &wp : workers) {
     Worker *w = wp.get();
     // uploader: stages bundle k of this worker into device slot k % 3 on the context's copy stream while the runner
@@ -567,7 +628,7 @@ extern "C" int br_cli_main(int argc, char **argv) {
       }
     });
   }
-  for (auto &w : workers) { w->uploader.join(); w->runner.join(); }
+  for (auto &w : workers) { if (w->uploader.joinable()) w->uploader.join(); if (w->runner.joinable()) w->runner.join(); }
   { std::lock_guard<std::mutex> l(out_m); out_done = true; }
   out_cv.notify_all();
   reader.join(); writer.join();
@@ -592,7 +653,7 @@ extern "C" int br_cli_main(int argc, char **argv) {
   // the command line's process ends here: handing tens of gigabytes of device and pinned memory back piece by piece is
   // 0.12-0.16 s that the process exit does for nothing (bramble-cli keeps its index in a ManuallyDrop for the same reason,
   // bramble-cli/src/main.rs:56-60); a host that calls br_cli_main as a function sets BRAMBLE_AMD_CLI_CLEANUP=1
-  if (getenv("BRAMBLE_AMD_CLI_CLEANUP")) free_all();
+  if (getenv("BRAMBLE_AMD_CLI_CLEANUP")) { free_all(); if (dev_reader) br_bam_reader_free(dev_reader); dev_reader = nullptr; }
   double t_freed = since();
   if (!o.quiet) {  // src/bramble.cpp:727-736
     printf("\n[bramble] final report:\n");
@@ -614,7 +675,8 @@ extern "C" int br_cli_main(int argc, char **argv) {
       fclose(f);
     }
   }
-  if (getenv("BRAMBLE_AMD_TIMING")) fprintf(stderr, "[bramble] reader thread: %.2fs in all, %.2fs reserving buffers, %.2fs waiting for a free queue slot\n", t_reader, t_reserve, t_put);
+  if (getenv("BRAMBLE_AMD_TIMING") && use_dev_reader) fprintf(stderr, "[bramble] device reader thread (upload of the compressed file, inflate, record split, cuts): %.2fs in all\n", t_dev_reader);
+  if (getenv("BRAMBLE_AMD_TIMING") && !use_dev_reader) fprintf(stderr, "[bramble] reader thread: %.2fs in all, %.2fs reserving buffers, %.2fs waiting for a free queue slot\n", t_reader, t_reserve, t_put);
   // the unwinding below this line (record buffers, worker contexts, reader and writer pools) was 0.5 s of a 1.9 s run
   if (g_exit_at_end.load() && !getenv("BRAMBLE_AMD_CLI_CLEANUP")) {   // (tools that write their results from exit handlers -- a profiler -- ask for the clean return)
     if (getenv("BRAMBLE_AMD_TIMING")) { struct timespec t; clock_gettime(CLOCK_REALTIME, &t); fprintf(stderr, "[bramble] leaving at %.3f\n", (double)t.tv_sec + 1e-9 * (double)t.tv_nsec); }

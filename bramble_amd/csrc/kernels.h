@@ -300,6 +300,7 @@ struct SplitArgs {
   uint64_t *totals;                        // [0] unmapped records, [1] bytes consumed
 };
 void launch_split_guess(hipStream_t st, const SplitArgs &S);
+void launch_split_spoil(hipStream_t st, const SplitArgs &S, int k);
 void launch_split_walk(hipStream_t st, const SplitArgs &S, const uint32_t *redo);
 void launch_split_check(hipStream_t st, const SplitArgs &S, uint32_t *redo);
 void launch_split_emit(hipStream_t st, const SplitArgs &S);

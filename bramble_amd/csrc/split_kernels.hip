@@ -50,6 +50,7 @@ __global__ void __launch_bounds__(64) k_split_guess(SplitArgs S) {
   for (uint64_t p = lo; p < hi && p + 36 <= S.n_bytes; p++) {
     if (!plausible(S, p)) continue;
     const uint64_t p1 = p + 4 + sl32(S.data + p);
+    if (p1 > S.n_bytes) continue;   // a record that does not fit: only the chain's very last record may look like that, and the check finds that one
     bool ok = true;
     if (p1 + 36 <= S.n_bytes) {
       ok = plausible(S, p1);
@@ -110,8 +111,10 @@ __global__ void __launch_bounds__(64) k_split_check(SplitArgs S, uint32_t *redo)
     const uint64_t lo = (uint64_t)s * S.seg_bytes, hi = lo + S.seg_bytes < S.n_bytes ? lo + S.seg_bytes : S.n_bytes;
     int64_t t = s - 1;
     while (t > 0 && S.entry[t] == ~0ull) t--;                 // (segment 0 always has an entry)
+    // (the chain arrives in a segment between t and s that has no entry yet -- one that is being repaired: s keeps what it has
+    // until that one has walked)
     uint64_t want = ~0ull;
-    if (!S.ended[t]) { const uint64_t e = S.exit_[t]; if (e >= lo && e < hi) want = e; }
+    if (!S.ended[t]) { const uint64_t e = S.exit_[t]; if (e >= lo && e < hi) want = e; else if (e < lo) want = S.entry[s]; }
     S.entry_next[s] = want;
     if (S.entry[s] != want) { changed = 1; atomicAdd(S.flags + 1, 1u); }
   } else S.entry_next[0] = 0;
@@ -178,6 +181,17 @@ void launch_last_group(hipStream_t st, const uint8_t *data, const uint64_t *rec_
 void launch_unmapped_before(hipStream_t st, const SplitArgs &S, uint64_t limit, unsigned long long *out) {
   hipLaunchKernelGGL(k_unmapped_before, dim3((unsigned)((S.n_seg + 255) / 256)), dim3(256), 0, st, S, limit, out);
 }
+
+// test hook (BRAMBLE_AMD_SPLIT_SPOIL=k): wrong guesses on purpose -- every k-th segment forgets its entry, the segments in
+// between every 2k-th take a byte offset that starts no record, runs of them included -- so that the check / repair passes
+// are exercised on data whose honest guesses are all right
+__global__ void __launch_bounds__(64) k_split_spoil(SplitArgs S, int k) {
+  const int64_t s = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (s < 1 || s >= S.n_seg) return;
+  if (s % k == 0) S.entry[s] = ~0ull;
+  else if (s % (2 * k) < 4 && S.entry[s] != ~0ull && S.entry[s] + 40 < S.n_bytes) S.entry[s] += 1 + (uint64_t)(s % 3);
+}
+void launch_split_spoil(hipStream_t st, const SplitArgs &S, int k) { if (k > 0) hipLaunchKernelGGL(k_split_spoil, dim3((unsigned)((S.n_seg + 63) / 64)), dim3(64), 0, st, S, k); }
 
 void launch_split_guess(hipStream_t st, const SplitArgs &S) { hipLaunchKernelGGL(k_split_guess, dim3((unsigned)((S.n_seg + 63) / 64)), dim3(64), 0, st, S); }
 void launch_split_walk(hipStream_t st, const SplitArgs &S, const uint32_t *redo) { hipLaunchKernelGGL(k_split_walk, dim3((unsigned)((S.n_seg + 63) / 64)), dim3(64), 0, st, S, redo); }

@@ -127,7 +127,8 @@ def test_cli_result_does_not_depend_on_bundle_size(tmp_path):
     in_bam = str(tmp_path / "in.bam")
     bamio.write_bam(in_bam, "@HD\tVN:1.6\n", bam_refs, stream.tobytes())
     outs = []
-    for k, (bundle, extra) in enumerate(((1, ["--host-deflate"]), (777, ["--compression-level", "1"]), (10 ** 7, []), (900, ["--device-deflate"]))):
+    for k, (bundle, extra) in enumerate(((1, ["--host-deflate", "--host-reader"]), (777, ["--compression-level", "1"]), (10 ** 7, []), (900, ["--device-deflate"]),
+                                         (1200, ["--device-reader"]), (40, ["--device-reader", "--compression-level", "1"]), (10 ** 7, ["--device-reader"]))):
         out_bam = str(tmp_path / ("o%d.bam" % k))
         r = subprocess.run([BIN, in_bam, "-G", gtf, "-o", out_bam, "-p", "2", "--bundle-size", str(bundle), "--quiet",
                             "--strict", "--max-soft-clip", "3"] + extra, capture_output=True, text=True, timeout=600)
@@ -138,6 +139,8 @@ def test_cli_result_does_not_depend_on_bundle_size(tmp_path):
     assert len(outs[0]) > 100000
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
     assert np.array_equal(outs[0], outs[3])   # BGZF blocks made on the device hold the same stream
+    for k in (4, 5, 6):                       # inflate, record split and bundle cuts on the device (br_bam_reader): the same stream
+        assert np.array_equal(outs[0], outs[k]), k
 
 
 def test_cli_reads_stdin_and_writes_stdout(tmp_path):
@@ -170,12 +173,13 @@ def test_cli_empty_and_all_unmapped_inputs(tmp_path):
     for label, stream in (("empty", b""), ("unmapped", unmapped)):
         in_bam, out_bam = str(tmp_path / (label + ".bam")), str(tmp_path / (label + ".out.bam"))
         bamio.write_bam(in_bam, "@HD\tVN:1.6\n@SQ\tSN:chr1\tLN:10000\n", refs, stream)
-        r = subprocess.run([BIN, in_bam, "-G", gtf, "-o", out_bam], capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr
-        text, orefs, recs = bamio.read_bam(out_bam)
-        assert orefs == [("t1", 491)] and recs.size == 0
-        assert "# input alignments:   %d" % (0 if label == "empty" else 10) in r.stdout
-        assert "# unmapped reads:     %d" % (0 if label == "empty" else 10) in r.stdout
+        for reader in ("--host-reader", "--device-reader"):
+            r = subprocess.run([BIN, in_bam, "-G", gtf, "-o", out_bam, reader], capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr
+            text, orefs, recs = bamio.read_bam(out_bam)
+            assert orefs == [("t1", 491)] and recs.size == 0
+            assert "# input alignments:   %d" % (0 if label == "empty" else 10) in r.stdout, reader
+            assert "# unmapped reads:     %d" % (0 if label == "empty" else 10) in r.stdout, reader
 
 
 def test_cli_errors(tmp_path):
@@ -236,7 +240,8 @@ def test_cli_failed_run_leaves_no_output_file(tmp_path):
     for k in range(8):
         raw[at + k] ^= 0x5a
     open(in_bam, "wb").write(bytes(raw))
-    r = subprocess.run([BIN, in_bam, "-G", gtf, "-o", out_bam, "-p", "2", "--bundle-size", "500", "--devices", "0,0"],
-                       capture_output=True, text=True, timeout=600)
-    assert r.returncode != 0 and "error" in r.stderr
-    assert not os.path.exists(out_bam) and not os.path.exists(out_bam + ".tmp-bramble")
+    for extra in (["--devices", "0,0"], ["--device-reader"]):     # the host reader (two workers); the device reader
+        r = subprocess.run([BIN, in_bam, "-G", gtf, "-o", out_bam, "-p", "2", "--bundle-size", "500"] + extra,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode != 0 and "error" in r.stderr, extra
+        assert not os.path.exists(out_bam) and not os.path.exists(out_bam + ".tmp-bramble")

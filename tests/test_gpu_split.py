@@ -218,3 +218,26 @@ def test_reader_refuses_truncated_and_corrupt_files():
     assert _read_all(L, cut, 3, len(header), 3072, 1 << 30)[0] != 0                                          # ends inside a record
     bad = bytearray(raw); bad[200] ^= 0x40
     assert _read_all(L, bytes(bad), 3, len(header), 3072, 1 << 30)[0] != 0                                   # a flipped bit
+
+
+def test_wrong_guesses_are_repaired(monkeypatch):
+    """BRAMBLE_AMD_SPLIT_SPOIL (test hook): after the honest guesses, every k-th segment forgets its entry and others take
+    an offset that starts no record (runs of up to four in a row): whatever the walk from there does -- stops at once as
+    malformed, runs off as a huge record, or happens to meet the chain again -- the check / repair passes must end with the
+    host's result."""
+    idx, ctx = _ctx()
+    stream = records_stream(6000, 21)
+    rng = np.random.RandomState(6)
+    recs = bamio.split_stream(stream)
+    big = [bamio.bam_record(b"long%d" % k, 1, 500 + k, [(70000 << 4) | 0], 70000, seq=rng.randint(0, 256, size=35000).astype(np.uint8).tobytes(),
+                            qual=rng.randint(0, 42, size=70000).astype(np.uint8).tobytes()) for k in range(3)]
+    mixed = recs[:4000] + big[:1] + recs[4000:9000] + big[1:] + recs[9000:]
+    stream2 = bamio.frame(mixed)
+    for k in (1, 2, 3, 5, 17):
+        monkeypatch.setenv("BRAMBLE_AMD_SPLIT_SPOIL", str(k))
+        check(ctx, stream)
+        check(ctx, stream2)
+        check(ctx, stream2[:stream2.size - 9999])
+    monkeypatch.delenv("BRAMBLE_AMD_SPLIT_SPOIL")
+    check(ctx, stream2)
+    ctx.close(); idx.close()
