@@ -254,7 +254,26 @@ def main():
             while key in res:
                 key += "'"
             ru1 = resource.getrusage(resource.RUSAGE_CHILDREN)
-            res[key] = {"wall_s": round(wall, 2), "user_s": round(ru1.ru_utime - ru0.ru_utime, 2), "sys_s": round(ru1.ru_stime - ru0.ru_stime, 2),
+            import xxhash
+            hx = xxhash.xxh64()
+            with open(out_bam, "rb") as fh:
+                for blk in iter(lambda: fh.read(1 << 24), b""):
+                    hx.update(blk)
+            rec_hash = None
+            if os.environ.get("CLI_VERIFY"):   # the inflated record stream (whatever the bundle cuts and the BGZF framing were)
+                L.br_bgzf_read_file.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+                L.br_free_buffer.argtypes = [C.c_void_p]
+                pp, nn = C.c_void_p(), C.c_uint64()
+                assert L.br_bgzf_read_file(out_bam.encode(), args.threads, C.byref(pp), C.byref(nn)) == 0
+                view = (C.c_uint8 * nn.value).from_address(pp.value)
+                hr = xxhash.xxh64()
+                mv = memoryview(view)
+                for q in range(0, nn.value, 1 << 26):
+                    hr.update(mv[q:q + (1 << 26)])
+                rec_hash = hr.hexdigest()
+                del mv, view
+                L.br_free_buffer(pp)
+            res[key] = {"out_xxh64": hx.hexdigest(), "inflated_xxh64": rec_hash, "wall_s": round(wall, 2), "user_s": round(ru1.ru_utime - ru0.ru_utime, 2), "sys_s": round(ru1.ru_stime - ru0.ru_stime, 2),
                         "max_rss_gb": round(ru1.ru_maxrss / 1048576.0, 2), "alignments_per_s": len(rlen) / wall, "out_bam_bytes": os.path.getsize(out_bam),
                                        "report": " | ".join(tail)}
         print(json.dumps({"config": "cli", "workload": "%d paired-end alignments, BAM file -> BAM file, -p %d, GENCODE-shaped GTF (%d transcripts)" % (len(rlen), args.threads, len(annd["transcripts"])),

@@ -291,6 +291,7 @@ extern "C" int br_cli_main(int argc, char **argv) {
   struct DevBundle { br_device_records recs; int64_t id; uint64_t seq; };
   Slot<DevBundle> to_dev(64);
   br_bam_reader *dev_reader = nullptr;
+  if (o.device_reader < 0) if (const char *e = getenv("BRAMBLE_AMD_DEVICE_READER")) o.device_reader = atoi(e) != 0;   // (A/B with one command line: the @PG line quotes it)
   const bool use_dev_reader = o.device_reader != 0 && o.devices.size() == 1 && rd.mapped() && (o.device_reader > 0 || rd.mapped_size() >= (1u << 20));
   double t_dev_reader = 0;
   std::thread reader = use_dev_reader ? std::thread([&]() {

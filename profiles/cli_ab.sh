@@ -11,5 +11,5 @@ d = json.loads(open(sys.argv[1]).read())
 for k, v in d["results"].items():
     rep = v["report"]
     inside = rep.split("summed), ")[1].split("s wall")[0]
-    print("%-60s wall %.2f s  inside %s s  user %.2f  sys %.2f  |%s" % (k, v["wall_s"], inside, v["user_s"], v["sys_s"], rep.split("stage busy time:")[1][:140]))
+    print("%-60s wall %.2f s  inside %s s  user %.2f  sys %.2f  out %s |%s" % (k, v["wall_s"], inside, v["user_s"], v["sys_s"], v.get("out_xxh64", "")[:8], rep.split("stage busy time:")[1][:140]))
 PY
