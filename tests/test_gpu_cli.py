@@ -59,7 +59,8 @@ def tx_len(tx):
     return sum(e - s for s, e in tx["exons"])
 
 
-def test_cli_short_reads_header_and_records(tmp_path):
+@pytest.mark.parametrize("reader", ["--host-reader", "--device-reader"])
+def test_cli_short_reads_header_and_records(tmp_path, reader):
     ann = synth.Annotation("G", n_genes=1200, n_refs=5)
     annd = ann.as_dict()
     b = ann.reads(8000, "pe", with_records=1, xs_tag=True)
@@ -72,7 +73,7 @@ def test_cli_short_reads_header_and_records(tmp_path):
     bam_refs[5] = ("chrUn_extra", 500)
     in_header = "@HD\tVN:1.6\tSO:unsorted\tGO:query\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % r for r in bam_refs) + \
         "@RG\tID:rg1\tSM:s\n@PG\tID:aligner\tPN:aligner\tVN:2.1\n@PG\tID:sorter\tPN:sorter\tPP:aligner\n@CO\tuser comment\n"
-    text, refs, got, orc, sorted_ann, out, gtf, n_un, n_rec = run_cli(tmp_path, annd, remap_refs(stream, perm), bam_refs, [], {}, in_header)
+    text, refs, got, orc, sorted_ann, out, gtf, n_un, n_rec = run_cli(tmp_path, annd, remap_refs(stream, perm), bam_refs, [reader], {}, in_header)
     # header: @HD first, one @SQ per transcript in guide order, the other input lines, the chained @PG, the @CO
     lines = text.rstrip("\n").split("\n")
     assert lines[0] == "@HD\tVN:1.6\tSO:unsorted\tGO:query"
@@ -92,7 +93,8 @@ def test_cli_short_reads_header_and_records(tmp_path):
     assert "# dropped alignments: %d" % orc["dropped_reads"] in out
 
 
-def test_cli_long_reads_with_genome(tmp_path):
+@pytest.mark.parametrize("reader", ["--host-reader", "--device-reader"])
+def test_cli_long_reads_with_genome(tmp_path, reader):
     ann = synth.Annotation("G", n_genes=300, n_refs=2, with_genome=True)
     annd = ann.as_dict()
     b = ann.reads(3000, "ont", with_seq=1, with_records=1)
@@ -108,7 +110,7 @@ def test_cli_long_reads_with_genome(tmp_path):
                 f.write(seq[a:a + 70] + "\n")
     bam_refs = [(n, len(annd["ref_seqs"][i])) for i, n in enumerate(annd["refnames"])]
     in_header = "".join("@SQ\tSN:%s\tLN:%d\n" % r for r in bam_refs)   # no @HD, no @PG
-    text, refs, got, orc, sorted_ann, out, gtf, _, _ = run_cli(tmp_path, annd, stream, bam_refs, ["--lr"], {"lr": 1, "use_fasta": 1},
+    text, refs, got, orc, sorted_ann, out, gtf, _, _ = run_cli(tmp_path, annd, stream, bam_refs, ["--lr", reader], {"lr": 1, "use_fasta": 1},
                                                              in_header, fasta=fasta, bundle=700)
     lines = text.rstrip("\n").split("\n")
     assert lines[0].startswith("@SQ\tSN:") and lines[-2].startswith("@PG\tID:bramble\tPN:bramble\tVN:") and lines[-1].startswith("@CO\t")
