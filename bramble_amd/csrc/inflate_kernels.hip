@@ -114,11 +114,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     uint4 ahead = load_chunk(2);
     __builtin_amdgcn_wave_barrier();
 
-    uint64_t bb = 0; uint32_t bc = 0, ip = 0;                 // bit buffer, bits in it, bytes taken from the ring
+    // bit buffer: the next bc (<= 128) bits of the stream in bh:bb, ip = bytes taken from the ring.  After refill() more than
+    // 96 are there: a whole token (<= 48 bits) at each of the first 48 bit offsets, for the lanes that decode ahead
+    uint64_t bb = 0, bh = 0; uint32_t bc = 0, ip = 0;
     auto refill = [&]() {
-      if (bc <= 32u) {
-        const uint32_t w = uni(W.in[(ip >> 2) & (IN_RING_DW - 1u)]);
-        bb |= (uint64_t)w << bc; bc += 32u; ip += 4u;
+      while (bc <= 96u) {
+        const uint64_t w = (uint64_t)uni(W.in[(ip >> 2) & (IN_RING_DW - 1u)]);
+        if (bc < 64u) { bb |= w << bc; if (bc > 32u) bh |= w >> (64u - bc); }
+        else bh |= w << (bc - 64u);
+        bc += 32u; ip += 4u;
         if ((ip & (IN_CHUNK - 1u)) == 0u) {                   // entering chunk k: chunk k - 1's half takes chunk k + 1, k + 2 is asked for
           const uint32_t k = ip / IN_CHUNK;
           __builtin_amdgcn_wave_barrier();
@@ -128,12 +132,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
         }
       }
     };
-    auto bits = [&](uint32_t n) { const uint32_t v = (uint32_t)bb & ((1u << n) - 1u); bb >>= n; bc -= n; return v; };
+    auto consume = [&](uint32_t n) {                          // n <= bc
+      if (n >= 64u) { bb = bh >> (n - 64u); bh = 0; }
+      else if (n) { bb = (bb >> n) | (bh << (64u - n)); bh >>= n; }
+      bc -= n;
+    };
+    auto bits = [&](uint32_t n) { const uint32_t v = (uint32_t)bb & ((1u << n) - 1u); consume(n); return v; };
     // a code longer than the primary table (or an unused entry): bit by bit against the canonical counts
     auto slow = [&](const uint16_t *cnt, const uint16_t *sorted) -> int {
       uint32_t code = 0, first = 0, index = 0;
       for (int l = 1; l <= 15; l++) {
-        code |= (uint32_t)bb & 1u; bb >>= 1; bc -= 1u;
+        code |= (uint32_t)bb & 1u; consume(1u);
         const uint32_t count = uni(cnt[l]);
         if (code < first + count) return (int)uni(sorted[index + (code - first)]);
         index += count; first += count; first <<= 1; code <<= 1;
@@ -172,7 +181,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
         if ((len ^ nlen) != 0xffffu || pos + len > ulen) { bad = true; break; }
         // bytes still in the bit buffer first, then straight from the source
         uint32_t done = 0;
-        while (done < len && bc >= 8u) { if (lane == 0) win8[(pos + done) & (OUT_WIN - 1u)] = (uint8_t)bb; bb >>= 8; bc -= 8u; done++; }
+        while (done < len && bc >= 8u) { if (lane == 0) win8[(pos + done) & (OUT_WIN - 1u)] = (uint8_t)bb; consume(8u); done++; }
         // (bc is 0 here unless len ran out: the ring position ip is the next source byte)
         for (uint32_t base = done; base < len; base += 64u) {
           const uint32_t i = base + (uint32_t)lane;
@@ -192,7 +201,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
           __builtin_amdgcn_wave_barrier();
           put_chunk(k, load_chunk(k)); put_chunk(k + 1u, load_chunk(k + 1u)); ahead = load_chunk(k + 2u);
           __builtin_amdgcn_wave_barrier();
-          bb = 0; bc = 0;
+          bb = 0; bh = 0; bc = 0;
           refill();
           bits(8u * (np & 3u));
         }
@@ -226,7 +235,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
           refill();
           int sym;
           const uint32_t e = uni(W.lut_d[(uint32_t)bb & 127u]);
-          if (e >> 5) { sym = (int)(e & 31u); bb >>= (e >> 5); bc -= (e >> 5); } else sym = slow(W.cnt_d, W.sorted_d);
+          if (e >> 5) { sym = (int)(e & 31u); consume(e >> 5); } else sym = slow(W.cnt_d, W.sorted_d);
           if (sym < 0 || sym > 18) { bad = true; break; }
           if (sym < 16) { if (lane == 0) W.lens[i] = (uint8_t)sym; i++; __builtin_amdgcn_wave_barrier(); continue; }
           uint32_t rep, val = 0;
@@ -252,17 +261,40 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
       if (!build_tables(W, W.lens + 288, n_d, W.cnt_d, W.sorted_d, W.lut_d, D_BITS, 5, lane)) { bad = true; break; }
 
       // ---- symbols
+      bool in_run = false;                                      // the last token was a literal: the next ones probably are
       for (;;) {
         refill();
+        if (in_run) {
+          // A run of literals at once: lane i decodes the code that would start at bit offset i of the buffer (one LDS gather),
+          // the chain of real starts is followed from offset 0 through the lanes (a v_readlane and an add per literal where
+          // the serial path needs a broadcast LDS read and ~25 scalar instructions), and the lanes on the chain store their bytes.
+          uint64_t v = bb >> (uint32_t)lane;
+          if (lane) v |= bh << (64u - (uint32_t)lane);
+          const uint32_t el = W.lut_ll[(uint32_t)v & ((1u << LL_BITS) - 1u)];
+          const uint32_t l1 = el >> 9, sy = el & 511u;
+          const uint64_t lit = __ballot(l1 != 0u && sy < 256u);
+          const uint32_t lim = bc - 16u < 64u ? bc - 16u : 64u, room = ulen - pos;   // a code must lie inside the buffer; the block's bytes are counted
+          uint64_t sel = 0; uint32_t at = 0, n_lit = 0;
+          while (at < lim && ((lit >> at) & 1ull) && n_lit < room) { sel |= 1ull << at; at += (uint32_t)__builtin_amdgcn_readlane((int)l1, (int)at); n_lit++; }
+          if (n_lit) {
+            if ((sel >> lane) & 1ull) win8[(pos + (uint32_t)__builtin_popcountll(sel & ((1ull << lane) - 1ull))) & (OUT_WIN - 1u)] = (uint8_t)sy;
+            pos += n_lit;
+            consume(at);
+            if ((pos & ~(OUT_PIECE - 1u)) > flushed) flush_to(pos & ~(OUT_PIECE - 1u));
+            continue;
+          }
+          in_run = false;
+        }
         int sym;
         const uint32_t e = uni(W.lut_ll[(uint32_t)bb & ((1u << LL_BITS) - 1u)]);
-        if (e >> 9) { sym = (int)(e & 511u); bb >>= (e >> 9); bc -= (e >> 9); } else sym = slow(W.cnt_ll, W.sorted_ll);
+        if (e >> 9) { sym = (int)(e & 511u); consume(e >> 9); } else sym = slow(W.cnt_ll, W.sorted_ll);
         if (sym < 0 || sym > 285) { bad = true; break; }
         if (sym < 256) {
           if (pos >= ulen) { bad = true; break; }
           if (lane == 0) win8[pos & (OUT_WIN - 1u)] = (uint8_t)sym;
           pos++;
           if ((pos & (OUT_PIECE - 1u)) == 0u) flush_to(pos);   // every finished piece leaves at once: the window never holds more than a piece + a match of unsent bytes
+          in_run = true;
           continue;
         }
         if (sym == 256) break;
@@ -275,7 +307,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
         refill();
         int ds;
         const uint32_t ed = uni(W.lut_d[(uint32_t)bb & ((1u << D_BITS) - 1u)]);
-        if (ed >> 5) { ds = (int)(ed & 31u); bb >>= (ed >> 5); bc -= (ed >> 5); } else ds = slow(W.cnt_d, W.sorted_d);
+        if (ed >> 5) { ds = (int)(ed & 31u); consume(ed >> 5); } else ds = slow(W.cnt_d, W.sorted_d);
         if (ds < 0 || ds > 29) { bad = true; break; }
         uint32_t dist;
         if (ds < 4) dist = (uint32_t)ds + 1u;
