@@ -3,11 +3,12 @@
 //
 // k_inflate: one wave per BGZF block (persistent waves taking blocks off one counter).  A BGZF block is a complete DEFLATE
 // stream of at most 64 KiB (RFC 1951: stored, fixed and dynamic blocks, several per stream).  Symbol decoding is a serial
-// chain: every lane of the wave runs the same chain on wave-uniform values (broadcast LDS reads), and the parallelism is
-// across blocks -- a 3 GB file is 50 000 of them.  The lanes work together where there is width: the compressed bytes come
+// chain: every lane of the wave runs the same chain on wave-uniform values (broadcast LDS reads) -- except behind a literal,
+// where the lanes decode the codes at every bit offset of the buffer and the run of literals is taken in one go -- and the
+// parallelism is across blocks: a 3 GB file is 50 000 of them.  The lanes work together where there is width: the compressed bytes come
 // in through a 2 KiB LDS ring (one coalesced 1 KiB load ahead of the decoder), the decode tables (10-bit primary table for
 // literal/length codes, 8-bit for distances, canonical count arrays for the longer codes) are built by all lanes, a match
-// is copied by as many lanes as it has bytes, the output leaves through an 8 KiB LDS window in coalesced 1 KiB pieces
+// is copied by as many lanes as it has bytes, the output leaves through a 4 KiB LDS window in coalesced 1 KiB pieces
 // (matches that reach further back read the wave's own earlier output from HBM), and the CRC32 of the result is computed
 // over 64 lane-chunks and folded with a precomputed zero-append operator (as in codec_kernels.hip).
 #include <hip/hip_runtime.h>
