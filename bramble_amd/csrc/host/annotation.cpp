@@ -52,6 +52,7 @@ struct Tx {
   char strand = '.';
   uint32_t start = 0, end = 0;                   // feature line coordinates (used when exonless)
   bool has_line = false;
+  int ref_rank = 0;                              // place of the reference name in strcmp order (for the final sort)
   bool by_exon = false;                          // GffObj::createdByExon: the record began with an exon-like line (never cleared, gff.cpp:1486)
   uint32_t cur_start = 0;                        // GffObj::start while the file is read: what gfoFind measures the locus distance from
   int level = 0;                                 // GffObj::gff_level
@@ -391,9 +392,20 @@ extern "C" int br_annotation_load_mt(const char *path, int threads, br_annotatio
     order.push_back(&tx);
   }
   if (order.empty()) { fprintf(stderr, "[bramble_amd] could not find valid reference transcripts in %s\n", path); return BR_ERR_ANNOTATION; }
+  // (the references' strcmp order as a rank per transcript: 18 comparisons per transcript otherwise each start with a strcmp)
+  {
+    std::vector<std::string> sorted_refs(refnames);
+    std::sort(sorted_refs.begin(), sorted_refs.end(), [](const std::string &a, const std::string &b) { return strcmp(a.c_str(), b.c_str()) < 0; });
+    std::unordered_map<std::string, int> rank;
+    for (size_t k = 0; k < sorted_refs.size(); k++) rank.emplace(sorted_refs[k], (int)k);
+    const std::string *last = nullptr; int last_rank = 0;
+    for (Tx *tx : order) {
+      if (!last || *last != tx->seqname) { last = &tx->seqname; last_rank = rank[tx->seqname]; }
+      tx->ref_rank = last_rank;
+    }
+  }
   std::stable_sort(order.begin(), order.end(), [](const Tx *a, const Tx *b) {  // gfo_cmpByLoc
-    int c = strcmp(a->seqname.c_str(), b->seqname.c_str());
-    if (c) return c < 0;
+    if (a->ref_rank != b->ref_rank) return a->ref_rank < b->ref_rank;
     if (a->start != b->start) return a->start < b->start;
     if (a->level != b->level) return a->level < b->level;
     if (a->end != b->end) return a->end < b->end;
@@ -403,8 +415,9 @@ extern "C" int br_annotation_load_mt(const char *path, int threads, br_annotatio
   if (getenv("BRAMBLE_AMD_TIMING")) fprintf(stderr, "[annotation] sort %.3f\n", T_read);
   br_annotation *A = new br_annotation();
   A->refnames = refnames;
+  A->ids.reserve(order.size()); A->seqnames.reserve(order.size()); A->strands.reserve(order.size()); A->exons.reserve(order.size()); A->view.reserve(order.size());
   for (Tx *tx : order) {
-    A->ids.push_back(tx->id); A->seqnames.push_back(tx->seqname); A->strands.push_back(tx->strand);
+    A->ids.push_back(std::move(tx->id)); A->seqnames.push_back(std::move(tx->seqname)); A->strands.push_back(tx->strand);
     std::vector<br_exon> ex;
     for (auto &sg : tx->segs) ex.push_back({sg.first, sg.second + 1});
     A->exons.push_back(std::move(ex));
