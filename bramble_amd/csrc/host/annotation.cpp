@@ -307,84 +307,109 @@ extern "C" int br_annotation_load_mt(const char *path, int threads, br_annotatio
     }
   };
 
-  // the file in blocks of whole lines; a block's lines are taken apart by the worker threads, then applied in order
-  const size_t BLOCK = 64u << 20;
-  double T_read = 0, T_parse = 0, T_apply = 0; auto T0 = std::chrono::steady_clock::now();
-  auto lap = [&](double &acc) { auto n = std::chrono::steady_clock::now(); acc += std::chrono::duration<double>(n - T0).count(); T0 = n; };
-  std::string data, carry;
-  std::vector<std::vector<Rec>> recs((size_t)threads);
+  // The file in blocks of whole lines.  A block's lines are taken apart by the worker threads (produce, on a thread of its own:
+  // read, cut at "##FASTA", parse) while the lines of the block before it are applied, in order, by this one: what a line
+  // means depends on everything in front of it, so the applying stays serial -- it is the longer of the two.
+  const size_t BLOCK = 16u << 20;
+  double T_read = 0, T_parse = 0, T_apply = 0;
+  auto secs_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
+  struct Block { std::string data; std::vector<std::vector<Rec>> recs; bool any = false; };
+  Block blk[2];
+  for (auto &bk : blk) bk.recs.resize((size_t)threads);
+  std::string carry;
   bool eof = false, fasta = false;
-  while (!eof && !fasta) {
-    data.assign(carry); carry.clear();
-    const size_t had = data.size();
-    data.resize(had + BLOCK);
-    size_t got = 0;
-    while (got < BLOCK) {
-      const int n = gzread(f, &data[had + got], (unsigned)std::min<size_t>(BLOCK - got, 1u << 30));
-      if (n <= 0) { eof = true; break; }
-      got += (size_t)n;
-    }
-    data.resize(had + got);
-    if (!eof) {   // keep the unfinished last line for the next block
-      const size_t nl = data.rfind('\n');
-      if (nl == std::string::npos) { carry.swap(data); continue; }   // (a line longer than a block: read on)
-      carry.assign(data, nl + 1, std::string::npos);
-      data.resize(nl + 1);
-    }
-    if (data.empty()) break;
-    lap(T_read);
-    // "##FASTA" ends the annotation (the sequence section of a GFF3 file)
-    {
-      size_t p = 0;
-      while ((p = data.find("##FASTA", p)) != std::string::npos) {
-        const bool at_start = p == 0 || data[p - 1] == '\n';
-        size_t q = p + 7;
-        while (q < data.size() && data[q] == '\r') q++;
-        if (at_start && (q == data.size() || data[q] == '\n')) { data.resize(p); fasta = true; break; }
-        p += 7;
+  // fills B with the next block; B.any = false when the file has ended
+  auto produce = [&](Block &B) {
+    B.any = false;
+    std::string &data = B.data;
+    while (!eof && !fasta) {
+      auto t0 = std::chrono::steady_clock::now();
+      data.assign(carry); carry.clear();
+      const size_t had = data.size();
+      data.resize(had + BLOCK);
+      size_t got = 0;
+      while (got < BLOCK) {
+        const int n = gzread(f, &data[had + got], (unsigned)std::min<size_t>(BLOCK - got, 1u << 30));
+        if (n <= 0) { eof = true; break; }
+        got += (size_t)n;
       }
-    }
-    // thread t takes the lines that START in its slice of the block
-    const char *base = data.data(), *end = base + data.size();
-    std::vector<const char *> cut((size_t)threads + 1);
-    cut[0] = base; cut[(size_t)threads] = end;
-    for (int t = 1; t < threads; t++) {
-      const char *p = base + data.size() * (size_t)t / (size_t)threads;
-      if (p < cut[(size_t)t - 1]) p = cut[(size_t)t - 1];
-      while (p < end && p > base && p[-1] != '\n') p++;
-      cut[(size_t)t] = p;
-    }
-    auto work = [&](int t) {
-      std::vector<Rec> &v = recs[(size_t)t];
-      v.clear();
-      const char *p = cut[(size_t)t], *pe = cut[(size_t)t + 1];
-      while (p < pe) {
-        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
-        const char *le = nl ? nl + 1 : end;
-        Rec r;
-        parse_line(p, le, r);
-        if (r.state) v.push_back(r);
-        p = le;
+      data.resize(had + got);
+      if (!eof) {   // keep the unfinished last line for the next block
+        const size_t nl = data.rfind('\n');
+        if (nl == std::string::npos) { carry.swap(data); continue; }   // (a line longer than a block: read on)
+        carry.assign(data, nl + 1, std::string::npos);
+        data.resize(nl + 1);
       }
-    };
-    if (threads == 1) work(0);
-    else {
-      std::vector<std::thread> th;
-      for (int t = 1; t < threads; t++) th.emplace_back(work, t);
-      work(0);
-      for (auto &x : th) x.join();
-    }
-    lap(T_parse);
-    for (int t = 0; t < threads; t++)
-      for (const Rec &r : recs[(size_t)t]) {
-        if (r.state == 1) { gzclose(f); fprintf(stderr, "[bramble_amd] bad strand in annotation line\n"); return BR_ERR_ANNOTATION; }
-        apply(r);
+      if (data.empty()) return;
+      // "##FASTA" ends the annotation (the sequence section of a GFF3 file)
+      {
+        size_t p = 0;
+        while ((p = data.find("##FASTA", p)) != std::string::npos) {
+          const bool at_start = p == 0 || data[p - 1] == '\n';
+          size_t q = p + 7;
+          while (q < data.size() && data[q] == '\r') q++;
+          if (at_start && (q == data.size() || data[q] == '\n')) { data.resize(p); fasta = true; break; }
+          p += 7;
+        }
       }
-    lap(T_apply);
+      T_read += secs_since(t0); t0 = std::chrono::steady_clock::now();
+      // thread t takes the lines that START in its slice of the block
+      const char *base = data.data(), *end = base + data.size();
+      std::vector<const char *> cut((size_t)threads + 1);
+      cut[0] = base; cut[(size_t)threads] = end;
+      for (int t = 1; t < threads; t++) {
+        const char *p = base + data.size() * (size_t)t / (size_t)threads;
+        if (p < cut[(size_t)t - 1]) p = cut[(size_t)t - 1];
+        while (p < end && p > base && p[-1] != '\n') p++;
+        cut[(size_t)t] = p;
+      }
+      auto work = [&](int t) {
+        std::vector<Rec> &v = B.recs[(size_t)t];
+        v.clear();
+        const char *p = cut[(size_t)t], *pe = cut[(size_t)t + 1];
+        while (p < pe) {
+          const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+          const char *le = nl ? nl + 1 : end;
+          Rec r;
+          parse_line(p, le, r);
+          if (r.state) v.push_back(r);
+          p = le;
+        }
+      };
+      if (threads == 1) work(0);
+      else {
+        std::vector<std::thread> th;
+        for (int t = 1; t < threads; t++) th.emplace_back(work, t);
+        work(0);
+        for (auto &x : th) x.join();
+      }
+      T_parse += secs_since(t0);
+      B.any = true;
+      return;
+    }
+  };
+  {
+    int cur = 0;
+    produce(blk[0]);
+    while (blk[cur].any) {
+      std::thread next(produce, std::ref(blk[cur ^ 1]));
+      auto t0 = std::chrono::steady_clock::now();
+      bool bad_strand = false;
+      for (int t = 0; t < threads && !bad_strand; t++)
+        for (const Rec &r : blk[cur].recs[(size_t)t]) {
+          if (r.state == 1) { bad_strand = true; break; }
+          apply(r);
+        }
+      T_apply += secs_since(t0);
+      next.join();
+      if (bad_strand) { gzclose(f); fprintf(stderr, "[bramble_amd] bad strand in annotation line\n"); return BR_ERR_ANNOTATION; }
+      cur ^= 1;
+    }
   }
   gzclose(f);
   if (getenv("BRAMBLE_AMD_TIMING")) fprintf(stderr, "[annotation] read %.3f parse %.3f apply %.3f\n", T_read, T_parse, T_apply);
   // exonless transcripts get one exon over the feature; ids that only ever appeared as gene features are not transcripts
+  const auto t_sort0 = std::chrono::steady_clock::now();
   std::vector<Tx *> order;
   for (auto &tx : txs) {
     if (tx.segs.empty()) { if (!tx.has_line) continue; tx.segs.push_back({tx.start, tx.end}); }
@@ -411,8 +436,7 @@ extern "C" int br_annotation_load_mt(const char *path, int threads, br_annotatio
     if (a->end != b->end) return a->end < b->end;
     return strcmp(a->id.c_str(), b->id.c_str()) < 0;
   });
-  lap(T_read);
-  if (getenv("BRAMBLE_AMD_TIMING")) fprintf(stderr, "[annotation] sort %.3f\n", T_read);
+  if (getenv("BRAMBLE_AMD_TIMING")) fprintf(stderr, "[annotation] finish + sort %.3f\n", secs_since(t_sort0));
   br_annotation *A = new br_annotation();
   A->refnames = refnames;
   A->ids.reserve(order.size()); A->seqnames.reserve(order.size()); A->strands.reserve(order.size()); A->exons.reserve(order.size()); A->view.reserve(order.size());
