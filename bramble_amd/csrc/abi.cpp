@@ -5,6 +5,8 @@
 
 #include <algorithm>
 #include <chrono>
+#include <thread>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <atomic>
@@ -137,48 +139,78 @@ static int build_index_flat(size_t n_tx, const int32_t *tx_ref, const int8_t *tx
   }
   ix->tx_first.push_back((uint32_t)ix->tx_ex.size());
   for (int pad = 0; pad < 4; pad++) ix->tx_ex.push_back(make_uint4(0xffffffffu, 0xffffffffu, 0, 0));  // prefetch slack
-  ix->slab_off.push_back(0);
-  for (auto &rows : slabs) {
+  // The slabs (one per reference and strand) and the bucket tables (one per reference) are independent of each other: their
+  // places in the flat arrays are fixed first, then a few host threads sort and fill them side by side (the command line
+  // waits for this between the guide loader and the first bundle).
+  auto for_each_par = [](size_t n, const std::function<void(size_t)> &fn) {
+    unsigned hw = std::thread::hardware_concurrency();
+    const size_t nt = std::min<size_t>(n, std::max(1u, std::min(hw ? hw : 1u, 16u)));
+    if (nt <= 1) { for (size_t i = 0; i < n; i++) fn(i); return; }
+    std::atomic<size_t> next{0};
+    auto body = [&]() { for (;;) { const size_t i = next.fetch_add(1); if (i >= n) break; fn(i); } };
+    std::vector<std::thread> th;
+    for (size_t t = 1; t < nt; t++) th.emplace_back(body);
+    body();
+    for (auto &x : th) x.join();
+  };
+  ix->slab_off.assign(slabs.size() + 1, 0);
+  {
+    uint64_t tot = 0;
+    for (size_t k = 0; k < slabs.size(); k++) { tot += slabs[k].size(); if (tot >= 0xfffffff0ull) { delete ix; return BR_ERR_CAPACITY; } ix->slab_off[k + 1] = (uint32_t)tot; }
+    ix->s_start.resize((size_t)tot); ix->s_pmax.resize((size_t)tot); ix->s_tid.resize((size_t)tot); ix->s_row.resize((size_t)tot * 2);
+  }
+  for_each_par(slabs.size(), [&](size_t k) {
+    auto &rows = slabs[k];
     std::stable_sort(rows.begin(), rows.end(), [](const Row &a, const Row &b) { return a.start < b.start; });
     uint32_t m = 0;
+    size_t at = ix->slab_off[k];
     for (auto &r : rows) {
       m = std::max(m, r.end);
-      ix->s_start.push_back(r.start); ix->s_pmax.push_back(m);
+      ix->s_start[at] = r.start; ix->s_pmax[at] = m;
       // one 32-byte row = everything a candidate lane needs, in one 64-byte sector
-      ix->s_row.push_back(make_uint4(r.start, r.end, ix->tx_ex[ix->tx_first[r.tid] + r.gidx + 1].x /* sentinel start = ~0u */, r.pos_start));
+      ix->s_row[2 * at] = make_uint4(r.start, r.end, ix->tx_ex[ix->tx_first[r.tid] + r.gidx + 1].x /* sentinel start = ~0u */, r.pos_start);
       const uint32_t n_ex = ix->tx_first[r.tid + 1] - ix->tx_first[r.tid] - 1;  // rows of the transcript minus its sentinel
-      ix->s_row.push_back(make_uint4(r.tid, r.gidx | (n_ex > 256u ? 0x80000000u : 0u), ix->tx_first[r.tid], ix->tx_ex[ix->tx_first[r.tid] + r.gidx + 1].y /* next exon's end */));
-      ix->s_tid.push_back(r.tid);
+      ix->s_row[2 * at + 1] = make_uint4(r.tid, r.gidx | (n_ex > 256u ? 0x80000000u : 0u), ix->tx_first[r.tid], ix->tx_ex[ix->tx_first[r.tid] + r.gidx + 1].y /* next exon's end */);
+      ix->s_tid[at] = r.tid;
+      at++;
     }
-    ix->slab_off.push_back((uint32_t)ix->s_start.size());
-  }
+  });
   // bucket tables (replace the per-read binary search of the slab)
   const uint32_t SHIFT = 10;
-  ix->bin_off.push_back(0);
-  for (uint32_t r = 0; r < ix->n_refs; r++) {
-    uint64_t nb = 2;
-    for (int s = 0; s < 2; s++) {
-      uint32_t sb = ix->slab_off[2 * r + s], se = ix->slab_off[2 * r + s + 1];
-      if (se > sb) nb = std::max<uint64_t>(nb, ((uint64_t)std::max(ix->s_start[se - 1], ix->s_pmax[se - 1]) >> SHIFT) + 2);
+  std::vector<uint64_t> n_bins(ix->n_refs, 2);
+  ix->bin_off.assign((size_t)ix->n_refs + 1, 0);
+  {
+    uint64_t tot = 0;
+    for (uint32_t r = 0; r < ix->n_refs; r++) {
+      uint64_t nb = 2;
+      for (int sd = 0; sd < 2; sd++) {
+        uint32_t sb = ix->slab_off[2 * r + sd], se = ix->slab_off[2 * r + sd + 1];
+        if (se > sb) nb = std::max<uint64_t>(nb, ((uint64_t)std::max(ix->s_start[se - 1], ix->s_pmax[se - 1]) >> SHIFT) + 2);
+      }
+      n_bins[r] = nb;
+      tot += nb + 1;
+      if (tot >= 0xfffffff0ull) { delete ix; return BR_ERR_CAPACITY; }
+      ix->bin_off[r + 1] = (uint32_t)tot;
     }
-    const size_t first = ix->t_bin.size();
-    ix->t_bin.resize(first + nb + 1);
-    for (int s = 0; s < 2; s++) {
-      uint32_t sb = ix->slab_off[2 * r + s], se = ix->slab_off[2 * r + s + 1];
+    ix->t_bin.resize((size_t)tot);
+  }
+  for_each_par(ix->n_refs, [&](size_t r) {
+    const uint64_t nb = n_bins[r];
+    const size_t first = ix->bin_off[r];
+    for (int sd = 0; sd < 2; sd++) {
+      uint32_t sb = ix->slab_off[2 * r + sd], se = ix->slab_off[2 * r + sd + 1];
       uint32_t rh = sb, rl = sb;
-      for (uint64_t b = 0; b <= nb; b++) {
-        if (b < nb) {
-          uint64_t edge = b << SHIFT;
+      for (uint64_t bk = 0; bk <= nb; bk++) {
+        if (bk < nb) {
+          uint64_t edge = bk << SHIFT;
           while (rh < se && (uint64_t)ix->s_start[rh] < edge) rh++;
           while (rl < se && (uint64_t)ix->s_pmax[rl] <= edge) rl++;
         } else rh = rl = se;
-        uint4 &e = ix->t_bin[first + b];
-        if (s == 0) { e.x = rl; e.y = rh; } else { e.z = rl; e.w = rh; }
+        uint4 &e = ix->t_bin[first + bk];
+        if (sd == 0) { e.x = rl; e.y = rh; } else { e.z = rl; e.w = rh; }
       }
     }
-    if (ix->t_bin.size() >= 0xfffffff0ull) { delete ix; return BR_ERR_CAPACITY; }
-    ix->bin_off.push_back((uint32_t)ix->t_bin.size());
-  }
+  });
   ix->device = device;
   if (device >= 0) {
     int rc = check_device(device);
