@@ -266,6 +266,11 @@ extern "C" int br_cli_main(int argc, char **argv) {
   if (o.out_bam == "-") o.quiet = true;   // the BAM stream owns standard output
   if (!o.quiet) { printf("\n[bramble] starting version: %s (bramble_amd %s)\n", BRAMBLE_REF_VERSION, br_version()); printf("[bramble] loading reference annotation...\n"); }
 
+  // the guide loader starts first, on a thread of its own: opening the input, reading its header and starting the reader
+  // (below) happen beside it instead of in front of it
+  br_annotation *ann = nullptr;
+  std::future<int> ann_job = std::async(std::launch::async, [&]() { return br_annotation_load_mt(o.gff.c_str(), std::max(1, std::min(o.threads, 32)), &ann); });   // the lines are taken apart by -p threads
+  struct AnnJoin { std::future<int> &f; br_annotation *&a; ~AnnJoin() { if (f.valid()) { (void)f.get(); if (a) br_annotation_free(a); a = nullptr; } } } ann_join{ann_job, ann};   // (an early return: wait for it, drop its result)
   // the devices' first touch (runtime start-up, contexts) happens beside the guide parsing, not in front of the index build
   std::vector<std::thread> warm;
   for (int d : o.devices) warm.emplace_back([d]() { (void)br_device_warmup(d); });
@@ -433,8 +438,7 @@ extern "C" int br_cli_main(int argc, char **argv) {
 
   // the reader is already inflating while the guides are parsed and the indexes are built
   auto stop_reader = [&]() -> int { cancel = true; while (to_gpu.take()) {} while (to_dev.take()) {} reader.join(); if (dev_reader) br_bam_reader_free(dev_reader); dev_reader = nullptr; return 1; };
-  br_annotation *ann = nullptr;
-  int rc = br_annotation_load_mt(o.gff.c_str(), std::max(1, std::min(o.threads, 32)), &ann);   // the lines are taken apart by -p threads
+  int rc = ann_job.get();
   const double t_guides = since();
   if (rc) { fprintf(stderr, "error: could not load reference annotation %s: %s\n", o.gff.c_str(), br_strerror(rc)); return stop_reader(); }
   size_t n_tx = br_annotation_num_transcripts(ann), n_refs = br_annotation_num_refs(ann);
