@@ -657,8 +657,9 @@ extern "C" int br_cli_main(int argc, char **argv) {
   }
   // the command line's process ends here: handing tens of gigabytes of device and pinned memory back piece by piece is
   // 0.12-0.16 s that the process exit does for nothing (bramble-cli keeps its index in a ManuallyDrop for the same reason,
-  // bramble-cli/src/main.rs:56-60); a host that calls br_cli_main as a function sets BRAMBLE_AMD_CLI_CLEANUP=1
-  if (getenv("BRAMBLE_AMD_CLI_CLEANUP")) { free_all(); if (dev_reader) br_bam_reader_free(dev_reader); dev_reader = nullptr; }
+  // bramble-cli/src/main.rs:56-60).  That is the `bramble` binary (br_cli_exit_at_end); a host that calls br_cli_main as a
+  // function gets everything released, and so does a run under BRAMBLE_AMD_CLI_CLEANUP=1
+  if (!g_exit_at_end.load() || getenv("BRAMBLE_AMD_CLI_CLEANUP")) { free_all(); if (dev_reader) br_bam_reader_free(dev_reader); dev_reader = nullptr; }
   double t_freed = since();
   if (!o.quiet) {  // src/bramble.cpp:727-736
     printf("\n[bramble] final report:\n");

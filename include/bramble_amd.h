@@ -541,7 +541,8 @@ int br_cli_main(int argc, char **argv);
 /* For a process whose only job is that one call (the `bramble` binary): with `on` != 0 br_cli_main does not return after a
  * run that got as far as the final report -- the output file is closed and renamed, the streams are flushed, and the process
  * leaves through _exit(code) without unwinding gigabytes of record buffers, pinned memory and device allocations first
- * (bramble-cli/src/main.rs:56-60 keeps its index in a ManuallyDrop for the same reason).  Off by default. */
+ * (bramble-cli/src/main.rs:56-60 keeps its index in a ManuallyDrop for the same reason).  Off by default: a host that calls
+ * br_cli_main as a function gets every device and pinned allocation of the run released before the call returns. */
 void br_cli_exit_at_end(int on);
 /* First touch of a device (HIP runtime start-up, context creation): callable from a thread of its own so that it overlaps
  * other start-up work.  BR_ERR_NO_DEVICE when the device does not exist. */
