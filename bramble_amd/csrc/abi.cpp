@@ -1833,7 +1833,7 @@ static int inflate_impl(br_ctx *c, const uint8_t *src, uint64_t n_src, const br_
   A.src = src; A.n_src = n_src; A.dst = dst_ext ? dst_ext : c->inf_out.as<uint8_t>(); A.blocks = (const InflateBlock *)c->inf_blocks.p; A.n_blocks = (uint64_t)n_blocks;
   A.queue = c->inf_cnt.as<uint32_t>(); A.n_bad = c->inf_cnt.as<uint32_t>() + 1;
   A.crc_tab4 = c->inf_tabs.as<uint32_t>(); A.crc_shift = c->inf_tabs.as<uint32_t>() + 1024;
-  const int waves = (int)std::min<uint64_t>(((uint64_t)n_blocks + 3) / 4 * 4, (uint64_t)c->n_cu * 12);   // three workgroups of four waves per CU (their LDS)
+  const int waves = (int)std::min<uint64_t>(((uint64_t)n_blocks + 3) / 4 * 4, (uint64_t)c->n_cu * 20);   // five workgroups of four waves per CU (their LDS and registers)
   Prof pf{c, st};
   c->events_used = 0;
   RC(pf.begin(BR_K_CODEC));

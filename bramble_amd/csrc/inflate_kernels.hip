@@ -6,9 +6,9 @@
 // chain: every lane of the wave runs the same chain on wave-uniform values (broadcast LDS reads) -- except behind a literal,
 // where the lanes decode the codes at every bit offset of the buffer and the run of literals is taken in one go -- and the
 // parallelism is across blocks: a 3 GB file is 50 000 of them.  The lanes work together where there is width: the compressed bytes come
-// in through a 2 KiB LDS ring (one coalesced 1 KiB load ahead of the decoder), the decode tables (10-bit primary table for
+// in through a 1 KiB LDS ring (one coalesced 512-byte load ahead of the decoder), the decode tables (10-bit primary table for
 // literal/length codes, 8-bit for distances, canonical count arrays for the longer codes) are built by all lanes, a match
-// is copied by as many lanes as it has bytes, the output leaves through a 4 KiB LDS window in coalesced 1 KiB pieces
+// is copied by as many lanes as it has bytes, the output leaves through a 2 KiB LDS window in coalesced 512-byte pieces
 // (matches that reach further back read the wave's own earlier output from HBM), and the CRC32 of the result is computed
 // over 64 lane-chunks and folded with a precomputed zero-append operator (as in codec_kernels.hip).
 #include <hip/hip_runtime.h>
@@ -18,10 +18,10 @@
 
 namespace br {
 
-#define IN_RING_DW 512u          // 2 KiB of compressed input per wave
-#define IN_CHUNK 1024u           // refilled 1 KiB at a time
-#define OUT_WIN 4096u            // output window in LDS
-#define OUT_PIECE 1024u          // flushed to HBM in pieces of this size
+#define IN_RING_DW 256u          // 1 KiB of compressed input per wave
+#define IN_CHUNK 512u            // refilled half a KiB at a time
+#define OUT_WIN 2048u            // output window in LDS
+#define OUT_PIECE 512u           // flushed to HBM in pieces of this size
 #define OUT_NEAR (OUT_WIN - OUT_PIECE - 258u)   // a match at most this far back is served from the window
 #define LL_BITS 10
 #define D_BITS 8
@@ -77,7 +77,7 @@ __device__ __forceinline__ bool build_tables(WaveLds &W, const uint8_t *lens, in
   return true;
 }
 
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) k_inflate(InflateArgs A) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) k_inflate(InflateArgs A) {
   __shared__ WaveLds sh_w[4];
   __shared__ uint32_t sh_crc[4][256];
   for (int i = threadIdx.x; i < 1024; i += 256) sh_crc[i >> 8][i & 255] = A.crc_tab4[i];
@@ -105,11 +105,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
       const uint64_t o = (uint64_t)k * IN_CHUNK + 16u * (uint32_t)lane;
       struct __attribute__((packed, aligned(1))) IW2 { uint32_t a, b; };
       uint4 v = make_uint4(0, 0, 0, 0);
+      if (16u * (uint32_t)lane >= IN_CHUNK) return v;          // (a chunk is IN_CHUNK / 16 lanes wide)
       if (o + 8 <= src_room) { const IW2 t = *(const IW2 *)(src + o); v.x = t.a; v.y = t.b; }
       if (o + 16 <= src_room) { const IW2 t = *(const IW2 *)(src + o + 8); v.z = t.a; v.w = t.b; }
       return v;
     };
-    auto put_chunk = [&](uint32_t k, uint4 v) { *(uint4 *)(W.in + (k & 1u) * (IN_CHUNK / 4) + 4u * (uint32_t)lane) = v; };
+    auto put_chunk = [&](uint32_t k, uint4 v) { if (16u * (uint32_t)lane < IN_CHUNK) *(uint4 *)(W.in + (k & 1u) * (IN_CHUNK / 4) + 4u * (uint32_t)lane) = v; };
     put_chunk(0, load_chunk(0));
     put_chunk(1, load_chunk(1));
     uint4 ahead = load_chunk(2);
