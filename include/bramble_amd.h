@@ -536,7 +536,9 @@ const char *const *br_annotation_refnames(const br_annotation *);
 
 /* The reference's command line (src/bramble.cpp:443-485): in.bam -G -o [-S] [-p] [--fr|--rf]
  * [--lr|--lr-hq] [--strict] [--max-*] [--similarity-threshold] [--quiet], plus --device-deflate (default: BGZF blocks made on the
- * GPU) / --host-deflate / --compression-level N (host codec), --bundle-size and --device.  Returns the process exit code. */
+ * GPU) / --host-deflate / --compression-level N (host codec), --device-reader (default for a regular file on one device: the
+ * input is inflated and split into records on the GPU, br_bam_reader) / --host-reader, --bundle-size and --device / --devices.
+ * Returns the process exit code. */
 int br_cli_main(int argc, char **argv);
 /* For a process whose only job is that one call (the `bramble` binary): with `on` != 0 br_cli_main does not return after a
  * run that got as far as the final report -- the output file is closed and renamed, the streams are flushed, and the process
