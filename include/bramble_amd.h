@@ -477,7 +477,9 @@ int br_bam_split_device(br_ctx *, const uint8_t *data, uint64_t n_bytes, int32_t
  *                          HBM (mapped records only, like br_bam_split; *n_unmapped = the ones skipped), valid until
  *                          br_bam_reader_release(id).  The last, possibly unfinished group stays behind for the next call;
  *                          the call that ends the file returns everything.  A bundle may be empty.
- * BR_ERR_INVALID_ARG for malformed BGZF / BAM, a block whose CRC32 is wrong, a file that ends inside a block or a record. */
+ * BR_ERR_INVALID_ARG for malformed BGZF / BAM, a block whose CRC32 is wrong, a file that ends inside a block or a record; a
+ * reader that has returned an error is to be freed.  br_bam_reader_next is called from one thread; br_bam_reader_release may
+ * come from another (the thread that projects the bundles). */
 typedef struct br_bam_reader br_bam_reader;
 int br_bam_reader_new(int device, int32_t n_ref, uint64_t header_bytes, br_bam_reader **out);
 int br_bam_reader_next(br_bam_reader *, const uint8_t *data, uint64_t n_bytes, int last, uint64_t *consumed,
