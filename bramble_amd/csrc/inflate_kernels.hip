@@ -274,10 +274,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
           if (lane) v |= bh << (64u - (uint32_t)lane);
           const uint32_t el = W.lut_ll[(uint32_t)v & ((1u << LL_BITS) - 1u)];
           const uint32_t l1 = el >> 9, sy = el & 511u;
-          const uint64_t lit = __ballot(l1 != 0u && sy < 256u);
-          const uint32_t lim = bc - 16u < 64u ? bc - 16u : 64u, room = ulen - pos;   // a code must lie inside the buffer; the block's bytes are counted
+          // where the token behind this lane's literal starts; 255: no (short-coded) literal here, or its code would leave the buffer
+          const uint32_t lim = bc - 16u < 64u ? bc - 16u : 64u;
+          const uint32_t nxt = (l1 != 0u && sy < 256u && (uint32_t)lane < lim) ? (uint32_t)lane + l1 : 255u;
           uint64_t sel = 0; uint32_t at = 0, n_lit = 0;
-          while (at < lim && ((lit >> at) & 1ull) && n_lit < room) { sel |= 1ull << at; at += (uint32_t)__builtin_amdgcn_readlane((int)l1, (int)at); n_lit++; }
+          for (;;) {                                            // (kept this plain: every test in here is scalar instructions per literal)
+            const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)nxt, (int)at);
+            if (n >= 128u) break;
+            sel |= 1ull << at; n_lit++;
+            at = n;
+            if (at >= 64u) break;
+          }
+          if (n_lit > ulen - pos) { bad = true; break; }        // more bytes than the block holds
           if (n_lit) {
             if ((sel >> lane) & 1ull) win8[(pos + (uint32_t)__builtin_popcountll(sel & ((1ull << lane) - 1ull))) & (OUT_WIN - 1u)] = (uint8_t)sy;
             pos += n_lit;
