@@ -1952,7 +1952,11 @@ extern "C" int br_bam_reader_new(int device, int32_t n_ref, uint64_t header_byte
   auto r = std::make_unique<br_bam_reader>();
   r->shell.device = device; r->n_ref = n_ref; r->skip = header_bytes;
   RC(br_ctx_new(&r->shell, &r->c));
-  HIPCHK(hipStreamCreateWithFlags(&r->st, hipStreamNonBlocking));
+  // the lowest priority the device offers: once the projection has started, its kernels go first (what the reader makes is
+  // needed a few bundles later; what the runner makes is what the writer waits for)
+  int prio_low = 0, prio_high = 0;
+  HIPCHK(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+  HIPCHK(hipStreamCreateWithPriority(&r->st, hipStreamNonBlocking, prio_low));
   *out = r.release();
   return BR_OK;
 }
