@@ -448,6 +448,7 @@ struct br_ctx {
   int group_lanes = 8;
   int bam_lanes = 0;   // 0: k_bam_tasks (a wave per 32 rows); 4..64: k_bam_encode<G>, G lanes per row
   int blocks_per_cu = 8;
+  int split_spoil = 0;   // test hook: k_split_spoil plants wrong segment guesses (tests/test_gpu_split.py)
   int n_cu = 256;
   bool profiling = false;
   std::vector<KEvent> events; size_t events_used = 0;
@@ -632,6 +633,7 @@ extern "C" int br_ctx_set_param(br_ctx *c, const char *key, int64_t v) {
   if (!strcmp(key, "ksw_tape_pct")) { if (v < 0 || v > 100) return BR_ERR_INVALID_ARG; c->ksw_tape_pct = (int)v; return BR_OK; }
   if (!strcmp(key, "ksw_tape_mb")) { if (v < 1) return BR_ERR_INVALID_ARG; c->ksw_tape_mb = v; return BR_OK; }
   if (!strcmp(key, "host_detail")) { c->host_detail = v != 0; return BR_OK; }
+  if (!strcmp(key, "split_spoil")) { if (v < 0 || v > 1000000) return BR_ERR_INVALID_ARG; c->split_spoil = (int)v; return BR_OK; }   // test hook, see split_impl
   if (!strcmp(key, "blocks_per_cu")) { if (v < 1 || v > 64) return BR_ERR_INVALID_ARG; c->blocks_per_cu = (int)v; return BR_OK; }
   return BR_ERR_INVALID_ARG;
 }
@@ -1877,7 +1879,7 @@ static int split_impl(br_ctx *c, const uint8_t *data, uint64_t n_bytes, int32_t 
   S.flags = c->sp_small.as<uint32_t>(); S.totals = (uint64_t *)(c->sp_small.as<uint8_t>() + 16);
   uint32_t *redo = c->sp_redo.as<uint32_t>();
   launch_split_guess(st, S);
-  if (const char *sp = getenv("BRAMBLE_AMD_SPLIT_SPOIL")) launch_split_spoil(st, S, atoi(sp));   // test hook: wrong guesses on purpose
+  if (c->split_spoil > 0) launch_split_spoil(st, S, c->split_spoil);   // test hook (br_ctx_set_param "split_spoil"): wrong guesses on purpose
   launch_split_walk(st, S, nullptr);
   for (int pass = 0;; pass++) {
     // every guess against where the chain of the segments in front arrives; the segments that were wrong walk again
@@ -1887,7 +1889,8 @@ static int split_impl(br_ctx *c, const uint8_t *data, uint64_t n_bytes, int32_t 
     HIPCHK(hipMemcpyAsync(&changed, S.flags + 1, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     std::swap(S.entry, S.entry_next);
-    if (getenv("BRAMBLE_AMD_SPLIT_DEBUG") && (pass < 12 || !changed)) fprintf(stderr, "[split] pass %d: %u of %lld segments took another entry\n", pass, changed, (long long)n_seg);
+    static const bool split_debug = getenv("BRAMBLE_AMD_SPLIT_DEBUG") != nullptr;
+    if (split_debug && (pass < 12 || !changed)) fprintf(stderr, "[split] pass %d: %u of %lld segments took another entry\n", pass, changed, (long long)n_seg);
     if (!changed) break;
     if (pass > n_seg + 2) return BR_ERR_INVALID_ARG;   // (cannot happen: every pass settles at least the first wrong segment)
     launch_split_walk(st, S, redo);

@@ -319,7 +319,7 @@ extern "C" int br_cli_main(int argc, char **argv) {
       b->seq = next_seq++;
       to_dev.put(std::move(b));
     }
-    if (rrc) reader_err = std::string("malformed or truncated BAM file (") + br_strerror(rrc) + ")";
+    if (rrc) reader_err = rrc == BR_ERR_INVALID_ARG ? std::string("malformed or truncated BAM file (") + br_strerror(rrc) + ")" : std::string("device reader: ") + br_strerror(rrc);
     to_dev.finish();
   }) : std::thread([&]() {
     buf.erase_front(pos); pos = 0;
@@ -437,7 +437,8 @@ extern "C" int br_cli_main(int argc, char **argv) {
   });
 
   // the reader is already inflating while the guides are parsed and the indexes are built
-  auto stop_reader = [&]() -> int { cancel = true; while (to_gpu.take()) {} while (to_dev.take()) {} reader.join(); if (dev_reader) br_bam_reader_free(dev_reader); dev_reader = nullptr; return 1; };
+  // (only the queue the running reader feeds is ever finished: taking from the other one would wait for ever)
+  auto stop_reader = [&]() -> int { cancel = true; if (use_dev_reader) { while (to_dev.take()) {} } else { while (to_gpu.take()) {} } reader.join(); if (dev_reader) br_bam_reader_free(dev_reader); dev_reader = nullptr; return 1; };
   int rc = ann_job.get();
   const double t_guides = since();
   if (rc) { fprintf(stderr, "error: could not load reference annotation %s: %s\n", o.gff.c_str(), br_strerror(rc)); return stop_reader(); }
@@ -522,6 +523,7 @@ extern "C" int br_cli_main(int argc, char **argv) {
   std::atomic<int> fail{0};
   auto raise_fail = [&]() {
     for (auto &x : workers) { std::lock_guard<std::mutex> l(x->done_m); fail = 1; }
+    cancel = true;   // the reader stops making bundles nobody will project (the runners keep draining what is queued)
     for (auto &x : workers) x->done_cv.notify_all();
   };
 

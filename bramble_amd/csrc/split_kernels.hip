@@ -182,7 +182,7 @@ void launch_unmapped_before(hipStream_t st, const SplitArgs &S, uint64_t limit, 
   hipLaunchKernelGGL(k_unmapped_before, dim3((unsigned)((S.n_seg + 255) / 256)), dim3(256), 0, st, S, limit, out);
 }
 
-// test hook (BRAMBLE_AMD_SPLIT_SPOIL=k): wrong guesses on purpose -- every k-th segment forgets its entry, the segments in
+// test hook (br_ctx_set_param "split_spoil" = k): wrong guesses on purpose -- every k-th segment forgets its entry, the segments in
 // between every 2k-th take a byte offset that starts no record, runs of them included -- so that the check / repair passes
 // are exercised on data whose honest guesses are all right
 __global__ void __launch_bounds__(64) k_split_spoil(SplitArgs S, int k) {

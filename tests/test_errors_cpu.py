@@ -80,3 +80,22 @@ def test_bam_split_partial_and_malformed_records():
     tiny[0:4] = np.frombuffer((5).to_bytes(4, "little"), dtype=np.uint8)   # block_size < 32
     with pytest.raises(lib.BrambleError):
         lib.bam_split(tiny)
+
+
+def test_cli_setup_errors_after_the_reader_started_exit_instead_of_hanging(tmp_path):
+    """A setup error that comes after the reader thread has started (the guides are loaded beside it) must end the run with
+    a non-zero code: the command once drained the queue of the reader that was NOT running and waited for ever.
+    Both readers, plus the default; no GPU is needed to get as far as the guide loader."""
+    import os
+    import subprocess
+    from tests import bamio
+    BIN = os.path.join(os.path.dirname(lib.__file__), "bin", "bramble")
+    if not os.path.exists(BIN):
+        pytest.skip("command line not built")
+    recs = [bamio.bam_record(b"r%d" % i, 0, 100 + i, [(50 << 4) | 0], 50) for i in range(200)]
+    in_bam = str(tmp_path / "in.bam")
+    bamio.write_bam(in_bam, "@HD\tVN:1.6\n", [("chr1", 100000)], bamio.frame(recs).tobytes())
+    for extra in ([], ["--host-reader"], ["--device-reader"]):
+        r = subprocess.run([BIN, in_bam, "-G", str(tmp_path / "missing.gtf"), "-o", str(tmp_path / "o.bam")] + extra,
+                           capture_output=True, text=True, timeout=120)
+        assert r.returncode != 0 and "annotation" in r.stderr, (extra, r.stderr)

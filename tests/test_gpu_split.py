@@ -220,8 +220,8 @@ def test_reader_refuses_truncated_and_corrupt_files():
     assert _read_all(L, bytes(bad), 3, len(header), 3072, 1 << 30)[0] != 0                                   # a flipped bit
 
 
-def test_wrong_guesses_are_repaired(monkeypatch):
-    """BRAMBLE_AMD_SPLIT_SPOIL (test hook): after the honest guesses, every k-th segment forgets its entry and others take
+def test_wrong_guesses_are_repaired():
+    """The context parameter "split_spoil" (test hook): after the honest guesses, every k-th segment forgets its entry and others take
     an offset that starts no record (runs of up to four in a row): whatever the walk from there does -- stops at once as
     malformed, runs off as a huge record, or happens to meet the chain again -- the check / repair passes must end with the
     host's result."""
@@ -234,10 +234,10 @@ def test_wrong_guesses_are_repaired(monkeypatch):
     mixed = recs[:4000] + big[:1] + recs[4000:9000] + big[1:] + recs[9000:]
     stream2 = bamio.frame(mixed)
     for k in (1, 2, 3, 5, 17):
-        monkeypatch.setenv("BRAMBLE_AMD_SPLIT_SPOIL", str(k))
+        ctx.set_param("split_spoil", k)
         check(ctx, stream)
         check(ctx, stream2)
         check(ctx, stream2[:stream2.size - 9999])
-    monkeypatch.delenv("BRAMBLE_AMD_SPLIT_SPOIL")
+    ctx.set_param("split_spoil", 0)
     check(ctx, stream2)
     ctx.close(); idx.close()
