@@ -496,6 +496,14 @@ struct br_ctx {
   DevBuf wl, p1;         // the single pass's work list and counters
   uint64_t p1_hw[3] = {0, 0, 0};   // high-water marks of its three allocators (match slots, work-list entries, arena words): next call's capacities
   DevBuf walk_list, pmask, pbit, pick;
+  // direct rows (run_device_direct): presets without the similarity filter and without -S pair on the count pass's survivor
+  // sets before anything is emitted, and the emit kernels write the packed rows themselves
+  int direct_rows = 1;       // "direct_rows" / BRAMBLE_AMD_DIRECT_ROWS=0: the match-table path (k_emit_dense -> k_pair -> k_rows), the A/B switch
+  DevBuf d_fm, d_nkept, d_desc, d_hi0, d_clspos, d_rnd, d_side, d_sidectr;
+  uint64_t d_side_cap = 0;
+  bool last_direct = false;  // the last call's rows came from the direct path: the detail column is re-emitted on request, not gathered
+  bool want_x = false;       // the caller of run_device needs the detail column (input alignment, HI: the BAM encoder) with the rows
+  ProjectArgs dA{}; DirectArgs dD{}; int64_t d_kept = 0, d_simple = 0; bool d_split = false;
   // packed row table (the product of the row stage) and what its kernels need
   DevBuf r_rec, pk_a, pk_c, pk_x, pk_sim, pk_clip;
   DevBuf pool, pool_sizes, pool_off, pk_ch;   // dense long-CIGAR pool + rewritten references for host downloads
@@ -515,7 +523,7 @@ struct br_ctx {
   // rows / offsets, the direction tape, raw traceback ops
   DevBuf ksw_desc, ksw_dp, ksw_left, ksw_cnt, ksw_group, ksw_tape, ksw_raw;
   int ksw_fast = 1;            // 0: every problem through the general kernel k_ksw
-  hipStream_t ksw_stream = nullptr; hipEvent_t ksw_ev[KSW_N_BINS + 1] = {}; hipEvent_t aux_ev[2] = {};   // the second stream
+  hipStream_t ksw_stream = nullptr; hipEvent_t ksw_ev[KSW_N_BINS + 1] = {}; hipEvent_t aux_ev[8] = {};   // the second stream
   uint32_t ksw_groups[KSW_N_BINS] = {0};
   int64_t ksw_tape_mb = 49152; // HBM set aside for the direction tape; larger batches go through in pieces
   int ksw_tape_pct = 100;      // test hook: the share of the computed tape the DP kernels may use (the rest of the problems goes to k_ksw)
@@ -564,6 +572,8 @@ extern "C" int br_ctx_new(const br_index *ix, br_ctx **out) {
   if (spec) c->speculate = atoi(spec) != 0;
   const char *sp = getenv("BRAMBLE_AMD_SINGLE_PASS");   // A/B: 0 = the two-pass count / scan / expand / emit path
   if (sp) c->single_pass = atoi(sp) != 0;
+  const char *dr = getenv("BRAMBLE_AMD_DIRECT_ROWS");   // A/B: 0 = the match-table path
+  if (dr) c->direct_rows = atoi(dr) != 0;
   const char *g = getenv("BRAMBLE_AMD_GROUP_LANES");
   if (g) { int v = atoi(g); if (v == 8 || v == 16 || v == 32 || v == 64) c->group_lanes = v; }
   *out = c;
@@ -585,6 +595,7 @@ extern "C" void br_ctx_free(br_ctx *c) {
                     &c->cigar_out, &c->r_paired, &c->r_same, &c->r_first, &c->r_primary, &c->b_name_off, &c->b_names, &c->b_ref_id, &c->b_ref_start,
                     &c->b_flags, &c->b_xs, &c->b_ts, &c->b_cigar_off, &c->b_cigar, &c->b_mate_idx,
                     &c->b_group_off, &c->b_lqseq, &c->walk_list, &c->pmask, &c->pbit, &c->pick, &c->wl, &c->p1, &c->g_dev,
+                    &c->d_fm, &c->d_nkept, &c->d_desc, &c->d_hi0, &c->d_clspos, &c->d_rnd, &c->d_side, &c->d_sidectr,
                     &c->fa_srcs, &c->fa_want, &c->ksw_desc, &c->ksw_dp, &c->ksw_left, &c->ksw_cnt, &c->ksw_group, &c->ksw_tape, &c->ksw_raw};
   for (DevBuf *b : bufs) b->release();
   for (auto &e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -623,6 +634,7 @@ extern "C" int br_ctx_set_param(br_ctx *c, const char *key, int64_t v) {
   if (!strcmp(key, "emit_split")) { c->emit_split = v != 0; return BR_OK; }
   if (!strcmp(key, "count_split")) { c->count_split = v != 0; return BR_OK; }
   if (!strcmp(key, "single_pass")) { c->single_pass = v != 0; return BR_OK; }
+  if (!strcmp(key, "direct_rows")) { c->direct_rows = v != 0; return BR_OK; }
   if (!strcmp(key, "small_batch")) { c->small_batch = v != 0; return BR_OK; }
   if (!strcmp(key, "speculate")) { c->speculate = v != 0; return BR_OK; }
   if (!strcmp(key, "speculate_n")) { if (v < 0) return BR_ERR_INVALID_ARG; c->speculate_n = v; return BR_OK; }
@@ -701,6 +713,10 @@ struct Prof {
 };
 
 #define RC(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+
+// the next run_device call should leave the detail column (input alignment, junc_hits, aligned_len, HI) next to the rows:
+// the direct path then writes it in the emit pass instead of emitting a second time on request
+struct WantDetail { br_ctx *c; bool old; WantDetail(br_ctx *c_, bool v) : c(c_), old(c_->want_x) { c->want_x = v; } ~WantDetail() { c->want_x = old; } };
 
 // a second stream for kernels that can run beside the main one (a shape's tracebacks beside the next shape's DP; the
 // few-block emit kernel of the > 64-candidate alignments beside the work-list kernels)
@@ -1046,6 +1062,183 @@ static int run_device_small(br_ctx *c, const DevCfg &dc, const br_device_batch *
 }
 
 // The HIP pipeline over a device-resident batch.
+// Direct rows: presets without the similarity filter and without -S (every short-read preset; long reads with the filter
+// switched off).  segment -> count -> [k_pair_mask || k_big<0> + k_pair_big] -> k_scan5 (one host wait: sizes) ->
+// k_expand_rows -> k_emit_rows (|| k_big<1>): the packed rows are written once, by the lane that computes the match; the
+// match table, the per-record r_rec, k_pair<true> and k_rows do not exist on this path.  On the second stream: the name
+// seeds of the primary tie-break (beside segment + count), the big alignments' pairing (beside k_pair_mask), k_group_desc
+// (beside the scan), k_big<1> (beside the emit kernels).
+static int run_device_direct(br_ctx *c, const DevCfg &dc, const br_device_batch *b, hipStream_t st, br_device_rows *out, Prof &pf,
+                             bool keep_events) {
+  const br_index *ix = c->ix;
+  const int64_t n = b->n_aln, ng = b->n_groups;
+  const int64_t tiles = std::max<int64_t>(scan_tiles_for(std::max<int64_t>(n, ng) + 1), 1);
+  RC(c->seg.ensure((size_t)(b->n_cigar_words + n) * sizeof(uint2)));
+  RC(c->meta.ensure((size_t)n * sizeof(AlnMeta))); RC(c->head.ensure((size_t)n * sizeof(uint4))); RC(c->head2.ensure((size_t)n * sizeof(uint4)));
+  RC(c->fast_flag.ensure((size_t)n * 4)); RC(c->n_matches.ensure((size_t)n * 4)); RC(c->ranges.ensure((size_t)n * sizeof(uint4)));
+  RC(c->mask.ensure((size_t)n * 8)); RC(c->cig_base.ensure((size_t)(n + 1) * 8)); RC(c->tile_sums.ensure((size_t)tiles * 8 * 5));
+  RC(c->totals.ensure(16 * 8)); RC(c->counters_d.ensure(4 * 8));
+  RC(c->big_list.ensure((size_t)n * 4)); RC(c->n_big.ensure(16)); RC(c->walk_list.ensure((size_t)n * 4));
+  RC(c->aln_group.ensure((size_t)n * 4)); RC(c->n_rows.ensure((size_t)n * 4)); RC(c->pbit.ensure((size_t)n));
+  RC(c->d_fm.ensure((size_t)n * sizeof(uint4))); RC(c->d_nkept.ensure((size_t)n * 4)); RC(c->d_desc.ensure((size_t)n * sizeof(uint4)));
+  RC(c->d_hi0.ensure((size_t)n * 4)); RC(c->d_clspos.ensure((size_t)n * 4)); RC(c->d_rnd.ensure((size_t)std::max<int64_t>(ng, 1) * 8));
+  RC(c->d_sidectr.ensure(16));
+  if (c->d_side_cap == 0) c->d_side_cap = std::max<uint64_t>((uint64_t)n / 4, 1u << 20);
+  RC(c->d_side.ensure((size_t)c->d_side_cap * sizeof(uint2)));
+  // (a buffer that a queued packed download still reads must not be reallocated under it)
+  if (c->rows_busy_set && c->row_off.cap < (size_t)(n + 1) * 8) HIPCHK(hipEventSynchronize(c->rows_busy));
+  RC(c->row_off.ensure((size_t)(n + 1) * 8));
+  RC(ensure_aux_stream(c));
+  hipStream_t ax = c->ksw_stream;
+  uint64_t *d_tot = c->totals.as<uint64_t>();
+
+  ProjectArgs A{};
+  A.ix = ix->dev; A.cfg = dc; A.n_aln = n; A.ref_id = b->ref_id; A.cigar_off = b->cigar_off; A.cigar = b->cigar;
+  A.seg = c->seg.as<uint2>(); A.meta = c->meta.as<AlnMeta>(); A.head = c->head.as<uint4>(); A.head2 = c->head2.as<uint4>();
+  A.fast_flag = c->fast_flag.as<uint32_t>(); A.n_matches = c->n_matches.as<uint32_t>();
+  A.ranges = c->ranges.as<uint4>(); A.mask = c->mask.as<uint64_t>();
+  A.big_list = c->big_list.as<uint32_t>(); A.n_big = c->n_big.as<uint32_t>();
+  if (c->count_split) { A.walk_list = c->walk_list.as<uint32_t>(); A.n_walk = c->n_big.as<uint32_t>() + 1; }
+  const bool have_names = b->names && b->name_off;
+  DirectArgs D{};
+  D.n_aln = n; D.n_groups = ng; D.group_off = b->group_off; D.aln_group = c->aln_group.as<uint32_t>(); D.mate_idx = b->mate_idx;
+  D.n_matches = c->n_matches.as<uint32_t>(); D.mask = c->mask.as<uint64_t>(); D.ranges = c->ranges.as<uint4>();
+  D.fast_flag = c->fast_flag.as<uint32_t>(); D.s_tid = ix->dev.s_tid; D.big_list = A.big_list; D.n_big = A.n_big;
+  D.fm = c->d_fm.as<uint4>(); D.n_kept = c->d_nkept.as<uint32_t>(); D.n_rows = c->n_rows.as<uint32_t>(); D.pflag = c->pbit.as<uint8_t>();
+  D.side = c->d_side.as<uint2>(); D.side_cap = c->d_side_cap; D.side_used = c->d_sidectr.as<unsigned long long>();
+  D.cls_pos = c->d_clspos.as<uint32_t>(); D.cig_base = c->cig_base.as<uint64_t>(); D.row_off = c->row_off.as<uint64_t>();
+  D.name_off = have_names ? b->name_off : nullptr; D.names = have_names ? b->names : nullptr; D.rnd0 = c->d_rnd.as<uint64_t>();
+  D.desc = c->d_desc.as<uint4>(); D.hi0 = c->d_hi0.as<uint32_t>(); D.counters = c->counters_d.as<uint64_t>(); D.tot = d_tot;
+
+  // second stream: the name seeds need nothing the main stream makes
+  HIPCHK(hipEventRecord(c->aux_ev[0], st));
+  HIPCHK(hipStreamWaitEvent(ax, c->aux_ev[0], 0));
+  if (have_names) {
+    RC(pf.begin(BR_K_NAME_SEED, ax));
+    launch_name_seed(ax, D);
+    RC(pf.end());
+  }
+  // a1/a2/a6: CIGAR -> read exons; a3-a8, a11-a14 (survival only): the count pass
+  RC(pf.begin(BR_K_SEGMENT));
+  launch_segment(st, n, b->ref_id, b->ref_start, b->flags, b->xs, b->ts, b->cigar_off, b->cigar, dc, ix->n_refs,
+                 c->seg.as<uint2>(), c->meta.as<AlnMeta>(), c->head.as<uint4>(), c->head2.as<uint4>(), c->fast_flag.as<uint32_t>());
+  RC(pf.end());
+  RC(pf.begin(BR_K_GROUP_IDS));
+  launch_group_ids(st, ng, b->group_off, c->aln_group.as<uint32_t>());
+  RC(pf.end());
+  HIPCHK(hipMemsetAsync(c->n_big.p, 0, 8, st));
+  const int n_blocks = c->n_cu * c->blocks_per_cu;
+  const bool split = A.walk_list != nullptr;
+  RC(pf.begin(BR_K_COUNT));
+  launch_project(st, A, false, c->group_lanes, n_blocks, split ? 1 : 0);
+  RC(pf.end());
+  if (split) {
+    RC(pf.begin(BR_K_COUNT_WALK));
+    launch_project(st, A, false, c->group_lanes, n_blocks, 2);
+    RC(pf.end());
+  }
+  // a packed download of the previous call may still be reading row_off / the row tables (br_project_staged)
+  if (c->rows_busy_set) { HIPCHK(hipStreamWaitEvent(st, c->rows_busy, 0)); }
+  // a16 (src/mates.cpp:150-261) on the survivor sets, then placement
+  const int big_blocks = c->n_cu * 4;
+  uint64_t kept = 0, arena = 0, n_simple = 0, n_rows = 0, n_raw = 0;
+  for (int attempt = 0;; attempt++) {
+    HIPCHK(hipMemsetAsync(c->d_sidectr.p, 0, 16, st));
+    HIPCHK(hipMemsetAsync(c->counters_d.p, 0, 4 * 8, st));
+    HIPCHK(hipEventRecord(c->aux_ev[1], st));
+    HIPCHK(hipStreamWaitEvent(ax, c->aux_ev[1], 0));
+    RC(pf.begin(BR_K_PAIR_BIG, ax));
+    launch_big_collect(ax, A, D, big_blocks);
+    launch_pair_big(ax, D, big_blocks);
+    RC(pf.end());
+    HIPCHK(hipEventRecord(c->aux_ev[2], ax));
+    RC(pf.begin(BR_K_PAIR_MASK));
+    launch_pair_mask(st, D);
+    RC(pf.end());
+    HIPCHK(hipStreamWaitEvent(st, c->aux_ev[2], 0));
+    // NH / HI / primary per read name on the second stream beside the scan
+    HIPCHK(hipEventRecord(c->aux_ev[3], st));
+    HIPCHK(hipStreamWaitEvent(ax, c->aux_ev[3], 0));
+    RC(pf.begin(BR_K_GROUP_DESC, ax));
+    launch_group_desc(ax, D);
+    RC(pf.end());
+    HIPCHK(hipEventRecord(c->aux_ev[4], ax));
+    RC(pf.begin(BR_K_SCAN));
+    launch_scan5(st, D, c->tile_sums.as<uint64_t>(), d_tot);
+    RC(pf.end());
+    HIPCHK(hipMemcpyAsync(c->h_totals, d_tot, 5 * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(c->h_totals + 8, c->d_sidectr.p, 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (c->h_totals[9]) {   // the side arena of the > 64-candidate alignments ran out: grow it to what was asked for, repeat
+      if (attempt >= 3) return BR_ERR_CAPACITY;
+      HIPCHK(hipEventSynchronize(c->aux_ev[4]));
+      c->d_side_cap = c->h_totals[8] + c->h_totals[8] / 4 + 4096;
+      RC(c->d_side.ensure((size_t)c->d_side_cap * sizeof(uint2)));
+      D.side = c->d_side.as<uint2>(); D.side_cap = c->d_side_cap;
+      continue;
+    }
+    kept = c->h_totals[0]; arena = c->h_totals[1]; n_simple = c->h_totals[2]; n_rows = c->h_totals[3]; n_raw = c->h_totals[4];
+    break;
+  }
+  if (n_raw >= 0xffffffffull || kept >= 0xffffffffull) return BR_ERR_CAPACITY;
+  if (kept != n_rows) return BR_ERR_HIP;   // (every kept match is one record: the pairing kernels disagree with themselves)
+  out->n_matches = (int64_t)n_raw; out->n_rows = (int64_t)n_rows; out->n_pool_words = (int64_t)arena;
+
+  const size_t nr = (size_t)std::max<uint64_t>(n_rows, 1);
+  if (c->rows_busy_set && (c->pk_a.cap < nr * sizeof(uint4) || c->pk_c.cap < nr * sizeof(uint2))) HIPCHK(hipEventSynchronize(c->rows_busy));
+  RC(c->pk_a.ensure(nr * sizeof(uint4))); RC(c->pk_c.ensure(nr * sizeof(uint2)));
+  RC(c->m_aln.ensure(nr * 4)); RC(c->cig_arena.ensure((size_t)std::max<uint64_t>(arena, 1) * 4));
+  const bool with_x = c->want_x;
+  if (with_x) {
+    if (c->rows_busy_set && c->pk_x.cap < nr * sizeof(uint4)) HIPCHK(hipEventSynchronize(c->rows_busy));
+    RC(c->pk_x.ensure(nr * sizeof(uint4)));
+  }
+  A.cig_arena = c->cig_arena.as<uint32_t>();
+  D.m_aln = c->m_aln.as<uint32_t>(); D.r_a = c->pk_a.as<uint4>(); D.r_c = c->pk_c.as<uint2>(); D.r_x = with_x ? c->pk_x.as<uint4>() : nullptr;
+  const bool emit_split = c->emit_split != 0;
+  if (kept) {
+    HIPCHK(hipStreamWaitEvent(st, c->aux_ev[4], 0));
+    RC(pf.begin(BR_K_EXPAND_ROWS));
+    launch_expand_rows(st, D);
+    RC(pf.end());
+    HIPCHK(hipEventRecord(c->aux_ev[5], st));
+    HIPCHK(hipStreamWaitEvent(ax, c->aux_ev[5], 0));
+    RC(pf.begin(BR_K_BIG_EMIT, ax));
+    launch_big_emit(ax, A, D, big_blocks);
+    RC(pf.end());
+    HIPCHK(hipEventRecord(c->aux_ev[6], ax));
+    if (emit_split) {
+      RC(pf.begin(BR_K_EMIT_ROWS_SIMPLE));
+      launch_emit_rows(st, A, D, (int64_t)kept, (int64_t)n_simple, 1);
+      RC(pf.end());
+      RC(pf.begin(BR_K_EMIT_ROWS));
+      launch_emit_rows(st, A, D, (int64_t)kept, (int64_t)n_simple, 2);
+      RC(pf.end());
+    } else {
+      RC(pf.begin(BR_K_EMIT_ROWS));
+      launch_emit_rows(st, A, D, (int64_t)kept, (int64_t)n_simple, 0);
+      RC(pf.end());
+    }
+    HIPCHK(hipStreamWaitEvent(st, c->aux_ev[6], 0));
+  } else {
+    HIPCHK(hipStreamWaitEvent(st, c->aux_ev[4], 0));
+  }
+  HIPCHK(hipMemcpyAsync(c->h_totals + 4, c->counters_d.p, 4 * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (!keep_events) RC(pf.collect());
+  if (c->h_totals[7]) return BR_ERR_UNSUPPORTED;  // a rewritten CIGAR with more than 2^24 - 1 ops, or NH beyond 28 bits
+  out->total_complete = n_rows; out->total_unique = c->h_totals[5]; out->dropped_reads = c->h_totals[6];
+  c->hist_n = 0;   // (nothing a later speculative launch of the match-table path could be sized from)
+  out->a = (const br_row_a *)c->pk_a.p; out->cigar = (const uint64_t *)c->pk_c.p; out->x = with_x ? (const br_row_x *)c->pk_x.p : nullptr;
+  out->similarity_score = nullptr; out->clip_score = nullptr;
+  out->pool = c->cig_arena.as<uint32_t>(); out->row_off = c->row_off.as<uint64_t>();
+  c->counters[6] = n_raw;
+  c->last_n_rows = (int64_t)n_rows; c->last_n_aln = n; c->last_n_pool = (int64_t)arena;
+  c->last_aux_cols = false; c->wide_valid = false; c->detail_valid = with_x; c->last_l_qseq = b->l_qseq; c->last_long_reads = dc.long_reads;
+  c->last_direct = true; c->dA = A; c->dD = D; c->d_kept = (int64_t)kept; c->d_simple = (int64_t)n_simple; c->d_split = emit_split;
+  return BR_OK;
+}
+
 static int run_device_impl(br_ctx *c, const br_config *cfg, const br_device_batch *b, hipStream_t st, br_device_rows *out,
                            bool keep_events);
 int run_device(br_ctx *c, const br_config *cfg, const br_device_batch *b, hipStream_t st, br_device_rows *out) {
@@ -1066,7 +1259,7 @@ static int run_device_impl(br_ctx *c, const br_config *cfg, const br_device_batc
   Prof pf{c, st};
   if (!keep_events) c->events_used = 0;
   out->total_processed = (uint64_t)n;
-  c->last_n_rows = 0; c->last_n_aln = n; c->last_n_pool = 0; c->wide_valid = false; c->last_aux_cols = false;
+  c->last_n_rows = 0; c->last_n_aln = n; c->last_n_pool = 0; c->wide_valid = false; c->last_aux_cols = false; c->last_direct = false;
   c->last_l_qseq = b->l_qseq; c->last_long_reads = dc.long_reads;
   if (n == 0) { pf.collect(); return BR_OK; }
   if (!fa_mode && c->small_batch && ix->dev.n_rows != 0) {
@@ -1081,6 +1274,8 @@ static int run_device_impl(br_ctx *c, const br_config *cfg, const br_device_batc
       if (!keep_events) c->events_used = 0;
     }
   }
+
+  if (!fa_mode && !dc.filter_by_similarity && c->direct_rows && !c->single_pass) return run_device_direct(c, dc, b, st, out, pf, keep_events);
 
   int64_t tiles = std::max<int64_t>(scan_tiles_for(std::max<int64_t>(n, ng) + 1), 1);
   RC(c->seg.ensure((size_t)(b->n_cigar_words + n) * sizeof(uint2)));
@@ -1399,6 +1594,19 @@ static int ensure_detail(br_ctx *c, hipStream_t st) {
   const size_t nr = (size_t)std::max<int64_t>(c->last_n_rows, 1);
   if (c->rows_busy_set && c->pk_x.cap < nr * sizeof(uint4)) HIPCHK(hipEventSynchronize(c->rows_busy));   // a download may still read it
   RC(c->pk_x.ensure(nr * sizeof(uint4)));
+  if (c->last_direct) {
+    // direct rows keep no match table to gather from: the emit kernels run once more and write the detail column next to
+    // the rows (the last call's batch and the context's tables are still in place: nothing has run since)
+    if (c->last_n_rows > 0) {
+      DirectArgs D = c->dD;
+      D.r_x = c->pk_x.as<uint4>();
+      if (c->d_split) { launch_emit_rows(st, c->dA, D, c->d_kept, c->d_simple, 1); launch_emit_rows(st, c->dA, D, c->d_kept, c->d_simple, 2); }
+      else launch_emit_rows(st, c->dA, D, c->d_kept, c->d_simple, 0);
+      launch_big_emit(st, c->dA, D, c->n_cu * 4);
+    }
+    c->detail_valid = true;
+    return BR_OK;
+  }
   if (c->last_n_rows > 0) {
     PairArgs P{};
     P.n_rows_total = c->last_n_rows; P.r_rec = c->r_rec.as<uint4>(); P.m_x = c->m_x.as<uint2>(); P.r_x = c->pk_x.as<uint4>();
@@ -1486,6 +1694,22 @@ extern "C" int br_ctx_collect_counters(br_ctx *c, const br_device_batch *b, void
   if (!c || !b) return BR_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;
   HIPCHK(hipSetDevice(c->ix->device));
+  if (c->last_direct) {
+    // The formula's B_out counts the rewritten CIGAR words of every MATCH (the evaluator's output, before pairing), and
+    // only the match table holds those: this diagnostic projects the batch once more through the match-table path (never timed).
+    br_config cfgc; memset(&cfgc, 0, sizeof(cfgc)); cfgc.junc_miss_discount = 1.0;
+    const DevCfg &d = c->dA.cfg;
+    cfgc.lr = d.long_reads; cfgc.fr = d.fr; cfgc.rf = d.rf;
+    cfgc.has_max_clip = 1; cfgc.max_clip = d.max_clip; cfgc.has_max_junc_ins = 1; cfgc.max_junc_ins = d.max_junc_ins;
+    cfgc.has_max_junc_gap = 1; cfgc.max_junc_gap = d.max_junc_gap; cfgc.has_max_error_exon = 1; cfgc.max_error_exon = d.max_error_exon;
+    cfgc.has_sim_thr = 1; cfgc.sim_thr = 1.0f;
+    const int keep_direct = c->direct_rows, keep_small = c->small_batch;
+    c->direct_rows = 0; c->small_batch = 0;
+    br_device_rows tmp;
+    const int rc = run_device(c, &cfgc, b, st, &tmp);
+    c->direct_rows = keep_direct; c->small_batch = keep_small;
+    if (rc) return rc;
+  }
   RC(c->totals.ensure(16 * 8));
   DevBuf stats; RC(stats.ensure(8 * 8));
   HIPCHK(hipMemsetAsync(stats.p, 0, 8 * 8, st));
@@ -1526,6 +1750,10 @@ static int bam_encode_impl(br_ctx *c, const br_config *cfg, const br_device_reco
   B.aux = (BamAux *)c->bam_aux.p; B.base_len = c->bam_base.as<uint32_t>();
   RC(c->bam_end.ensure(8)); B.blob_end = c->bam_end.as<uint64_t>();
   B.r_a = c->pk_a.as<uint4>(); B.r_c = c->pk_c.as<uint2>(); B.r_rec = c->r_rec.as<uint4>();
+  if (c->last_direct) {   // no r_rec on the direct path: the detail column carries the input alignment and HI
+    RC(ensure_detail(c, st));
+    B.r_rec = c->pk_x.as<uint4>(); B.rec_x = 1;
+  }
   B.r_sim = c->last_aux_cols ? c->pk_sim.as<double>() : nullptr; B.r_clip = c->last_aux_cols ? c->pk_clip.as<int32_t>() : nullptr;
   B.pool = c->cig_arena.as<uint32_t>(); B.l_qseq = c->last_l_qseq;
   B.out_len = c->bam_len.as<uint32_t>(); B.out_off = c->bam_off.as<uint64_t>();
@@ -1680,7 +1908,7 @@ extern "C" int br_project_bam_device(br_ctx *c, const br_config *cfg, const br_d
   db.mate_idx = P.mate_idx; db.group_off = P.group_off; db.l_qseq = P.l_qseq;
   db.n_cigar_words = (int64_t)n_words; db.max_n_cigar = (int32_t)max_nc;
   db.name_off = P.name_off; db.names = P.names;
-  RC(run_device_impl(c, cfg, &db, st, rows, true));
+  { WantDetail wd(c, true); RC(run_device_impl(c, cfg, &db, st, rows, true)); }   // the encoder reads input alignment and HI of every row
   RC(bam_encode_impl(c, cfg, recs, st, out, true, true));
   return BR_OK;
 }
@@ -2369,7 +2597,7 @@ extern "C" int br_project_staged(br_ctx *c, const br_config *cfg, int slot, br_h
   RC(prep_staged(c, cfg, S, st, &db));
   S.staged = false;
   br_device_rows pr;
-  RC(run_device(c, cfg, &db, st, &pr));   // returns with the stream drained
+  { WantDetail wd(c, c->host_detail != 0); RC(run_device(c, cfg, &db, st, &pr)); }   // returns with the stream drained
   const size_t nr = (size_t)pr.n_rows, nn = (size_t)S.n;
   // the long (> 2 op) rewritten CIGARs sit in the sparse arena: a dense copy for the host (sizes -> scan -> copy)
   size_t np = 0;
@@ -2450,7 +2678,7 @@ extern "C" int br_project_batch(br_ctx *c, const br_config *cfg, const br_batch 
   RC(prep_staged(c, cfg, S, st, &db));
   S.staged = false;
   br_device_rows pr;
-  RC(run_device(c, cfg, &db, st, &pr));
+  { WantDetail wd(c, true); RC(run_device(c, cfg, &db, st, &pr)); }
   br_device_wide_rows dr;
   RC(expand_rows(c, st, &dr));
 
@@ -2543,7 +2771,8 @@ static int project_groups_lean(br_ctx *c, const br_config *cfg, const br_batch &
   if (b.seq_off) { db.seq_off = (const uint32_t *)(d + o_soff); db.seqs = d + o_seqs; db.seq_src = (const int32_t *)(d + o_ssrc); db.max_soft_clip = max_clip; }
   br_device_rows pr;
   c->rows_to_host = true;
-  const int rrc = run_device(c, cfg, &db, st, &pr);   // returns with the stream drained
+  int rrc;
+  { WantDetail wd(c, true); rrc = run_device(c, cfg, &db, st, &pr); }   // returns with the stream drained
   c->rows_to_host = false;
   RC(rrc);
   const size_t nr = (size_t)pr.n_rows, np = (size_t)pr.n_pool_words;

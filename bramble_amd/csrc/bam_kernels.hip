@@ -30,6 +30,9 @@ struct __attribute__((packed, aligned(1))) W4 { uint32_t a, b, c, d; };
 typedef uint32_t u32u __attribute__((aligned(1)));
 typedef uint16_t u16u __attribute__((aligned(1)));
 __device__ __forceinline__ uint32_t fix_nib(uint32_t x) { return rec_fix_nib(x); }   // records_inl.h
+// The input alignment behind output row r: word 1 of the match-table path's r_rec {match, input, NH, HI | flags}, word 0 of
+// the direct path's detail row {input, junc_hits, aligned_len, HI} (B.rec_x); HI is word 3 of either.
+__device__ __forceinline__ uint32_t rec_input(const BamArgs &B, int64_t r) { return ((const uint32_t *)(B.r_rec + r))[B.rec_x ? 0 : 1]; }
 
 __global__ void __launch_bounds__(256) k_bam_scan(BamArgs B) {
   __shared__ unsigned long long sh_end[4];
@@ -50,7 +53,7 @@ __global__ void __launch_bounds__(256) k_bam_scan(BamArgs B) {
 __global__ void __launch_bounds__(256) k_bam_size(BamArgs B) {
   int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= B.n_rows) return;
-  int32_t a = (int32_t)((const uint32_t *)(B.r_rec + r))[1];
+  int32_t a = (int32_t)rec_input(B, r);
   const uint32_t n_cig = ((const uint32_t *)(B.r_a + r))[2] & RM_NCIG;
   // more than 65535 ops: bam_write1's placeholder (8 bytes) in the CIGAR field, "CGBI" + count + the ops behind the aux area
   B.out_len[r] = B.base_len[a] + 4u * n_cig + (n_cig > 65535u ? 16u : 0u);
@@ -111,7 +114,7 @@ __device__ __forceinline__ void encode_row(const BamArgs &B, int64_t r, int lane
   uint32_t ls = l_seq > 0 ? (uint32_t)l_seq : 0;
   // the packed row {tid, pos, meta, NH} + the record {match, input, NH, HI | flags}; the pair's other record is the adjacent row
   const uint4 ra = B.r_a[r];
-  const uint32_t meta = ra.z, nh = ra.w, hi = ((const uint32_t *)(B.r_rec + r))[3] & RR_HI;
+  const uint32_t meta = ra.z, nh = ra.w, hi = ((const uint32_t *)(B.r_rec + r))[3] & RR_HI;   // (a detail row's HI has no flag bits above it)
   uint32_t n_cig = meta & RM_NCIG;
   // more than 65535 ops: what htslib's bam_write1 does -- the CIGAR field holds <l_seq>S<ref_len>N, the ops follow the
   // aux area as a CG:B,I tag
@@ -131,7 +134,7 @@ __device__ __forceinline__ void encode_row(const BamArgs &B, int64_t r, int lane
     mpos = (int32_t)rb.y;
     if (same) {
       flag |= 0x2u; mtid = (int32_t)ra.x;
-      const int32_t lq = B.l_qseq[((const uint32_t *)(B.r_rec + r))[1]];
+      const int32_t lq = B.l_qseq[rec_input(B, r)];
       tlen = (my_pos <= mpos) ? (mpos + lq) - my_pos : -((my_pos + lq) - mpos);
     } else { flag &= ~0x2u; mtid = (int32_t)rb.x; }
   }
@@ -243,7 +246,7 @@ __global__ void __launch_bounds__(256) k_bam_encode(BamArgs B) {
   const int lane = threadIdx.x & (G - 1);
   int64_t r = (int64_t)blockIdx.x * (256 / G) + (threadIdx.x / G);
   if (r >= B.n_rows) return;
-  int32_t a = (int32_t)((const uint32_t *)(B.r_rec + r))[1];
+  int32_t a = (int32_t)rec_input(B, r);
   encode_row<G>(B, r, lane, B.blob + B.rec_off[a], B.aux[a], B.out + B.out_off[r], (uint32_t)(B.out_off[r + 1] - B.out_off[r]));
 }
 
@@ -303,12 +306,11 @@ __global__ void __launch_bounds__(256) k_bam_tasks(BamArgs B) {
   bool slow = false;   // a record whose CIGAR came out of a CG tag, or a row whose CIGAR must go into one: encode_row, below
   if (lane < nr) {
     const int64_t r = r0 + lane;
-    const uint4 rr = B.r_rec[r];
     const uint4 ra = B.r_a[r];
     const uint2 c = B.r_c[r];
     const uint64_t oo = B.out_off[r];
     const uint32_t total = (uint32_t)(B.out_off[r + 1] - oo);
-    const int32_t a = (int32_t)rr.y;
+    const int32_t a = (int32_t)rec_input(B, r);
     const BamAux x = B.aux[a];
     const uint64_t ro = B.rec_off[a];
     row_at = (uint32_t)(oo - span0);
@@ -339,7 +341,7 @@ __global__ void __launch_bounds__(256) k_bam_tasks(BamArgs B) {
     const uint32_t mapq = B.long_reads ? (nh > 1 ? 0u : 3u) : (nh == 1 ? 255u : nh == 2 ? 3u : (nh == 3 || nh == 4) ? 1u : 0u);  // get_mapq (src/core.cpp:46-58)
     h0 = total - 4u; h1 = ra.x; h2 = ra.y; h3 = l_qname | (mapq << 8) | (bin << 16);
     h4 = (n_cig & 0xffffu) | (flag << 16); h5 = (uint32_t)l_seq; h6 = (uint32_t)mtid; h7 = (uint32_t)mpos; h8 = (uint32_t)tlen;
-    tag_nh = nh; tag_hi = rr.w & RR_HI;
+    tag_nh = nh; tag_hi = ((const uint32_t *)(B.r_rec + r))[3] & RR_HI;
     if (B.long_reads) tag_as = (uint32_t)(int32_t)(((double)x.as_val + (double)(B.r_clip ? B.r_clip[r] : 0)) * (B.r_sim ? B.r_sim[r] : 0.0));  // set_as_tag
     slow = x.cg_len != 0u || n_cig > 65535u;
     BamTaskRow &D = L.d[lane];
@@ -535,7 +537,7 @@ __global__ void __launch_bounds__(256) k_bam_tasks(BamArgs B) {
     const int i = __builtin_ctzll(slowm);
     slowm &= slowm - 1;
     const int64_t r = r0 + i;
-    const int32_t a = (int32_t)((const uint32_t *)(B.r_rec + r))[1];
+    const int32_t a = (int32_t)rec_input(B, r);
     encode_row<64>(B, r, lane, B.blob + B.rec_off[a], B.aux[a], B.out + B.out_off[r], (uint32_t)(B.out_off[r + 1] - B.out_off[r]));
   }
 }

@@ -180,6 +180,67 @@ __device__ __forceinline__ bool rows_over(const uint64_t *tot, uint64_t lim_r) {
 #define RR_SAME (1u << 30)
 #define RR_FIRST (1u << 31)
 
+// ---------------------------------------------------------------------------
+// Direct rows (direct_kernels.inc): presets without the similarity filter and without -S.  Pairing is decided on the
+// count pass's survivor sets BEFORE anything is emitted (src/mates.cpp:150-261 needs only the two mates' transcript-id
+// sets), one fused scan places every kept match, and the emit kernels write the packed rows themselves: no match table,
+// no per-record r_rec, no k_pair<true> / k_rows.
+//   k_name_seed     per read name: the first mt19937_64 output of its seed (the primary tie-break's only heavy part; it
+//                   needs nothing but the name, so it runs beside the count pass)
+//   k_pair_mask     per alignment: filtered survivor mask + tid rank of every kept survivor, records per leader
+//   k_big_collect / k_pair_big   the same for alignments with > 64 candidate rows (tid lists in a side arena)
+//   k_scan5_*       kept matches -> class-list position, CIGAR arena base, row offsets (one pass, one host wait)
+//   k_group_desc    per read name: NH, first HI of every alignment, the primary record (all scores tie: core.cpp:283-303)
+//   k_expand_rows   emit work list + the 16-byte emit descriptor of every alignment
+//   k_emit_rows<CLS>, k_big_emit   one lane per kept match -> packed row at row_off[leader] + stride * rank (+ is_mate)
+// ---------------------------------------------------------------------------
+enum : uint32_t { PF_PAIRED = 1, PF_SAME = 2, PF_MATE = 4, PF_BIG = 8 };   // pflag / low byte of the descriptor's .y
+struct DirectArgs {
+  int64_t n_aln, n_groups;
+  const uint32_t *group_off;     // [n_groups + 1]
+  const uint32_t *aln_group;     // [n_aln]
+  const int32_t *mate_idx;       // [n_aln] mutual mate pointers (br_batch_prepare / k_mates) or -1
+  const uint32_t *n_matches;     // [n_aln] count pass: survivors per alignment
+  const uint64_t *mask;          // [n_aln] count pass: survivor bit per candidate row (<= 64 rows)
+  const uint4 *ranges;           // [n_aln] count pass: candidate row ranges
+  const uint32_t *fast_flag;     // [n_aln] k_segment: class bit + CIGAR slot capacity
+  const uint32_t *s_tid;         // index: tid of every slab row
+  const uint32_t *big_list; const uint32_t *n_big;   // alignments with > 64 candidate rows and >= 1 survivor
+  // k_pair_mask / k_pair_big
+  uint4 *fm;                     // [n_aln] {filtered mask lo, hi, rank nibbles lo, hi}: nibble j = tid rank (among the kept) of the
+                                 // j-th kept survivor, valid when <= 16 are kept; big alignments: {side offset lo, hi, survivors, 0}
+  uint32_t *n_kept;              // [n_aln] kept survivors = emitted records of the alignment
+  uint32_t *n_rows;              // [n_aln] records of a leader (its own + its mate's), else 0
+  uint8_t *pflag;                // [n_aln] PF_*
+  uint2 *side;                   // big alignments: {tid, rank among the kept | ~0u: dropped} per survivor, candidate order
+  uint64_t side_cap;
+  unsigned long long *side_used; // [0] entries handed out, [1] set when the arena ran out (the host grows it and repeats)
+  // fused scan
+  uint32_t *cls_pos;             // [n_aln] first entry of the alignment in the class-partitioned emit work list
+  uint64_t *cig_base;            // [n_aln + 1]
+  uint64_t *row_off;             // [n_aln + 1] first record of leader a (br_device_rows.row_off)
+  // primary choice
+  const uint32_t *name_off; const uint8_t *names;   // null: no primary flags
+  uint64_t *rnd0;                // [n_groups] k_name_seed
+  uint4 *desc;                   // [n_aln] {first record, PF_* | (primary rank + 1) << 8, NH, class-list position}
+  uint32_t *hi0;                 // [n_aln] HI of the alignment's first record
+  uint64_t *counters;            // [4] total_complete, total_unique, dropped_reads, a field overflowed its packed width
+  const uint64_t *tot;           // scan totals on the device: [0] kept, [1] arena words, [2] kept of the simple class, [3] records, [4] survivors
+  // emit
+  uint32_t *m_aln;               // emit work list
+  uint4 *r_a; uint2 *r_c;        // packed rows
+  uint4 *r_x;                    // detail column {input, junc_hits, aligned_len, HI} or null
+};
+void launch_name_seed(hipStream_t st, const DirectArgs &D);
+void launch_pair_mask(hipStream_t st, const DirectArgs &D);
+void launch_big_collect(hipStream_t st, const ProjectArgs &A, const DirectArgs &D, int n_blocks);
+void launch_pair_big(hipStream_t st, const DirectArgs &D, int n_blocks);
+void launch_scan5(hipStream_t st, const DirectArgs &D, uint64_t *tile_sums, uint64_t *total_out5);
+void launch_group_desc(hipStream_t st, const DirectArgs &D);
+void launch_expand_rows(hipStream_t st, const DirectArgs &D);
+void launch_emit_rows(hipStream_t st, const ProjectArgs &A, const DirectArgs &D, int64_t n_kept, int64_t n_simple, int part);
+void launch_big_emit(hipStream_t st, const ProjectArgs &A, const DirectArgs &D, int n_blocks);
+
 // dense copy of the long (> 2 op) rewritten CIGARs for the host (the device rows point into the sparse arena)
 struct PoolArgs {
   int64_t n_rows;
@@ -244,6 +305,7 @@ struct BamArgs {
   BamAux *aux;               // [n_aln]
   uint32_t *base_len;        // [n_aln] bytes of an output row of this record without its CIGAR (k_bam_scan -> k_bam_size)
   const uint4 *r_a; const uint2 *r_c; const uint4 *r_rec;  // packed rows + the records behind them (PairArgs)
+  int32_t rec_x;             // r_rec holds the direct path's detail rows (br_row_x) instead of k_pair_emit's records
   const double *r_sim; const int32_t *r_clip;              // null: all zero
   const uint32_t *pool;
   const int32_t *l_qseq;

@@ -2419,6 +2419,7 @@ __global__ void __launch_bounds__(256) k_sum_ncig(const uint2 *m_p, const uint32
 #define FA_GROUP_LANES 8   // lanes per alignment in the -S kernels
 #endif
 #include "rescue_kernels.inc"
+#include "direct_kernels.inc"
 
 // ---------------------------------------------------------------------------
 // launchers

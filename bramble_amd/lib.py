@@ -12,12 +12,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbramble_amd.so")
 _P = C.POINTER
 
-K_SEGMENT, K_COUNT, K_EMIT, K_PAIR_COUNT, K_PAIR_EMIT, K_GATHER, K_SCAN, K_EMIT_AUX, K_KSW, K_BAM, K_PARSE, K_CODEC, K_EMIT_SIMPLE, K_PRIMARY, K_CIGAR_POOL, K_COUNT_WALK, K_EXPAND, K_GROUP_IDS, K_P1, K_P1_WALK, K_EMIT_WL, K_NUM = range(22)
+K_SEGMENT, K_COUNT, K_EMIT, K_PAIR_COUNT, K_PAIR_EMIT, K_GATHER, K_SCAN, K_EMIT_AUX, K_KSW, K_BAM, K_PARSE, K_CODEC, K_EMIT_SIMPLE, K_PRIMARY, K_CIGAR_POOL, K_COUNT_WALK, K_EXPAND, K_GROUP_IDS, K_P1, K_P1_WALK, K_EMIT_WL, K_NAME_SEED, K_PAIR_MASK, K_PAIR_BIG, K_GROUP_DESC, K_EXPAND_ROWS, K_EMIT_ROWS_SIMPLE, K_EMIT_ROWS, K_BIG_EMIT, K_NUM = range(30)
 KERNEL_NAMES = ["k_segment", "k_project<G,false,false,1>", "k_emit_dense<false,2>", "k_pair<false>", "k_pair<true>",
                 "k_rows", "k_scan_*", "k_project<64,true>", "k_ksw", "k_bam_scan+k_bam_size+k_bam_encode",
                 "k_rec_fields+k_group_off+k_rec_copy+k_mates+k_seq_*", "k_deflate_*+k_bgzf_compact",
                 "k_emit_dense<false,1>", "k_primary", "(unused)", "k_project<G,false,false,2>", "k_expand", "k_group_ids",
-                "k_project1<G,1>", "k_project1<G,2>", "k_emit_wl"]
+                "k_project1<G,1>", "k_project1<G,2>", "k_emit_wl", "k_name_seed", "k_pair_mask", "k_big<0>+k_pair_big", "k_group_desc",
+                "k_expand_rows", "k_emit_rows<1>", "k_emit_rows<2>", "k_big<1>"]
 
 
 class BrambleError(RuntimeError):

@@ -584,7 +584,15 @@ const char *br_bgzf_codec(void); /* "libdeflate" (bound at run time when present
 #define BR_K_P1 18        /* k_project1<G,1>: single-pass count + emit, main kernel (simple class written, general class listed) */
 #define BR_K_P1_WALK 19   /* k_project1<G,2>: the alignments that need the exon walk */
 #define BR_K_EMIT_WL 20   /* k_emit_wl: the general class from the single pass's work list */
-#define BR_K_NUM 21
+#define BR_K_NAME_SEED 21  /* k_name_seed: first mt19937_64 output per read name (direct rows) */
+#define BR_K_PAIR_MASK 22  /* k_pair_mask: pairing on the survivor sets, before the emit pass */
+#define BR_K_PAIR_BIG 23   /* k_big<0> + k_pair_big: the same for alignments with > 64 candidate rows */
+#define BR_K_GROUP_DESC 24 /* k_group_desc: NH / HI / primary per read name (+ the per-read-name counters) */
+#define BR_K_EXPAND_ROWS 25 /* k_expand_rows: emit work list + emit descriptors */
+#define BR_K_EMIT_ROWS_SIMPLE 26 /* k_emit_rows<1>: packed rows of the simple class */
+#define BR_K_EMIT_ROWS 27  /* k_emit_rows<2|0>: packed rows of the general class (or of everything) */
+#define BR_K_BIG_EMIT 28   /* k_big<1>: packed rows of the alignments with > 64 candidate rows */
+#define BR_K_NUM 29
 /* When enabled, every launch is bracketed by hipEvents on the launch stream. */
 int br_ctx_set_profiling(br_ctx *, int enabled);
 /* Launch tuning: "group_lanes" (8|16|32|64 lanes cooperating on one alignment),
