@@ -1080,7 +1080,8 @@ static int run_device_direct(br_ctx *c, const DevCfg &dc, const br_device_batch 
   RC(c->totals.ensure(16 * 8)); RC(c->counters_d.ensure(4 * 8));
   RC(c->big_list.ensure((size_t)n * 4)); RC(c->n_big.ensure(16)); RC(c->walk_list.ensure((size_t)n * 4));
   RC(c->aln_group.ensure((size_t)n * 4)); RC(c->n_rows.ensure((size_t)n * 4)); RC(c->pbit.ensure((size_t)n));
-  RC(c->d_fm.ensure((size_t)n * sizeof(uint4))); RC(c->d_nkept.ensure((size_t)n * 4)); RC(c->d_desc.ensure((size_t)n * sizeof(uint4)));
+  RC(c->d_fm.ensure((size_t)n * sizeof(uint2) + (size_t)(n / 64 + 2) * 4));   // + the window list of k_pair_mask
+  RC(c->d_nkept.ensure((size_t)n * 4)); RC(c->d_desc.ensure((size_t)n * sizeof(uint4)));
   RC(c->d_hi0.ensure((size_t)n * 4)); RC(c->d_clspos.ensure((size_t)n * 4)); RC(c->d_rnd.ensure((size_t)std::max<int64_t>(ng, 1) * 8));
   RC(c->d_sidectr.ensure(16));
   if (c->d_side_cap == 0) c->d_side_cap = std::max<uint64_t>((uint64_t)n / 4, 1u << 20);
@@ -1104,7 +1105,7 @@ static int run_device_direct(br_ctx *c, const DevCfg &dc, const br_device_batch 
   D.n_aln = n; D.n_groups = ng; D.group_off = b->group_off; D.aln_group = c->aln_group.as<uint32_t>(); D.mate_idx = b->mate_idx;
   D.n_matches = c->n_matches.as<uint32_t>(); D.mask = c->mask.as<uint64_t>(); D.ranges = c->ranges.as<uint4>();
   D.fast_flag = c->fast_flag.as<uint32_t>(); D.s_tid = ix->dev.s_tid; D.big_list = A.big_list; D.n_big = A.n_big;
-  D.fm = c->d_fm.as<uint4>(); D.n_kept = c->d_nkept.as<uint32_t>(); D.n_rows = c->n_rows.as<uint32_t>(); D.pflag = c->pbit.as<uint8_t>();
+  D.fm = c->d_fm.as<uint2>(); D.pm_list = (uint32_t *)(c->d_fm.as<uint2>() + n); D.pm_n = c->n_big.as<uint32_t>() + 2; D.n_kept = c->d_nkept.as<uint32_t>(); D.n_rows = c->n_rows.as<uint32_t>(); D.pflag = c->pbit.as<uint8_t>();
   D.side = c->d_side.as<uint2>(); D.side_cap = c->d_side_cap; D.side_used = c->d_sidectr.as<unsigned long long>();
   D.cls_pos = c->d_clspos.as<uint32_t>(); D.cig_base = c->cig_base.as<uint64_t>(); D.row_off = c->row_off.as<uint64_t>();
   D.name_off = have_names ? b->name_off : nullptr; D.names = have_names ? b->names : nullptr; D.rnd0 = c->d_rnd.as<uint64_t>();
@@ -1126,7 +1127,7 @@ static int run_device_direct(br_ctx *c, const DevCfg &dc, const br_device_batch 
   RC(pf.begin(BR_K_GROUP_IDS));
   launch_group_ids(st, ng, b->group_off, c->aln_group.as<uint32_t>());
   RC(pf.end());
-  HIPCHK(hipMemsetAsync(c->n_big.p, 0, 8, st));
+  HIPCHK(hipMemsetAsync(c->n_big.p, 0, 16, st));
   const int n_blocks = c->n_cu * c->blocks_per_cu;
   const bool split = A.walk_list != nullptr;
   RC(pf.begin(BR_K_COUNT));
@@ -1145,6 +1146,7 @@ static int run_device_direct(br_ctx *c, const DevCfg &dc, const br_device_batch 
   for (int attempt = 0;; attempt++) {
     HIPCHK(hipMemsetAsync(c->d_sidectr.p, 0, 16, st));
     HIPCHK(hipMemsetAsync(c->counters_d.p, 0, 4 * 8, st));
+    HIPCHK(hipMemsetAsync(D.pm_n, 0, 4, st));
     HIPCHK(hipEventRecord(c->aux_ev[1], st));
     HIPCHK(hipStreamWaitEvent(ax, c->aux_ev[1], 0));
     RC(pf.begin(BR_K_PAIR_BIG, ax));
@@ -1153,7 +1155,7 @@ static int run_device_direct(br_ctx *c, const DevCfg &dc, const br_device_batch 
     RC(pf.end());
     HIPCHK(hipEventRecord(c->aux_ev[2], ax));
     RC(pf.begin(BR_K_PAIR_MASK));
-    launch_pair_mask(st, D);
+    launch_pair_mask(st, D, c->n_cu * 2);
     RC(pf.end());
     HIPCHK(hipStreamWaitEvent(st, c->aux_ev[2], 0));
     // NH / HI / primary per read name on the second stream beside the scan

@@ -187,7 +187,7 @@ __device__ __forceinline__ bool rows_over(const uint64_t *tot, uint64_t lim_r) {
 // no per-record r_rec, no k_pair<true> / k_rows.
 //   k_name_seed     per read name: the first mt19937_64 output of its seed (the primary tie-break's only heavy part; it
 //                   needs nothing but the name, so it runs beside the count pass)
-//   k_pair_mask     per alignment: filtered survivor mask + tid rank of every kept survivor, records per leader
+//   k_pair_mask     per alignment: filtered survivor mask, records per leader
 //   k_big_collect / k_pair_big   the same for alignments with > 64 candidate rows (tid lists in a side arena)
 //   k_scan5_*       kept matches -> class-list position, CIGAR arena base, row offsets (one pass, one host wait)
 //   k_group_desc    per read name: NH, first HI of every alignment, the primary record (all scores tie: core.cpp:283-303)
@@ -207,13 +207,13 @@ struct DirectArgs {
   const uint32_t *s_tid;         // index: tid of every slab row
   const uint32_t *big_list; const uint32_t *n_big;   // alignments with > 64 candidate rows and >= 1 survivor
   // k_pair_mask / k_pair_big
-  uint4 *fm;                     // [n_aln] {filtered mask lo, hi, rank nibbles lo, hi}: nibble j = tid rank (among the kept) of the
-                                 // j-th kept survivor, valid when <= 16 are kept; big alignments: {side offset lo, hi, survivors, 0}
+  uint2 *fm;                     // [n_aln] the filtered survivor mask (the kept ones); big alignments: offset of their list in the side arena
   uint32_t *n_kept;              // [n_aln] kept survivors = emitted records of the alignment
   uint32_t *n_rows;              // [n_aln] records of a leader (its own + its mate's), else 0
   uint8_t *pflag;                // [n_aln] PF_*
   uint2 *side;                   // big alignments: {tid, rank among the kept | ~0u: dropped} per survivor, candidate order
   uint64_t side_cap;
+  uint32_t *pm_list, *pm_n;      // k_pair_mask: windows (index / 64) whose tid lists exceed its staging area, and their count
   unsigned long long *side_used; // [0] entries handed out, [1] set when the arena ran out (the host grows it and repeats)
   // fused scan
   uint32_t *cls_pos;             // [n_aln] first entry of the alignment in the class-partitioned emit work list
@@ -232,7 +232,7 @@ struct DirectArgs {
   uint4 *r_x;                    // detail column {input, junc_hits, aligned_len, HI} or null
 };
 void launch_name_seed(hipStream_t st, const DirectArgs &D);
-void launch_pair_mask(hipStream_t st, const DirectArgs &D);
+void launch_pair_mask(hipStream_t st, const DirectArgs &D, int wide_blocks);
 void launch_big_collect(hipStream_t st, const ProjectArgs &A, const DirectArgs &D, int n_blocks);
 void launch_pair_big(hipStream_t st, const DirectArgs &D, int n_blocks);
 void launch_scan5(hipStream_t st, const DirectArgs &D, uint64_t *tile_sums, uint64_t *total_out5);
