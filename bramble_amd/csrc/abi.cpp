@@ -1080,7 +1080,7 @@ static int run_device_direct(br_ctx *c, const DevCfg &dc, const br_device_batch 
   RC(c->totals.ensure(16 * 8)); RC(c->counters_d.ensure(4 * 8));
   RC(c->big_list.ensure((size_t)n * 4)); RC(c->n_big.ensure(16)); RC(c->walk_list.ensure((size_t)n * 4));
   RC(c->aln_group.ensure((size_t)n * 4)); RC(c->n_rows.ensure((size_t)n * 4)); RC(c->pbit.ensure((size_t)n));
-  RC(c->d_fm.ensure((size_t)n * sizeof(uint2) + (size_t)(n / 64 + 2) * 4));   // + the window list of k_pair_mask
+  RC(c->d_fm.ensure((size_t)n * sizeof(uint2) + (size_t)(n / 62 + 2) * 4));   // + the window list of k_pair_mask
   RC(c->d_nkept.ensure((size_t)n * 4)); RC(c->d_desc.ensure((size_t)n * sizeof(uint4)));
   RC(c->d_hi0.ensure((size_t)n * 4)); RC(c->d_clspos.ensure((size_t)n * 4)); RC(c->d_rnd.ensure((size_t)std::max<int64_t>(ng, 1) * 8));
   RC(c->d_sidectr.ensure(16));
@@ -1717,7 +1717,7 @@ extern "C" int br_ctx_collect_counters(br_ctx *c, const br_device_batch *b, void
   HIPCHK(hipMemsetAsync(stats.p, 0, 8 * 8, st));
   StatsArgs T{};
   T.ix = c->ix->dev; T.n_aln = b->n_aln; T.ref_id = b->ref_id; T.cigar_off = b->cigar_off;
-  T.seg = c->seg.as<uint2>(); T.head = c->head.as<uint4>(); T.out = stats.as<uint64_t>();
+  T.seg = c->seg.as<uint2>(); T.head = c->head.as<uint4>(); T.head2 = c->head2.as<uint4>(); T.out = stats.as<uint64_t>();
   int64_t nm = (int64_t)c->counters[6];
   launch_stats(st, T, nm ? c->m_p.as<uint2>() : nullptr, c->match_off.as<uint32_t>(), c->n_matches.as<uint32_t>());
   uint64_t h[8];

@@ -279,7 +279,7 @@ struct StatsArgs {
   const int32_t *ref_id;
   const uint32_t *cigar_off;
   const uint2 *seg;
-  const uint4 *head;
+  const uint4 *head, *head2;
   uint64_t *out;  // [8]
 };
 void launch_stats(hipStream_t st, const StatsArgs &T, const uint2 *m_p, const uint32_t *match_off, const uint32_t *n_matches);

@@ -83,7 +83,8 @@ __global__ void __launch_bounds__(256) k_segment(int64_t n_aln, const int32_t *_
           ex_end = (uint32_t)(pos0 + l); ex_start = (uint32_t)(exstart + 1);
           const uint2 v = make_uint2(ex_start, ex_end + 1);
           if (n == 0) e0 = v; else if (n == 1) e1 = v; else if (n == 2) e2 = v;
-          out[n++] = v;
+          else { if (n == 3) { out[0] = e0; out[1] = e1; out[2] = e2; } out[n] = v; }   // seg[] is read from exon 3 on (ReadCtx::exon): reads of up to three exons never write it
+          n++;
         }
         l += (int)len; exstart = pos0 + l; intron = true;
         break;
@@ -95,7 +96,8 @@ __global__ void __launch_bounds__(256) k_segment(int64_t n_aln, const int32_t *_
     ex_start = (uint32_t)(exstart + 1); ex_end = (uint32_t)(pos0 + l);
     const uint2 v = make_uint2(ex_start, ex_end + 1);
     if (n == 0) e0 = v; else if (n == 1) e1 = v; else if (n == 2) e2 = v;
-    out[n++] = v;
+    else { if (n == 3) { out[0] = e0; out[1] = e1; out[2] = e2; } out[n] = v; }
+    n++;
   }
   if (ex_end == 0) n = 0;  // the reference aborts here (GSam.cpp:290); we project nothing
   int32_t rid = ref_id[a];
@@ -140,8 +142,9 @@ __global__ void __launch_bounds__(256) k_segment(int64_t n_aln, const int32_t *_
   // everything k_project needs for read exon 0 in one 16-byte record
   uint2 q0 = n ? e0 : make_uint2(0, 0);
   head[a] = make_uint4(q0.x, q0.y, n, n ? (((uint32_t)rid << 2) | smode) : 0u);
-  uint2 q1 = n > 1 ? e1 : make_uint2(0, 0), q2 = n > 2 ? e2 : make_uint2(0, 0);
-  head2[a] = make_uint4(q1.x, q1.y, q2.x, q2.y);
+  // read exons 1 and 2: only a spliced read has them (the readers load the record unconditionally and use it from two
+  // exons on: for the others the 16 bytes are not written)
+  if (n > 1) { const uint2 q2 = n > 2 ? e2 : make_uint2(0, 0); head2[a] = make_uint4(e1.x, e1.y, q2.x, q2.y); }
   // "simple" alignments: one read exon from a single M op, short-read presets.  They
   // are processed first (k_perm) so that whole waves take the short code paths.
   uint32_t fast = (n == 1 && n_cigar == 1 && CIG_OP(cg[0]) == OP_M && !cfg.filter_by_similarity && !cfg.long_reads) ? 1u : 0u;
@@ -2372,6 +2375,7 @@ __global__ void __launch_bounds__(256) k_stats(StatsArgs T) {
     ncig = T.cigar_off[a + 1] - c0;
     if (mt.n_seg) {
       const uint2 *seg = T.seg + (size_t)c0 + (size_t)a;
+      const uint4 h2 = mt.n_seg > 1 ? T.head2[a] : make_uint4(0, 0, 0, 0);
       uint32_t rid = (uint32_t)T.ref_id[a];
       exons = mt.n_seg;
       for (int s = 0; s < 2; s++) {
@@ -2380,7 +2384,7 @@ __global__ void __launch_bounds__(256) k_stats(StatsArgs T) {
         uint32_t N = se - sb, lg = 0;
         while ((1u << lg) < N) lg++;
         for (uint32_t j = 0; j < mt.n_seg; j++) {
-          uint2 q = seg[j];
+          uint2 q = j == 0 ? make_uint2(hd.x, hd.y) : j == 1 ? make_uint2(h2.x, h2.y) : j == 2 ? make_uint2(h2.z, h2.w) : seg[j];   // (k_segment writes seg[] from the fourth exon on)
           uint32_t x = sb, y = se;
           while (x < y) { uint32_t m = (x + y) >> 1; if (T.ix.s_start[m] < q.y) x = m + 1; else y = m; }
           uint32_t hi = x; x = sb; y = hi;
