@@ -524,6 +524,7 @@ struct br_ctx {
   DevBuf ksw_desc, ksw_dp, ksw_left, ksw_cnt, ksw_group, ksw_tape, ksw_raw;
   int ksw_fast = 1;            // 0: every problem through the general kernel k_ksw
   hipStream_t ksw_stream = nullptr; hipEvent_t ksw_ev[KSW_N_BINS + 1] = {}; hipEvent_t aux_ev[8] = {};   // the second stream
+  hipStream_t aux2_stream = nullptr; hipEvent_t aux2_ev = nullptr;   // a third one: the name seeds of the direct path beside k_pair_mask
   uint32_t ksw_groups[KSW_N_BINS] = {0};
   int64_t ksw_tape_mb = 49152; // HBM set aside for the direction tape; larger batches go through in pieces
   int ksw_tape_pct = 100;      // test hook: the share of the computed tape the DP kernels may use (the rest of the problems goes to k_ksw)
@@ -613,6 +614,7 @@ extern "C" void br_ctx_free(br_ctx *c) {
     S.h_clip.release(); S.h_sim.release();
   }
   if (c->rows_busy) (void)hipEventDestroy(c->rows_busy);
+  if (c->aux2_stream) { (void)hipStreamDestroy(c->aux2_stream); (void)hipEventDestroy(c->aux2_ev); }
   if (c->ksw_stream) { (void)hipStreamDestroy(c->ksw_stream); for (auto &e : c->ksw_ev) if (e) (void)hipEventDestroy(e); for (auto &e : c->aux_ev) if (e) (void)hipEventDestroy(e); }
   if (c->run_stream) (void)hipStreamDestroy(c->run_stream);
   if (c->d2h_stream) (void)hipStreamDestroy(c->d2h_stream);
@@ -1111,14 +1113,10 @@ static int run_device_direct(br_ctx *c, const DevCfg &dc, const br_device_batch 
   D.name_off = have_names ? b->name_off : nullptr; D.names = have_names ? b->names : nullptr; D.rnd0 = c->d_rnd.as<uint64_t>();
   D.desc = c->d_desc.as<uint4>(); D.hi0 = c->d_hi0.as<uint32_t>(); D.counters = c->counters_d.as<uint64_t>(); D.tot = d_tot;
 
-  // second stream: the name seeds need nothing the main stream makes
+  if (!c->aux2_stream) { HIPCHK(hipStreamCreateWithFlags(&c->aux2_stream, hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&c->aux2_ev, hipEventDisableTiming)); }
+  hipStream_t ax2 = c->aux2_stream;
   HIPCHK(hipEventRecord(c->aux_ev[0], st));
   HIPCHK(hipStreamWaitEvent(ax, c->aux_ev[0], 0));
-  if (have_names) {
-    RC(pf.begin(BR_K_NAME_SEED, ax));
-    launch_name_seed(ax, D);
-    RC(pf.end());
-  }
   // a1/a2/a6: CIGAR -> read exons; a3-a8, a11-a14 (survival only): the count pass
   RC(pf.begin(BR_K_SEGMENT));
   launch_segment(st, n, b->ref_id, b->ref_start, b->flags, b->xs, b->ts, b->cigar_off, b->cigar, dc, ix->n_refs,
@@ -1143,6 +1141,16 @@ static int run_device_direct(br_ctx *c, const DevCfg &dc, const br_device_batch 
   // a16 (src/mates.cpp:150-261) on the survivor sets, then placement
   const int big_blocks = c->n_cu * 4;
   uint64_t kept = 0, arena = 0, n_simple = 0, n_rows = 0, n_raw = 0;
+  // third stream: the name seeds need nothing but the names, and their 156 dependent multiplies per read name are pure ALU work:
+  // beside k_pair_mask, which waits on LDS and memory most of the time
+  if (have_names) {
+    HIPCHK(hipEventRecord(c->aux_ev[7], st));
+    HIPCHK(hipStreamWaitEvent(ax2, c->aux_ev[7], 0));
+    RC(pf.begin(BR_K_NAME_SEED, ax2));
+    launch_name_seed(ax2, D);
+    RC(pf.end());
+    HIPCHK(hipEventRecord(c->aux2_ev, ax2));
+  }
   for (int attempt = 0;; attempt++) {
     HIPCHK(hipMemsetAsync(c->d_sidectr.p, 0, 16, st));
     HIPCHK(hipMemsetAsync(c->counters_d.p, 0, 4 * 8, st));
@@ -1161,6 +1169,7 @@ static int run_device_direct(br_ctx *c, const DevCfg &dc, const br_device_batch 
     // NH / HI / primary per read name on the second stream beside the scan
     HIPCHK(hipEventRecord(c->aux_ev[3], st));
     HIPCHK(hipStreamWaitEvent(ax, c->aux_ev[3], 0));
+    if (have_names) HIPCHK(hipStreamWaitEvent(ax, c->aux2_ev, 0));
     RC(pf.begin(BR_K_GROUP_DESC, ax));
     launch_group_desc(ax, D);
     RC(pf.end());
@@ -1199,10 +1208,10 @@ static int run_device_direct(br_ctx *c, const DevCfg &dc, const br_device_batch 
   D.m_aln = c->m_aln.as<uint32_t>(); D.r_a = c->pk_a.as<uint4>(); D.r_c = c->pk_c.as<uint2>(); D.r_x = with_x ? c->pk_x.as<uint4>() : nullptr;
   const bool emit_split = c->emit_split != 0;
   if (kept) {
-    HIPCHK(hipStreamWaitEvent(st, c->aux_ev[4], 0));
     RC(pf.begin(BR_K_EXPAND_ROWS));
     launch_expand_rows(st, D);
     RC(pf.end());
+    HIPCHK(hipStreamWaitEvent(st, c->aux_ev[4], 0));   // k_group_desc: the descriptors' first halves
     HIPCHK(hipEventRecord(c->aux_ev[5], st));
     HIPCHK(hipStreamWaitEvent(ax, c->aux_ev[5], 0));
     RC(pf.begin(BR_K_BIG_EMIT, ax));
