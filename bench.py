@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Headline benchmark: projected alignments/sec against a GENCODE-scale annotation.
 
-One "step" = one pass of the projection hot path (k_segment -> count pass -> scans ->
-emit pass -> k_pair -> k_rows -> k_primary) over one synthetic name-collated batch.  At N=1
+One "step" = one pass of the projection hot path (k_segment -> count pass -> k_pair_mask ->
+scan -> k_group_desc -> k_expand_rows -> k_emit_rows: "direct rows") over
+one synthetic name-collated batch.  At N=1
 the workload is BASELINE.json configs[1] (paired-end short reads vs a GENCODE-shaped
 annotation, 1 x MI355X); N>1 shards read-name groups across ranks (one process per GPU, a
 private index replica each, no collective on the data path) -- weak scaling.
@@ -45,6 +46,11 @@ def kernel_bytes(cn, n_aln, n_rows):
         "count": cn["B_in"] + hits40,                      # heads again + one 40-byte row per overlap hit
         "emit": 4 * n_aln + 40 * cn["matches"] + match_rec,  # one row re-read + one match record written per match
         "rows": match_rec + 24 * n_rows,                   # match records read, 24 B per emitted record written
+        # direct rows: the pairing reads a 4-byte transcript id per survivor and writes 4 B per alignment (records of the
+        # leader); the emit kernels re-read one 40-byte row per EMITTED record and write its 24 bytes + its CIGAR words
+        # (the formula's per-match CIGAR words stand in for the emitted ones: an upper bound by the dropped 9 %)
+        "pairing": 4 * cn["matches"] + 4 * n_aln,
+        "emit_rows": 4 * n_aln + 40 * n_rows + 24 * n_rows + 4 * cn["out_cigar_words"],
     }
 
 
@@ -233,13 +239,21 @@ def main():
             "count (k_project<G,false,false,1|2>)": entry(g("k_project<G,false,false,1>", 0.0) + g("k_project<G,false,false,2>", 0.0),
                                                           kb["count"],
                                                           ["k_project<G,false,false,1>", "k_project<G,false,false,2>"]),
-            "emit (k_expand + k_emit_dense<false,1|2> + k_project<64,true>)": entry(
-                g("k_expand", 0.0) + g("k_emit_dense<false,1>", 0.0) + g("k_emit_dense<false,2>", 0.0) + g("k_project<64,true>", 0.0),
-                kb["emit"], ["k_expand", "k_emit_dense<false,1>", "k_emit_dense<false,2>", "k_project<64,true>"]),
-            "rows (k_group_ids + k_pair<false|true> + k_primary + k_rows)": entry(
-                g("k_group_ids", 0.0) + g("k_pair<false>", 0.0) + g("k_pair<true>", 0.0) + g("k_rows", 0.0) + g("k_primary", 0.0),
-                kb["rows"], ["k_group_ids", "k_pair<false>", "k_pair<true>", "k_rows", "k_primary"]),
         }
+        if g("k_emit_rows<2>", 0.0) or g("k_emit_rows<1>", 0.0):
+            # direct rows (the default): pairing on the survivor sets, then the emit kernels write the packed rows
+            pair_names = ["k_group_ids", "k_pair_mask", "k_big<0>+k_pair_big", "k_name_seed", "k_group_desc"]
+            emit_names = ["k_expand_rows", "k_emit_rows<1>", "k_emit_rows<2>", "k_big<1>"]
+            table["pairing (k_group_ids + k_pair_mask + k_big<0> + k_pair_big + k_name_seed + k_group_desc)"] = entry(
+                sum(g(x, 0.0) for x in pair_names), kb["pairing"], pair_names)
+            table["emit (k_expand_rows + k_emit_rows<1|2> + k_big<1>)"] = entry(sum(g(x, 0.0) for x in emit_names), kb["emit_rows"], emit_names)
+        else:
+            table["emit (k_expand + k_emit_dense<false,1|2> + k_project<64,true>)"] = entry(
+                g("k_expand", 0.0) + g("k_emit_dense<false,1>", 0.0) + g("k_emit_dense<false,2>", 0.0) + g("k_project<64,true>", 0.0),
+                kb["emit"], ["k_expand", "k_emit_dense<false,1>", "k_emit_dense<false,2>", "k_project<64,true>"])
+            table["rows (k_group_ids + k_pair<false|true> + k_primary + k_rows)"] = entry(
+                g("k_group_ids", 0.0) + g("k_pair<false>", 0.0) + g("k_pair<true>", 0.0) + g("k_rows", 0.0) + g("k_primary", 0.0),
+                kb["rows"], ["k_group_ids", "k_pair<false>", "k_pair<true>", "k_rows", "k_primary"])
         # dominant = the single kernel with the most device time per step (k_scan_* is a group of small launches)
         single = {k: v for k, v in per_ms.items() if k != "k_scan_*"}
         dom = max(single, key=lambda k: single[k])
@@ -294,10 +308,11 @@ def main():
                 "per_kernel": table,
                 "note": "achieved = the SURVEY 8d algorithmic bytes of one step over the whole step (every launch of the path); "
                         "per_kernel charges each stage only the formula terms it must move itself (DESIGN.md section 4) over its "
-                        "own hipEvent time (k_project<64,true> and k_primary run on the context's second stream beside "
-                        "k_emit_dense / k_pair<true>: overlapped kernels stretch each other, so the stage times sum to more "
-                        "than ms_per_step and the emit / rows fractions are lower bounds); traffic = corrected rocprofv3 "
-                        "FETCH_SIZE + WRITE_SIZE per launch (profiles/pmc_traffic.json) when collected for this workload",
+                        "own hipEvent time (k_big<0> + k_pair_big, k_name_seed, k_group_desc and k_big<1> run on the context's second "
+                        "and third streams beside k_pair_mask, the scan and the emit kernels: overlapped kernels stretch each other, "
+                        "so the stage times sum to more than ms_per_step and the pairing / emit fractions are lower bounds); traffic "
+                        "is NOT measured by this run: it is the corrected rocprofv3 FETCH_SIZE + WRITE_SIZE per launch that the builder "
+                        "collected for this workload and committed as profiles/pmc_traffic.json (null when that file is for another size)",
             },
         }
         if not args.no_cpu_baseline and world == 1:   # the CPU leg is timed at N=1 only (the other ranks would wait for it)

@@ -1111,7 +1111,7 @@ static int run_device_direct(br_ctx *c, const DevCfg &dc, const br_device_batch 
   D.side = c->d_side.as<uint2>(); D.side_cap = c->d_side_cap; D.side_used = c->d_sidectr.as<unsigned long long>();
   D.cls_pos = c->d_clspos.as<uint32_t>(); D.cig_base = c->cig_base.as<uint64_t>(); D.row_off = c->row_off.as<uint64_t>();
   D.name_off = have_names ? b->name_off : nullptr; D.names = have_names ? b->names : nullptr; D.rnd0 = c->d_rnd.as<uint64_t>();
-  D.desc = c->d_desc.as<uint4>(); D.hi0 = c->d_hi0.as<uint32_t>(); D.counters = c->counters_d.as<uint64_t>(); D.tot = d_tot;
+  D.gd = c->d_desc.as<uint2>(); D.dpos = c->d_desc.as<uint2>() + n; D.hi0 = c->d_hi0.as<uint32_t>(); D.counters = c->counters_d.as<uint64_t>(); D.tot = d_tot;
 
   if (!c->aux2_stream) { HIPCHK(hipStreamCreateWithFlags(&c->aux2_stream, hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&c->aux2_ev, hipEventDisableTiming)); }
   hipStream_t ax2 = c->aux2_stream;

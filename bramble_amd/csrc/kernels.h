@@ -222,7 +222,9 @@ struct DirectArgs {
   // primary choice
   const uint32_t *name_off; const uint8_t *names;   // null: no primary flags
   uint64_t *rnd0;                // [n_groups] k_name_seed
-  uint4 *desc;                   // [n_aln] {first record, PF_* | (primary rank + 1) << 8, NH, class-list position}
+  // the emit descriptor of an alignment, as two dense 8-byte arrays (their writers run on different streams):
+  uint2 *gd;                     // [n_aln] k_group_desc: {PF_* | (primary rank + 1) << 8, NH}
+  uint2 *dpos;                   // [n_aln] k_expand_rows: {first record, position of its entries in the emit work list}
   uint32_t *hi0;                 // [n_aln] HI of the alignment's first record
   uint64_t *counters;            // [4] total_complete, total_unique, dropped_reads, a field overflowed its packed width
   const uint64_t *tot;           // scan totals on the device: [0] kept, [1] arena words, [2] kept of the simple class, [3] records, [4] survivors

@@ -72,11 +72,22 @@ def main():
             return "k_emit_dense<%s,%s>" % (m.group(1), m.group(2))   # the timer's name (the third parameter is the -S variant)
         if k == "k_pair_emit":
             return "k_pair<true>"                                      # the emit pass keeps its timer's name
+        if k in ("k_big<0>", "k_pair_big"):
+            return "k_big<0>+k_pair_big"
+        if k == "k_pair_mask_wide":
+            return "k_pair_mask"
         return k
+    # direct rows (the default path): bench.py's counter diagnostic at the end of the run projects the batch once more through
+    # the match-table path (br_ctx_collect_counters); those kernels are not part of the timed step
+    direct = any(k.startswith("k_emit_rows") for k in full)
+    direct_step = re.compile(r"^(k_segment|k_group_ids|k_project<\d+, ?false, ?false, ?[12]>|k_name_seed|k_pair_mask(_wide)?|k_big<[01]>|k_pair_big|"
+                             r"k_scan5_\w+|k_group_desc|k_expand_rows|k_emit_rows<[012]>)$")
     kern = {}
     for k, v in full.items():
         if k in ("k_stats", "k_sum_ncig"):
             continue   # diagnostics outside the timed step
+        if direct and not direct_step.match(k):
+            continue
         key = bench_key(k)
         if key in kern:
             t = dict(kern[key])

@@ -61,6 +61,10 @@ def run(rounds, seed, verbose=True, read_counts=(500, 3000, 9000), gene_counts=(
         ctx.set_param("small_batch", it & 1)        # the path without host round trips on odd rounds, the ordinary one on even rounds
         desc["small_batch"] = it & 1
         ctx.set_param("group_lanes", int(rng.choice([8, 16, 32, 64])))
+        # direct rows (pairing before the emit pass) is the default of the ordinary pipeline; one round in four takes the
+        # match-table path it replaced (still the path of the similarity-filter presets and of -S)
+        desc["direct_rows"] = int(rng.rand() >= 0.25)
+        ctx.set_param("direct_rows", desc["direct_rows"])
         cfg = lib.make_config(**flags)
         oi = ob.OracleIndex(annd)
         try:
