@@ -2180,6 +2180,13 @@ struct br_bam_reader {
   std::mutex m;
   Chunk *carry_from = nullptr; uint64_t carry_off = 0, carry_len = 0;
   DevBuf comp, small;
+  // piece-wise reading (br_bam_piece_*): two upload slots, filled on a copy stream of their own beside the processing of the
+  // piece before
+  struct PieceSlot { DevBuf comp; hipEvent_t up = nullptr; int64_t b0 = -1, b1x = -1; uint64_t src0 = 0, n_src = 0; };
+  PieceSlot pslot[2];
+  hipStream_t copy_st = nullptr;
+  std::vector<br_bgzf_block> pblocks;
+  double t_proc = 0;
   std::vector<br_bgzf_block> blocks;
   int64_t next_id = 0;
   bool finished = false;
@@ -2214,6 +2221,8 @@ extern "C" void br_bam_reader_free(br_bam_reader *r) {
   (void)hipSetDevice(r->shell.device);
   for (auto &ch : r->chunks) { ch->data.release(); ch->off.release(); ch->len.release(); }
   r->comp.release(); r->small.release();
+  for (auto &ps : r->pslot) { ps.comp.release(); if (ps.up) (void)hipEventDestroy(ps.up); }
+  if (r->copy_st) (void)hipStreamDestroy(r->copy_st);
   if (r->st) (void)hipStreamDestroy(r->st);
   if (r->c) br_ctx_free(r->c);
   delete r;
@@ -2319,6 +2328,120 @@ extern "C" int br_bam_reader_next(br_bam_reader *r, const uint8_t *data, uint64_
   *id = ch->id; *n_unmapped = unm;
   return BR_OK;
 }
+
+// ---------------------------------------------------------------------------
+// Piece-wise device reader.  The caller holds the whole file's block table (br_bgzf_scan over the mapping) and hands out
+// pieces [b0, b1) of it -- to one reader in order, or to several readers on several devices: a piece needs nothing from
+// its neighbours (see split_kernels.hip: the cut rule).  br_bam_piece_upload may run on another thread than
+// br_bam_piece_process, one piece ahead (two slots).
+// ---------------------------------------------------------------------------
+extern "C" int br_bam_piece_upload(br_bam_reader *r, int slot, const uint8_t *file, uint64_t file_bytes, const br_bgzf_block *blocks,
+                                   int64_t n_blocks, int64_t b0, int64_t b1x) {
+  if (!r || slot < 0 || slot > 1 || !file || !blocks || b0 < 0 || b1x <= b0 || b1x > n_blocks) return BR_ERR_INVALID_ARG;
+  HIPCHK(hipSetDevice(r->shell.device));
+  if (!r->copy_st) HIPCHK(hipStreamCreateWithFlags(&r->copy_st, hipStreamNonBlocking));
+  br_bam_reader::PieceSlot &P = r->pslot[slot];
+  if (!P.up) HIPCHK(hipEventCreateWithFlags(&P.up, hipEventDisableTiming));
+  const uint64_t src0 = blocks[b0].src_off, src1 = blocks[b1x - 1].src_off + blocks[b1x - 1].clen + 8;
+  if (src1 > file_bytes || src1 <= src0) return BR_ERR_INVALID_ARG;
+  RC(P.comp.ensure((size_t)(src1 - src0) + 64));
+  HIPCHK(hipMemcpyAsync(P.comp.p, file + src0, (size_t)(src1 - src0), hipMemcpyHostToDevice, r->copy_st));
+  HIPCHK(hipEventRecord(P.up, r->copy_st));
+  HIPCHK(hipStreamSynchronize(r->copy_st));   // (a pageable source: the call has staged it all by now anyway)
+  P.b0 = b0; P.b1x = b1x; P.src0 = src0; P.n_src = src1 - src0;
+  return BR_OK;
+}
+
+// Inflates the slot's blocks [b0, b1x) (b1x >= b1: the piece's own blocks and a few of the next piece's, for the END cut),
+// splits them into records and returns the piece's bundle.
+//   start_rel >= 0: the piece's first record starts that many inflated bytes behind the start of block b0 (the BAM header's
+//                   size for the first piece; the END of the piece in front otherwise);  -1: guess it
+//   info->start_rel / end_rel: where the bundle starts (behind block b0) and ends (behind block b1); end_rel of piece k is
+//                   the start_rel of piece k + 1 -- a guessing reader's start_rel must equal its neighbour's end_rel, or the
+//                   piece is to be processed again with that value
+// Returns BR_PIECE_MORE (1) when the END cut lies beyond block b1x: upload more blocks and call again.
+extern "C" int br_bam_piece_process(br_bam_reader *r, int slot, const br_bgzf_block *blocks, int64_t n_blocks, int64_t b1,
+                                    int64_t start_rel, br_device_records *bundle, int64_t *id, br_piece_info *info) {
+  if (!r || slot < 0 || slot > 1 || !blocks || !bundle || !id || !info) return BR_ERR_INVALID_ARG;
+  br_bam_reader::PieceSlot &P = r->pslot[slot];
+  const int64_t b0 = P.b0, b1x = P.b1x;
+  if (b0 < 0 || b1 <= b0 || b1 > b1x || b1x > n_blocks) return BR_ERR_INVALID_ARG;
+  memset(bundle, 0, sizeof(*bundle)); memset(info, 0, sizeof(*info));
+  *id = -1;
+  HIPCHK(hipSetDevice(r->shell.device));
+  hipStream_t st = r->st;
+  auto tp = std::chrono::steady_clock::now();
+  const bool file_ends = b1x == n_blocks, last_piece = b1 == n_blocks;
+  const uint64_t dst0 = blocks[b0].dst_off;
+  const uint64_t total = blocks[b1x - 1].dst_off + blocks[b1x - 1].ulen - dst0;
+  const uint64_t bound = last_piece ? total : blocks[b1].dst_off - dst0;   // where the next piece's first block starts
+  r->pblocks.assign(blocks + b0, blocks + b1x);
+  for (auto &b : r->pblocks) { b.src_off -= P.src0; b.dst_off -= dst0; }
+  br_bam_reader::Chunk *ch = nullptr;
+  {
+    std::lock_guard<std::mutex> l(r->m);
+    for (auto &x : r->chunks) if (!x->out) { ch = x.get(); break; }
+    if (!ch) { r->chunks.push_back(std::make_unique<br_bam_reader::Chunk>()); ch = r->chunks.back().get(); }
+  }
+  RC(ch->data.ensure((size_t)total + 64));
+  HIPCHK(hipStreamWaitEvent(st, P.up, 0));
+  const uint8_t *o = nullptr; uint64_t ob = 0;
+  RC(inflate_impl(r->c, P.comp.as<uint8_t>(), P.n_src, r->pblocks.data(), b1x - b0, st, ch->data.as<uint8_t>(), &o, &ob));
+  RC(r->small.ensure(64));
+  unsigned long long *cut = (unsigned long long *)r->small.p;
+  uint64_t start = 0;
+  const int guess = start_rel < 0 ? 1 : 0;
+  if (guess) {   // the first offset that starts a run of records
+    SplitArgs G{}; G.data = ch->data.as<uint8_t>(); G.n_bytes = total; G.n_ref = r->n_ref;
+    launch_first_record(st, G, total, cut);
+    unsigned long long e = 0;
+    HIPCHK(hipMemcpyAsync(&e, cut, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (e == ~0ull) { if (file_ends) e = total; else return 1; }   // no record starts in here (one long record): more blocks
+    start = e;
+  } else {
+    if ((uint64_t)start_rel > total) return file_ends ? BR_ERR_INVALID_ARG : 1;
+    start = (uint64_t)start_rel;
+  }
+  const uint8_t *base = ch->data.as<uint8_t>() + start;
+  const uint64_t nbytes = total - start;
+  br_device_records recs; int64_t unm_all = 0; uint64_t used_bytes = 0; SplitArgs S{};
+  RC(split_impl(r->c, base, nbytes, r->n_ref, st, &recs, &unm_all, &used_bytes, &S));
+  if (file_ends && used_bytes != nbytes) return BR_ERR_INVALID_ARG;   // a truncated record at the end of the file
+  const int64_t n = recs.n_aln;
+  // the two cuts (see split_kernels.hip), their offsets, the unmapped records between: one read-back
+  const unsigned long long init[5] = {guess ? (unsigned long long)n : 0ull, ~0ull, 0, 0, 0};
+  HIPCHK(hipMemcpyAsync(cut, init, sizeof(init), hipMemcpyHostToDevice, st));
+  const uint64_t bound_rel = bound > start ? bound - start : 0;   // (relative to base)
+  launch_piece_cut(st, S, recs.rec_off, n, last_piece ? ~0ull : bound_rel, used_bytes, guess, cut);
+  unsigned long long h[5];
+  HIPCHK(hipMemcpyAsync(h, cut, sizeof(h), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  int64_t iS = (int64_t)std::min<unsigned long long>(h[0], (unsigned long long)n), iE = n;
+  if (!last_piece) {
+    if (h[1] == ~0ull) { if (!file_ends) return 1; }   // the group at the boundary goes on past the data: more blocks (or the file ends: all of it)
+    else iE = (int64_t)h[1];
+  }
+  if (iS > iE) iS = iE;   // (a read-name group that covers the whole piece and more: the piece in front takes it all)
+  const uint64_t off_S = h[2], off_E = std::max<uint64_t>(h[3], h[2]);
+  const int64_t n_take = iE - iS;
+  if (n_take) {
+    RC(ch->off.ensure((size_t)n_take * 8)); RC(ch->len.ensure((size_t)n_take * 4));
+    HIPCHK(hipMemcpyAsync(ch->off.p, recs.rec_off + iS, (size_t)n_take * 8, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(ch->len.p, recs.rec_len + iS, (size_t)n_take * 4, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+  }
+  { std::lock_guard<std::mutex> l(r->m); ch->id = r->next_id++; ch->out = true; }
+  bundle->blob = base; bundle->rec_off = ch->off.as<uint64_t>(); bundle->rec_len = ch->len.as<uint32_t>(); bundle->n_aln = n_take;
+  *id = ch->id;
+  info->start_rel = start + off_S;
+  info->end_rel = start + off_E >= bound ? start + off_E - bound : 0;
+  info->n_unmapped = (int64_t)h[4];
+  info->guessed = guess; info->at_end = last_piece ? 1 : 0;
+  r->t_proc += std::chrono::duration<double>(std::chrono::steady_clock::now() - tp).count();
+  return BR_OK;
+}
+extern "C" double br_bam_reader_seconds(const br_bam_reader *r) { return r ? r->t_proc : 0.0; }
 
 extern "C" int br_bam_split(const uint8_t *data, uint64_t n_bytes, int64_t cap, uint64_t *rec_off, uint32_t *rec_len,
                             int64_t *n_records, int64_t *n_unmapped, uint64_t *consumed) {

@@ -371,6 +371,9 @@ void launch_split_emit(hipStream_t st, const SplitArgs &S);
 void launch_split_totals(hipStream_t st, const SplitArgs &S);
 void launch_last_group(hipStream_t st, const uint8_t *data, const uint64_t *rec_off, int64_t n, unsigned long long *out);
 void launch_unmapped_before(hipStream_t st, const SplitArgs &S, uint64_t limit, unsigned long long *out);
+// piece-wise reading: first plausible record start; the piece's two cuts, their byte offsets and the unmapped records between (see split_kernels.hip)
+void launch_first_record(hipStream_t st, const SplitArgs &S, uint64_t limit, unsigned long long *out);
+void launch_piece_cut(hipStream_t st, const SplitArgs &S, const uint64_t *rec_off, int64_t n, uint64_t bound, uint64_t used, int guess, unsigned long long *cut);
 
 // BAM records -> input tables (parse_kernels.hip)
 struct ParseArgs {

@@ -175,6 +175,88 @@ __global__ void __launch_bounds__(256) k_unmapped_before(SplitArgs S, uint64_t l
   if ((threadIdx.x & 63) == 0 && n) atomicAdd(out, n);
 }
 
+// ---------------------------------------------------------------------------
+// Piece-wise reading (br_bam_piece_*): a piece = a run of BGZF blocks [b0, b1) handled on its own, by whatever device.  It owns
+// the records from its START to its END, both defined by the same rule on either side of a block boundary B:
+//     q = the first mapped record that starts at or after B;  the cut = the first record after q whose read name differs
+//     from its predecessor's (the read-name group that holds q goes to the piece in front).
+// The piece in front walks the true record chain across B (it inflates a few blocks past its end); the piece behind does not
+// know where a record starts in its first block and GUESSES q's predecessor-free start (k_first_record: the first offset
+// whose fixed fields and next hops look like records) -- the caller compares the two cuts and repeats the piece with the
+// true start when they differ, so the result never depends on the guess.
+// ---------------------------------------------------------------------------
+// first plausible record start in data[0, limit): one wave, 64 offsets per step
+__global__ void __launch_bounds__(64) k_first_record(SplitArgs S, uint64_t limit, unsigned long long *out) {
+  const int lane = threadIdx.x;
+  if (limit > S.n_bytes) limit = S.n_bytes;
+  for (uint64_t p0 = 0; p0 < limit; p0 += 64) {
+    const uint64_t p = p0 + lane;
+    bool ok = false;
+    if (p < limit && p + 36 <= S.n_bytes && plausible(S, p)) {
+      uint64_t q = p; ok = true;
+      for (int hop = 0; hop < 4 && ok; hop++) {   // four more records in a row (or the end of the data)
+        q += 4 + (uint64_t)sl32(S.data + q);
+        if (q > S.n_bytes) { ok = false; break; }
+        if (q + 36 > S.n_bytes) break;
+        ok = plausible(S, q);
+      }
+    }
+    const unsigned long long m = __ballot(ok);
+    if (m) { if (lane == 0) out[0] = p0 + (unsigned long long)__builtin_ctzll(m); return; }
+  }
+  if (lane == 0) out[0] = ~0ull;
+}
+// cut[0] (preset n, or 0 for a known start) = first i >= 1 whose name differs from record i - 1's; cut[1] (preset ~0) = the
+// first such i whose predecessor starts at or after `bound`
+__global__ void __launch_bounds__(256) k_piece_bounds(const uint8_t *data, const uint64_t *rec_off, int64_t n, uint64_t bound, int guess,
+                                                      unsigned long long *cut) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < 1 || i >= n) return;
+  const uint64_t oa = rec_off[i - 1];
+  const uint8_t *a = data + oa, *b = data + rec_off[i];
+  const uint32_t la = a[8], lb = b[8];
+  bool same = la == lb;
+  for (uint32_t k = 0; same && k < la; k++) same = a[32 + k] == b[32 + k];
+  if (same) return;
+  if (guess) atomicMin(&cut[0], (unsigned long long)i);
+  if (oa - 4 >= bound) atomicMin(&cut[1], (unsigned long long)i);
+}
+// cut[2] / cut[3] = byte offsets of records cut[0] / cut[1] (their block_size fields; `used` = the end of the last complete
+// record when the index is n or beyond); cut[0] is left as it is for a known start (offset 0)
+__global__ void k_piece_offsets(const uint64_t *rec_off, int64_t n, uint64_t used, int guess, unsigned long long *cut) {
+  const unsigned long long iS = cut[0], iE = cut[1] < (unsigned long long)n ? cut[1] : (unsigned long long)n;
+  cut[2] = guess ? (iS < (unsigned long long)n ? rec_off[iS] - 4 : used) : 0ull;
+  cut[3] = iE < (unsigned long long)n ? rec_off[iE] - 4 : used;
+  cut[4] = 0;
+}
+// cut[4] += unmapped records that start in [cut[2], cut[3])
+__global__ void __launch_bounds__(256) k_unmapped_in(SplitArgs S, unsigned long long *cut) {
+  const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t from = cut[2], limit = cut[3];
+  unsigned long long n = 0;
+  if (s < S.n_seg && S.entry[s] != ~0ull) {
+    const uint64_t lo = (uint64_t)s * S.seg_bytes, hi = lo + S.seg_bytes;
+    if (lo >= from && hi <= limit) n = S.n_unm[s];
+    else if (hi > from && lo < limit) {
+      uint64_t p = S.entry[s];
+      while (p < limit && p < hi && p + 4 <= S.n_bytes) {
+        const uint32_t bs = sl32(S.data + p);
+        if (bs < 32u || p + 4 + (uint64_t)bs > S.n_bytes) break;
+        if (p >= from && ((sl32(S.data + p + 4 + 12) >> 16) & 0x4u)) n++;
+        p += 4 + (uint64_t)bs;
+      }
+    }
+  }
+  for (int o = 32; o; o >>= 1) n += __shfl_xor(n, o);
+  if ((threadIdx.x & 63) == 0 && n) atomicAdd(&cut[4], n);
+}
+void launch_first_record(hipStream_t st, const SplitArgs &S, uint64_t limit, unsigned long long *out) { hipLaunchKernelGGL(k_first_record, dim3(1), dim3(64), 0, st, S, limit, out); }
+void launch_piece_cut(hipStream_t st, const SplitArgs &S, const uint64_t *rec_off, int64_t n, uint64_t bound, uint64_t used, int guess, unsigned long long *cut) {
+  if (n > 1) hipLaunchKernelGGL(k_piece_bounds, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, S.data, rec_off, n, bound, guess, cut);
+  hipLaunchKernelGGL(k_piece_offsets, dim3(1), dim3(1), 0, st, rec_off, n, used, guess, cut);
+  if (S.n_seg > 0) hipLaunchKernelGGL(k_unmapped_in, dim3((unsigned)((S.n_seg + 255) / 256)), dim3(256), 0, st, S, cut);
+}
+
 void launch_last_group(hipStream_t st, const uint8_t *data, const uint64_t *rec_off, int64_t n, unsigned long long *out) {
   if (n > 1) hipLaunchKernelGGL(k_last_group, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, data, rec_off, n, out);
 }

@@ -329,9 +329,14 @@ int br_unpin_host(void *p);
 /* AoS convenience mirroring project_group_with (bramble-rs/src/api.rs:285-464):
  * all alignments of ONE query name in, one br_projected per emitted record out
  * (array owned by the context; alignments with ref_id < 0 are skipped, api.rs:316-318).
- * The shape is the Rust library's, the values are the C++ path's: mates
- * pair up by the C++ rule (name + position, src/bramble.cpp:272-311), not by the mutual
- * mate pointers of groups.rs:126-190; hit_index is carried for layout parity only (neither
+ * The shape is the Rust library's, the values are the C++ path's.
+ * NOTE FOR CALLERS COMING FROM bramble-rs -- PAIRING DIFFERS: mates pair up by the C++ rule
+ * (process_pairs, src/bramble.cpp:272-311: the LEFT mate, mate_start > start, is entered
+ * under name + position and only a later RIGHT mate looks it up), not by the order-independent
+ * mutual match of find_mate_pairs (groups.rs:125-193).  A group that lists the right-hand mate
+ * BEFORE the left-hand one is a pair in bramble-rs and two unpaired alignments here (and in the
+ * C++ binary: groups.rs:131-140 describes exactly this).  There is no switch: the C++ path is
+ * the results authority of this library.  hit_index is carried for layout parity only (neither
  * rule reads it).  br_project_groups takes any number of name-collated groups in one call
  * (the Rust CLI hands over 64 at a time, bramble-cli/src/pipeline.rs:29): one trip through
  * the device pipeline instead of one per group. */
@@ -486,6 +491,33 @@ int br_bam_reader_next(br_bam_reader *, const uint8_t *data, uint64_t n_bytes, i
                        br_device_records *bundle, int64_t *id, int64_t *n_unmapped);
 int br_bam_reader_set_piece_blocks(br_bam_reader *, int64_t blocks);   /* BGZF blocks per br_bam_reader_next call (default 3072) */
 int br_bam_reader_release(br_bam_reader *, int64_t id);
+/* Piece-wise form (round 4: several readers on several devices, uploads beside the inflating of the piece before).  The caller
+ * holds the whole file's block table (br_bgzf_scan over the mapping) and hands out pieces [b0, b1) of it, to one reader in
+ * order or to several readers: a piece needs nothing from its neighbours.  A piece owns the records between two cuts that
+ * are defined the same way at either end (the read-name group that straddles a piece boundary goes to the piece in front,
+ * which inflates blocks up to b1x > b1 to find its end); a piece that does not know where a record starts in its first
+ * block (start_rel = -1) guesses, and reports where it started: when that differs from the end_rel its neighbour in front
+ * reports, the caller processes the piece again with start_rel = that end_rel (the result never depends on a guess).
+ *   br_bam_piece_upload    compressed bytes of blocks [b0, b1x) into upload slot 0 / 1 (its own stream; may be called from a
+ *                          second thread, one piece ahead of br_bam_piece_process)
+ *   br_bam_piece_process   inflate + record split + cuts of the slot's piece [b0, b1) -> bundle (valid until
+ *                          br_bam_reader_release(id)) and info.  start_rel >= 0: inflated bytes from the start of block b0 to
+ *                          the piece's first record (the BAM header's size for the first piece).  Returns 1 (BR_PIECE_MORE)
+ *                          when the end cut lies beyond block b1x: upload up to a larger b1x and call again. */
+#define BR_PIECE_MORE 1
+/* one BGZF block: its deflate payload in the file, where its bytes go in the inflated stream (br_bgzf_scan) */
+typedef struct br_bgzf_block { uint64_t src_off, dst_off; uint32_t clen, ulen, crc, pad; } br_bgzf_block;
+typedef struct br_piece_info {
+  uint64_t start_rel;   /* where the bundle starts: inflated bytes behind the start of block b0 */
+  uint64_t end_rel;     /* where it ends: inflated bytes behind the start of block b1 (= the next piece's start_rel) */
+  int64_t n_unmapped;   /* unmapped records between the two (not in the bundle) */
+  int32_t guessed, at_end;
+} br_piece_info;
+int br_bam_piece_upload(br_bam_reader *, int slot, const uint8_t *file, uint64_t file_bytes, const br_bgzf_block *blocks,
+                        int64_t n_blocks, int64_t b0, int64_t b1x);
+int br_bam_piece_process(br_bam_reader *, int slot, const br_bgzf_block *blocks, int64_t n_blocks, int64_t b1, int64_t start_rel,
+                         br_device_records *bundle, int64_t *id, br_piece_info *info);
+double br_bam_reader_seconds(const br_bam_reader *);   /* time spent inside br_bam_piece_process so far */
 void br_bam_reader_free(br_bam_reader *);
 /* br_project_bam_staged / _nowait for records that are in HBM already (a br_bam_reader bundle, or br_bam_split_device's) */
 int br_project_bam_resident(br_ctx *, const br_config *, const br_device_records *recs, const int32_t *ref_map, int32_t n_ref_map,
@@ -498,7 +530,6 @@ int br_project_bam_resident(br_ctx *, const br_config *, const br_device_records
  * br_bgzf_inflate_device inflates the listed blocks of the same bytes in HBM (`src`, `n_src`); *out is a device pointer to
  * the inflated stream, valid until the next call on the context.  BR_ERR_INVALID_ARG for a malformed header, or for a block
  * that does not inflate to ISIZE bytes with its CRC32 (what htslib's bgzf_read reports as a read error). */
-typedef struct br_bgzf_block { uint64_t src_off, dst_off; uint32_t clen, ulen, crc, pad; } br_bgzf_block;
 int br_bgzf_scan(const uint8_t *data, uint64_t n_bytes, int64_t cap, br_bgzf_block *blocks, int64_t *n_blocks,
                  uint64_t *consumed, uint64_t *out_bytes);
 int br_bgzf_inflate_device(br_ctx *, const uint8_t *src, uint64_t n_src, const br_bgzf_block *blocks, int64_t n_blocks,
