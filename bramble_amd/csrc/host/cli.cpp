@@ -290,37 +290,144 @@ extern "C" int br_cli_main(int argc, char **argv) {
   auto now = []() { return std::chrono::steady_clock::now(); };
   auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
 
-  // Device reader (br_bam_reader): the mapped file's bytes go to the GPU as they are; inflate, the record split and the cut at
-  // a read-name change happen there, beside the guide parsing and the index build (it needs neither), and the bundles it
-  // makes stay in HBM until the runner has projected them.  One device, a regular file; else the host reader below.
+  // Device readers (br_bam_reader, piece-wise): the mapped file's bytes go to the GPUs as they are; inflate, the record split
+  // and the cuts at read-name changes happen there, beside the guide parsing and the index build (they need neither), and the
+  // bundles stay in the HBM of the device that made them until its runner has projected them.  The file's BGZF blocks are cut
+  // into pieces of --bundle-size x 3 / 1000 blocks; piece k goes to device k mod N (reader k mod N inflates it, worker k mod N
+  // projects it, the writer puts the results back in piece order), so N devices read, project and deflate N pieces at a
+  // time -- nothing here is one host thread wide (the reference's one reader thread, src/bramble.cpp:329-435, feeds all its
+  // workers).  Every piece cuts itself off at read-name changes by a rule both neighbours can evaluate (include/bramble_amd.h,
+  // br_bam_piece_process); with one device the pieces follow each other and every start is known, with several a piece guesses
+  // where its first record starts and the guess is checked against what the piece in front found: a piece that guessed wrong is
+  // processed again with the true start before anything of it is used.
   struct DevBundle { br_device_records recs; int64_t id; uint64_t seq; };
-  Slot<DevBundle> to_dev(64);
-  br_bam_reader *dev_reader = nullptr;
+  std::mutex out_m; std::condition_variable out_cv; std::map<uint64_t, OutChunk> out_map; uint64_t out_next = 0; bool out_done = false;   // the ordered writer's inbox
   if (o.device_reader < 0) if (const char *e = getenv("BRAMBLE_AMD_DEVICE_READER")) o.device_reader = atoi(e) != 0;   // (A/B with one command line: the @PG line quotes it)
-  const bool use_dev_reader = o.device_reader != 0 && o.devices.size() == 1 && rd.mapped() && (o.device_reader > 0 || rd.mapped_size() >= (1u << 20));
-  double t_dev_reader = 0;
-  std::thread reader = use_dev_reader ? std::thread([&]() {
-    auto tr0 = now();
-    struct Clock { double &t; std::chrono::steady_clock::time_point t0; ~Clock() { t = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } clock{t_dev_reader, tr0};
-    int rrc = br_bam_reader_new(o.devices[0], (int32_t)hdr.ref_names.size(), (uint64_t)pos, &dev_reader);
-    if (!rrc) rrc = br_bam_reader_set_piece_blocks(dev_reader, std::max<int64_t>(1, std::min<int64_t>(o.bundle_records * 3 / 1000, 8192)));
-    const uint8_t *file = rd.mapped(); const uint64_t size = rd.mapped_size();
-    uint64_t at = 0;
-    while (!rrc && at < size && !cancel) {
-      auto b = std::make_unique<DevBundle>();
-      uint64_t used = 0; int64_t unm = 0;
-      rrc = br_bam_reader_next(dev_reader, file + at, size - at, 1, &used, &b->recs, &b->id, &unm);
-      if (rrc) break;
-      if (used == 0 && b->id < 0) { rrc = BR_ERR_INVALID_ARG; break; }
-      at += used;
-      total_reads += (uint64_t)(b->recs.n_aln + unm); unmapped_reads += (uint64_t)unm;
-      if (b->id < 0) continue;
-      if (b->recs.n_aln == 0) { (void)br_bam_reader_release(dev_reader, b->id); continue; }
-      b->seq = next_seq++;
-      to_dev.put(std::move(b));
+  const bool use_dev_reader = o.device_reader != 0 && rd.mapped() && (o.device_reader > 0 || rd.mapped_size() >= (1u << 20));
+  const size_t n_dev = o.devices.size();
+  std::vector<std::unique_ptr<Slot<DevBundle>>> to_dev;
+  std::vector<br_bam_reader *> dev_readers(n_dev, nullptr);
+  for (size_t d = 0; d < n_dev; d++) to_dev.emplace_back(new Slot<DevBundle>(64));
+  std::vector<br_bgzf_block> blk;           // the whole file's block table
+  int64_t n_blk = 0, piece_blocks = 0, n_pieces = 0;
+  std::mutex piece_m; std::condition_variable piece_cv;
+  std::vector<uint64_t> piece_end; std::vector<char> piece_known;   // end_rel of every finished piece (the next one's true start)
+  bool table_ready = false, table_failed = false;
+  std::atomic<uint64_t> total_reads_a{0}, unmapped_reads_a{0}, reprocessed{0};
+  const int64_t piece_spoil = getenv("BRAMBLE_AMD_PIECE_SPOIL") ? atoll(getenv("BRAMBLE_AMD_PIECE_SPOIL")) : 0;   // test hook (tests/test_gpu_cli.py): every k-th guessed start counts as wrong
+  std::mutex err_m;
+  double t_dev_reader = 0, t_block_scan = 0;
+  std::vector<std::thread> dev_threads;
+  struct UpState { std::mutex m; std::condition_variable cv; int free_slots = 2; std::deque<int64_t> ready; bool done = false; };
+  std::vector<std::unique_ptr<UpState>> ups;
+  for (size_t d = 0; d < n_dev; d++) ups.emplace_back(new UpState());
+  auto set_reader_err = [&](const std::string &m) { std::lock_guard<std::mutex> l(err_m); if (reader_err.empty()) reader_err = m; cancel = true; piece_cv.notify_all(); for (auto &u : ups) u->cv.notify_all(); };
+  auto piece_range = [&](int64_t k, int64_t extra, int64_t &b0, int64_t &b1, int64_t &b1x) { b0 = k * piece_blocks; b1 = std::min(n_blk, b0 + piece_blocks); b1x = std::min(n_blk, b1 + extra); };
+  if (use_dev_reader) {
+    const uint8_t *file = rd.mapped(); const uint64_t fsize = rd.mapped_size();
+    // the block table: one walk over the block headers of the mapping (a cache line per block)
+    dev_threads.emplace_back([&, file, fsize]() {
+      auto t0 = now();
+      std::vector<br_bgzf_block> tab((size_t)(fsize / 28 + 16));   // (a block is at least 28 bytes)
+      int64_t nb = 0; uint64_t used = 0, total = 0;
+      int rc2 = br_bgzf_scan(file, fsize, (int64_t)tab.size(), tab.data(), &nb, &used, &total);
+      if (!rc2 && used != fsize) rc2 = BR_ERR_INVALID_ARG;   // a truncated block at the end of the file
+      tab.resize((size_t)nb);
+      t_block_scan = secs(t0, now());
+      {
+        std::lock_guard<std::mutex> l(piece_m);
+        blk.swap(tab); n_blk = nb;
+        piece_blocks = std::max<int64_t>(1, std::min<int64_t>(o.bundle_records * 3 / 1000, 8192));
+        n_pieces = nb ? (nb + piece_blocks - 1) / piece_blocks : 0;
+        piece_end.assign((size_t)n_pieces, 0); piece_known.assign((size_t)n_pieces, 0);
+        table_ready = true; table_failed = rc2 != 0;
+      }
+      if (rc2) set_reader_err(std::string("malformed or truncated BAM file (") + br_strerror(rc2) + ")");
+      piece_cv.notify_all();
+    });
+    for (size_t d = 0; d < n_dev; d++) {
+      // uploader of device d: the compressed bytes of its pieces, one piece ahead of the processing
+      dev_threads.emplace_back([&, d, file, fsize]() {
+        { std::unique_lock<std::mutex> l(piece_m); piece_cv.wait(l, [&] { return table_ready || cancel; }); }
+        UpState &U = *ups[d];
+        int rrc = (table_failed || cancel) ? 0 : br_bam_reader_new(o.devices[d], (int32_t)hdr.ref_names.size(), (uint64_t)pos, &dev_readers[d]);
+        if (rrc) set_reader_err(std::string("device reader: ") + br_strerror(rrc));
+        int64_t j = 0;
+        for (int64_t k = (int64_t)d; !rrc && !table_failed && k < n_pieces && !cancel; k += (int64_t)n_dev, j++) {
+          { std::unique_lock<std::mutex> l(U.m); U.cv.wait(l, [&] { return U.free_slots > 0 || cancel; }); if (cancel) break; U.free_slots--; }
+          int64_t b0, b1, b1x; piece_range(k, 2, b0, b1, b1x);
+          rrc = br_bam_piece_upload(dev_readers[d], (int)(j & 1), file, fsize, blk.data(), n_blk, b0, b1x);
+          if (rrc) { set_reader_err(std::string("device reader: ") + br_strerror(rrc)); break; }
+          { std::lock_guard<std::mutex> l(U.m); U.ready.push_back(k); }
+          U.cv.notify_all();
+        }
+        { std::lock_guard<std::mutex> l(U.m); U.done = true; }
+        U.cv.notify_all();
+      });
+      // processor of device d: inflate, split and cut its pieces; check a guessed start against the piece in front
+      dev_threads.emplace_back([&, d, file, fsize]() {
+        auto tr0 = now();
+        UpState &U = *ups[d];
+        int64_t j = 0;
+        for (;; j++) {
+          int64_t k = -1;
+          { std::unique_lock<std::mutex> l(U.m); U.cv.wait(l, [&] { return !U.ready.empty() || U.done || cancel; }); if (!U.ready.empty()) { k = U.ready.front(); U.ready.pop_front(); } }
+          if (k < 0) break;
+          const int slot = (int)(j & 1);
+          br_bam_reader *R = dev_readers[d];
+          int64_t b0, b1, b1x; piece_range(k, 2, b0, b1, b1x);
+          auto b = std::make_unique<DevBundle>();
+          br_piece_info info; memset(&info, 0, sizeof(info));
+          // the start: the header's end (first piece), the end of the piece in front when this reader made it itself, else a guess
+          int64_t start_rel = -1;
+          if (k == 0) start_rel = (int64_t)pos;
+          else if (n_dev == 1) start_rel = (int64_t)piece_end[(size_t)k - 1];
+          int rrc = 0;
+          int64_t extra = 2;
+          for (int tries = 0;; tries++) {
+            rrc = cancel ? BR_ERR_INVALID_ARG : br_bam_piece_process(R, slot, blk.data(), n_blk, b1, start_rel, &b->recs, &b->id, &info);
+            if (rrc == BR_PIECE_MORE && tries < 12) {   // the group at the piece's end goes on: more of the next piece's blocks
+              extra *= 8; piece_range(k, extra, b0, b1, b1x);
+              rrc = br_bam_piece_upload(R, slot, file, fsize, blk.data(), n_blk, b0, b1x);
+              if (!rrc) continue;
+            }
+            if (rrc) break;
+            if (start_rel >= 0) break;
+            // a guessed start: what did the piece in front find?
+            uint64_t want = 0;
+            { std::unique_lock<std::mutex> l(piece_m); piece_cv.wait(l, [&] { return piece_known[(size_t)k - 1] || cancel; }); want = piece_end[(size_t)k - 1]; }
+            if (cancel) { rrc = BR_ERR_INVALID_ARG; break; }
+            if (piece_spoil > 0 && k % piece_spoil == 0) info.start_rel ^= 1u;   // test hook: treat the guess as wrong
+            if (info.start_rel == want) break;
+            (void)br_bam_reader_release(R, b->id);    // the guess was wrong: once more, from the true start
+            reprocessed++;
+            start_rel = (int64_t)want;
+          }
+          if (rrc) { if (!cancel) set_reader_err(rrc == BR_PIECE_MORE ? std::string("a read-name group spans more than the reader can hold") : rrc == BR_ERR_INVALID_ARG ? std::string("malformed or truncated BAM file (") + br_strerror(rrc) + ")" : std::string("device reader: ") + br_strerror(rrc)); break; }
+          { std::lock_guard<std::mutex> l(piece_m); piece_end[(size_t)k] = info.end_rel; piece_known[(size_t)k] = 1; }
+          piece_cv.notify_all();
+          { std::lock_guard<std::mutex> l(U.m); U.free_slots++; }
+          U.cv.notify_all();
+          total_reads_a += (uint64_t)(b->recs.n_aln + info.n_unmapped); unmapped_reads_a += (uint64_t)info.n_unmapped;
+          b->seq = (uint64_t)k;
+          if (b->recs.n_aln == 0) {   // nothing to project: the writer steps over this piece
+            (void)br_bam_reader_release(R, b->id);
+            { std::lock_guard<std::mutex> l(out_m); out_map[(uint64_t)k] = OutChunk{nullptr, 0, -1}; }
+            out_cv.notify_all();
+            continue;
+          }
+          to_dev[d]->put(std::move(b));
+        }
+        to_dev[d]->finish();
+        const double t = secs(tr0, now());
+        { std::lock_guard<std::mutex> l(err_m); t_dev_reader = std::max(t_dev_reader, t); }
+      });
     }
-    if (rrc) reader_err = rrc == BR_ERR_INVALID_ARG ? std::string("malformed or truncated BAM file (") + br_strerror(rrc) + ")" : std::string("device reader: ") + br_strerror(rrc);
-    to_dev.finish();
+  }
+  std::thread reader = use_dev_reader ? std::thread([&]() {
+    // (the device readers run on dev_threads; this thread only waits for the block table, for next_seq)
+    std::unique_lock<std::mutex> l(piece_m); piece_cv.wait(l, [&] { return table_ready || cancel; });
+    next_seq = (uint64_t)n_pieces;
   }) : std::thread([&]() {
     buf.erase_front(pos); pos = 0;
     std::vector<uint64_t> off; std::vector<uint32_t> len;
@@ -437,8 +544,16 @@ extern "C" int br_cli_main(int argc, char **argv) {
   });
 
   // the reader is already inflating while the guides are parsed and the indexes are built
-  // (only the queue the running reader feeds is ever finished: taking from the other one would wait for ever)
-  auto stop_reader = [&]() -> int { cancel = true; if (use_dev_reader) { while (to_dev.take()) {} } else { while (to_gpu.take()) {} } reader.join(); if (dev_reader) br_bam_reader_free(dev_reader); dev_reader = nullptr; return 1; };
+  // (only the queues the running reader feeds are ever finished: taking from the others would wait for ever)
+  auto join_dev_threads = [&]() { for (auto &t : dev_threads) if (t.joinable()) t.join(); };
+  auto free_dev_readers = [&]() { for (auto &r : dev_readers) { if (r) br_bam_reader_free(r); r = nullptr; } };
+  auto stop_reader = [&]() -> int {
+    cancel = true;
+    piece_cv.notify_all(); for (auto &u : ups) u->cv.notify_all();
+    if (use_dev_reader) { for (auto &q : to_dev) while (q->take()) {} } else { while (to_gpu.take()) {} }
+    reader.join(); join_dev_threads(); free_dev_readers();
+    return 1;
+  };
   int rc = ann_job.get();
   const double t_guides = since();
   if (rc) { fprintf(stderr, "error: could not load reference annotation %s: %s\n", o.gff.c_str(), br_strerror(rc)); return stop_reader(); }
@@ -528,7 +643,6 @@ extern "C" int br_cli_main(int argc, char **argv) {
   };
 
   // ordered writer: chunks arrive tagged with their bundle's sequence number
-  std::mutex out_m; std::condition_variable out_cv; std::map<uint64_t, OutChunk> out_map; uint64_t out_next = 0; bool out_done = false;
   std::thread writer([&]() {
     for (;;) {
       OutChunk c;
@@ -550,6 +664,7 @@ extern "C" int br_cli_main(int argc, char **argv) {
         raise_fail();                      // nothing projected from here on could be written: the runners drain
       }
       t_deflate += secs(td0, now());
+      if (c.worker < 0) continue;   // (a piece without records: nothing was produced for it)
       Worker *w = workers[(size_t)c.worker].get();
       { std::lock_guard<std::mutex> l(w->done_m); w->written++; }
       w->done_cv.notify_all();
@@ -557,31 +672,34 @@ extern "C" int br_cli_main(int argc, char **argv) {
   });
 
   if (use_dev_reader) {
-    // one worker, no uploader: the bundles are in HBM already
-    Worker *w = workers[0].get();
-    w->runner = std::thread([&, w]() {
-      for (;;) {
-        auto tw0 = now();
-        auto b = to_dev.take();
-        w->t_wait_in += secs(tw0, now());
-        if (!b) break;
-        br_host_bam hb;
-        memset(&hb, 0, sizeof(hb));
-        if (!fail) {
-          { std::unique_lock<std::mutex> l(w->done_m); w->done_cv.wait(l, [&] { return w->written + 2 > w->produced || fail; }); }
-          auto t0 = now();
-          int prc2 = fail ? 0 : br_project_bam_resident(w->ctx, &o.cfg, &b->recs, ref_map.data(), (int32_t)ref_map.size(), o.device_deflate ? 1 : 0, 1, &hb);
-          w->gpu_seconds += secs(t0, now());
-          if (prc2) { fprintf(stderr, "error: projection failed on device %d: %s\n", w->device, br_strerror(prc2)); raise_fail(); }
+    // no uploaders: every worker's bundles are in its device's HBM already (its own reader made them)
+    for (auto &wp : workers) {
+      Worker *w = wp.get();
+      w->runner = std::thread([&, w]() {
+        Slot<DevBundle> &in = *to_dev[(size_t)w->id];
+        for (;;) {
+          auto tw0 = now();
+          auto b = in.take();
+          w->t_wait_in += secs(tw0, now());
+          if (!b) break;
+          br_host_bam hb;
+          memset(&hb, 0, sizeof(hb));
+          if (!fail) {
+            { std::unique_lock<std::mutex> l(w->done_m); w->done_cv.wait(l, [&] { return w->written + 2 > w->produced || fail; }); }
+            auto t0 = now();
+            int prc2 = fail ? 0 : br_project_bam_resident(w->ctx, &o.cfg, &b->recs, ref_map.data(), (int32_t)ref_map.size(), o.device_deflate ? 1 : 0, 1, &hb);
+            w->gpu_seconds += secs(t0, now());
+            if (prc2) { fprintf(stderr, "error: projection failed on device %d: %s\n", w->device, br_strerror(prc2)); raise_fail(); }
+          }
+          (void)br_bam_reader_release(dev_readers[(size_t)w->id], b->id);
+          if (fail) continue;  // drain
+          w->total_complete += hb.total_complete; w->total_unique += hb.total_unique; w->dropped += hb.dropped_reads; w->n_bundles++;
+          { std::lock_guard<std::mutex> l(w->done_m); w->produced++; }
+          { std::lock_guard<std::mutex> l(out_m); out_map[b->seq] = OutChunk{hb.data, hb.n_bytes, w->id}; }
+          out_cv.notify_all();
         }
-        (void)br_bam_reader_release(dev_reader, b->id);
-        if (fail) continue;  // drain
-        w->total_complete += hb.total_complete; w->total_unique += hb.total_unique; w->dropped += hb.dropped_reads; w->n_bundles++;
-        { std::lock_guard<std::mutex> l(w->done_m); w->produced++; }
-        { std::lock_guard<std::mutex> l(out_m); out_map[b->seq] = OutChunk{hb.data, hb.n_bytes, w->id}; }
-        out_cv.notify_all();
-      }
-    });
+      });
+    }
   } else
   for (auto &wp : workers) {
     Worker *w = wp.get();
@@ -638,7 +756,8 @@ extern "C" int br_cli_main(int argc, char **argv) {
   for (auto &w : workers) { if (w->uploader.joinable()) w->uploader.join(); if (w->runner.joinable()) w->runner.join(); }
   { std::lock_guard<std::mutex> l(out_m); out_done = true; }
   out_cv.notify_all();
-  reader.join(); writer.join();
+  reader.join(); join_dev_threads(); writer.join();
+  if (use_dev_reader) { total_reads = total_reads_a.load(); unmapped_reads = unmapped_reads_a.load(); }
   int failed = fail.load();
   if (!reader_err.empty()) { fprintf(stderr, "error: %s: %s\n", o.in_bam.c_str(), reader_err.c_str()); failed = 1; }
   if (!writer_err.empty()) { fprintf(stderr, "error: %s: %s\n", o.out_bam.c_str(), writer_err.c_str()); failed = 1; }
@@ -661,7 +780,7 @@ extern "C" int br_cli_main(int argc, char **argv) {
   // 0.12-0.16 s that the process exit does for nothing (bramble-cli keeps its index in a ManuallyDrop for the same reason,
   // bramble-cli/src/main.rs:56-60).  That is the `bramble` binary (br_cli_exit_at_end); a host that calls br_cli_main as a
   // function gets everything released, and so does a run under BRAMBLE_AMD_CLI_CLEANUP=1
-  if (!g_exit_at_end.load() || getenv("BRAMBLE_AMD_CLI_CLEANUP")) { free_all(); if (dev_reader) br_bam_reader_free(dev_reader); dev_reader = nullptr; }
+  if (!g_exit_at_end.load() || getenv("BRAMBLE_AMD_CLI_CLEANUP")) { free_all(); free_dev_readers(); }
   double t_freed = since();
   if (!o.quiet) {  // src/bramble.cpp:727-736
     printf("\n[bramble] final report:\n");
@@ -683,7 +802,12 @@ extern "C" int br_cli_main(int argc, char **argv) {
       fclose(f);
     }
   }
-  if (getenv("BRAMBLE_AMD_TIMING") && use_dev_reader) fprintf(stderr, "[bramble] device reader thread (upload of the compressed file, inflate, record split, cuts): %.2fs in all\n", t_dev_reader);
+  if (getenv("BRAMBLE_AMD_TIMING") && use_dev_reader) {
+    double t_in = 0;
+    for (auto r : dev_readers) t_in = std::max(t_in, br_bam_reader_seconds(r));
+    fprintf(stderr, "[bramble] device readers: block table %.2fs; the longest processing thread %.2fs in all (inflate + record split + cuts: %.2fs; the rest: waiting for its uploads, its neighbour's cut, the runner's queue); %llu pieces, %llu processed again from the true start\n",
+            t_block_scan, t_dev_reader, t_in, (unsigned long long)n_pieces, (unsigned long long)reprocessed.load());
+  }
   if (getenv("BRAMBLE_AMD_TIMING") && !use_dev_reader) fprintf(stderr, "[bramble] reader thread: %.2fs in all, %.2fs reserving buffers, %.2fs waiting for a free queue slot\n", t_reader, t_reserve, t_put);
   // the unwinding below this line (record buffers, worker contexts, reader and writer pools) was 0.5 s of a 1.9 s run
   if (g_exit_at_end.load() && !getenv("BRAMBLE_AMD_CLI_CLEANUP")) {   // (tools that write their results from exit handlers -- a profiler -- ask for the clean return)

@@ -145,6 +145,44 @@ def test_cli_result_does_not_depend_on_bundle_size(tmp_path):
         assert np.array_equal(outs[0], outs[k]), k
 
 
+def test_cli_device_readers_on_several_devices_give_the_single_device_stream(tmp_path):
+    """--devices a,b,... with the device reader: the file's BGZF blocks are cut into pieces, piece k is inflated, split and
+    projected by device k mod N (one br_bam_reader per device, nothing one host thread wide).  A piece's first block starts
+    anywhere -- inside a record, inside a multi-mapper's read-name group (p_multimap = 0.4: groups of up to eight records;
+    with two or three blocks per piece nearly every boundary falls inside both) -- so a piece guesses its first record, cuts
+    itself off at read-name changes by the rule its neighbour uses too, and the guess is checked against the neighbour's
+    chain.  The GPU box has one card: the same device is listed two and three times (separate readers, contexts, index
+    replicas).  The record stream and the report must be those of the single-device run with the host reader; with the
+    BRAMBLE_AMD_PIECE_SPOIL hook every second / every guessed start is treated as wrong and the piece is processed again from
+    the start its neighbour found: the same stream again."""
+    ann = synth.Annotation("G", n_genes=900, n_refs=3)
+    annd = ann.as_dict()
+    b = ann.reads(15000, "pe", with_records=1, p_multimap=0.4)
+    stream = framed_stream(b, unmapped_every=37)
+    gtf, in_bam = str(tmp_path / "g.gtf"), str(tmp_path / "in.bam")
+    bamio.write_gtf(gtf, annd)
+    bamio.write_bam(in_bam, "@HD\tVN:1.6\n", [(n, 1000000) for n in annd["refnames"]], stream.tobytes())
+    assert len(bamio.bgzf_block_sizes(in_bam)) > 60
+    outs, reports = [], []
+    cases = ((["--device", "0", "--host-reader"], "900", {}), (["--devices", "0,0", "--device-reader"], "900", {}),
+             (["--devices", "0,0,0", "--device-reader"], "400", {}), (["--devices", "0,0", "--device-reader"], "1400", {"BRAMBLE_AMD_PIECE_SPOIL": "2"}),
+             (["--devices", "0,0,0", "--device-reader", "--host-deflate"], "700", {"BRAMBLE_AMD_PIECE_SPOIL": "1"}), (["--device", "0", "--device-reader"], "400", {}))
+    for k, (extra, bundle, env) in enumerate(cases):
+        out_bam = str(tmp_path / ("o%d.bam" % k))
+        e = dict(os.environ); e.update(env); e["BRAMBLE_AMD_TIMING"] = "1"
+        r = subprocess.run([BIN, in_bam, "-G", gtf, "-o", out_bam, "-p", "4", "--bundle-size", bundle] + extra,
+                           capture_output=True, text=True, timeout=900, env=e)
+        assert r.returncode == 0, r.stderr + r.stdout
+        outs.append(bamio.read_bam(out_bam))
+        reports.append([l for l in r.stdout.splitlines() if l.startswith("# ")])
+        if env:
+            assert "processed again from the true start" in r.stderr and " 0 processed again" not in r.stderr, r.stderr
+    assert len(outs[0][2]) > 500000
+    for k, o in enumerate(outs[1:]):
+        assert o[1] == outs[0][1] and np.array_equal(o[2], outs[0][2]), k + 1
+        assert reports[k + 1] == reports[0], (k + 1, reports[k + 1], reports[0])
+
+
 def test_cli_reads_stdin_and_writes_stdout(tmp_path):
     """"-" as in.bam / out.bam: a pipeline stage like `aligner | samtools view -b | bramble - -G g.gtf -o - | ...`."""
     ann = synth.Annotation("G", n_genes=300, n_refs=2)
