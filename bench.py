@@ -90,11 +90,23 @@ def main():
         # with fewer GPUs than ranks (ranks then share devices)
         backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
         ndev = max(torch.cuda.device_count(), 1)
-        if backend == "nccl":
-            dist_mod.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                        device_id=torch.device("cuda", local_rank % ndev))
-        else:
-            dist_mod.init_process_group(backend=backend, rank=rank, world_size=world)
+        try:
+            if backend == "nccl":
+                dist_mod.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                            device_id=torch.device("cuda", local_rank % ndev))
+                # the first collective is where RCCL really connects the ranks: do it here, so that a failure names its rank
+                probe = torch.ones(1, device="cuda:%d" % (local_rank % ndev))
+                dist_mod.all_reduce(probe)
+                torch.cuda.synchronize()
+            else:
+                dist_mod.init_process_group(backend=backend, rank=rank, world_size=world)
+        except Exception as e:  # noqa: BLE001 -- say which rank / device before the non-zero exit
+            sys.stderr.write("bench.py: rank %d of %d (local rank %d, device cuda:%d of %d visible, backend %s, "
+                             "HSA_ENABLE_IPC_MODE_LEGACY=%s) could not join the process group: %s: %s\n"
+                             % (rank, world, local_rank, local_rank % ndev, ndev, backend,
+                                os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), type(e).__name__, e))
+            sys.stderr.flush()
+            raise SystemExit(3)
         dist = dist_mod
     local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
@@ -200,11 +212,13 @@ def main():
         run_pipelined(args.steps)
         barrier()
         p_el = time.perf_counter() - t1
+        p_per_rank_ms = [1e3 * e / args.steps for e in gather_all(p_el)]   # N ranks share one host's PCIe root and memory: what the max hides
         p_el, p_total = reduce_max_sum(p_el, n_aln)
         r = res[(args.steps - 1) % 2]
         d2h_bytes = 24 * int(r.n_rows) + 4 * int(r.n_pool_words) + 12 * n_aln + 8
         assert int(r.n_rows) == n_rows
         pcie = {"value": p_total * args.steps / p_el, "unit": "alignments/s", "ms_per_step": 1e3 * p_el / args.steps,
+                "per_rank_ms_per_step": [round(x, 3) for x in p_per_rank_ms],
                 "h2d_bytes_per_step": h2d_bytes, "d2h_bytes_per_step": d2h_bytes,
                 "what": "br_batch_stage / br_project_staged / br_host_rows_wait: pinned host SoA in -> packed rows (24 B per "
                         "record + row_off + mate_idx) in pinned host memory; read-name groups and mate index computed on the "

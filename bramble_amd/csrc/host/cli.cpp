@@ -11,6 +11,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <time.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -308,11 +309,14 @@ extern "C" int br_cli_main(int argc, char **argv) {
   std::vector<std::unique_ptr<Slot<DevBundle>>> to_dev;
   std::vector<br_bam_reader *> dev_readers(n_dev, nullptr);
   for (size_t d = 0; d < n_dev; d++) to_dev.emplace_back(new Slot<DevBundle>(64));
-  std::vector<br_bgzf_block> blk;           // the whole file's block table
-  int64_t n_blk = 0, piece_blocks = 0, n_pieces = 0;
+  // the whole file's block table: it grows while the readers are already at work on its first pieces (a lazily committed
+  // mapping of the worst-case size, so that the table never moves: a block is at least 28 bytes)
+  struct BlockTable { br_bgzf_block *p = nullptr; size_t bytes = 0; ~BlockTable() { if (p) munmap(p, bytes); } } blk;
+  int64_t n_blk = 0, n_pieces = 0;          // blocks known so far (under piece_m); pieces: known once the table is done
+  const int64_t piece_blocks = std::max<int64_t>(1, std::min<int64_t>(o.bundle_records * 3 / 1000, 8192));
   std::mutex piece_m; std::condition_variable piece_cv;
   std::vector<uint64_t> piece_end; std::vector<char> piece_known;   // end_rel of every finished piece (the next one's true start)
-  bool table_ready = false, table_failed = false;
+  bool table_ready = false, table_failed = false;   // ready: the whole file has been walked
   std::atomic<uint64_t> total_reads_a{0}, unmapped_reads_a{0}, reprocessed{0};
   const int64_t piece_spoil = getenv("BRAMBLE_AMD_PIECE_SPOIL") ? atoll(getenv("BRAMBLE_AMD_PIECE_SPOIL")) : 0;   // test hook (tests/test_gpu_cli.py): every k-th guessed start counts as wrong
   std::mutex err_m;
@@ -322,24 +326,46 @@ extern "C" int br_cli_main(int argc, char **argv) {
   std::vector<std::unique_ptr<UpState>> ups;
   for (size_t d = 0; d < n_dev; d++) ups.emplace_back(new UpState());
   auto set_reader_err = [&](const std::string &m) { std::lock_guard<std::mutex> l(err_m); if (reader_err.empty()) reader_err = m; cancel = true; piece_cv.notify_all(); for (auto &u : ups) u->cv.notify_all(); };
-  auto piece_range = [&](int64_t k, int64_t extra, int64_t &b0, int64_t &b1, int64_t &b1x) { b0 = k * piece_blocks; b1 = std::min(n_blk, b0 + piece_blocks); b1x = std::min(n_blk, b1 + extra); };
+  // blocks [b0, b1) of piece k and the `extra` blocks behind them; waits until the table has grown past them (or is whole).
+  // false: no such piece (the table ended in front of it), or the run is being cancelled
+  auto piece_range = [&](int64_t k, int64_t extra, int64_t &b0, int64_t &b1, int64_t &b1x, int64_t &nb_now) -> bool {
+    std::unique_lock<std::mutex> l(piece_m);
+    const int64_t want = (k + 1) * piece_blocks + extra;
+    piece_cv.wait(l, [&] { return n_blk > want || table_ready || cancel; });
+    if (cancel || table_failed) return false;
+    nb_now = n_blk;
+    b0 = k * piece_blocks;
+    if (b0 >= n_blk) return false;
+    b1 = std::min(n_blk, b0 + piece_blocks); b1x = std::min(n_blk, b1 + extra);
+    return true;
+  };
   if (use_dev_reader) {
     const uint8_t *file = rd.mapped(); const uint64_t fsize = rd.mapped_size();
-    // the block table: one walk over the block headers of the mapping (a cache line per block)
+    // the block table: one walk over the block headers of the mapping (a cache line per block), published as it grows
+    blk.bytes = (size_t)(fsize / 28 + 16) * sizeof(br_bgzf_block);
+    void *tab_mem = mmap(nullptr, blk.bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (tab_mem == MAP_FAILED) { fprintf(stderr, "error: out of memory (block table)\n"); return 1; }
+    blk.p = (br_bgzf_block *)tab_mem;
     dev_threads.emplace_back([&, file, fsize]() {
       auto t0 = now();
-      std::vector<br_bgzf_block> tab((size_t)(fsize / 28 + 16));   // (a block is at least 28 bytes)
-      int64_t nb = 0; uint64_t used = 0, total = 0;
-      int rc2 = br_bgzf_scan(file, fsize, (int64_t)tab.size(), tab.data(), &nb, &used, &total);
-      if (!rc2 && used != fsize) rc2 = BR_ERR_INVALID_ARG;   // a truncated block at the end of the file
-      tab.resize((size_t)nb);
+      int64_t nb = 0; uint64_t src_base = 0, dst_base = 0;
+      int rc2 = 0;
+      const int64_t step = std::max<int64_t>(256, std::min<int64_t>(piece_blocks, 4096));
+      while (!rc2 && src_base < fsize && !cancel) {
+        int64_t got = 0; uint64_t used = 0, total = 0;
+        rc2 = br_bgzf_scan(file + src_base, fsize - src_base, step, blk.p + nb, &got, &used, &total);
+        if (rc2) break;
+        for (int64_t i = 0; i < got; i++) { blk.p[nb + i].src_off += src_base; blk.p[nb + i].dst_off += dst_base; }
+        if (used == 0) { rc2 = BR_ERR_INVALID_ARG; break; }   // a truncated block at the end of the file
+        src_base += used; dst_base += total; nb += got;
+        { std::lock_guard<std::mutex> l(piece_m); n_blk = nb; const size_t np = (size_t)((nb + piece_blocks - 1) / piece_blocks); piece_end.resize(np, 0); piece_known.resize(np, 0); }
+        piece_cv.notify_all();
+      }
       t_block_scan = secs(t0, now());
       {
         std::lock_guard<std::mutex> l(piece_m);
-        blk.swap(tab); n_blk = nb;
-        piece_blocks = std::max<int64_t>(1, std::min<int64_t>(o.bundle_records * 3 / 1000, 8192));
-        n_pieces = nb ? (nb + piece_blocks - 1) / piece_blocks : 0;
-        piece_end.assign((size_t)n_pieces, 0); piece_known.assign((size_t)n_pieces, 0);
+        n_blk = nb; n_pieces = nb ? (nb + piece_blocks - 1) / piece_blocks : 0;
+        piece_end.resize((size_t)n_pieces, 0); piece_known.resize((size_t)n_pieces, 0);
         table_ready = true; table_failed = rc2 != 0;
       }
       if (rc2) set_reader_err(std::string("malformed or truncated BAM file (") + br_strerror(rc2) + ")");
@@ -348,15 +374,15 @@ extern "C" int br_cli_main(int argc, char **argv) {
     for (size_t d = 0; d < n_dev; d++) {
       // uploader of device d: the compressed bytes of its pieces, one piece ahead of the processing
       dev_threads.emplace_back([&, d, file, fsize]() {
-        { std::unique_lock<std::mutex> l(piece_m); piece_cv.wait(l, [&] { return table_ready || cancel; }); }
         UpState &U = *ups[d];
-        int rrc = (table_failed || cancel) ? 0 : br_bam_reader_new(o.devices[d], (int32_t)hdr.ref_names.size(), (uint64_t)pos, &dev_readers[d]);
+        int rrc = cancel ? 0 : br_bam_reader_new(o.devices[d], (int32_t)hdr.ref_names.size(), (uint64_t)pos, &dev_readers[d]);
         if (rrc) set_reader_err(std::string("device reader: ") + br_strerror(rrc));
         int64_t j = 0;
-        for (int64_t k = (int64_t)d; !rrc && !table_failed && k < n_pieces && !cancel; k += (int64_t)n_dev, j++) {
+        for (int64_t k = (int64_t)d; !rrc && !cancel; k += (int64_t)n_dev, j++) {
+          int64_t b0, b1, b1x, nb_now;
+          if (!piece_range(k, 2, b0, b1, b1x, nb_now)) break;
           { std::unique_lock<std::mutex> l(U.m); U.cv.wait(l, [&] { return U.free_slots > 0 || cancel; }); if (cancel) break; U.free_slots--; }
-          int64_t b0, b1, b1x; piece_range(k, 2, b0, b1, b1x);
-          rrc = br_bam_piece_upload(dev_readers[d], (int)(j & 1), file, fsize, blk.data(), n_blk, b0, b1x);
+          rrc = br_bam_piece_upload(dev_readers[d], (int)(j & 1), file, fsize, blk.p, nb_now, b0, b1x);
           if (rrc) { set_reader_err(std::string("device reader: ") + br_strerror(rrc)); break; }
           { std::lock_guard<std::mutex> l(U.m); U.ready.push_back(k); }
           U.cv.notify_all();
@@ -375,20 +401,22 @@ extern "C" int br_cli_main(int argc, char **argv) {
           if (k < 0) break;
           const int slot = (int)(j & 1);
           br_bam_reader *R = dev_readers[d];
-          int64_t b0, b1, b1x; piece_range(k, 2, b0, b1, b1x);
+          int64_t b0, b1, b1x, nb_now;
+          if (!piece_range(k, 2, b0, b1, b1x, nb_now)) break;   // (the uploader has seen this range already: no waiting here)
           auto b = std::make_unique<DevBundle>();
           br_piece_info info; memset(&info, 0, sizeof(info));
           // the start: the header's end (first piece), the end of the piece in front when this reader made it itself, else a guess
           int64_t start_rel = -1;
           if (k == 0) start_rel = (int64_t)pos;
-          else if (n_dev == 1) start_rel = (int64_t)piece_end[(size_t)k - 1];
+          else if (n_dev == 1) { std::lock_guard<std::mutex> l(piece_m); start_rel = (int64_t)piece_end[(size_t)k - 1]; }
           int rrc = 0;
           int64_t extra = 2;
           for (int tries = 0;; tries++) {
-            rrc = cancel ? BR_ERR_INVALID_ARG : br_bam_piece_process(R, slot, blk.data(), n_blk, b1, start_rel, &b->recs, &b->id, &info);
+            rrc = cancel ? BR_ERR_INVALID_ARG : br_bam_piece_process(R, slot, blk.p, nb_now, b1, start_rel, &b->recs, &b->id, &info);
             if (rrc == BR_PIECE_MORE && tries < 12) {   // the group at the piece's end goes on: more of the next piece's blocks
-              extra *= 8; piece_range(k, extra, b0, b1, b1x);
-              rrc = br_bam_piece_upload(R, slot, file, fsize, blk.data(), n_blk, b0, b1x);
+              extra *= 8;
+              if (!piece_range(k, extra, b0, b1, b1x, nb_now)) { rrc = BR_ERR_INVALID_ARG; break; }
+              rrc = br_bam_piece_upload(R, slot, file, fsize, blk.p, nb_now, b0, b1x);
               if (!rrc) continue;
             }
             if (rrc) break;

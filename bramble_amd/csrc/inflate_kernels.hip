@@ -22,7 +22,6 @@ namespace br {
 #define IN_CHUNK 512u            // refilled half a KiB at a time
 #define OUT_WIN 2048u            // output window in LDS
 #define OUT_PIECE 512u           // flushed to HBM in pieces of this size
-#define OUT_NEAR (OUT_WIN - OUT_PIECE - 258u)   // a match at most this far back is served from the window
 #define LL_BITS 10
 #define D_BITS 8
 
@@ -33,7 +32,7 @@ __constant__ uint8_t INFLATE_ORD[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4,
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
 struct __attribute__((aligned(16))) WaveLds {
-  uint32_t in[IN_RING_DW];
+  uint32_t in[IN_RING_DW + 4];             // (+ the first four dwords once more)
   uint32_t win[OUT_WIN / 4];
   uint16_t lut_ll[1u << LL_BITS];          // symbol | length << 9 (0: the code is longer than LL_BITS, or unused)
   uint16_t lut_d[1u << D_BITS];            // symbol | length << 5 (also the 7-bit table of the code-length alphabet)
@@ -96,11 +95,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
     const uint64_t src_room = A.n_src - B.src_off;           // bytes that may be read from src on
     uint8_t *out = A.dst + B.dst_off;
     const uint32_t ulen = B.ulen;
+    const uint32_t bit_end = (B.clen + 64u) * 8u;             // a decoder that is still going this far behind the payload is lost
     bool bad = false;
 
-    // ---- input ring: chunk k of the block's bytes sits in ring half k & 1; chunk k + 1 is there too, chunk k + 2 on its way
-    // (eight bytes at a time: a piece that holds payload bytes ends inside the block's eight-byte trailer at the latest, so
-    // nothing is read past the buffer and nothing needs a byte loop)
+    // ---- input ring: chunk k of the block's bytes (512 of them) sits in ring half k & 1.  While the decoder is in chunk k,
+    // chunks k and k + 1 are in the ring and chunk k + 2 is on its way (in `ahead`); the ring's first four dwords are kept
+    // once more behind its end, so that three consecutive dwords can be read from any index without wrapping.
+    // (Eight bytes at a time: a piece that holds payload bytes ends inside the block's eight-byte trailer at the latest, so
+    // nothing is read past the buffer and nothing needs a byte loop; what lies behind the buffer reads as zero.)
     auto load_chunk = [&](uint32_t k) {
       const uint64_t o = (uint64_t)k * IN_CHUNK + 16u * (uint32_t)lane;
       struct __attribute__((packed, aligned(1))) IW2 { uint32_t a, b; };
@@ -110,43 +112,43 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
       if (o + 16 <= src_room) { const IW2 t = *(const IW2 *)(src + o + 8); v.z = t.a; v.w = t.b; }
       return v;
     };
-    auto put_chunk = [&](uint32_t k, uint4 v) { if (16u * (uint32_t)lane < IN_CHUNK) *(uint4 *)(W.in + (k & 1u) * (IN_CHUNK / 4) + 4u * (uint32_t)lane) = v; };
-    put_chunk(0, load_chunk(0));
-    put_chunk(1, load_chunk(1));
-    uint4 ahead = load_chunk(2);
-    __builtin_amdgcn_wave_barrier();
-
-    // bit buffer: the next bc (<= 128) bits of the stream in bh:bb, ip = bytes taken from the ring.  After refill() more than
-    // 96 are there: a whole token (<= 48 bits) at each of the first 48 bit offsets, for the lanes that decode ahead
-    uint64_t bb = 0, bh = 0; uint32_t bc = 0, ip = 0;
-    auto refill = [&]() {
-      while (bc <= 96u) {
-        const uint64_t w = (uint64_t)uni(W.in[(ip >> 2) & (IN_RING_DW - 1u)]);
-        if (bc < 64u) { bb |= w << bc; if (bc > 32u) bh |= w >> (64u - bc); }
-        else bh |= w << (bc - 64u);
-        bc += 32u; ip += 4u;
-        if ((ip & (IN_CHUNK - 1u)) == 0u) {                   // entering chunk k: chunk k - 1's half takes chunk k + 1, k + 2 is asked for
-          const uint32_t k = ip / IN_CHUNK;
-          __builtin_amdgcn_wave_barrier();
-          put_chunk(k + 1u, ahead);
-          ahead = load_chunk(k + 2u);
-          __builtin_amdgcn_wave_barrier();
-        }
+    auto put_chunk = [&](uint32_t k, uint4 v) {
+      if (16u * (uint32_t)lane < IN_CHUNK) *(uint4 *)(W.in + (k & 1u) * (IN_CHUNK / 4) + 4u * (uint32_t)lane) = v;
+      if (lane == 0 && !(k & 1u)) *(uint4 *)(W.in + IN_RING_DW) = v;
+    };
+    uint32_t bitpos = 0, chunk = 0;                            // the next bit of the stream; the chunk it lies in
+    uint4 ahead;
+    auto prime = [&]() {                                       // the ring around bitpos, from the source
+      chunk = bitpos / (8u * IN_CHUNK);
+      __builtin_amdgcn_wave_barrier();
+      put_chunk(chunk, load_chunk(chunk)); put_chunk(chunk + 1u, load_chunk(chunk + 1u)); ahead = load_chunk(chunk + 2u);
+      __builtin_amdgcn_wave_barrier();
+    };
+    prime();
+    auto skip = [&](uint32_t n) {                              // n <= 8 * IN_CHUNK bits
+      bitpos += n;
+      if (bitpos / (8u * IN_CHUNK) != chunk) {                 // entering chunk k + 1: chunk k's half takes chunk k + 2, k + 3 is asked for
+        chunk++;
+        __builtin_amdgcn_wave_barrier();
+        put_chunk(chunk + 1u, ahead);
+        ahead = load_chunk(chunk + 2u);
+        __builtin_amdgcn_wave_barrier();
       }
     };
-    auto consume = [&](uint32_t n) {                          // n <= bc
-      if (n >= 64u) { bb = bh >> (n - 64u); bh = 0; }
-      else if (n) { bb = (bb >> n) | (bh << (64u - n)); bh >>= n; }
-      bc -= n;
+    auto peek = [&]() -> uint32_t {                            // the next 32 bits, wave-uniform
+      const uint32_t k = (bitpos >> 5) & (IN_RING_DW - 1u);
+      const uint32_t d0 = uni(W.in[k]), d1 = uni(W.in[k + 1u]);
+      return (uint32_t)(((((uint64_t)d1) << 32) | (uint64_t)d0) >> (bitpos & 31u));
     };
-    auto bits = [&](uint32_t n) { const uint32_t v = (uint32_t)bb & ((1u << n) - 1u); consume(n); return v; };
+    auto bits = [&](uint32_t n) { const uint32_t v = peek() & ((1u << n) - 1u); skip(n); return v; };   // n <= 16
     // a code longer than the primary table (or an unused entry): bit by bit against the canonical counts
     auto slow = [&](const uint16_t *cnt, const uint16_t *sorted) -> int {
+      uint32_t w = peek();
       uint32_t code = 0, first = 0, index = 0;
-      for (int l = 1; l <= 15; l++) {
-        code |= (uint32_t)bb & 1u; consume(1u);
+      for (uint32_t l = 1; l <= 15u; l++) {
+        code |= w & 1u; w >>= 1;
         const uint32_t count = uni(cnt[l]);
-        if (code < first + count) return (int)uni(sorted[index + (code - first)]);
+        if (code < first + count) { skip(l); return (int)uni(sorted[index + (code - first)]); }
         index += count; first += count; first <<= 1; code <<= 1;
       }
       return -1;
@@ -168,47 +170,56 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
         flushed += n;
       }
     };
+    // a match: len bytes from dist back, by as many lanes as it has bytes (dist >= 1, dist <= pos, pos + len <= ulen)
+    auto copy_match = [&](uint32_t len, uint32_t dist) {
+      __builtin_amdgcn_wave_barrier();
+      if (dist + len <= OUT_WIN) {                              // the source is still in the window when the last byte lands
+        const float rcp = 1.0f / (float)dist;
+        for (uint32_t i = (uint32_t)lane; i < len; i += 64u) {
+          uint32_t so = i;
+          if (dist < len) {                                     // the match overlaps itself: byte i repeats byte i mod dist
+            const uint32_t q = (uint32_t)((float)i * rcp);      // (i < 258: the quotient is exact or one short)
+            so = i - q * dist;
+            if (so >= dist) so -= dist;
+          }
+          win8[(pos + i) & (OUT_WIN - 1u)] = win8[(pos - dist + so) & (OUT_WIN - 1u)];
+        }
+      } else {
+        // far back: the bytes left the window, they are in HBM (written by this wave; dist > len here: no overlap with [pos, ..))
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        for (uint32_t i = (uint32_t)lane; i < len; i += 64u) win8[(pos + i) & (OUT_WIN - 1u)] = out[pos - dist + i];
+      }
+      __builtin_amdgcn_wave_barrier();
+      pos += len;
+      if ((pos & ~(OUT_PIECE - 1u)) > flushed) flush_to(pos & ~(OUT_PIECE - 1u));
+    };
 
     // ---- the DEFLATE blocks of the stream
     bool last = false;
     while (!last && !bad) {
-      refill();
+      if (bitpos > bit_end) { bad = true; break; }
       last = bits(1) != 0u;
       const uint32_t btype = bits(2);
       if (btype == 0u) {                                      // stored: to the byte boundary, LEN, NLEN, bytes
-        bits(bc & 7u);
-        refill();
-        const uint32_t len = bits(16); refill();
+        skip((8u - (bitpos & 7u)) & 7u);
+        const uint32_t len = bits(16);
         const uint32_t nlen = bits(16);
         if ((len ^ nlen) != 0xffffu || pos + len > ulen) { bad = true; break; }
-        // bytes still in the bit buffer first, then straight from the source
-        uint32_t done = 0;
-        while (done < len && bc >= 8u) { if (lane == 0) win8[(pos + done) & (OUT_WIN - 1u)] = (uint8_t)bb; consume(8u); done++; }
-        // (bc is 0 here unless len ran out: the ring position ip is the next source byte)
-        for (uint32_t base = done; base < len; base += 64u) {
+        const uint32_t sp = bitpos >> 3;                        // the bytes come straight from the source
+        for (uint32_t base = 0; base < len; base += 64u) {
           const uint32_t i = base + (uint32_t)lane;
           if (i < len) {
-            const uint64_t so = (uint64_t)ip + (i - done);
+            const uint64_t so = (uint64_t)sp + i;
             win8[(pos + i) & (OUT_WIN - 1u)] = so < src_room ? src[so] : (uint8_t)0;
           }
           // finished pieces leave at once (the window holds OUT_WIN bytes)
           const uint32_t reach = pos + (base + 64u < len ? base + 64u : len);
           if ((reach & ~(OUT_PIECE - 1u)) > flushed) flush_to(reach & ~(OUT_PIECE - 1u));
         }
-        if (done < len) {
-          // the ring continues behind the copied bytes: reload it from there
-          const uint32_t np = ip + (len - done);
-          ip = np & ~3u;
-          const uint32_t k = ip / IN_CHUNK;
-          __builtin_amdgcn_wave_barrier();
-          put_chunk(k, load_chunk(k)); put_chunk(k + 1u, load_chunk(k + 1u)); ahead = load_chunk(k + 2u);
-          __builtin_amdgcn_wave_barrier();
-          bb = 0; bh = 0; bc = 0;
-          refill();
-          bits(8u * (np & 3u));
-        }
         pos += len;
         flush_to(pos & ~(OUT_PIECE - 1u));
+        if (len) { bitpos += 8u * len; prime(); }               // the ring continues behind the copied bytes
         continue;
       }
       if (btype == 3u) { bad = true; break; }
@@ -219,13 +230,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
         __builtin_amdgcn_wave_barrier();
         n_ll = 288; n_d = 30;
       } else {                                                // dynamic code (3.2.7)
-        refill();
         const uint32_t hlit = bits(5) + 257u, hdist = bits(5) + 1u, hclen = bits(4) + 4u;
         if (hlit > 286u || hdist > 30u) { bad = true; break; }
         if (lane < 19) W.lens[320 + lane] = 0;
         __builtin_amdgcn_wave_barrier();
         for (uint32_t i = 0; i < hclen; i++) {
-          refill();
           const uint32_t v = bits(3);
           if (lane == 0) W.lens[320 + INFLATE_ORD[i]] = (uint8_t)v;
         }
@@ -234,16 +243,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
         const uint32_t total = hlit + hdist;
         uint32_t i = 0;
         while (i < total && !bad) {
-          refill();
           int sym;
-          const uint32_t e = uni(W.lut_d[(uint32_t)bb & 127u]);
-          if (e >> 5) { sym = (int)(e & 31u); consume(e >> 5); } else sym = slow(W.cnt_d, W.sorted_d);
+          const uint32_t w = peek();
+          const uint32_t e = uni(W.lut_d[w & 127u]);
+          uint32_t used = e >> 5;
+          if (used) sym = (int)(e & 31u); else sym = slow(W.cnt_d, W.sorted_d);   // (slow() skips its bits itself)
           if (sym < 0 || sym > 18) { bad = true; break; }
-          if (sym < 16) { if (lane == 0) W.lens[i] = (uint8_t)sym; i++; __builtin_amdgcn_wave_barrier(); continue; }
+          const uint32_t x = w >> used;                          // the extra bits of 16 / 17 / 18 (used + 7 <= 14 bits of w)
+          if (sym < 16) { if (used) skip(used); if (lane == 0) W.lens[i] = (uint8_t)sym; i++; __builtin_amdgcn_wave_barrier(); continue; }
+          if (!used) { bad = true; break; }                      // (a code-length code is at most seven bits long: the table holds all of them)
           uint32_t rep, val = 0;
-          if (sym == 16) { if (i == 0) { bad = true; break; } __builtin_amdgcn_wave_barrier(); val = uni(W.lens[i - 1]); rep = 3u + bits(2); }
-          else if (sym == 17) rep = 3u + bits(3);
-          else rep = 11u + bits(7);
+          if (sym == 16) { if (i == 0) { bad = true; break; } __builtin_amdgcn_wave_barrier(); val = uni(W.lens[i - 1]); rep = 3u + (x & 3u); used += 2u; }
+          else if (sym == 17) { rep = 3u + (x & 7u); used += 3u; }
+          else { rep = 11u + (x & 127u); used += 7u; }
+          skip(used);
           if (i + rep > total) { bad = true; break; }
           for (uint32_t k = (uint32_t)lane; k < rep; k += 64u) W.lens[i + k] = (uint8_t)val;
           i += rep;
@@ -262,82 +275,102 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
       if (!build_tables(W, W.lens, n_ll, W.cnt_ll, W.sorted_ll, W.lut_ll, LL_BITS, 9, lane)) { bad = true; break; }
       if (!build_tables(W, W.lens + 288, n_d, W.cnt_d, W.sorted_d, W.lut_d, D_BITS, 5, lane)) { bad = true; break; }
 
-      // ---- symbols
-      bool in_run = false;                                      // the last token was a literal: the next ones probably are
+      // ---- symbols.  Lane i decodes the whole token that would start at bit offset i behind bitpos (two LDS gathers: the
+      // literal/length table, the distance table); the chain of real token starts is then followed from offset 0 through the
+      // lanes' "next" values by the scalar unit (a v_readlane and four scalar instructions per literal), up to the first
+      // token that is not a literal; the literals on the chain are stored by their lanes, the token behind them (a match,
+      // the end of the block) is taken from its lane's registers.  Only codes longer than the tables go bit by bit.
       for (;;) {
-        refill();
-        if (in_run) {
-          // A run of literals at once: lane i decodes the code that would start at bit offset i of the buffer (one LDS gather),
-          // the chain of real starts is followed from offset 0 through the lanes (a v_readlane and an add per literal where
-          // the serial path needs a broadcast LDS read and ~25 scalar instructions), and the lanes on the chain store their bytes.
-          uint64_t v = bb >> (uint32_t)lane;
-          if (lane) v |= bh << (64u - (uint32_t)lane);
-          const uint32_t el = W.lut_ll[(uint32_t)v & ((1u << LL_BITS) - 1u)];
-          const uint32_t l1 = el >> 9, sy = el & 511u;
-          // where the token behind this lane's literal starts; 255: no (short-coded) literal here, or its code would leave the buffer
-          const uint32_t lim = bc - 16u < 64u ? bc - 16u : 64u;
-          const uint32_t nxt = (l1 != 0u && sy < 256u && (uint32_t)lane < lim) ? (uint32_t)lane + l1 : 255u;
-          uint64_t sel = 0; uint32_t at = 0, n_lit = 0;
-          for (;;) {                                            // (kept this plain: every test in here is scalar instructions per literal)
-            const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)nxt, (int)at);
-            if (n >= 128u) break;
-            sel |= 1ull << at; n_lit++;
-            at = n;
-            if (at >= 64u) break;
+        if (bitpos > bit_end) { bad = true; break; }
+        const uint32_t p = bitpos + (uint32_t)lane;
+        const uint32_t k = (p >> 5) & (IN_RING_DW - 1u);
+        const uint32_t d0 = W.in[k], d1 = W.in[k + 1u], d2 = W.in[k + 2u];
+        const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, p & 31u), hi = __builtin_amdgcn_alignbit(d2, d1, p & 31u);
+        const uint32_t el = W.lut_ll[lo & ((1u << LL_BITS) - 1u)];
+        const uint32_t l1 = el >> 9, sy = el & 511u;
+        // next: where the token behind this lane's literal starts; 128 + lane: no literal here
+        uint32_t nxt = 128u + (uint32_t)lane;
+        uint32_t info = 0;                                       // len | (dist - 1) << 9 | bits << 24 | kind << 30 (1: match, 2: end of block; 0: not decoded here)
+        if (l1) {
+          if (sy < 256u) nxt = (uint32_t)lane + l1;
+          else if (sy == 256u) info = (2u << 30) | (l1 << 24);
+          else if (sy < 286u) {
+            const uint32_t s = sy - 257u;                         // 0 .. 28
+            const uint32_t eb = s < 8u || s == 28u ? 0u : (s - 4u) >> 2;
+            const uint32_t base = s < 8u ? s + 3u : s == 28u ? 258u : ((4u + ((s - 4u) & 3u)) << eb) + 3u;
+            const uint64_t v = ((((uint64_t)hi) << 32) | (uint64_t)lo) >> l1;
+            const uint32_t len = base + ((uint32_t)v & ((1u << eb) - 1u));
+            const uint32_t x = (uint32_t)(v >> eb);               // 32 bits from the distance code on (l1 + eb <= 15 of the 64 are gone)
+            const uint32_t ed = W.lut_d[x & ((1u << D_BITS) - 1u)];
+            const uint32_t dl = ed >> 5, ds = ed & 31u;
+            if (dl && ds < 30u) {
+              const uint32_t deb = ds < 4u ? 0u : (ds >> 1) - 1u;
+              const uint32_t dbase = ds < 4u ? ds + 1u : ((2u + (ds & 1u)) << deb) + 1u;
+              const uint32_t dist = dbase + ((x >> dl) & ((1u << deb) - 1u));
+              info = (1u << 30) | ((l1 + eb + dl + deb) << 24) | ((dist - 1u) << 9) | len;
+            }
           }
-          if (n_lit > ulen - pos) { bad = true; break; }        // more bytes than the block holds
-          if (n_lit) {
-            if ((sel >> lane) & 1ull) win8[(pos + (uint32_t)__builtin_popcountll(sel & ((1ull << lane) - 1ull))) & (OUT_WIN - 1u)] = (uint8_t)sy;
-            pos += n_lit;
-            consume(at);
-            if ((pos & ~(OUT_PIECE - 1u)) > flushed) flush_to(pos & ~(OUT_PIECE - 1u));
-            continue;
-          }
-          in_run = false;
         }
+        // the chain (wave-uniform): offsets of the literals in front of the first other token
+        uint32_t at = 0, n;
+        uint64_t sel = 0;
+        do {
+          n = (uint32_t)__builtin_amdgcn_readlane((int)nxt, (int)at);
+          sel |= 1ull << at;
+          at = n;
+        } while (n < 64u);
+        uint32_t term = 64u;                                     // the lane of the token that ended the run, if it starts inside the buffer
+        if (at >= 128u) { term = at - 128u; sel &= ~(1ull << term); at = term; }
+        const uint32_t n_lit = (uint32_t)__builtin_popcountll(sel);
+        if (n_lit > ulen - pos) { bad = true; break; }           // more bytes than the block holds
+        if (n_lit) {
+          if ((sel >> lane) & 1ull) win8[(pos + __builtin_amdgcn_mbcnt_hi((uint32_t)(sel >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sel, 0u))) & (OUT_WIN - 1u)] = (uint8_t)sy;
+          pos += n_lit;
+          if ((pos & ~(OUT_PIECE - 1u)) > flushed) flush_to(pos & ~(OUT_PIECE - 1u));
+        }
+        if (term == 64u) { skip(at); continue; }                 // the run goes on behind the buffer
+        const uint32_t ti = (uint32_t)__builtin_amdgcn_readlane((int)info, (int)term);
+        const uint32_t kind = ti >> 30;
+        if (kind == 1u) {
+          const uint32_t len = ti & 511u, dist = ((ti >> 9) & 0x7fffu) + 1u;
+          skip(at + ((ti >> 24) & 63u));
+          if (dist > pos || pos + len > ulen) { bad = true; break; }
+          copy_match(len, dist);
+          continue;
+        }
+        if (kind == 2u) { skip(at + ((ti >> 24) & 63u)); break; }
+        // not decoded by the lane (a code longer than a table): this one token bit by bit
+        skip(at);
         int sym;
-        const uint32_t e = uni(W.lut_ll[(uint32_t)bb & ((1u << LL_BITS) - 1u)]);
-        if (e >> 9) { sym = (int)(e & 511u); consume(e >> 9); } else sym = slow(W.cnt_ll, W.sorted_ll);
+        {
+          const uint32_t e = uni(W.lut_ll[peek() & ((1u << LL_BITS) - 1u)]);
+          if (e >> 9) { sym = (int)(e & 511u); skip(e >> 9); } else sym = slow(W.cnt_ll, W.sorted_ll);
+        }
         if (sym < 0 || sym > 285) { bad = true; break; }
         if (sym < 256) {
           if (pos >= ulen) { bad = true; break; }
           if (lane == 0) win8[pos & (OUT_WIN - 1u)] = (uint8_t)sym;
           pos++;
-          if ((pos & (OUT_PIECE - 1u)) == 0u) flush_to(pos);   // every finished piece leaves at once: the window never holds more than a piece + a match of unsent bytes
-          in_run = true;
+          if ((pos & (OUT_PIECE - 1u)) == 0u) flush_to(pos);
           continue;
         }
         if (sym == 256) break;
-        // length
         uint32_t len;
         const uint32_t s = (uint32_t)sym;
         if (s < 265u) len = s - 254u;
         else if (s == 285u) len = 258u;
         else { const uint32_t eb = (s - 261u) >> 2; len = ((4u + ((s - 261u) & 3u)) << eb) + 3u + bits(eb); }
-        refill();
         int ds;
-        const uint32_t ed = uni(W.lut_d[(uint32_t)bb & ((1u << D_BITS) - 1u)]);
-        if (ed >> 5) { ds = (int)(ed & 31u); consume(ed >> 5); } else ds = slow(W.cnt_d, W.sorted_d);
+        {
+          const uint32_t ed = uni(W.lut_d[peek() & ((1u << D_BITS) - 1u)]);
+          if (ed >> 5) { ds = (int)(ed & 31u); skip(ed >> 5); } else ds = slow(W.cnt_d, W.sorted_d);
+        }
         if (ds < 0 || ds > 29) { bad = true; break; }
         uint32_t dist;
         if (ds < 4) dist = (uint32_t)ds + 1u;
         else { const uint32_t eb = ((uint32_t)ds >> 1) - 1u; dist = ((2u + ((uint32_t)ds & 1u)) << eb) + 1u + bits(eb); }
         if (dist > pos || pos + len > ulen) { bad = true; break; }
-        __builtin_amdgcn_wave_barrier();
-        if (dist <= OUT_NEAR) {
-          for (uint32_t i = (uint32_t)lane; i < len; i += 64u) {
-            const uint32_t so = dist >= len ? i : i % dist;
-            win8[(pos + i) & (OUT_WIN - 1u)] = win8[(pos - dist + so) & (OUT_WIN - 1u)];
-          }
-        } else {
-          // far back: the bytes left the window, they are in HBM (written by this wave; at most 258 bytes, no overlap with [pos, ..))
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-          for (uint32_t i = (uint32_t)lane; i < len; i += 64u) win8[(pos + i) & (OUT_WIN - 1u)] = out[pos - dist + i];
-        }
-        __builtin_amdgcn_wave_barrier();
-        pos += len;
-        if ((pos & ~(OUT_PIECE - 1u)) > flushed) flush_to(pos & ~(OUT_PIECE - 1u));
+        copy_match(len, dist);
       }
     }
     if (!bad && pos != ulen) bad = true;
