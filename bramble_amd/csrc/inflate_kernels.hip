@@ -39,6 +39,8 @@ struct __attribute__((aligned(16))) WaveLds {
   uint16_t sorted_ll[288], sorted_d[32];   // symbols in canonical order (by length, then by value)
   uint16_t cnt_ll[16], cnt_d[16];
   uint16_t fcode[16], findex[16];          // table construction: first code / first index of a length
+  uint32_t long_lim[6];                    // literal/length codes longer than LL_BITS: the first code past length LL_BITS + k, left-aligned to 15 bits
+  int32_t long_base[6];                    // ... and what turns a code of length LL_BITS + k into its index in sorted_ll (k = 1 .. 5)
   uint8_t lens[352];                       // code lengths: [0, 320) literal/length + distance, [320, 339) the code-length alphabet
 };
 
@@ -273,6 +275,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
         __builtin_amdgcn_wave_barrier();
       }
       if (!build_tables(W, W.lens, n_ll, W.cnt_ll, W.sorted_ll, W.lut_ll, LL_BITS, 9, lane)) { bad = true; break; }
+      if (lane < 6) {                                           // (fcode / findex are the next build's scratch)
+        const uint32_t l = (uint32_t)(LL_BITS + lane);
+        W.long_lim[lane] = ((uint32_t)W.fcode[l] + (uint32_t)W.cnt_ll[l]) << (15u - l);
+        W.long_base[lane] = (int32_t)W.findex[l] - (int32_t)W.fcode[l];
+      }
+      __builtin_amdgcn_wave_barrier();
       if (!build_tables(W, W.lens + 288, n_d, W.cnt_d, W.sorted_d, W.lut_d, D_BITS, 5, lane)) { bad = true; break; }
 
       // ---- symbols.  Lane i decodes the whole token that would start at bit offset i behind bitpos (two LDS gathers: the
@@ -286,39 +294,60 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
         const uint32_t k = (p >> 5) & (IN_RING_DW - 1u);
         const uint32_t d0 = W.in[k], d1 = W.in[k + 1u], d2 = W.in[k + 2u];
         const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, p & 31u), hi = __builtin_amdgcn_alignbit(d2, d1, p & 31u);
-        const uint32_t el = W.lut_ll[lo & ((1u << LL_BITS) - 1u)];
-        const uint32_t l1 = el >> 9, sy = el & 511u;
-        // next: where the token behind this lane's literal starts; 128 + lane: no literal here
-        uint32_t nxt = 128u + (uint32_t)lane;
-        uint32_t info = 0;                                       // len | (dist - 1) << 9 | bits << 24 | kind << 30 (1: match, 2: end of block; 0: not decoded here)
-        if (l1) {
-          if (sy < 256u) nxt = (uint32_t)lane + l1;
-          else if (sy == 256u) info = (2u << 30) | (l1 << 24);
-          else if (sy < 286u) {
-            const uint32_t s = sy - 257u;                         // 0 .. 28
-            const uint32_t eb = s < 8u || s == 28u ? 0u : (s - 4u) >> 2;
-            const uint32_t base = s < 8u ? s + 3u : s == 28u ? 258u : ((4u + ((s - 4u) & 3u)) << eb) + 3u;
-            const uint64_t v = ((((uint64_t)hi) << 32) | (uint64_t)lo) >> l1;
-            const uint32_t len = base + ((uint32_t)v & ((1u << eb) - 1u));
-            const uint32_t x = (uint32_t)(v >> eb);               // 32 bits from the distance code on (l1 + eb <= 15 of the 64 are gone)
-            const uint32_t ed = W.lut_d[x & ((1u << D_BITS) - 1u)];
-            const uint32_t dl = ed >> 5, ds = ed & 31u;
-            if (dl && ds < 30u) {
-              const uint32_t deb = ds < 4u ? 0u : (ds >> 1) - 1u;
-              const uint32_t dbase = ds < 4u ? ds + 1u : ((2u + (ds & 1u)) << deb) + 1u;
-              const uint32_t dist = dbase + ((x >> dl) & ((1u << deb) - 1u));
-              info = (1u << 30) | ((l1 + eb + dl + deb) << 24) | ((dist - 1u) << 9) | len;
-            }
-          }
+        uint32_t el = W.lut_ll[lo & ((1u << LL_BITS) - 1u)];
+        if (el < 512u) {
+          // no code of at most LL_BITS bits starts here: a longer one, by its place among the canonical codes (the codes of
+          // length l are the 15-bit left-aligned values in [lim[l - 1], lim[l]))
+          const uint32_t rev = __builtin_bitreverse32(lo) >> 17;
+          const uint32_t k = (uint32_t)(rev >= W.long_lim[1]) + (uint32_t)(rev >= W.long_lim[2]) + (uint32_t)(rev >= W.long_lim[3]) + (uint32_t)(rev >= W.long_lim[4]) + 1u;
+          if (rev >= W.long_lim[0] && rev < W.long_lim[5]) el = (uint32_t)W.sorted_ll[(uint32_t)(W.long_base[k] + (int32_t)(rev >> (5u - k)))] | ((LL_BITS + k) << 9);
         }
-        // the chain (wave-uniform): offsets of the literals in front of the first other token
+        const uint32_t l1 = el >> 9, sy = el & 511u;
+        const bool coded = el >= 512u;                           // a literal/length code starts here
+        // next: where the token behind this lane's literal starts; 128 + lane: no literal here
+        const uint32_t nxt = coded && sy < 256u ? (uint32_t)lane + l1 : 128u + (uint32_t)lane;
+        // the token as a match, whatever it is (no branch: a lane at a wrong offset decodes noise and nobody asks for it)
+        const uint32_t ls = sy - 257u;                            // 0 .. 28 for a length code
+        const bool len_short = ls < 8u, len_top = ls == 28u;
+        const uint32_t eb = len_short || len_top ? 0u : ((ls - 4u) >> 2) & 7u;
+        const uint32_t base = len_short ? ls + 3u : len_top ? 258u : ((4u + ((ls - 4u) & 3u)) << eb) + 3u;
+        const uint64_t v = ((((uint64_t)hi) << 32) | (uint64_t)lo) >> l1;
+        const uint32_t mlen = base + ((uint32_t)v & ((1u << eb) - 1u));
+        const uint32_t x = (uint32_t)(v >> eb);                  // 32 bits from the distance code on (l1 + eb <= 15 of the 64 are gone)
+        const uint32_t ed = W.lut_d[x & ((1u << D_BITS) - 1u)];
+        const uint32_t mdl = ed >> 5, mds = ed & 31u;
+        const uint32_t deb = mds < 4u ? 0u : (mds >> 1) - 1u;
+        const uint32_t dbase = mds < 4u ? mds + 1u : ((2u + (mds & 1u)) << deb) + 1u;
+        const uint32_t mdist = dbase + ((x >> mdl) & ((1u << deb) - 1u));
+        // len | (dist - 1) << 9 | bits << 24 | kind << 30 (1: match, 2: end of block; 0: not decoded here)
+        uint32_t info = coded && ls < 29u && ed >= 32u && mds < 30u ? (1u << 30) | ((l1 + eb + mdl + deb) << 24) | ((mdist - 1u) << 9) | mlen : 0u;
+        if (coded && sy == 256u) info = (2u << 30) | (l1 << 24);
+        // the chain of token starts from offset 0: the scalar unit follows every fourth token (pointers doubled twice by the
+        // lanes), the tokens between are marked by their predecessors (a push to the lane of the offset; nobody pushes to
+        // lane 0 -- an offset behind a token is at least 1 -- so the lanes with nothing to say push there)
+        const uint32_t t1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((nxt & 63u) << 2), (int)nxt);
+        const uint32_t j1 = nxt < 64u ? t1 : nxt;                // two tokens on (or where the first one left the buffer / was no literal)
+        const uint32_t t2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((j1 & 63u) << 2), (int)j1);
+        const uint32_t j2 = j1 < 64u ? t2 : j1;                  // four tokens on
         uint32_t at = 0, n;
         uint64_t sel = 0;
         do {
-          n = (uint32_t)__builtin_amdgcn_readlane((int)nxt, (int)at);
+          n = (uint32_t)__builtin_amdgcn_readlane((int)j2, (int)at);
           sel |= 1ull << at;
           at = n;
         } while (n < 64u);
+        {
+          const bool in = (sel >> lane) & 1ull;
+          const bool push = in && j1 < 64u;
+          const uint32_t got = (uint32_t)__builtin_amdgcn_ds_permute((int)(push ? j1 << 2 : 0u), push ? 1 : 0);
+          sel |= __builtin_amdgcn_ballot_w64(got != 0u);
+        }
+        {
+          const bool in = (sel >> lane) & 1ull;
+          const bool push = in && nxt < 64u;
+          const uint32_t got = (uint32_t)__builtin_amdgcn_ds_permute((int)(push ? nxt << 2 : 0u), push ? 1 : 0);
+          sel |= __builtin_amdgcn_ballot_w64(got != 0u);
+        }
         uint32_t term = 64u;                                     // the lane of the token that ended the run, if it starts inside the buffer
         if (at >= 128u) { term = at - 128u; sel &= ~(1ull << term); at = term; }
         const uint32_t n_lit = (uint32_t)__builtin_popcountll(sel);
