@@ -172,10 +172,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
         flushed += n;
       }
     };
-    // a match: len bytes from dist back, by as many lanes as it has bytes (dist >= 1, dist <= pos, pos + len <= ulen)
-    auto copy_match = [&](uint32_t len, uint32_t dist) {
+    // a match: len bytes at `at` from dist back, by as many lanes as it has bytes (1 <= dist <= at; hi: the end of what this
+    // step has written to the window so far -- literals behind the match included)
+    auto copy_bytes = [&](uint32_t at, uint32_t len, uint32_t dist, uint32_t hi) {
       __builtin_amdgcn_wave_barrier();
-      if (dist + len <= OUT_WIN) {                              // the source is still in the window when the last byte lands
+      if (dist + (hi - at) <= OUT_WIN) {                        // the source is still in the window
         const float rcp = 1.0f / (float)dist;
         for (uint32_t i = (uint32_t)lane; i < len; i += 64u) {
           uint32_t so = i;
@@ -184,15 +185,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
             so = i - q * dist;
             if (so >= dist) so -= dist;
           }
-          win8[(pos + i) & (OUT_WIN - 1u)] = win8[(pos - dist + so) & (OUT_WIN - 1u)];
+          win8[(at + i) & (OUT_WIN - 1u)] = win8[(at - dist + so) & (OUT_WIN - 1u)];
         }
       } else {
-        // far back: the bytes left the window, they are in HBM (written by this wave; dist > len here: no overlap with [pos, ..))
+        // far back: the bytes left the window, they are in HBM (written by this wave, flushed long ago: a step writes at most
+        // 1024 + 258 bytes; dist > len here: no overlap with [at, ..))
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        for (uint32_t i = (uint32_t)lane; i < len; i += 64u) win8[(pos + i) & (OUT_WIN - 1u)] = out[pos - dist + i];
+        for (uint32_t i = (uint32_t)lane; i < len; i += 64u) win8[(at + i) & (OUT_WIN - 1u)] = out[at - dist + i];
       }
       __builtin_amdgcn_wave_barrier();
+    };
+    auto copy_match = [&](uint32_t len, uint32_t dist) {        // dist <= pos, pos + len <= ulen
+      copy_bytes(pos, len, dist, pos + len);
       pos += len;
       if ((pos & ~(OUT_PIECE - 1u)) > flushed) flush_to(pos & ~(OUT_PIECE - 1u));
     };
@@ -305,7 +310,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
         const uint32_t l1 = el >> 9, sy = el & 511u;
         const bool coded = el >= 512u;                           // a literal/length code starts here
         // next: where the token behind this lane's literal starts; 128 + lane: no literal here
-        const uint32_t nxt = coded && sy < 256u ? (uint32_t)lane + l1 : 128u + (uint32_t)lane;
         // the token as a match, whatever it is (no branch: a lane at a wrong offset decodes noise and nobody asks for it)
         const uint32_t ls = sy - 257u;                            // 0 .. 28 for a length code
         const bool len_short = ls < 8u, len_top = ls == 28u;
@@ -320,8 +324,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
         const uint32_t dbase = mds < 4u ? mds + 1u : ((2u + (mds & 1u)) << deb) + 1u;
         const uint32_t mdist = dbase + ((x >> mdl) & ((1u << deb) - 1u));
         // len | (dist - 1) << 9 | bits << 24 | kind << 30 (1: match, 2: end of block; 0: not decoded here)
-        uint32_t info = coded && ls < 29u && ed >= 32u && mds < 30u ? (1u << 30) | ((l1 + eb + mdl + deb) << 24) | ((mdist - 1u) << 9) | mlen : 0u;
+        const bool matched = coded && ls < 29u && ed >= 32u && mds < 30u;
+        const uint32_t mbits = l1 + eb + mdl + deb;
+        uint32_t info = matched ? (1u << 30) | (mbits << 24) | ((mdist - 1u) << 9) | mlen : 0u;
         if (coded && sy == 256u) info = (2u << 30) | (l1 << 24);
+        // next: where the token behind this lane's starts, for a literal and for a short match (at most 32 bytes: a step then
+        // writes at most 1024 of them); 128 + lane: a token that ends the step (a long match, the end of the block, a distance
+        // code longer than its table)
+        const bool through = matched && mlen <= 32u;
+        const uint32_t nxt = coded && sy < 256u ? (uint32_t)lane + l1 : through ? (uint32_t)lane + mbits : 128u + (uint32_t)lane;
         // the chain of token starts from offset 0: the scalar unit follows every fourth token (pointers doubled twice by the
         // lanes), the tokens between are marked by their predecessors (a push to the lane of the offset; nobody pushes to
         // lane 0 -- an offset behind a token is at least 1 -- so the lanes with nothing to say push there)
@@ -350,11 +361,41 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
         }
         uint32_t term = 64u;                                     // the lane of the token that ended the run, if it starts inside the buffer
         if (at >= 128u) { term = at - 128u; sel &= ~(1ull << term); at = term; }
-        const uint32_t n_lit = (uint32_t)__builtin_popcountll(sel);
-        if (n_lit > ulen - pos) { bad = true; break; }           // more bytes than the block holds
-        if (n_lit) {
-          if ((sel >> lane) & 1ull) win8[(pos + __builtin_amdgcn_mbcnt_hi((uint32_t)(sel >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sel, 0u))) & (OUT_WIN - 1u)] = (uint8_t)sy;
-          pos += n_lit;
+        const uint64_t msel = sel & __builtin_amdgcn_ballot_w64(through);   // the short matches on the chain
+        const uint64_t lsel = sel & ~msel;                       // its literals
+        const uint32_t n_lit = (uint32_t)__builtin_popcountll(lsel);
+        if (msel == 0ull) {
+          if (n_lit > ulen - pos) { bad = true; break; }         // more bytes than the block holds
+          if (n_lit) {
+            if ((lsel >> lane) & 1ull) win8[(pos + __builtin_amdgcn_mbcnt_hi((uint32_t)(lsel >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lsel, 0u))) & (OUT_WIN - 1u)] = (uint8_t)sy;
+            pos += n_lit;
+            if ((pos & ~(OUT_PIECE - 1u)) > flushed) flush_to(pos & ~(OUT_PIECE - 1u));
+          }
+        } else {
+          // literals and matches: every literal lands behind the bytes of the matches in front of it (all literals first: they
+          // need nothing), then the matches in stream order (a match may repeat what an earlier token of the step wrote)
+          uint32_t before = 0, tot_m = 0;                        // bytes of the matches in front of this lane's token; of all
+          for (uint64_t mm = msel; mm; mm &= mm - 1ull) {
+            const uint32_t m = (uint32_t)__builtin_ctzll(mm);
+            const uint32_t L = (uint32_t)__builtin_amdgcn_readlane((int)info, (int)m) & 511u;
+            before += (uint32_t)lane > m ? L : 0u;
+            tot_m += L;
+          }
+          const uint32_t total = n_lit + tot_m;
+          if (total > ulen - pos) { bad = true; break; }
+          if ((lsel >> lane) & 1ull) win8[(pos + before + __builtin_amdgcn_mbcnt_hi((uint32_t)(lsel >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lsel, 0u))) & (OUT_WIN - 1u)] = (uint8_t)sy;
+          uint32_t run = 0;
+          for (uint64_t mm = msel; mm; mm &= mm - 1ull) {
+            const uint32_t m = (uint32_t)__builtin_ctzll(mm);
+            const uint32_t tm = (uint32_t)__builtin_amdgcn_readlane((int)info, (int)m);
+            const uint32_t L = tm & 511u, D = ((tm >> 9) & 0x7fffu) + 1u;
+            const uint32_t mpos = pos + (uint32_t)__builtin_popcountll(lsel & ((1ull << m) - 1ull)) + run;
+            if (D > mpos) { bad = true; break; }
+            copy_bytes(mpos, L, D, pos + total);
+            run += L;
+          }
+          if (bad) break;
+          pos += total;
           if ((pos & ~(OUT_PIECE - 1u)) > flushed) flush_to(pos & ~(OUT_PIECE - 1u));
         }
         if (term == 64u) { skip(at); continue; }                 // the run goes on behind the buffer
