@@ -831,8 +831,10 @@ extern "C" int br_cli_main(int argc, char **argv) {
     }
   }
   if (getenv("BRAMBLE_AMD_TIMING") && use_dev_reader) {
-    double t_in = 0;
-    for (auto r : dev_readers) t_in = std::max(t_in, br_bam_reader_seconds(r));
+    double t_in = 0, t_up = 0;
+    for (auto r : dev_readers) { t_in = std::max(t_in, br_bam_reader_seconds(r)); t_up = std::max(t_up, br_bam_reader_upload_seconds(r)); }
+    fprintf(stderr, "[bramble] device readers: the compressed bytes went up in %.2fs of the longest uploader (%.1f GB/s of the file's %.2f GB; pinned buffers filled by four threads)\n",
+            t_up, t_up > 0 ? 1e-9 * (double)rd.mapped_size() / (double)n_dev / t_up : 0.0, 1e-9 * (double)rd.mapped_size());
     fprintf(stderr, "[bramble] device readers: block table %.2fs; the longest processing thread %.2fs in all (inflate + record split + cuts: %.2fs; the rest: waiting for its uploads, its neighbour's cut, the runner's queue); %llu pieces, %llu processed again from the true start\n",
             t_block_scan, t_dev_reader, t_in, (unsigned long long)n_pieces, (unsigned long long)reprocessed.load());
   }

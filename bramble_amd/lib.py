@@ -163,7 +163,7 @@ EXPORTS = ["br_index_build", "br_index_build_flat", "br_index_free", "br_index_n
            "br_config_long_read", "br_config_resolve", "br_batch_prepare", "br_batch_seq_source", "br_ctx_new", "br_ctx_free",
            "br_project_batch", "br_project_batch_device", "br_device_rows_expand", "br_batch_stage", "br_project_staged", "br_host_rows_wait", "br_project_batch_packed",
            "br_pin_host", "br_unpin_host", "br_project_group", "br_project_groups", "br_bam_encode_device", "br_project_bam_device", "br_project_bam_bundle", "br_bam_bundle_stage", "br_project_bam_staged", "br_bam_split", "br_annotation_load", "br_annotation_load_mt", "br_annotation_free",
-           "br_annotation_num_transcripts", "br_annotation_transcripts", "br_annotation_num_refs", "br_annotation_refnames", "br_cli_main", "br_cli_exit_at_end", "br_device_warmup", "br_project_bam_staged_nowait", "br_host_bam_wait", "br_bgzf_scan", "br_bgzf_inflate_device", "br_bam_split_device", "br_bam_reader_new", "br_bam_reader_next", "br_bam_reader_set_piece_blocks", "br_bam_reader_release", "br_bam_reader_free", "br_bam_piece_upload", "br_bam_piece_process", "br_bam_reader_seconds", "br_project_bam_resident", "br_bgzf_write_file", "br_bgzf_read_file",
+           "br_annotation_num_transcripts", "br_annotation_transcripts", "br_annotation_num_refs", "br_annotation_refnames", "br_cli_main", "br_cli_exit_at_end", "br_device_warmup", "br_project_bam_staged_nowait", "br_host_bam_wait", "br_bgzf_scan", "br_bgzf_inflate_device", "br_bam_split_device", "br_bam_reader_new", "br_bam_reader_next", "br_bam_reader_set_piece_blocks", "br_bam_reader_release", "br_bam_reader_free", "br_bam_piece_upload", "br_bam_piece_process", "br_bam_reader_seconds", "br_bam_reader_upload_seconds", "br_project_bam_resident", "br_bgzf_write_file", "br_bgzf_read_file",
            "br_free_buffer", "br_bgzf_codec", "br_bgzf_deflate_device", "br_ctx_set_profiling",
            "br_ctx_set_param", "br_ctx_kernel_ms", "br_ctx_collect_counters", "br_ctx_last_counters", "br_ctx_rescue_stats", "br_ctx_ksw_diag", "br_device_rows_detail", "br_ctx_ksw_pairs", "br_primary_pick", "br_row_mapq", "br_version", "br_strerror"]
 

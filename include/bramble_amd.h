@@ -518,6 +518,7 @@ int br_bam_piece_upload(br_bam_reader *, int slot, const uint8_t *file, uint64_t
 int br_bam_piece_process(br_bam_reader *, int slot, const br_bgzf_block *blocks, int64_t n_blocks, int64_t b1, int64_t start_rel,
                          br_device_records *bundle, int64_t *id, br_piece_info *info);
 double br_bam_reader_seconds(const br_bam_reader *);   /* time spent inside br_bam_piece_process so far */
+double br_bam_reader_upload_seconds(const br_bam_reader *);   /* ... inside br_bam_piece_upload (host copies into pinned buffers + queueing) */
 void br_bam_reader_free(br_bam_reader *);
 /* br_project_bam_staged / _nowait for records that are in HBM already (a br_bam_reader bundle, or br_bam_split_device's) */
 int br_project_bam_resident(br_ctx *, const br_config *, const br_device_records *recs, const int32_t *ref_map, int32_t n_ref_map,

@@ -2,7 +2,7 @@
 # kernel stats + issue counters of the -S DP kernels on a 200k-read C3 batch: profiles/ksw_prof.sh <tag>
 set -o pipefail
 T=${1:-ksw}
-O=gpurun_out/r02/$T
+O=gpurun_out/${ROUND:-r04}/$T
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 timeout -k 10 300 rocprofv3 --output-format csv --kernel-trace --stats -d $O/stats -o run -- python3 bench_extra.py c3 --reads ${READS:-200000} --steps 2 --warmup 1 > $O/stats.log 2>&1 || exit 1

@@ -66,6 +66,24 @@ def payloads():
     yield "repeats at the window's edge", np.tile(rng.randint(0, 256, size=6900).astype(np.uint8), 12).tobytes() + np.tile(rng.randint(0, 256, size=7000).astype(np.uint8), 12).tobytes()
     yield "short periods", b"".join(bytes(rng.randint(0, 256, size=p).astype(np.uint8)) * (2000 // p) for p in (1, 2, 3, 5, 7, 63, 64, 65, 257, 258, 259))
     yield "skewed (codes longer than ten bits)", np.concatenate([np.full(50000, 7, dtype=np.uint8), np.repeat(np.arange(256, dtype=np.uint8), rng.randint(1, 4, size=256))]).tobytes()
+    # the lanes' token decode: code lengths 2 .. 15 side by side, many short matches between literals (near and far back),
+    # one- and two-bit codes (dozens of tokens in one 64-bit buffer, overlapping matches among them), all of it mixed
+    geo = np.minimum(rng.geometric(0.06, size=260_000) - 1, 255).astype(np.uint8)
+    yield "geometric symbols (codes of 2 to 15 bits)", geo.tobytes()
+    four = rng.randint(0, 4, size=300_000).astype(np.uint8) * 37 + 11
+    yield "four letters (short matches everywhere)", four.tobytes()
+    two = (rng.rand(200_000) < 0.9).astype(np.uint8) * 3 + 64
+    yield "two letters, one of them rare", two.tobytes()
+    mix = []
+    for k in range(120):
+        n = int(rng.randint(200, 9000))
+        kind = k % 5
+        if kind == 0: mix.append(np.minimum(rng.geometric(0.03 + 0.2 * rng.rand(), size=n) - 1, 255).astype(np.uint8))
+        elif kind == 1: mix.append((rng.randint(0, int(rng.randint(2, 9)), size=n) * 29 + 3).astype(np.uint8))
+        elif kind == 2: mix.append(np.tile(rng.randint(0, 256, size=int(rng.randint(1, 40))).astype(np.uint8), n // 8 + 1)[:n])
+        elif kind == 3: mix.append(rng.randint(0, 256, size=n).astype(np.uint8))
+        else: mix.append(np.concatenate(mix[-3:])[:n][::-1].copy() if len(mix) >= 3 else np.zeros(n, dtype=np.uint8))
+    yield "a mixture of all of these", np.concatenate(mix).tobytes()
     yield "exactly one block", rng.randint(65, 70, size=0xff00).astype(np.uint8).tobytes()
     yield "one block + 1", rng.randint(65, 70, size=0xff00 + 1).astype(np.uint8).tobytes()
 
