@@ -196,14 +196,22 @@ def main():
         L = lib.lib()
         res = [lib.BrHostRows(), lib.BrHostRows()]
 
+        trace = os.environ.get("BENCH_PCIE_TRACE") is not None   # per-call host times of the loop on stderr
+
         def run_pipelined(n_steps):
             lib.check(L.br_batch_stage(ctx.h, C.byref(bs), 0), "br_batch_stage")
             for k in range(n_steps):
+                ta = time.perf_counter()
                 if k + 1 < n_steps:
                     lib.check(L.br_batch_stage(ctx.h, C.byref(bs), (k + 1) % 2), "br_batch_stage")
+                tb = time.perf_counter()
                 lib.check(L.br_project_staged(ctx.h, C.byref(cfg), k % 2, C.byref(res[k % 2])), "br_project_staged")
+                tc = time.perf_counter()
                 if k >= 1:
                     lib.check(L.br_host_rows_wait(ctx.h, (k - 1) % 2), "br_host_rows_wait")
+                if trace:
+                    sys.stderr.write("pcie step %d: stage %.1f ms, project %.1f ms, wait %.1f ms\n"
+                                     % (k, 1e3 * (tb - ta), 1e3 * (tc - tb), 1e3 * (time.perf_counter() - tc)))
             lib.check(L.br_host_rows_wait(ctx.h, (n_steps - 1) % 2), "br_host_rows_wait")
 
         run_pipelined(max(args.warmup, 2))

@@ -474,8 +474,12 @@ struct br_ctx {
   };
   InSlot in_slot[2];
   hipStream_t run_stream = nullptr, d2h_stream = nullptr;
-  hipEvent_t rows_busy = nullptr;   // recorded after the last packed download was queued: k_rows of the next call waits for it
+  hipEvent_t rows_busy = nullptr;   // recorded after the last packed download of the CURRENT row-table set was queued: the kernels that write the set wait for it
   bool rows_busy_set = false;
+  // br_project_staged alternates between two sets of the tables a packed download reads (rows, detail, scores, dense CIGAR
+  // references + pool, row_off): batch k's kernels write one set while batch k - 1's rows are still crossing PCIe out of the
+  // other -- with one set the projection of batch k stood still behind the count pass until the wire was idle
+  struct RowSetAlt { DevBuf pk_a, pk_x, pk_sim, pk_clip, pk_ch, pool, row_off; hipEvent_t busy = nullptr; bool busy_set = false; } alt;
   int host_detail = 0;              // br_host_rows carries the x (detail) array
   DevBuf z_slots, z_sizes, z_off, z_dense, z_dense_alt, z_tabs, z_tokens;
   DevBuf inf_out, inf_blocks, inf_tabs, inf_cnt; bool inf_tabs_ready = false;   // br_bgzf_inflate_device
@@ -597,7 +601,8 @@ extern "C" void br_ctx_free(br_ctx *c) {
                     &c->b_flags, &c->b_xs, &c->b_ts, &c->b_cigar_off, &c->b_cigar, &c->b_mate_idx,
                     &c->b_group_off, &c->b_lqseq, &c->walk_list, &c->pmask, &c->pbit, &c->pick, &c->wl, &c->p1, &c->g_dev,
                     &c->d_fm, &c->d_nkept, &c->d_desc, &c->d_hi0, &c->d_clspos, &c->d_rnd, &c->d_side, &c->d_sidectr,
-                    &c->fa_srcs, &c->fa_want, &c->ksw_desc, &c->ksw_dp, &c->ksw_left, &c->ksw_cnt, &c->ksw_group, &c->ksw_tape, &c->ksw_raw};
+                    &c->fa_srcs, &c->fa_want, &c->ksw_desc, &c->ksw_dp, &c->ksw_left, &c->ksw_cnt, &c->ksw_group, &c->ksw_tape, &c->ksw_raw,
+                    &c->alt.pk_a, &c->alt.pk_x, &c->alt.pk_sim, &c->alt.pk_clip, &c->alt.pk_ch, &c->alt.pool, &c->alt.row_off};
   for (DevBuf *b : bufs) b->release();
   for (auto &e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if (c->h_totals) (void)hipHostFree(c->h_totals);
@@ -614,6 +619,7 @@ extern "C" void br_ctx_free(br_ctx *c) {
     S.h_clip.release(); S.h_sim.release();
   }
   if (c->rows_busy) (void)hipEventDestroy(c->rows_busy);
+  if (c->alt.busy) (void)hipEventDestroy(c->alt.busy);
   if (c->aux2_stream) { (void)hipStreamDestroy(c->aux2_stream); (void)hipEventDestroy(c->aux2_ev); }
   if (c->ksw_stream) { (void)hipStreamDestroy(c->ksw_stream); for (auto &e : c->ksw_ev) if (e) (void)hipEventDestroy(e); for (auto &e : c->aux_ev) if (e) (void)hipEventDestroy(e); }
   if (c->run_stream) (void)hipStreamDestroy(c->run_stream);
@@ -2509,7 +2515,7 @@ extern "C" int br_bam_bundle_stage(br_ctx *c, const br_bam_bundle *bb, int slot)
   if (n < 0 || (n && (!bb->blob || !bb->rec_off || !bb->rec_len))) return BR_ERR_INVALID_ARG;
   HIPCHK(hipSetDevice(c->ix->device));
   br_ctx::StageSlot &S = c->stage[slot];
-  if (!c->copy_stream) HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  if (!c->copy_stream) { int pl = 0, ph = 0; HIPCHK(hipDeviceGetStreamPriorityRange(&pl, &ph)); HIPCHK(hipStreamCreateWithPriority(&c->copy_stream, hipStreamNonBlocking, ph)); }   // (see ensure_streams)
   if (!S.ready) HIPCHK(hipEventCreateWithFlags(&S.ready, hipEventDisableTiming));
   S.n = n;
   if (n) {
@@ -2654,10 +2660,19 @@ static int d2h(PinnedVec<T> &dst, const void *src, size_t n, hipStream_t st) {
 
 // ---- flat batches: staging, the input contract on the device, packed rows home ----
 static int ensure_streams(br_ctx *c) {
-  if (!c->copy_stream) HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  // The runtime keeps a small pool of hardware queues per stream priority and lets streams of one priority share them once
+  // there are more streams than queues: two streams on one queue run one after the other.  The context's kernel streams
+  // (run, aux, aux2, the caller's) are of normal priority; the upload stream takes the high pool and the download stream the
+  // low one, so that neither transfer ever queues behind the other or behind a kernel stream (a context that had already
+  // created its aux streams -- a device-resident call first -- found its uploads and downloads serialised: 80 ms per
+  // PCIe-inclusive step where 60 is the wire, profiles/pcie_phases.py)
+  int prio_low = 0, prio_high = 0;
+  HIPCHK(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+  if (!c->copy_stream) HIPCHK(hipStreamCreateWithPriority(&c->copy_stream, hipStreamNonBlocking, prio_high));
   if (!c->run_stream) HIPCHK(hipStreamCreateWithFlags(&c->run_stream, hipStreamNonBlocking));
-  if (!c->d2h_stream) HIPCHK(hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
+  if (!c->d2h_stream) HIPCHK(hipStreamCreateWithPriority(&c->d2h_stream, hipStreamNonBlocking, prio_low));
   if (!c->rows_busy) HIPCHK(hipEventCreateWithFlags(&c->rows_busy, hipEventDisableTiming));
+  if (!c->alt.busy) HIPCHK(hipEventCreateWithFlags(&c->alt.busy, hipEventDisableTiming));
   return BR_OK;
 }
 
@@ -2766,6 +2781,11 @@ extern "C" int br_project_staged(br_ctx *c, const br_config *cfg, int slot, br_h
   RC(ensure_streams(c));
   if (S.rows_pending) { HIPCHK(hipEventSynchronize(S.rows_home)); S.rows_pending = false; }  // the slot's pinned arrays are rewritten below
   hipStream_t st = c->run_stream;
+  // the other set of row tables: what the last call's download reads stays untouched (rows_busy follows its set)
+  std::swap(c->pk_a, c->alt.pk_a); std::swap(c->pk_x, c->alt.pk_x); std::swap(c->pk_sim, c->alt.pk_sim); std::swap(c->pk_clip, c->alt.pk_clip);
+  std::swap(c->pk_ch, c->alt.pk_ch); std::swap(c->pool, c->alt.pool); std::swap(c->row_off, c->alt.row_off);
+  std::swap(c->rows_busy, c->alt.busy); std::swap(c->rows_busy_set, c->alt.busy_set);
+  c->detail_valid = false; c->wide_valid = false; c->last_direct = false;   // (they describe the other set)
   br_device_batch db;
   RC(prep_staged(c, cfg, S, st, &db));
   S.staged = false;

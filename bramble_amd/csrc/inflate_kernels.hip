@@ -176,7 +176,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))
     // step has written to the window so far -- literals behind the match included)
     auto copy_bytes = [&](uint32_t at, uint32_t len, uint32_t dist, uint32_t hi) {
       __builtin_amdgcn_wave_barrier();
+#ifdef INFLATE_FAKE_FAR
+      if (true) {   // (profiles/inflate_far_probe.py: what would the kernel cost if no match ever left the window?)
+#else
       if (dist + (hi - at) <= OUT_WIN) {                        // the source is still in the window
+#endif
         const float rcp = 1.0f / (float)dist;
         for (uint32_t i = (uint32_t)lane; i < len; i += 64u) {
           uint32_t so = i;

@@ -285,3 +285,24 @@ def test_cli_failed_run_leaves_no_output_file(tmp_path):
                            capture_output=True, text=True, timeout=600)
         assert r.returncode != 0 and "error" in r.stderr, extra
         assert not os.path.exists(out_bam) and not os.path.exists(out_bam + ".tmp-bramble")
+
+
+@pytest.mark.parametrize("reader", [[], ["--host-reader"], ["--device-reader"], ["--device-reader", "--devices", "0,0"]])
+def test_cli_setup_errors_after_the_reader_started_end_the_run(tmp_path, reader):
+    """A setup step that fails while the reader is already at work (the guide file missing or malformed, the output not
+    writable) must end the run with a non-zero exit, not leave it waiting for a queue nobody will finish."""
+    ann = synth.Annotation("G", n_genes=300, n_refs=2)
+    annd = ann.as_dict()
+    b = ann.reads(30000, "pe", with_records=1)
+    gtf, in_bam = str(tmp_path / "g.gtf"), str(tmp_path / "in.bam")
+    bamio.write_gtf(gtf, annd)
+    bamio.write_bam(in_bam, "@HD\tVN:1.6\n", [(n, 1000000) for n in annd["refnames"]], framed_stream(b).tobytes(), block=30000)
+    bad_gtf = str(tmp_path / "bad.gtf")
+    open(bad_gtf, "w").write("this is\tnot\ta guide file\n")
+    cases = [(str(tmp_path / "missing.gtf"), str(tmp_path / "o1.bam")),
+             (bad_gtf, str(tmp_path / "o2.bam")),
+             (gtf, str(tmp_path / "no_such_dir" / "o3.bam"))]
+    for g, o in cases:
+        r = subprocess.run([BIN, in_bam, "-G", g, "-o", o, "-p", "2", "--bundle-size", "500"] + reader, capture_output=True, text=True, timeout=120)
+        assert r.returncode != 0 and "error" in r.stderr, (g, o, r.stderr)
+        assert not os.path.exists(o)
