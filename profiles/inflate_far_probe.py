@@ -52,10 +52,10 @@ keep = so + ".keep"
 shutil.copy(so, keep)
 try:
     for v in ("base", "fakefar", "base", "fakefar"):
-        shutil.copy(os.path.join(ROOT, ".ab", v + ".so"), so)
+        shutil.copy(os.path.join(ROOT, ".ab", v + ".so"), so + ".new")
+        os.replace(so + ".new", so)   # (a rename: this process keeps the file it has mapped)
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one", path], capture_output=True, text=True)
         print(v, r.stdout.strip() or r.stderr[-300:], flush=True)
 finally:
-    shutil.copy(keep, so)
-    os.remove(keep)
+    os.replace(keep, so)
     shutil.rmtree(tmp, ignore_errors=True)
