@@ -728,9 +728,21 @@ struct WantDetail { br_ctx *c; bool old; WantDetail(br_ctx *c_, bool v) : c(c_),
 
 // a second stream for kernels that can run beside the main one (a shape's tracebacks beside the next shape's DP; the
 // few-block emit kernel of the > 64-candidate alignments beside the work-list kernels)
+// priority of the context's side streams (A/B: BRAMBLE_AMD_AUX_PRIO=low|high; default: normal)
+static int aux_stream_priority() {
+  static const int prio = []() {
+    int lo = 0, hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return 0;
+    const char *e = getenv("BRAMBLE_AMD_AUX_PRIO");
+    if (e && !strcmp(e, "low")) return lo;
+    if (e && !strcmp(e, "high")) return hi;
+    return 0;
+  }();
+  return prio;
+}
 static int ensure_aux_stream(br_ctx *c) {
   if (c->ksw_stream) return BR_OK;
-  HIPCHK(hipStreamCreateWithFlags(&c->ksw_stream, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithPriority(&c->ksw_stream, hipStreamNonBlocking, aux_stream_priority()));
   for (auto &e : c->ksw_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto &e : c->aux_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   return BR_OK;
@@ -1119,7 +1131,7 @@ static int run_device_direct(br_ctx *c, const DevCfg &dc, const br_device_batch 
   D.name_off = have_names ? b->name_off : nullptr; D.names = have_names ? b->names : nullptr; D.rnd0 = c->d_rnd.as<uint64_t>();
   D.gd = c->d_desc.as<uint2>(); D.dpos = c->d_desc.as<uint2>() + n; D.hi0 = c->d_hi0.as<uint32_t>(); D.counters = c->counters_d.as<uint64_t>(); D.tot = d_tot;
 
-  if (!c->aux2_stream) { HIPCHK(hipStreamCreateWithFlags(&c->aux2_stream, hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&c->aux2_ev, hipEventDisableTiming)); }
+  if (!c->aux2_stream) { HIPCHK(hipStreamCreateWithPriority(&c->aux2_stream, hipStreamNonBlocking, aux_stream_priority())); HIPCHK(hipEventCreateWithFlags(&c->aux2_ev, hipEventDisableTiming)); }
   hipStream_t ax2 = c->aux2_stream;
   HIPCHK(hipEventRecord(c->aux_ev[0], st));
   HIPCHK(hipStreamWaitEvent(ax, c->aux_ev[0], 0));
