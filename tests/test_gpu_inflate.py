@@ -169,3 +169,70 @@ def test_corrupt_blocks_are_refused():
     again = ctx.bgzf_inflate_device(torch.from_numpy(np.frombuffer(bytes(raw), dtype=np.uint8).copy()).to("cuda:0"), blocks)
     assert again.cpu().numpy().tobytes() == data
     ctx.close(); idx.close()
+
+
+def test_random_streams_of_every_make():
+    """The lane decoder against zlib on a few hundred random streams: random mixtures of symbol statistics (code lengths 1 to
+    15, literal runs, short and long matches near and far, overlapping runs), random zlib parameters (level, strategy, memory
+    level, window) and random BGZF block sizes -- so that token boundaries fall on every position of the 64-bit decode
+    window, of the input ring (its wrap, its 512-byte refills) and of the 512-byte output pieces."""
+    rng = np.random.RandomState(20261005)
+    idx, ctx = _ctx()
+
+    def piece(n):
+        kind = rng.randint(0, 8)
+        if kind == 0: return np.minimum(rng.geometric(0.02 + 0.5 * rng.rand(), size=n) - 1, 255).astype(np.uint8)
+        if kind == 1: return (rng.randint(0, rng.randint(2, 20), size=n) * rng.randint(1, 13) + rng.randint(0, 40)).astype(np.uint8)
+        if kind == 2: return np.tile(rng.randint(0, 256, size=rng.randint(1, 300)).astype(np.uint8), n // 2 + 1)[:n]
+        if kind == 3: return rng.randint(0, 256, size=n).astype(np.uint8)
+        if kind == 4: return np.full(n, rng.randint(0, 256), dtype=np.uint8)
+        if kind == 5: return np.where(rng.rand(n) < 0.02 + 0.3 * rng.rand(), rng.randint(0, 256, size=n), rng.randint(0, 256)).astype(np.uint8)
+        if kind == 6:   # a sawtooth with noise: matches at one distance, broken up
+            p = rng.randint(3, 2000)
+            base = np.tile(rng.randint(0, 256, size=p).astype(np.uint8), n // p + 2)[:n].copy()
+            hits = rng.rand(n) < 0.01 * rng.randint(1, 20)
+            base[hits] = rng.randint(0, 256, size=int(hits.sum()))
+            return base
+        return np.frombuffer((b"@r%06d/1\tchr%d\t%d\t60\t100M\n" % (rng.randint(0, 10**6), rng.randint(1, 23), rng.randint(0, 10**8))) * (n // 30 + 1), dtype=np.uint8)[:n]
+
+    made = []
+    total = 0
+    for k in range(240):
+        parts, size = [], int(rng.randint(1, 400_000) if k % 7 else rng.randint(1, 300))
+        while sum(len(p) for p in parts) < size:
+            parts.append(piece(int(rng.randint(1, 40_000))))
+        if len(parts) > 2 and rng.rand() < 0.5:   # something from far back, again
+            parts.append(np.concatenate(parts)[:int(rng.randint(1, 70_000))])
+        data = np.concatenate(parts)[:size].tobytes()
+        level = int(rng.choice([0, 1, 2, 4, 6, 9]))
+        strategy = int(rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED]))
+        mem, wbits = int(rng.randint(1, 10)), int(rng.randint(9, 16))
+        chunk = int(rng.choice([0xff00, 0xff00, 40_000, 9_000, 513, 65_280]))
+        out = []
+        for p in range(0, len(data), chunk):
+            seg = data[p:p + chunk]
+            c = zlib.compressobj(level, zlib.DEFLATED, -wbits, mem, strategy)
+            flush_at = int(rng.randint(1, len(seg) + 1)) if rng.rand() < 0.3 else len(seg)
+            payload = c.compress(seg[:flush_at]) + (c.flush(zlib.Z_SYNC_FLUSH) if flush_at < len(seg) else b"") + c.compress(seg[flush_at:]) + c.flush()
+            if len(payload) + 26 > 65536:          # (does not fit a BGZF block: stored halves)
+                half = len(seg) // 2
+                for s2 in (seg[:half], seg[half:]):
+                    c2 = zlib.compressobj(0, zlib.DEFLATED, -15)
+                    out.append(frame(c2.compress(s2) + c2.flush(), s2))
+                continue
+            out.append(frame(payload, seg))
+        made.append((b"".join(out), data, (k, level, strategy, mem, wbits, chunk, size)))
+        total += len(data)
+    # all of them in one call (one block table), and a sample one by one
+    raw = b"".join(m[0] for m in made)
+    got, blocks = inflate_on_device(ctx, raw)
+    want = b"".join(m[1] for m in made)
+    if got != want:
+        at = 0
+        for r, d, what in made:
+            assert got[at:at + len(d)] == d, what
+            at += len(d)
+    for r, d, what in made[::17]:
+        g, _ = inflate_on_device(ctx, r)
+        assert g == d, what
+    assert total > 20_000_000
