@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <sys/mman.h>
 #include <thread>
 #include <functional>
 #include <memory>
@@ -409,6 +410,38 @@ extern "C" int br_batch_seq_source(const br_batch *b, const uint32_t *group_off,
 // ---------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------
+// Large pinned host buffers: an anonymous mapping on transparent huge pages, touched, then registered -- 10-12 ms for 250 MB
+// and the same for two threads at once, where hipHostMalloc takes 33-41 ms and 83-101 ms for the second of two concurrent
+// calls (profiles/pin_probe.cpp: the command line's workers all pin their download buffers when their first bundles finish)
+struct BigPinned {
+  uint8_t *p = nullptr; size_t cap = 0; void *map = nullptr; size_t map_bytes = 0; bool registered = false;
+  int alloc(size_t bytes) {
+    release();
+    const size_t huge = (size_t)2 << 20;
+    map_bytes = ((bytes + huge - 1) & ~(huge - 1)) + huge;
+    map = mmap(nullptr, map_bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (map == MAP_FAILED) { map = nullptr; map_bytes = 0; return BR_ERR_CAPACITY; }
+    p = (uint8_t *)(((uintptr_t)map + huge - 1) & ~(uintptr_t)(huge - 1));
+    const size_t span = (bytes + huge - 1) & ~(huge - 1);
+    (void)madvise(p, span, MADV_HUGEPAGE);
+    for (size_t i = 0; i < span; i += 4096) p[i] = 0;
+    if (hipHostRegister(p, span, hipHostRegisterDefault) != hipSuccess) {   // (no registration: the plain way)
+      (void)hipGetLastError();
+      munmap(map, map_bytes); map = nullptr; map_bytes = 0; p = nullptr;
+      HIPCHK(hipHostMalloc((void **)&p, bytes, hipHostMallocDefault));
+      registered = false; cap = bytes;
+      return BR_OK;
+    }
+    registered = true; cap = span;
+    return BR_OK;
+  }
+  void release() {
+    if (p && registered) { (void)hipHostUnregister(p); munmap(map, map_bytes); }
+    else if (p) (void)hipHostFree(p);
+    p = nullptr; cap = 0; map = nullptr; map_bytes = 0; registered = false;
+  }
+};
+
 struct DevBuf {
   void *p = nullptr; size_t cap = 0;
   int ensure(size_t bytes) {
@@ -520,6 +553,7 @@ struct br_ctx {
   bool z_tabs_ready = false;
   DevBuf p_ncig, p_name_len, p_isnew, p_group_pre, p_small, p_big, p_seq_len, p_ref_map;
   uint8_t *h_bam[2] = {nullptr, nullptr}; size_t h_bam_cap[2] = {0, 0}; int h_bam_next = 0;  // pinned download buffers of br_project_bam_bundle (alternating)
+  BigPinned h_bam_mem[2];
   int64_t last_n_rows = 0, last_n_aln = 0;
   DevBuf fa_stats, fa_n_prob, fa_seq_bytes, fa_prob_off, fa_seqarena_off, fa_probs, fa_results, fa_seq_arena, fa_clip_ops,
       fa_ideal_cap, fa_scratch, fa_srcs, fa_want, b_seq_off, b_seqs, b_seq_src;
@@ -606,7 +640,7 @@ extern "C" void br_ctx_free(br_ctx *c) {
   for (DevBuf *b : bufs) b->release();
   for (auto &e : c->events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if (c->h_totals) (void)hipHostFree(c->h_totals);
-  for (int k = 0; k < 2; k++) if (c->h_bam[k]) (void)hipHostFree(c->h_bam[k]);
+  for (int k = 0; k < 2; k++) c->h_bam_mem[k].release();
   for (auto &S : c->stage) { S.blob.release(); S.off.release(); S.len.release(); if (S.ready) (void)hipEventDestroy(S.ready); }
   for (auto &S : c->in_slot) {
     DevBuf *ib[] = {&S.ref_id, &S.ref_start, &S.flags, &S.xs, &S.ts, &S.cigar_off64, &S.cigar, &S.mate_ref, &S.mate_start, &S.name_off64,
@@ -2569,10 +2603,10 @@ static int project_bam_tail(br_ctx *c, const br_config *cfg, const br_device_rec
   }
   auto t3 = tnow();
   if (db.n_bytes > c->h_bam_cap[hs]) {
-    if (c->h_bam[hs]) { HIPCHK(hipHostFree(c->h_bam[hs])); c->h_bam[hs] = nullptr; c->h_bam_cap[hs] = 0; }
+    c->h_bam[hs] = nullptr; c->h_bam_cap[hs] = 0;
     size_t want = (size_t)db.n_bytes + (size_t)db.n_bytes / 4 + 4096;
-    HIPCHK(hipHostMalloc((void **)&c->h_bam[hs], want, hipHostMallocDefault));
-    c->h_bam_cap[hs] = want;
+    RC(c->h_bam_mem[hs].alloc(want));
+    c->h_bam[hs] = c->h_bam_mem[hs].p; c->h_bam_cap[hs] = c->h_bam_mem[hs].cap;
   }
   if (later) {
     // everything on `st` is complete (the deflate step ends with the block sizes on the host): the copy goes to a stream of its
