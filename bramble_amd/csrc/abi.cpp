@@ -457,21 +457,23 @@ struct DevBuf {
 };
 
 // growable pinned host array (contents are not preserved across growth: every call rewrites it)
+// (large ones on huge pages, registered: BigPinned; small ones from hipHostMalloc)
 template <typename T>
 struct PinnedVec {
-  T *p = nullptr; size_t n = 0, cap = 0;
+  T *p = nullptr; size_t n = 0, cap = 0; BigPinned big;
   int resize(size_t m) {
     if (m > cap) {
-      if (p) { HIPCHK(hipHostFree(p)); p = nullptr; cap = 0; }
+      release();
       size_t want = m + m / 4 + 64;
-      HIPCHK(hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault));
+      if (want * sizeof(T) >= ((size_t)4 << 20)) { const int brc = big.alloc(want * sizeof(T)); if (brc) return brc; p = (T *)big.p; }
+      else HIPCHK(hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault));
       cap = want;
     }
     n = m;
     return BR_OK;
   }
   T *data() { return p; }
-  void release() { if (p) (void)hipHostFree(p); p = nullptr; n = cap = 0; }
+  void release() { if (big.p) big.release(); else if (p) (void)hipHostFree(p); p = nullptr; n = cap = 0; }
 };
 
 struct KEvent { int which; hipEvent_t a, b; };
