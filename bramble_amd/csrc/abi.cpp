@@ -1195,6 +1195,7 @@ static int run_device_direct(br_ctx *c, const DevCfg &dc, const br_device_batch 
   // a16 (src/mates.cpp:150-261) on the survivor sets, then placement
   const int big_blocks = c->n_cu * 4;
   uint64_t kept = 0, arena = 0, n_simple = 0, n_rows = 0, n_raw = 0;
+  bool expanded_ahead = false;
   // third stream: the name seeds need nothing but the names, and their 156 dependent multiplies per read name are pure ALU work:
   // beside k_pair_mask, which waits on LDS and memory most of the time
   if (have_names) {
@@ -1231,6 +1232,16 @@ static int run_device_direct(br_ctx *c, const DevCfg &dc, const br_device_batch 
     RC(pf.begin(BR_K_SCAN));
     launch_scan5(st, D, c->tile_sums.as<uint64_t>(), d_tot);
     RC(pf.end());
+    // the work list goes out at once, into the list the last call left (it checks the total against that room on the
+    // device): it runs while the host waits for the totals, wakes up and sizes the row tables
+    expanded_ahead = false;
+    if (c->m_aln.cap >= 4) {
+      D.m_aln = c->m_aln.as<uint32_t>(); D.m_aln_cap = c->m_aln.cap / 4;
+      RC(pf.begin(BR_K_EXPAND_ROWS));
+      launch_expand_rows(st, D);
+      RC(pf.end());
+      expanded_ahead = true;
+    }
     HIPCHK(hipMemcpyAsync(c->h_totals, d_tot, 5 * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(c->h_totals + 8, c->d_sidectr.p, 16, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -1252,6 +1263,7 @@ static int run_device_direct(br_ctx *c, const DevCfg &dc, const br_device_batch 
   const size_t nr = (size_t)std::max<uint64_t>(n_rows, 1);
   if (c->rows_busy_set && (c->pk_a.cap < nr * sizeof(uint4) || c->pk_c.cap < nr * sizeof(uint2))) HIPCHK(hipEventSynchronize(c->rows_busy));
   RC(c->pk_a.ensure(nr * sizeof(uint4))); RC(c->pk_c.ensure(nr * sizeof(uint2)));
+  if (expanded_ahead && kept > D.m_aln_cap) expanded_ahead = false;   // (the kernel saw the same and did nothing)
   RC(c->m_aln.ensure(nr * 4)); RC(c->cig_arena.ensure((size_t)std::max<uint64_t>(arena, 1) * 4));
   const bool with_x = c->want_x;
   if (with_x) {
@@ -1261,10 +1273,13 @@ static int run_device_direct(br_ctx *c, const DevCfg &dc, const br_device_batch 
   A.cig_arena = c->cig_arena.as<uint32_t>();
   D.m_aln = c->m_aln.as<uint32_t>(); D.r_a = c->pk_a.as<uint4>(); D.r_c = c->pk_c.as<uint2>(); D.r_x = with_x ? c->pk_x.as<uint4>() : nullptr;
   const bool emit_split = c->emit_split != 0;
+  D.m_aln_cap = 0;
   if (kept) {
-    RC(pf.begin(BR_K_EXPAND_ROWS));
-    launch_expand_rows(st, D);
-    RC(pf.end());
+    if (!expanded_ahead) {
+      RC(pf.begin(BR_K_EXPAND_ROWS));
+      launch_expand_rows(st, D);
+      RC(pf.end());
+    }
     HIPCHK(hipStreamWaitEvent(st, c->aux_ev[4], 0));   // k_group_desc: the descriptors' first halves
     HIPCHK(hipEventRecord(c->aux_ev[5], st));
     HIPCHK(hipStreamWaitEvent(ax, c->aux_ev[5], 0));

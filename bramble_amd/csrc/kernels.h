@@ -230,6 +230,7 @@ struct DirectArgs {
   const uint64_t *tot;           // scan totals on the device: [0] kept, [1] arena words, [2] kept of the simple class, [3] records, [4] survivors
   // emit
   uint32_t *m_aln;               // emit work list
+  uint64_t m_aln_cap;            // its room in entries when k_expand_rows is launched ahead of the host's look at the totals (0: the list was sized for them)
   uint4 *r_a; uint2 *r_c;        // packed rows
   uint4 *r_x;                    // detail column {input, junc_hits, aligned_len, HI} or null
 };
