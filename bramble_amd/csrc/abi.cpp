@@ -577,7 +577,7 @@ struct br_ctx {
   DevBuf b_name_off, b_names;
   // device staging of host batches (br_project_batch)
   DevBuf b_ref_id, b_ref_start, b_flags, b_xs, b_ts, b_cigar_off, b_cigar, b_mate_idx, b_group_off, b_lqseq;
-  uint64_t *h_totals = nullptr;  // pinned, 192 words
+  uint64_t *h_totals = nullptr;  // pinned, 512 words ([192..] the direct path's counters with k_group_desc's slots)
   // host result storage (br_project_batch / br_project_group)
   // pinned: the row download runs at PCIe speed instead of through the pageable bounce path
   PinnedVec<int32_t> h_input, h_clip, h_junc, h_refc, h_mate_tid, h_mate_pos, h_isize;
@@ -606,7 +606,7 @@ extern "C" int br_ctx_new(const br_index *ix, br_ctx **out) {
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, ix->device));
   c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  HIPCHK(hipHostMalloc((void **)&c->h_totals, 192 * sizeof(uint64_t), hipHostMallocDefault));   // [0..31] scan totals and counters, [96..] the single pass's counters
+  HIPCHK(hipHostMalloc((void **)&c->h_totals, 512 * sizeof(uint64_t), hipHostMallocDefault));   // [0..31] scan totals and counters, [96..] the single pass's counters
   const char *bl = getenv("BRAMBLE_AMD_BAM_LANES");
   if (bl) { int v = atoi(bl); if (v == 0 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) c->bam_lanes = v; }
   const char *spec = getenv("BRAMBLE_AMD_SPECULATE");      // A/B: 0 = large batches always through the ordinary pipeline (three host round trips)
@@ -947,7 +947,7 @@ static int run_device_small(br_ctx *c, const DevCfg &dc, const br_device_batch *
   RC(c->n_matches.ensure((size_t)n * 4)); RC(c->ranges.ensure((size_t)n * sizeof(uint4)));
   RC(c->mask.ensure((size_t)n * 8)); RC(c->match_off.ensure((size_t)(n + 1) * 4));
   RC(c->cig_base.ensure((size_t)(n + 1) * 8)); RC(c->tile_sums.ensure((size_t)tiles * 8 * 3));
-  RC(c->totals.ensure(16 * 8)); RC(c->counters_d.ensure(4 * 8));
+  RC(c->totals.ensure(16 * 8)); RC(c->counters_d.ensure(GD_COUNTER_WORDS * 8));
   RC(c->big_list.ensure((size_t)n * 4)); RC(c->n_big.ensure(16));
   if (!big) {
     RC(c->m_tid.ensure(cap_m * 4)); RC(c->m_aux.ensure(cap_m * 4)); RC(c->m_p.ensure(cap_m * sizeof(uint2))); RC(c->m_x.ensure(cap_m * sizeof(uint2)));
@@ -1131,11 +1131,11 @@ static int run_device_direct(br_ctx *c, const DevCfg &dc, const br_device_batch 
   const int64_t tiles = std::max<int64_t>(scan_tiles_for(std::max<int64_t>(n, ng) + 1), 1);
   RC(c->seg.ensure((size_t)(b->n_cigar_words + n) * sizeof(uint2)));
   RC(c->meta.ensure((size_t)n * sizeof(AlnMeta))); RC(c->head.ensure((size_t)n * sizeof(uint4))); RC(c->head2.ensure((size_t)n * sizeof(uint4)));
-  RC(c->fast_flag.ensure((size_t)n * 4)); RC(c->n_matches.ensure((size_t)n * 4)); RC(c->ranges.ensure((size_t)n * sizeof(uint4)));
+  RC(c->fast_flag.ensure((size_t)n * 4)); RC(c->n_matches.ensure((size_t)n * 4 + 16)); RC(c->ranges.ensure((size_t)n * sizeof(uint4)));   // (+ 16: k_group_desc reads four elements at a time)
   RC(c->mask.ensure((size_t)n * 8)); RC(c->cig_base.ensure((size_t)(n + 1) * 8)); RC(c->tile_sums.ensure((size_t)tiles * 8 * 5));
-  RC(c->totals.ensure(16 * 8)); RC(c->counters_d.ensure(4 * 8));
+  RC(c->totals.ensure(16 * 8)); RC(c->counters_d.ensure(GD_COUNTER_WORDS * 8));
   RC(c->big_list.ensure((size_t)n * 4)); RC(c->n_big.ensure(16)); RC(c->walk_list.ensure((size_t)n * 4));
-  RC(c->aln_group.ensure((size_t)n * 4)); RC(c->n_rows.ensure((size_t)n * 4)); RC(c->pbit.ensure((size_t)n));
+  RC(c->aln_group.ensure((size_t)n * 4)); RC(c->n_rows.ensure((size_t)n * 4 + 16)); RC(c->pbit.ensure((size_t)n + 16));
   RC(c->d_fm.ensure((size_t)n * sizeof(uint2) + (size_t)(n / 62 + 2) * 4));   // + the window list of k_pair_mask
   RC(c->d_nkept.ensure((size_t)n * 4)); RC(c->d_desc.ensure((size_t)n * sizeof(uint4)));
   RC(c->d_hi0.ensure((size_t)n * 4)); RC(c->d_clspos.ensure((size_t)n * 4)); RC(c->d_rnd.ensure((size_t)std::max<int64_t>(ng, 1) * 8));
@@ -1208,7 +1208,7 @@ static int run_device_direct(br_ctx *c, const DevCfg &dc, const br_device_batch 
   }
   for (int attempt = 0;; attempt++) {
     HIPCHK(hipMemsetAsync(c->d_sidectr.p, 0, 16, st));
-    HIPCHK(hipMemsetAsync(c->counters_d.p, 0, 4 * 8, st));
+    HIPCHK(hipMemsetAsync(c->counters_d.p, 0, GD_COUNTER_WORDS * 8, st));
     HIPCHK(hipMemsetAsync(D.pm_n, 0, 4, st));
     HIPCHK(hipEventRecord(c->aux_ev[1], st));
     HIPCHK(hipStreamWaitEvent(ax, c->aux_ev[1], 0));
@@ -1303,9 +1303,11 @@ static int run_device_direct(br_ctx *c, const DevCfg &dc, const br_device_batch 
   } else {
     HIPCHK(hipStreamWaitEvent(st, c->aux_ev[4], 0));
   }
-  HIPCHK(hipMemcpyAsync(c->h_totals + 4, c->counters_d.p, 4 * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(c->h_totals + 192, c->counters_d.p, GD_COUNTER_WORDS * 8, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   if (!keep_events) RC(pf.collect());
+  for (int k = 0; k < 4; k++) c->h_totals[4 + k] = c->h_totals[192 + k];
+  for (int k = 0; k < GD_SLOTS; k++) { c->h_totals[5] += c->h_totals[192 + GD_SLOT0 + k * GD_SLOT_STRIDE]; c->h_totals[6] += c->h_totals[192 + GD_SLOT0 + k * GD_SLOT_STRIDE + 1]; }
   if (c->h_totals[7]) return BR_ERR_UNSUPPORTED;  // a rewritten CIGAR with more than 2^24 - 1 ops, or NH beyond 28 bits
   out->total_complete = n_rows; out->total_unique = c->h_totals[5]; out->dropped_reads = c->h_totals[6];
   c->hist_n = 0;   // (nothing a later speculative launch of the match-table path could be sized from)

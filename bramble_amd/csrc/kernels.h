@@ -226,7 +226,7 @@ struct DirectArgs {
   uint2 *gd;                     // [n_aln] k_group_desc: {PF_* | (primary rank + 1) << 8, NH}
   uint2 *dpos;                   // [n_aln] k_expand_rows: {first record, position of its entries in the emit work list}
   uint32_t *hi0;                 // [n_aln] HI of the alignment's first record
-  uint64_t *counters;            // [4] total_complete, total_unique, dropped_reads, a field overflowed its packed width
+  uint64_t *counters;            // [4] total_complete, total_unique, dropped_reads, a field overflowed its packed width; + k_group_desc's slots (GD_*)
   const uint64_t *tot;           // scan totals on the device: [0] kept, [1] arena words, [2] kept of the simple class, [3] records, [4] survivors
   // emit
   uint32_t *m_aln;               // emit work list
@@ -234,6 +234,11 @@ struct DirectArgs {
   uint4 *r_a; uint2 *r_c;        // packed rows
   uint4 *r_x;                    // detail column {input, junc_hits, aligned_len, HI} or null
 };
+// k_group_desc's partial sums of total_unique / dropped_reads: GD_SLOTS pairs of u64, a cache line apart, behind the four counters
+#define GD_SLOTS 16
+#define GD_SLOT0 16
+#define GD_SLOT_STRIDE 16
+#define GD_COUNTER_WORDS (GD_SLOT0 + GD_SLOTS * GD_SLOT_STRIDE)
 void launch_name_seed(hipStream_t st, const DirectArgs &D);
 void launch_pair_mask(hipStream_t st, const DirectArgs &D, int wide_blocks);
 void launch_big_collect(hipStream_t st, const ProjectArgs &A, const DirectArgs &D, int n_blocks);
