@@ -670,6 +670,7 @@ __device__ __forceinline__ bool similarity(const DevCfg &cfg, const Acc &acc, do
 // ---------------------------------------------------------------------------
 #define SLAB_LDS 1025   // slab_off entries cached in LDS (<= 512 references)
 #define WALK_LDS 2048   // deferred alignments a block of the main count pass collects before it appends them
+#define BIG_LDS 256     // ... and alignments with more than 64 candidate rows
 #define LDS_SLOT 25     // words of CIGAR scratch per lane (odd: conflict-free)
 #define LDS_IDEAL 10    // ideal CIGAR words kept in LDS (n_seg <= 2)
 
@@ -686,7 +687,10 @@ __global__ void __launch_bounds__(256, EMIT ? 4 : 8) k_project(ProjectArgs A) {
   // end (a same-address atomic per deferred alignment serialises: 13 ms for ~1.5 M of them)
   __shared__ uint32_t sh_wl[MODE == 1 ? WALK_LDS : 1];
   __shared__ uint32_t sh_wn, sh_wbase;
-  if (MODE == 1) { if (threadIdx.x == 0) sh_wn = 0; __syncthreads(); }
+  // the count pass's alignments with more than 64 candidate rows (big_list) go the same way
+  __shared__ uint32_t sh_bl[EMIT ? 1 : BIG_LDS];
+  __shared__ uint32_t sh_bn, sh_bbase;
+  if (MODE == 1 || !EMIT) { if (threadIdx.x == 0) { sh_wn = 0; sh_bn = 0; } __syncthreads(); }
   const int gl = threadIdx.x & (G - 1);
   const int gbase = (threadIdx.x & 63) & ~(G - 1);
   const uint64_t gmask = (G == 64) ? ~0ull : ((1ull << G) - 1);
@@ -968,8 +972,19 @@ __global__ void __launch_bounds__(256, EMIT ? 4 : 8) k_project(ProjectArgs A) {
     }
     if (!EMIT && gl == 0) {
       A.n_matches[a] = total; A.mask[a] = mask_all;
-      if (n_items > 64 && total) { uint32_t k = atomicAdd(A.n_big, 1u); A.big_list[k] = (uint32_t)a; }
+      if (n_items > 64 && total) {
+        const uint32_t k = atomicAdd(&sh_bn, 1u);
+        if (k < BIG_LDS) sh_bl[EMIT ? 0 : k] = (uint32_t)a;
+        else { const uint32_t k2 = atomicAdd(A.n_big, 1u); A.big_list[k2] = (uint32_t)a; }   // (the block's list is full)
+      }
     }
+  }
+  if (!EMIT) {
+    __syncthreads();
+    const uint32_t n_loc = sh_bn < BIG_LDS ? sh_bn : BIG_LDS;
+    if (threadIdx.x == 0) sh_bbase = n_loc ? atomicAdd(A.n_big, n_loc) : 0u;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_loc; i += blockDim.x) A.big_list[sh_bbase + i] = sh_bl[EMIT ? 0 : i];
   }
   if (MODE == 1) {
     __syncthreads();
