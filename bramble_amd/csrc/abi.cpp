@@ -1133,13 +1133,16 @@ static int run_device_direct(br_ctx *c, const DevCfg &dc, const br_device_batch 
   RC(c->meta.ensure((size_t)n * sizeof(AlnMeta))); RC(c->head.ensure((size_t)n * sizeof(uint4))); RC(c->head2.ensure((size_t)n * sizeof(uint4)));
   RC(c->fast_flag.ensure((size_t)n * 4)); RC(c->n_matches.ensure((size_t)n * 4 + 16)); RC(c->ranges.ensure((size_t)n * sizeof(uint4)));   // (+ 16: k_group_desc reads four elements at a time)
   RC(c->mask.ensure((size_t)n * 8)); RC(c->cig_base.ensure((size_t)(n + 1) * 8)); RC(c->tile_sums.ensure((size_t)tiles * 8 * 5));
-  RC(c->totals.ensure(16 * 8)); RC(c->counters_d.ensure(GD_COUNTER_WORDS * 8));
-  RC(c->big_list.ensure((size_t)n * 4)); RC(c->n_big.ensure(16)); RC(c->walk_list.ensure((size_t)n * 4));
+  // every small counter of the step in one block, zeroed by one fill at the start: [0, GD_COUNTER_WORDS) the four counters + k_group_desc's
+  // slots, then the side arena's two words, then n_big | n_walk | pm_n | -
+  RC(c->totals.ensure(16 * 8)); RC(c->counters_d.ensure((GD_COUNTER_WORDS + 4) * 8));
+  uint64_t *const dz = c->counters_d.as<uint64_t>();
+  uint32_t *const dz_nbig = (uint32_t *)(dz + GD_COUNTER_WORDS + 2);
+  RC(c->big_list.ensure((size_t)n * 4)); RC(c->walk_list.ensure((size_t)n * 4));
   RC(c->aln_group.ensure((size_t)n * 4)); RC(c->n_rows.ensure((size_t)n * 4 + 16)); RC(c->pbit.ensure((size_t)n + 16));
   RC(c->d_fm.ensure((size_t)n * sizeof(uint2) + (size_t)(n / 62 + 2) * 4));   // + the window list of k_pair_mask
   RC(c->d_nkept.ensure((size_t)n * 4)); RC(c->d_desc.ensure((size_t)n * sizeof(uint4)));
   RC(c->d_hi0.ensure((size_t)n * 4)); RC(c->d_clspos.ensure((size_t)n * 4)); RC(c->d_rnd.ensure((size_t)std::max<int64_t>(ng, 1) * 8));
-  RC(c->d_sidectr.ensure(16));
   if (c->d_side_cap == 0) c->d_side_cap = std::max<uint64_t>((uint64_t)n / 4, 1u << 20);
   RC(c->d_side.ensure((size_t)c->d_side_cap * sizeof(uint2)));
   // (a buffer that a queued packed download still reads must not be reallocated under it)
@@ -1154,21 +1157,22 @@ static int run_device_direct(br_ctx *c, const DevCfg &dc, const br_device_batch 
   A.seg = c->seg.as<uint2>(); A.meta = c->meta.as<AlnMeta>(); A.head = c->head.as<uint4>(); A.head2 = c->head2.as<uint4>();
   A.fast_flag = c->fast_flag.as<uint32_t>(); A.n_matches = c->n_matches.as<uint32_t>();
   A.ranges = c->ranges.as<uint4>(); A.mask = c->mask.as<uint64_t>();
-  A.big_list = c->big_list.as<uint32_t>(); A.n_big = c->n_big.as<uint32_t>();
-  if (c->count_split) { A.walk_list = c->walk_list.as<uint32_t>(); A.n_walk = c->n_big.as<uint32_t>() + 1; }
+  A.big_list = c->big_list.as<uint32_t>(); A.n_big = dz_nbig;
+  if (c->count_split) { A.walk_list = c->walk_list.as<uint32_t>(); A.n_walk = dz_nbig + 1; }
   const bool have_names = b->names && b->name_off;
   DirectArgs D{};
   D.n_aln = n; D.n_groups = ng; D.group_off = b->group_off; D.aln_group = c->aln_group.as<uint32_t>(); D.mate_idx = b->mate_idx;
   D.n_matches = c->n_matches.as<uint32_t>(); D.mask = c->mask.as<uint64_t>(); D.ranges = c->ranges.as<uint4>();
   D.fast_flag = c->fast_flag.as<uint32_t>(); D.s_tid = ix->dev.s_tid; D.big_list = A.big_list; D.n_big = A.n_big;
-  D.fm = c->d_fm.as<uint2>(); D.pm_list = (uint32_t *)(c->d_fm.as<uint2>() + n); D.pm_n = c->n_big.as<uint32_t>() + 2; D.n_kept = c->d_nkept.as<uint32_t>(); D.n_rows = c->n_rows.as<uint32_t>(); D.pflag = c->pbit.as<uint8_t>();
-  D.side = c->d_side.as<uint2>(); D.side_cap = c->d_side_cap; D.side_used = c->d_sidectr.as<unsigned long long>();
+  D.fm = c->d_fm.as<uint2>(); D.pm_list = (uint32_t *)(c->d_fm.as<uint2>() + n); D.pm_n = dz_nbig + 2; D.n_kept = c->d_nkept.as<uint32_t>(); D.n_rows = c->n_rows.as<uint32_t>(); D.pflag = c->pbit.as<uint8_t>();
+  D.side = c->d_side.as<uint2>(); D.side_cap = c->d_side_cap; D.side_used = (unsigned long long *)(dz + GD_COUNTER_WORDS);
   D.cls_pos = c->d_clspos.as<uint32_t>(); D.cig_base = c->cig_base.as<uint64_t>(); D.row_off = c->row_off.as<uint64_t>();
   D.name_off = have_names ? b->name_off : nullptr; D.names = have_names ? b->names : nullptr; D.rnd0 = c->d_rnd.as<uint64_t>();
   D.gd = c->d_desc.as<uint2>(); D.dpos = c->d_desc.as<uint2>() + n; D.hi0 = c->d_hi0.as<uint32_t>(); D.counters = c->counters_d.as<uint64_t>(); D.tot = d_tot;
 
   if (!c->aux2_stream) { HIPCHK(hipStreamCreateWithPriority(&c->aux2_stream, hipStreamNonBlocking, aux_stream_priority())); HIPCHK(hipEventCreateWithFlags(&c->aux2_ev, hipEventDisableTiming)); }
   hipStream_t ax2 = c->aux2_stream;
+  HIPCHK(hipMemsetAsync(dz, 0, (GD_COUNTER_WORDS + 4) * 8, st));
   HIPCHK(hipEventRecord(c->aux_ev[0], st));
   HIPCHK(hipStreamWaitEvent(ax, c->aux_ev[0], 0));
   // a1/a2/a6: CIGAR -> read exons; a3-a8, a11-a14 (survival only): the count pass
@@ -1179,7 +1183,6 @@ static int run_device_direct(br_ctx *c, const DevCfg &dc, const br_device_batch 
   RC(pf.begin(BR_K_GROUP_IDS));
   launch_group_ids(st, ng, b->group_off, c->aln_group.as<uint32_t>());
   RC(pf.end());
-  HIPCHK(hipMemsetAsync(c->n_big.p, 0, 16, st));
   const int n_blocks = c->n_cu * c->blocks_per_cu;
   const bool split = A.walk_list != nullptr;
   RC(pf.begin(BR_K_COUNT));
@@ -1207,9 +1210,10 @@ static int run_device_direct(br_ctx *c, const DevCfg &dc, const br_device_batch 
     HIPCHK(hipEventRecord(c->aux2_ev, ax2));
   }
   for (int attempt = 0;; attempt++) {
-    HIPCHK(hipMemsetAsync(c->d_sidectr.p, 0, 16, st));
-    HIPCHK(hipMemsetAsync(c->counters_d.p, 0, GD_COUNTER_WORDS * 8, st));
-    HIPCHK(hipMemsetAsync(D.pm_n, 0, 4, st));
+    if (attempt) {   // (the first attempt's counters were zeroed with everything else at the start)
+      HIPCHK(hipMemsetAsync(dz, 0, (GD_COUNTER_WORDS + 2) * 8, st));
+      HIPCHK(hipMemsetAsync(D.pm_n, 0, 4, st));
+    }
     HIPCHK(hipEventRecord(c->aux_ev[1], st));
     HIPCHK(hipStreamWaitEvent(ax, c->aux_ev[1], 0));
     RC(pf.begin(BR_K_PAIR_BIG, ax));
@@ -1243,7 +1247,7 @@ static int run_device_direct(br_ctx *c, const DevCfg &dc, const br_device_batch 
       expanded_ahead = true;
     }
     HIPCHK(hipMemcpyAsync(c->h_totals, d_tot, 5 * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(c->h_totals + 8, c->d_sidectr.p, 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(c->h_totals + 8, dz + GD_COUNTER_WORDS, 16, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (c->h_totals[9]) {   // the side arena of the > 64-candidate alignments ran out: grow it to what was asked for, repeat
       if (attempt >= 3) return BR_ERR_CAPACITY;
