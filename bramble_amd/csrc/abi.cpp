@@ -488,6 +488,7 @@ struct br_ctx {
   bool profiling = false;
   std::vector<KEvent> events; size_t events_used = 0;
   double k_ms[BR_K_NUM] = {0}; int32_t k_launches[BR_K_NUM] = {0};
+  double k_ms_sum[BR_K_NUM] = {0}; int64_t k_launches_sum[BR_K_NUM] = {0};   // over the calls since profiling was switched on (br_ctx_kernel_ms_sum)
   uint64_t counters[8] = {0};
   uint64_t rescue_stats[4] = {0};  // problems, DP cells, accepted rescues, coded sequence bytes
   // device scratch
@@ -671,7 +672,18 @@ extern "C" void br_ctx_free(br_ctx *c) {
   delete c;
 }
 
-extern "C" int br_ctx_set_profiling(br_ctx *c, int enabled) { if (!c) return BR_ERR_INVALID_ARG; c->profiling = enabled != 0; return BR_OK; }
+extern "C" int br_ctx_set_profiling(br_ctx *c, int enabled) {
+  if (!c) return BR_ERR_INVALID_ARG;
+  if (enabled && !c->profiling) for (int k = 0; k < BR_K_NUM; k++) { c->k_ms_sum[k] = 0; c->k_launches_sum[k] = 0; }
+  c->profiling = enabled != 0;
+  return BR_OK;
+}
+extern "C" int br_ctx_kernel_ms_sum(br_ctx *c, int which, double *ms, int64_t *launches) {
+  if (!c || which < 0 || which >= BR_K_NUM) return BR_ERR_INVALID_ARG;
+  if (ms) *ms = c->k_ms_sum[which];
+  if (launches) *launches = c->k_launches_sum[which];
+  return BR_OK;
+}
 extern "C" int br_ctx_set_param(br_ctx *c, const char *key, int64_t v) {
   if (!c || !key) return BR_ERR_INVALID_ARG;
   if (!strcmp(key, "group_lanes")) { if (v != 8 && v != 16 && v != 32 && v != 64) return BR_ERR_INVALID_ARG; c->group_lanes = (int)v; return BR_OK; }
@@ -747,9 +759,14 @@ struct Prof {
     if (!c->profiling) return BR_OK;
     for (size_t i = 0; i < c->events_used; i++) {
       float ms = 0;
-      HIPCHK(hipEventSynchronize(c->events[i].b));
-      HIPCHK(hipEventElapsedTime(&ms, c->events[i].a, c->events[i].b));
+      // (the call has waited for its streams already: as a rule the events are complete and one query each is all it takes)
+      if (hipEventElapsedTime(&ms, c->events[i].a, c->events[i].b) != hipSuccess) {
+        (void)hipGetLastError();
+        HIPCHK(hipEventSynchronize(c->events[i].b));
+        HIPCHK(hipEventElapsedTime(&ms, c->events[i].a, c->events[i].b));
+      }
       c->k_ms[c->events[i].which] += ms; c->k_launches[c->events[i].which]++;
+      c->k_ms_sum[c->events[i].which] += ms; c->k_launches_sum[c->events[i].which]++;
     }
     c->events_used = 0;
     return BR_OK;

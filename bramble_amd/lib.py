@@ -165,7 +165,7 @@ EXPORTS = ["br_index_build", "br_index_build_flat", "br_index_free", "br_index_n
            "br_pin_host", "br_unpin_host", "br_project_group", "br_project_groups", "br_bam_encode_device", "br_project_bam_device", "br_project_bam_bundle", "br_bam_bundle_stage", "br_project_bam_staged", "br_bam_split", "br_annotation_load", "br_annotation_load_mt", "br_annotation_free",
            "br_annotation_num_transcripts", "br_annotation_transcripts", "br_annotation_num_refs", "br_annotation_refnames", "br_cli_main", "br_cli_exit_at_end", "br_device_warmup", "br_project_bam_staged_nowait", "br_host_bam_wait", "br_bgzf_scan", "br_bgzf_inflate_device", "br_bam_split_device", "br_bam_reader_new", "br_bam_reader_next", "br_bam_reader_set_piece_blocks", "br_bam_reader_release", "br_bam_reader_free", "br_bam_piece_upload", "br_bam_piece_process", "br_bam_reader_seconds", "br_bam_reader_upload_seconds", "br_project_bam_resident", "br_bgzf_write_file", "br_bgzf_read_file",
            "br_free_buffer", "br_bgzf_codec", "br_bgzf_deflate_device", "br_ctx_set_profiling",
-           "br_ctx_set_param", "br_ctx_kernel_ms", "br_ctx_collect_counters", "br_ctx_last_counters", "br_ctx_rescue_stats", "br_ctx_ksw_diag", "br_device_rows_detail", "br_ctx_ksw_pairs", "br_primary_pick", "br_row_mapq", "br_version", "br_strerror"]
+           "br_ctx_set_param", "br_ctx_kernel_ms", "br_ctx_kernel_ms_sum", "br_ctx_collect_counters", "br_ctx_last_counters", "br_ctx_rescue_stats", "br_ctx_ksw_diag", "br_device_rows_detail", "br_ctx_ksw_pairs", "br_primary_pick", "br_row_mapq", "br_version", "br_strerror"]
 
 _LIB = None
 
@@ -516,6 +516,17 @@ class Context:
         for k in range(K_NUM):
             ms, ln = C.c_double(), C.c_int32()
             check(lib().br_ctx_kernel_ms(self.h, k, C.byref(ms), C.byref(ln)), "br_ctx_kernel_ms")
+            out[KERNEL_NAMES[k]] = (ms.value, ln.value)
+        return out
+
+    def kernel_ms_sum(self):
+        """{kernel name: (ms, launches)} summed over the calls since set_profiling(True)."""
+        out = {}
+        L = lib()
+        L.br_ctx_kernel_ms_sum.argtypes = [C.c_void_p, C.c_int, _P(C.c_double), _P(C.c_int64)]
+        for k in range(K_NUM):
+            ms, ln = C.c_double(), C.c_int64()
+            check(L.br_ctx_kernel_ms_sum(self.h, k, C.byref(ms), C.byref(ln)), "br_ctx_kernel_ms_sum")
             out[KERNEL_NAMES[k]] = (ms.value, ln.value)
         return out
 

@@ -636,6 +636,8 @@ int br_ctx_set_param(br_ctx *, const char *key, int64_t value);
 /* Device time (ms) of kernel `which` during the last projection call, summed
  * over its launches; *launches receives the launch count. */
 int br_ctx_kernel_ms(br_ctx *, int which, double *ms, int32_t *launches);
+/* ... summed over every call since br_ctx_set_profiling(ctx, 1) (a timed loop reads it once, behind its last step) */
+int br_ctx_kernel_ms_sum(br_ctx *, int which, double *ms, int64_t *launches);
 /* Diagnostic pass (never part of a timed region): computes the exact counters below
  * for the device batch the context projected last. */
 int br_ctx_collect_counters(br_ctx *, const br_device_batch *, void *stream);
