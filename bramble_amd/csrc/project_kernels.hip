@@ -2248,11 +2248,17 @@ __global__ void __launch_bounds__(256) k_primary(PairArgs P, const uint32_t *__r
     flagw[4 * pick] = fw | RR_PRIMARY;
     if (fw & RR_PAIRED) flagw[4 * (pick + 1)] |= RR_PRIMARY;
   }
+  // (one pair of atomics per block: same-address atomics queue up in one L2 channel, see k_group_desc)
+  __shared__ unsigned long long sh_pc[4][2];
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) { uniq += __shfl_down(uniq, d, 64); dropped += __shfl_down(dropped, d, 64); }
-  if ((threadIdx.x & 63) == 0) {
-    if (uniq) atomicAdd((unsigned long long *)&P.counters[1], uniq);
-    if (dropped) atomicAdd((unsigned long long *)&P.counters[2], dropped);
+  if ((threadIdx.x & 63) == 0) { sh_pc[(threadIdx.x >> 6) & 3][0] = uniq; sh_pc[(threadIdx.x >> 6) & 3][1] = dropped; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long u = 0, dr = 0;
+    for (unsigned w = 0; w < (blockDim.x + 63) / 64 && w < 4; w++) { u += sh_pc[w][0]; dr += sh_pc[w][1]; }
+    if (u) atomicAdd((unsigned long long *)&P.counters[1], u);
+    if (dr) atomicAdd((unsigned long long *)&P.counters[2], dr);
   }
 }
 
