@@ -1851,7 +1851,7 @@ static int bam_encode_impl(br_ctx *c, const br_config *cfg, const br_device_reco
   RC(c->bam_base.ensure(std::max<size_t>((size_t)n, 1) * 4));
   RC(c->bam_len.ensure(std::max<size_t>((size_t)nr, 1) * 4)); RC(c->bam_off.ensure(((size_t)nr + 1) * 8));
   B.aux = (BamAux *)c->bam_aux.p; B.base_len = c->bam_base.as<uint32_t>();
-  RC(c->bam_end.ensure(8)); B.blob_end = c->bam_end.as<uint64_t>();
+  RC(c->bam_end.ensure(BLOB_END_SLOTS * BLOB_END_STRIDE * 8)); B.blob_end = c->bam_end.as<uint64_t>();
   B.r_a = c->pk_a.as<uint4>(); B.r_c = c->pk_c.as<uint2>(); B.r_rec = c->r_rec.as<uint4>();
   if (c->last_direct) {   // no r_rec on the direct path: the detail column carries the input alignment and HI
     RC(ensure_detail(c, st));
@@ -1865,7 +1865,7 @@ static int bam_encode_impl(br_ctx *c, const br_config *cfg, const br_device_reco
   B.too_long = c->totals.as<uint64_t>() + 6;
   HIPCHK(hipMemsetAsync(B.too_long, 0, 8, st));
   RC(pf.begin(BR_K_BAM));
-  if (!aux_done) { HIPCHK(hipMemsetAsync(B.blob_end, 0, 8, st)); launch_bam_scan(st, B); }
+  if (!aux_done) { HIPCHK(hipMemsetAsync(B.blob_end, 0, BLOB_END_SLOTS * BLOB_END_STRIDE * 8, st)); launch_bam_scan(st, B); }
   launch_bam_size(st, B);
   RC(pf.end());
   ScanArgs S{}; S.n = nr; S.src32 = B.out_len; S.tile_sums = c->tile_sums.as<uint64_t>();
@@ -1946,8 +1946,8 @@ extern "C" int br_project_bam_device(br_ctx *c, const br_config *cfg, const br_d
   BamArgs B{};
   B.n_aln = n; B.long_reads = dc.long_reads ? 1 : 0; B.blob = recs->blob; B.rec_off = recs->rec_off; B.rec_len = recs->rec_len;
   B.aux = (BamAux *)c->bam_aux.p; B.base_len = c->bam_base.as<uint32_t>(); B.xs_out = c->b_xs.as<int8_t>(); B.ts_out = c->b_ts.as<int8_t>();
-  RC(c->bam_end.ensure(8)); B.blob_end = c->bam_end.as<uint64_t>();
-  HIPCHK(hipMemsetAsync(B.blob_end, 0, 8, st));
+  RC(c->bam_end.ensure(BLOB_END_SLOTS * BLOB_END_STRIDE * 8)); B.blob_end = c->bam_end.as<uint64_t>();
+  HIPCHK(hipMemsetAsync(B.blob_end, 0, BLOB_END_SLOTS * BLOB_END_STRIDE * 8, st));
 
   // the aux walk of the records (one lane per record, latency-bound) on the second stream beside the reader side
   // (k_rec_fields .. k_mates, the same kind of kernel over the same records): joined below, in front of the projection

@@ -45,7 +45,7 @@ __global__ void __launch_bounds__(256) k_bam_scan(BamArgs B) {
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int w = 1; w < 4; w++) e = sh_end[w] > e ? sh_end[w] : e;
-    atomicMax((unsigned long long *)B.blob_end, e);
+    atomicMax((unsigned long long *)B.blob_end + (size_t)(blockIdx.x & (BLOB_END_SLOTS - 1)) * BLOB_END_STRIDE, e);   // (one of 64 lines: see kernels.h)
   }
   if (a < B.n_aln) bam_scan_one(B, a, GlobalRec{B.blob + B.rec_off[a]}, B.rec_len ? (uint64_t)B.rec_len[a] : B.rec_off[a + 1] - B.rec_off[a]);
 }
@@ -296,7 +296,10 @@ __global__ void __launch_bounds__(256) k_bam_tasks(BamArgs B) {
   if (r0 >= B.n_rows) return;
   const int nr = (int)(B.n_rows - r0 < R ? B.n_rows - r0 : R);
   const uint64_t span0 = B.out_off[r0];
-  const uint8_t *blob_end = B.blob + *B.blob_end;
+  uint64_t be = B.blob_end[(size_t)(lane & (BLOB_END_SLOTS - 1)) * BLOB_END_STRIDE];   // the maximum over k_bam_scan's slots
+#pragma unroll
+  for (int o = 32; o; o >>= 1) { const uint64_t t = __shfl_xor(be, o); be = t > be ? t : be; }
+  const uint8_t *blob_end = B.blob + be;
 
   // ---- 1. one lane per row ----
   uint32_t h0 = 0, h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0, h6 = 0, h7 = 0, h8 = 0;   // block_size + the 32 fixed bytes

@@ -303,6 +303,8 @@ struct BamAux {
   uint32_t c_a, c_b, c_c, qual_present;
   uint32_t cg_len;          // bytes of the CG:B,I tag that holds the record's real CIGAR (0: none), see bam_cg.h
 };
+#define BLOB_END_SLOTS 64
+#define BLOB_END_STRIDE 16
 struct BamArgs {
   int64_t n_aln, n_rows;
   int32_t long_reads;
@@ -321,7 +323,9 @@ struct BamArgs {
   const uint64_t *out_off;   // [n_rows + 1]
   uint8_t *out;
   uint64_t *too_long;        // set when a spilled CIGAR's reference length does not fit the placeholder's 28 bits (bam_write1 fails there)
-  uint64_t *blob_end;        // k_bam_scan: end (byte offset in blob) of the record that ends last; k_bam_tasks never loads past it
+  uint64_t *blob_end;        // k_bam_scan: end (byte offset in blob) of the record that ends last, as the maximum over BLOB_END_SLOTS words a
+                             // cache line apart (one atomicMax per block of k_bam_scan: 80 000 of them on one address queue up in one L2 channel);
+                             // k_bam_tasks never loads past it
 };
 void launch_bam_scan(hipStream_t st, const BamArgs &B);
 
