@@ -313,7 +313,8 @@ def main():
             "pcie_inclusive": pcie,
             "roofline": {
                 "bound": "hbm",
-                "kernel": "whole path (%d launches per step)" % int(sum(v[1] for v in kernel_ms.values()) / args.steps),
+                "kernel": "whole path (%d timed kernel groups per step: k_scan_* is three launches, k_pair_mask and "
+                          "k_big<0>+k_pair_big two each)" % int(sum(v[1] for v in kernel_ms.values()) / args.steps),
                 "achieved": alg_bytes / step_s / 1e9,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
