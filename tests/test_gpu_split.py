@@ -241,3 +241,94 @@ def test_wrong_guesses_are_repaired():
     ctx.set_param("split_spoil", 0)
     check(ctx, stream2)
     ctx.close(); idx.close()
+
+
+class _PieceInfo(C.Structure):
+    _fields_ = [("start_rel", C.c_uint64), ("end_rel", C.c_uint64), ("n_unmapped", C.c_int64), ("guessed", C.c_int32), ("at_end", C.c_int32)]
+
+
+def _pieces(L, raw, n_ref, header_bytes, piece_blocks, guess, extra=2):
+    """The piece-wise reader on the BGZF bytes `raw`: pieces of `piece_blocks` blocks, each with a known start (the end of
+    the piece in front) or a guessed one (guess: every piece but the first).  Returns (bundles as lists of record bytes,
+    unmapped total, infos, how often a piece asked for more blocks)."""
+    L.br_bam_reader_new.argtypes = [C.c_int, C.c_int32, C.c_uint64, C.POINTER(C.c_void_p)]
+    L.br_bam_piece_upload.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64]
+    L.br_bam_piece_process.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(lib.BrDeviceRecords), C.POINTER(C.c_int64), C.POINTER(_PieceInfo)]
+    L.br_bam_reader_release.argtypes = [C.c_void_p, C.c_int64]
+    L.br_bam_reader_free.argtypes = [C.c_void_p]
+    arr = np.frombuffer(raw, dtype=np.uint8)
+    blocks, consumed, total = lib.bgzf_scan(arr)
+    assert consumed == arr.size
+    bl = np.ascontiguousarray(blocks, dtype=lib.BGZF_BLOCK)
+    nb = len(bl)
+    rd = C.c_void_p()
+    assert L.br_bam_reader_new(0, n_ref, header_bytes, C.byref(rd)) == 0
+    bundles, infos, unm, more = [], [], 0, 0
+    n_pieces = (nb + piece_blocks - 1) // piece_blocks
+    for k in range(n_pieces):
+        b0, b1 = k * piece_blocks, min(nb, (k + 1) * piece_blocks)
+        ex = extra
+        start = header_bytes if k == 0 else (-1 if guess else int(infos[-1].end_rel))
+        while True:
+            b1x = min(nb, b1 + ex)
+            assert L.br_bam_piece_upload(rd, k & 1, arr.ctypes.data, arr.size, bl.ctypes.data, nb, b0, b1x) == 0
+            recs, bid, info = lib.BrDeviceRecords(), C.c_int64(), _PieceInfo()
+            rc = L.br_bam_piece_process(rd, k & 1, bl.ctypes.data, nb, b1, start, C.byref(recs), C.byref(bid), C.byref(info))
+            if rc == 1:                       # BR_PIECE_MORE
+                more += 1; ex *= 8
+                assert ex < 100000
+                continue
+            assert rc == 0, rc
+            if guess and k and int(info.start_rel) != int(infos[-1].end_rel):   # a wrong guess: once more, from the true start
+                assert L.br_bam_reader_release(rd, bid.value) == 0
+                start = int(infos[-1].end_rel)
+                continue
+            break
+        n = int(recs.n_aln)
+        out = []
+        if n:
+            off = torch.as_tensor(_DevArray(recs.rec_off, n, "<u8"), device="cuda:0").cpu().numpy()
+            ln = torch.as_tensor(_DevArray(recs.rec_len, n, "<u4"), device="cuda:0").cpu().numpy()
+            end = int(off[-1]) + int(ln[-1])
+            blob = torch.as_tensor(_DevArray(recs.blob, end, "|u1"), device="cuda:0").cpu().numpy()
+            out = [blob[int(o):int(o) + int(l)].tobytes() for o, l in zip(off, ln)]
+        bundles.append(out); infos.append(info); unm += int(info.n_unmapped)
+        assert L.br_bam_reader_release(rd, bid.value) == 0
+    L.br_bam_reader_free(rd)
+    return bundles, unm, infos, more
+
+
+@pytest.mark.parametrize("piece_blocks,chunk,guess", [(3, 20000, False), (3, 20000, True), (1, 9000, True), (7, 0xff00, True), (2, 700, True), (1000, 0xff00, False)])
+def test_pieces_tile_the_mapped_records_whoever_made_them(piece_blocks, chunk, guess):
+    """br_bam_piece_upload / br_bam_piece_process directly: the pieces' bundles, in piece order, are the file's mapped
+    records, cut at read-name changes only -- with every start known (one reader in order) and with every start guessed
+    and checked against the neighbour's END (readers on several devices); blocks smaller than a record (a piece must
+    ask for more of them) and multi-mapper name groups across piece boundaries included."""
+    stream = records_stream(2500, 31)
+    recs = bamio.split_stream(stream)
+    mixed = []
+    for k, r in enumerate(recs):
+        if k % 13 == 4:
+            u = bytearray(r); u[14] |= 4; mixed.append(bytes(u))            # an unmapped record in between
+        mixed.append(r)
+        if k % 97 == 50:                                                    # a long name group: six more records of the same name
+            mixed.extend([r] * 6)
+    stream = bamio.frame(mixed)
+    header = b"BAM\x01" + (0).to_bytes(4, "little") + (3).to_bytes(4, "little") + b"".join(
+        (5).to_bytes(4, "little") + b"chr%d\0" % k + (10 ** 8).to_bytes(4, "little") for k in range(3))
+    raw = _bgzf(header + stream.tobytes(), chunk=chunk)
+    bundles, unm, infos, more = _pieces(lib.lib(), raw, 3, len(header), piece_blocks, guess)
+    h = host_split(stream)
+    want = [stream[int(o):int(o) + int(l)].tobytes() for o, l in zip(h[1], h[2])]
+    got = [r for b in bundles for r in b]
+    assert got == want
+    assert unm == h[3]
+    name = lambda r: r[32:32 + r[8]]
+    full = [b for b in bundles if b]
+    for a, b in zip(full[:-1], full[1:]):
+        assert name(a[-1]) != name(b[0])
+    for a, b in zip(infos[:-1], infos[1:]):
+        assert int(b.start_rel) == int(a.end_rel)
+    assert infos[-1].at_end == 1
+    if chunk == 700:
+        assert more > 0          # blocks of 700 bytes: a name group at a boundary needs more than two of them
