@@ -475,14 +475,11 @@ __global__ void __launch_bounds__(256) k_bam_tasks(BamArgs B) {
       }
     }
     if (len >= 16u) {
-#ifdef BAM_NT_STORES
+      // (the output records are written once: streaming stores, the 24 GB do not displace the input records, which
+      // about five rows each come back to)
       typedef uint32_t ntw4 __attribute__((ext_vector_type(4), aligned(1)));
       const ntw4 o4 = {v.x, v.y, v.z, v.w};
       __builtin_nontemporal_store(o4, (ntw4 *)(S.d + S.at));
-#else
-      W4 o4; o4.a = v.x; o4.b = v.y; o4.c = v.z; o4.d = v.w;
-      *(W4 *)(S.d + S.at) = o4;
-#endif
     } else {
       typedef uint16_t u16u __attribute__((aligned(1)));
       struct __attribute__((packed, aligned(1))) W2 { uint32_t a, b; };
